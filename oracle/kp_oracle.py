@@ -1,0 +1,365 @@
+"""CPU oracle: a functional PyTorch-CPU restatement of the reference hot path.
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  The product path
+(keypoints_amd/) never imports this file.
+
+Pinning: the reference's own tests hold no golden values for this path
+(SURVEY.md section 4), so this restatement is pinned against the reference
+itself, imported in the build container: tools/make_golden.py asserts every
+function here equal to /root/reference's `keypoints.models.*` on seeded inputs
+and writes the vectors committed under tests/golden/.
+
+Everything is written as plain functions over a flat ``{name: tensor}``
+parameter dict whose keys are the reference's ``state_dict`` keys
+(``<net>.<block>.<sequential index>.<field>``), so reference checkpoints load
+directly.  All maths in fp32 on the CPU (or fp64 when the caller passes
+doubles, which the noise-floor tests do).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+# --------------------------------------------------------------------------
+# Architecture tables.  Restates keypoints/models/vgg.py:48-70: first entry is
+# the core's input width, ints are 3x3 conv widths, 'M' = 2x2/2 max-pool,
+# 'U' = bilinear x2 (align_corners=True).
+# --------------------------------------------------------------------------
+ENCODER_CORES = {
+    'A': [64, 'M', 128, 'M', 256, 256, 'M', 512, 512, 'M', 512, 512, 'M'],
+    'B': [64, 64, 'M', 128, 128, 'M', 256, 256, 'M', 512, 512, 'M', 512, 512, 'M'],
+    'D': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M'],
+    'E': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M',
+          512, 512, 512, 512, 'M'],
+    'F': [64, 128, 'M', 256, 256, 'M', 512, 512, 'M', 512, 512],
+    'VGG_PONG': [16, 'M', 16, 'M', 32],
+    'VGG_PONG_TRIVIAL': [16, 16],
+    'VGG_PONG_LAYERNECK': [16, 32],
+    'VGG_PACMAN': [16, 32, 32, 16],
+    'VGG_PACMAN_2': [16, 32, 32, 'M', 64],
+    'MAPPER': [8, 8],
+}
+DECODER_CORES = {
+    'A': [512, 512, 'U', 256, 256, 'U', 256, 256, 'U', 128, 'U', 64, 'U'],
+    'F': [512, 512, 'U', 256, 256, 'U', 256, 256, 'U', 128, 64],
+    'VGG_PONG': [32, 'U', 16, 'U', 16],
+    'VGG_PONG_TRIVIAL': [16, 16],
+    'VGG_PONG_LAYERNECK': [32, 32, 16, 16],
+    'VGG_PACMAN': [16, 32, 32, 16],
+    'VGG_PACMAN_2': [64, 'U', 32, 32, 16],
+}
+
+LEAKY = 0.01      # nn.LeakyReLU default slope (knn.py:118, transporter.py:121)
+BN_EPS = 1e-5     # nn.BatchNorm2d defaults
+BN_MOMENTUM = 0.1
+
+
+def unit_plan(core_cfg: List, in_channels: int, out_channels: int, core_slope: float) -> List[dict]:
+    """Flatten one `knn.Unit` (knn.py:110-130) into a list of steps.
+
+    in_block  = Pad(1), Conv3x3(in -> core_in), BN, LeakyReLU      (knn.py:115-119)
+    core      = vgg.make_layers(cfg)                               (vgg.py:16-39)
+    out_block = Conv1x1(core_out -> out), LeakyReLU                (knn.py:123-125)
+    `core_slope` is 0.0 for the decoder (ReLU, vgg.py:19) and 0.01 for the
+    encoder / keypoint nets (transporter.py:121-122).
+    """
+    steps = [dict(op='conv3', key='in_block.1', bn='in_block.2', cin=in_channels,
+                  cout=core_cfg[0], slope=LEAKY)]
+    idx, width = 0, core_cfg[0]
+    for v in core_cfg[1:]:
+        if v == 'M':
+            steps.append(dict(op='pool')); idx += 1
+        elif v == 'U':
+            steps.append(dict(op='up')); idx += 1
+        else:
+            steps.append(dict(op='conv3', key=f'core.{idx + 1}', bn=f'core.{idx + 2}',
+                              cin=width, cout=v, slope=core_slope))
+            width = v
+            idx += 4
+    steps.append(dict(op='conv1', key='out_block.0', cin=width, cout=out_channels, slope=LEAKY))
+    return steps
+
+
+def unit_forward(plan: List[dict], P: Params, prefix: str, x: Tensor,
+                 buffers: Optional[Params] = None, training: bool = True) -> Tensor:
+    """`knn.Unit.forward` (knn.py:127-130) on the CPU."""
+    h = x
+    for st in plan:
+        if st['op'] == 'conv3':
+            h = F.pad(h, (1, 1, 1, 1), mode='replicate')                      # vgg.py:30
+            h = F.conv2d(h, P[f"{prefix}.{st['key']}.weight"], P[f"{prefix}.{st['key']}.bias"])
+            bn = f"{prefix}.{st['bn']}"
+            rm = buffers[bn + '.running_mean'] if buffers is not None else None
+            rv = buffers[bn + '.running_var'] if buffers is not None else None
+            h = F.batch_norm(h, rm, rv, P[bn + '.weight'], P[bn + '.bias'],
+                             training=training or rm is None, momentum=BN_MOMENTUM, eps=BN_EPS)
+            if buffers is not None and training and bn + '.num_batches_tracked' in buffers:
+                buffers[bn + '.num_batches_tracked'] += 1
+            h = F.leaky_relu(h, st['slope']) if st['slope'] > 0 else F.relu(h)
+        elif st['op'] == 'pool':
+            h = F.max_pool2d(h, 2, 2)                                          # vgg.py:24
+        elif st['op'] == 'up':
+            h = F.interpolate(h, scale_factor=2, mode='bilinear', align_corners=True)  # vgg.py:26
+        else:
+            h = F.conv2d(h, P[f"{prefix}.{st['key']}.weight"], P[f"{prefix}.{st['key']}.bias"])
+            h = F.leaky_relu(h, st['slope'])
+    return h
+
+
+# --------------------------------------------------------------------------
+# Keypoint bottleneck (keypoints/models/functional.py)
+# --------------------------------------------------------------------------
+def ruler(n: int, like: Tensor) -> Tensor:
+    """linspace(0,1,n) exactly as torch builds it (functional.py:18,23,50)."""
+    return torch.linspace(0, 1, n, device=like.device).to(like.dtype)
+
+
+def spatial_logsoftmax(heatmap: Tensor) -> Tuple[Tensor, Tuple[Tensor, Tensor]]:
+    """functional.py:11-14,22-24,37-44: keypoints (y, x) in [0,1] + both marginals.
+
+    Row marginal: mean over width, log-softmax over height, expectation of the
+    ruler taken in the log domain (ruler[0]=0 -> log = -inf -> term is 0).
+    """
+    H, W = heatmap.shape[2], heatmap.shape[3]
+    row_lp = F.log_softmax(heatmap.mean(dim=3), dim=2)
+    col_lp = F.log_softmax(heatmap.mean(dim=2), dim=2)
+    ky = torch.exp(row_lp + torch.log(ruler(H, heatmap))).sum(dim=2)
+    kx = torch.exp(col_lp + torch.log(ruler(W, heatmap))).sum(dim=2)
+    return torch.stack((ky, kx), dim=2), (row_lp.exp(), col_lp.exp())
+
+
+def spatial_softmax(heatmap: Tensor) -> Tuple[Tensor, Tuple[Tensor, Tensor]]:
+    """functional.py:5-8,17-19,27-34 (the non-log variant used by tests / demo)."""
+    H, W = heatmap.shape[2], heatmap.shape[3]
+    row_p = F.softmax(heatmap.mean(dim=3), dim=2)
+    col_p = F.softmax(heatmap.mean(dim=2), dim=2)
+    ky = (row_p * ruler(H, heatmap)).sum(dim=2)
+    kx = (col_p * ruler(W, heatmap)).sum(dim=2)
+    return torch.stack((ky, kx), dim=2), (row_p, col_p)
+
+
+def gaussian_like(kp: Tensor, height: int, width: int, sigma: float = 0.1, eps: float = 1e-6) -> Tensor:
+    """functional.py:49-63: exp(-sqrt(dy^2 + dx^2 + eps) / (2 sigma^2))."""
+    dy2 = (ruler(height, kp)[None, None, :] - kp[:, :, 0:1]) ** 2          # [B,K,H]
+    dx2 = (ruler(width, kp)[None, None, :] - kp[:, :, 1:2]) ** 2           # [B,K,W]
+    d = (dy2[:, :, :, None] + dx2[:, :, None, :] + eps).sqrt()
+    return torch.exp(-d / (2 * sigma ** 2))
+
+
+def point_map(kp: Tensor, height: int, width: int) -> Tensor:
+    """functional.py:66-72: negative squared distance map."""
+    dy2 = (ruler(height, kp)[None, None, :] - kp[:, :, 0:1]) ** 2
+    dx2 = (ruler(width, kp)[None, None, :] - kp[:, :, 1:2]) ** 2
+    return -(dy2[:, :, :, None] + dx2[:, :, None, :])
+
+
+def transport(phi_s: Tensor, phi_t: Tensor, m_s: Tensor, m_t: Tensor, mode: str = 'max'):
+    """transporter.py:41-60.  Returns (phi', mask_s, mask_t)."""
+    if mode == 'max':
+        mask_s = m_s.max(dim=1, keepdim=True)[0]
+        mask_t = m_t.max(dim=1, keepdim=True)[0]
+    elif mode == 'sum_and_clamp':
+        mask_s = m_s.sum(dim=1, keepdim=True).clamp(0.0, 1.0)
+        mask_t = m_t.sum(dim=1, keepdim=True).clamp(0.0, 1.0)
+    elif mode == 'pretrained_network':
+        mask_s, mask_t = m_s, m_t
+    elif mode == 'loop':
+        phi = phi_s
+        for i in range(m_t.shape[1]):
+            mask_s, mask_t = m_s[:, i:i + 1], m_t[:, i:i + 1]
+            phi = phi * (1 - mask_s) * (1 - mask_t) + phi_t * mask_t
+        return phi, mask_s, mask_t
+    else:
+        raise ValueError(mode)
+    return phi_s * (1 - mask_s) * (1 - mask_t) + phi_t * mask_t, mask_s, mask_t
+
+
+# --------------------------------------------------------------------------
+# Model assemblies
+# --------------------------------------------------------------------------
+def transporter_plans(model_type: str, in_channels: int, z_channels: int, keypoints: int):
+    """transporter.make (transporter.py:112-129): encoder/keypoint LeakyReLU cores, decoder ReLU core."""
+    return dict(
+        feature=unit_plan(ENCODER_CORES[model_type], in_channels, z_channels, LEAKY),
+        keypoint=unit_plan(ENCODER_CORES[model_type], in_channels, keypoints, LEAKY),
+        decoder=unit_plan(DECODER_CORES[model_type], z_channels, in_channels, 0.0),
+    )
+
+
+def keynet_plans(model_type: str, in_channels: int, z_channels: int, keypoints: int):
+    """keynet.make as intended (keynet.py:50-59): decoder eats z + K channels."""
+    return dict(
+        encoder=unit_plan(ENCODER_CORES[model_type], in_channels, z_channels, LEAKY),
+        keypoint=unit_plan(ENCODER_CORES[model_type], in_channels, keypoints, LEAKY),
+        decoder=unit_plan(DECODER_CORES[model_type], z_channels + keypoints, in_channels, 0.0),
+    )
+
+
+def transporter_extract(plans, P, x, buffers, training, sigma=0.1):
+    """TransporterNet.extract (transporter.py:27-32)."""
+    phi = unit_forward(plans['feature'], P, 'feature', x, buffers, training)
+    heat = unit_forward(plans['keypoint'], P, 'keypoint', x, buffers, training)
+    k, p = spatial_logsoftmax(heat)
+    m = gaussian_like(k, phi.shape[2], phi.shape[3], sigma)
+    return phi, heat, k, p, m
+
+
+def transporter_forward(plans, P: Params, xs: Tensor, xt: Tensor, buffers: Optional[Params] = None,
+                        training: bool = True, combine: str = 'max', sigma: float = 0.1):
+    """TransporterNet.forward (transporter.py:34-64); source branch under no_grad."""
+    with torch.no_grad():
+        phi_s, _, _, _, m_s = transporter_extract(plans, P, xs, buffers, training, sigma)
+    phi_t, heat_t, k_t, p_t, m_t = transporter_extract(plans, P, xt, buffers, training, sigma)
+    phi, mask_s, mask_t = transport(phi_s, phi_t, m_s, m_t, combine)
+    x_t = unit_forward(plans['decoder'], P, 'decoder', phi, buffers, training)
+    return x_t, phi, k_t, m_t, p_t, heat_t, mask_s, mask_t
+
+
+def keynet_forward(plans, P: Params, x: Tensor, x_t: Tensor, buffers: Optional[Params] = None,
+                   training: bool = True, sigma: float = 0.1):
+    """KeyNet.forward (keynet.py:21-31)."""
+    z = unit_forward(plans['encoder'], P, 'encoder', x, buffers, training)
+    heat = unit_forward(plans['keypoint'], P, 'keypoint', x_t, buffers, training)
+    k, p = spatial_logsoftmax(heat)
+    m = gaussian_like(k, z.shape[2], z.shape[3], sigma)
+    out = unit_forward(plans['decoder'], P, 'decoder', torch.cat((z, m), dim=1), buffers, training)
+    return out, z, k, m, p, heat
+
+
+def l2_reconstruction_loss(x: Tensor, x_: Tensor, loss_mask: Optional[Tensor] = None) -> Tensor:
+    """transporter.py:56-60 / keypoints.py:54-58."""
+    d = (x - x_) ** 2
+    if loss_mask is not None:
+        d = d * loss_mask
+    return d.mean()
+
+
+# --------------------------------------------------------------------------
+# Parameters, Adam, one train step
+# --------------------------------------------------------------------------
+def param_shapes(plans) -> Dict[str, Tuple[int, ...]]:
+    shapes = {}
+    for net, plan in plans.items():
+        for st in plan:
+            if st['op'] == 'conv3':
+                shapes[f"{net}.{st['key']}.weight"] = (st['cout'], st['cin'], 3, 3)
+                shapes[f"{net}.{st['key']}.bias"] = (st['cout'],)
+                shapes[f"{net}.{st['bn']}.weight"] = (st['cout'],)
+                shapes[f"{net}.{st['bn']}.bias"] = (st['cout'],)
+            elif st['op'] == 'conv1':
+                shapes[f"{net}.{st['key']}.weight"] = (st['cout'], st['cin'], 1, 1)
+                shapes[f"{net}.{st['key']}.bias"] = (st['cout'],)
+    return shapes
+
+
+def init_params(plans, seed: int = 0, dtype=torch.float32) -> Tuple[Params, Params]:
+    """Container._initialize_weights (knn.py:12-23): conv ~ N(0, 2/fan_out), bias 0, BN gamma 1 beta 0.
+
+    Uses its own seeded generator (not the reference's RNG stream): tests feed
+    the same dict to both the oracle and the HIP path.
+    """
+    g = torch.Generator().manual_seed(seed)
+    P, B = {}, {}
+    for name, shp in param_shapes(plans).items():
+        if len(shp) == 4:
+            std = math.sqrt(2.0 / (shp[0] * shp[2] * shp[3]))
+            P[name] = (torch.randn(shp, generator=g) * std).to(dtype)
+        elif '.weight' in name:
+            P[name] = torch.ones(shp, dtype=dtype)
+        else:
+            P[name] = torch.zeros(shp, dtype=dtype)
+    for net, plan in plans.items():
+        for st in plan:
+            if st['op'] == 'conv3':
+                B[f"{net}.{st['bn']}.running_mean"] = torch.zeros(st['cout'], dtype=dtype)
+                B[f"{net}.{st['bn']}.running_var"] = torch.ones(st['cout'], dtype=dtype)
+                B[f"{net}.{st['bn']}.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    return P, B
+
+
+def adam_update(P: Params, G: Params, state: dict, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam defaults as used at transporter.py:47 (no weight decay, no amsgrad)."""
+    state['step'] = state.get('step', 0) + 1
+    t = state['step']
+    c1, c2 = 1 - b1 ** t, 1 - b2 ** t
+    for name, p in P.items():
+        g = G[name]
+        m = state.setdefault('m.' + name, torch.zeros_like(p))
+        v = state.setdefault('v.' + name, torch.zeros_like(p))
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v.sqrt() / math.sqrt(c2)).add_(eps)
+        p.data.addcdiv_(m, denom, value=-lr / c1)
+
+
+def transporter_train_step(plans, P: Params, buffers: Params, state: dict, xs: Tensor, xt: Tensor,
+                           loss_mask: Optional[Tensor] = None, combine: str = 'max', lr: float = 1e-4):
+    """zero_grad -> forward -> L2 loss -> backward -> Adam (transporter.py:79-89).
+
+    Returns (loss, outputs, grads); P / buffers / state are updated in place.
+    """
+    for p in P.values():
+        p.requires_grad_(True)
+        p.grad = None
+    out = transporter_forward(plans, P, xs, xt, buffers, True, combine)
+    loss = l2_reconstruction_loss(out[0], xt, loss_mask)
+    loss.backward()
+    G = {n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in P.items()}
+    with torch.no_grad():
+        adam_update(P, G, state, lr=lr)
+    return loss.detach(), tuple(o.detach() if torch.is_tensor(o) else o for o in out), G
+
+
+def keynet_train_step(plans, P: Params, buffers: Params, state: dict, x: Tensor, x_t: Tensor,
+                      loss_mask: Optional[Tensor] = None, lr: float = 1e-4):
+    """keypoints.py:74-84."""
+    for p in P.values():
+        p.requires_grad_(True)
+        p.grad = None
+    out = keynet_forward(plans, P, x, x_t, buffers, True)
+    loss = l2_reconstruction_loss(out[0], x_t, loss_mask)
+    loss.backward()
+    G = {n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in P.items()}
+    with torch.no_grad():
+        adam_update(P, G, state, lr=lr)
+    return loss.detach(), tuple(o.detach() if torch.is_tensor(o) else o for o in out), G
+
+
+def conv_flops_per_pair(plans, height: int, width: int, transporter: bool = True) -> float:
+    """Conv MACs x2 for one train step on one image pair (SURVEY.md section 8d accounting)."""
+    def unit_macs(plan, h, w):
+        total, first = 0.0, None
+        for st in plan:
+            if st['op'] == 'pool':
+                h, w = h // 2, w // 2
+            elif st['op'] == 'up':
+                h, w = h * 2, w * 2
+            else:
+                k = 9 if st['op'] == 'conv3' else 1
+                macs = h * w * st['cin'] * st['cout'] * k
+                if first is None:
+                    first = macs
+                total += macs
+        return total, first
+    nets = list(plans.keys())
+    macs = {n: unit_macs(plans[n], height, width) for n in nets if n != 'decoder'}
+    enc_h = height
+    for st in plans[nets[0]]:
+        if st['op'] == 'pool':
+            enc_h //= 2
+    enc_w = width * enc_h // height
+    macs['decoder'] = unit_macs(plans['decoder'], enc_h, enc_w)
+    tot = sum(m[0] for m in macs.values())
+    if transporter:
+        fwd = 2 * (macs['feature'][0] + macs['keypoint'][0]) + macs['decoder'][0]
+        bwd = 2 * tot - macs['feature'][1] - macs['keypoint'][1]
+    else:
+        fwd = tot
+        bwd = 2 * tot - macs['encoder'][1] - macs['keypoint'][1]
+    return 2.0 * (fwd + bwd)
