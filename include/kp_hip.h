@@ -1,0 +1,158 @@
+/*
+ * kp_hip.h -- C ABI of libkp_hip.so: the MI355X (gfx950) kernels behind the
+ * Transporter / KeyNet train-step hot path of DuaneNielsen/keypoints.
+ *
+ * The reference has no FFI: its path is Python calling torch.nn / torch.autograd
+ * (SURVEY.md section 8b).  Each entry point below therefore cites the reference
+ * Python statement(s) whose arithmetic it replaces; keypoints_amd/ binds them with
+ * ctypes (keypoints_amd/_lib.py) and INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer; the caller owns all memory (torch's
+ *     caching allocator in our host code) including workspaces;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and
+ *     the call never synchronises;
+ *   - return value: 0 = ok, <0 = error (KP_E_*); kp_last_error() gives text;
+ *   - dtype: KP_F32 (0) or KP_BF16 (1) = storage type of activations / packed
+ *     weights ("T" below).  Accumulation is always fp32, statistics fp64;
+ *   - activation images are NHWC with an optional physical border:
+ *     img[N][H+2*pad][W+2*pad][C]; (H, W) always name the interior size.
+ */
+#ifndef KP_HIP_H
+#define KP_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KP_F32 0
+#define KP_BF16 1
+
+#define KP_OK 0
+#define KP_E_ARG (-1)         /* bad argument / unsupported shape */
+#define KP_E_LAUNCH (-2)      /* hipGetLastError() != hipSuccess after a launch */
+#define KP_E_UNSUPPORTED (-3)
+
+/* BN+activation output modes (vgg.py:24-38: what follows the activation) */
+#define KP_TAIL_NONE 0
+#define KP_TAIL_MAXPOOL2 1    /* nn.MaxPool2d(2,2)            vgg.py:24 */
+#define KP_TAIL_UPSAMPLE2 2   /* nn.UpsamplingBilinear2d(x2)  vgg.py:26 */
+
+int kp_version(void);
+const char* kp_last_error(void);
+/* number of CUs of the current device (for grid sizing by host code) */
+int kp_device_cus(void);
+
+/* ---- layout ------------------------------------------------------------ */
+/* NCHW fp32 -> NHWC T with a replicated border of `pad` pixels.
+ * Replaces nn.ReplicationPad2d(1) in front of the first conv of a Unit
+ * (knn.py:115) plus the layout change into our internal format. */
+int kp_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int pad, int dtype, void* stream);
+/* Adjoint of the above: gsrc is the gradient w.r.t. the padded image
+ * [N][H+2pad][W+2pad][C] (T); border contributions are folded back onto the
+ * edge pixels and the result is written NCHW fp32. */
+int kp_nhwc_grad_to_nchw(const void* gsrc, float* dst, int N, int C, int H, int W, int pad, int dtype, void* stream);
+
+/* ---- weights ----------------------------------------------------------- */
+/* fp32 [K][C][R][R] (nn.Conv2d.weight) -> T [K][R][R][C] (forward operand) and,
+ * if w_dgrad != NULL, T [C][R][R][K] with the taps flipped (dgrad operand). */
+int kp_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int K, int C, int R, int dtype, void* stream);
+/* dw[K][C][R][R] += transpose(scratch[K][R][R][C])   (fp32 both) */
+int kp_wgrad_unpack(const float* scratch, float* dw, int K, int C, int R, void* stream);
+
+/* ---- convolution ------------------------------------------------------- */
+/* "Valid" RxR correlation (R = 1 or 3) over an already padded image:
+ *   y[n][p][q][k] = bias[k] + sum_{r,s,c} x[n][p+r][q+s][c] * w[k][r][s][c]
+ * x: [N][Hi][Wi][C] T, w: [K][R][R][C] T, y: [N][Hi-R+1][Wi-R+1][K] T.
+ * Forward of nn.Conv2d(k=3) after ReplicationPad2d (vgg.py:30-33, knn.py:115);
+ * with x = zero-padded dy and w = the flipped/transposed pack it is the
+ * data-gradient of the same layer.  If stats != NULL, stats[0..K) += sum_m y,
+ * stats[K..2K) += sum_m y^2 (fp64; BatchNorm batch statistics, vgg.py:35). */
+int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, double* stats,
+                int N, int Hi, int Wi, int C, int K, int R, int dtype, void* stream);
+/* Weight gradient: scratch[k][r][s][c] += sum_{n,p,q} dy[n][p][q][k] * x[n][p+r][q+s][c]
+ * x: [N][Ho+R-1][Wo+R-1][C] T; dy: interior of [N][Ho+2*dy_pad][Wo+2*dy_pad][K] T;
+ * scratch fp32 [K][R][R][C], zeroed by the caller (atomically accumulated). */
+int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R,
+                  int dy_pad, int dtype, void* stream);
+
+/* ---- BatchNorm(train) + activation (+ pool / upsample) ----------------- */
+/* stats (from kp_conv_fwd) -> batch mean / 1/sqrt(var+eps); updates running
+ * stats with momentum (unbiased var) like nn.BatchNorm2d in train mode. */
+int kp_bn_finalize(const double* stats, float* save_mean, float* save_invstd, float* running_mean,
+                   float* running_var, long long* num_batches_tracked, float momentum, float eps, long long count,
+                   int C, void* stream);
+/* out = tail(act((y - mean) * invstd * gamma + beta)); act = LeakyReLU(slope) (slope 0 = ReLU).
+ * y: [N][H][W][C] T.  out: [N][Ho+2*out_pad][Wo+2*out_pad][C] T with replicated border where
+ * (Ho,Wo) = (H,W) | (H/2,W/2) | (2H,2W) for tail none | maxpool2 | upsample2.
+ * argmax (maxpool only): u8 [N][H/2][W/2][C] = winning position 0..3 (row-major in the window).
+ * If mean == NULL the affine step is skipped (conv + activation without BN). */
+int kp_bn_act_fwd(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                  float slope, int tail, void* out, int out_pad, unsigned char* argmax,
+                  int N, int H, int W, int C, int dtype, void* stream);
+/* Backward, pass 1: sums[0..C) += sum g*act'(z), sums[C..2C) += sum g*act'(z)*xhat  (fp64, zeroed by caller).
+ * The incoming gradient g w.r.t. the activation output of this layer is read through `gsrc`:
+ *   tail none    : gsrc = [N][H+2gp][W+2gp][C] T, gp in {0,1}; gp=1 folds the border (adjoint of replicate pad)
+ *   tail maxpool2: gsrc = [N][H/2+2gp][W/2+2gp][C] T routed through argmax
+ *   (upsample: run kp_upsample2_bwd first, then tail none / gp = 0). */
+int kp_bn_act_bwd_reduce(const void* gsrc, int gp, int tail, const unsigned char* argmax, const void* y,
+                         const float* mean, const float* invstd, const float* gamma, const float* beta,
+                         float slope, double* sums, int N, int H, int W, int C, int dtype, void* stream);
+/* Backward, pass 2: dy = gamma*invstd*(ghat - dbeta/M - xhat*dgamma/M) written into
+ * [N][H+2dp][W+2dp][C] T with a ZERO border of dp pixels; dgamma/dbeta (fp32) += sums. */
+int kp_bn_act_bwd_apply(const void* gsrc, int gp, int tail, const unsigned char* argmax, const void* y,
+                        const float* mean, const float* invstd, const float* gamma, const float* beta,
+                        float slope, const double* sums, float* dgamma, float* dbeta, void* dy, int dp,
+                        int N, int H, int W, int C, int dtype, void* stream);
+/* Adjoint of bilinear x2 (align_corners=True): gsrc = [N][2H+2gp][2W+2gp][C] T (folded if gp=1)
+ * -> g [N][H][W][C] T. */
+int kp_upsample2_bwd(const void* gsrc, int gp, void* g, int N, int H, int W, int C, int dtype, void* stream);
+
+/* ---- 1x1 head: Conv2d(C->K, 1) + LeakyReLU (knn.py:123-125) ------------- */
+/* x: [N][H][W][C] T (no border); w fp32 [K][C]; out fp32 NCHW [N][K][H][W]. */
+int kp_head_fwd(const void* x, const float* w, const float* bias, float slope, float* out,
+                int N, int H, int W, int C, int K, int dtype, void* stream);
+/* gout/out fp32 NCHW; dx [N][H][W][C] T (may be NULL); dw [K][C] +=, db [K] += (fp32). */
+int kp_head_bwd(const float* gout, const float* out, const void* x, const float* w, float slope,
+                void* dx, float* dw, float* db, int N, int H, int W, int C, int K, int dtype, void* stream);
+
+/* ---- keypoint bottleneck (keypoints/models/functional.py) --------------- */
+/* heat fp32 [BK][H][W] -> k [BK][2] (y,x), p [BK][H], q [BK][W].
+ * log_domain=1: spacial_logsoftmax (functional.py:37-44); 0: spacial_softmax (:27-34). */
+int kp_spatial_softmax_fwd(const float* heat, float* k, float* p, float* q, int BK, int H, int W,
+                           int log_domain, void* stream);
+int kp_spatial_softmax_bwd(const float* gk, const float* k, const float* p, const float* q, float* dheat,
+                           int BK, int H, int W, void* stream);
+/* m[bk][i][j] = exp(-sqrt((r_i-ky)^2 + (c_j-kx)^2 + eps) / (2 sigma^2))   functional.py:56-63 */
+int kp_gaussian_fwd(const float* k, float* m, int BK, int H, int W, float sigma, float eps, void* stream);
+int kp_gaussian_bwd(const float* gm, const float* k, float* dk, int BK, int H, int W, float sigma, float eps,
+                    void* stream);
+/* -( (r_i-ky)^2 + (c_j-kx)^2 )   functional.py:66-72 */
+int kp_point_map_fwd(const float* k, float* m, int BK, int H, int W, void* stream);
+/* Transport, combine_method='max' (transporter.py:57-60):
+ *   Ms = max_k m_s, Mt = max_k m_t, phi = phi_s*(1-Ms)*(1-Mt) + phi_t*Mt.   All fp32 NCHW.
+ * arg_s/arg_t: u8 [B][H][W] argmax over K (first index wins, like torch.max). */
+int kp_transport_max_fwd(const float* phi_s, const float* phi_t, const float* m_s, const float* m_t,
+                         float* phi, float* mask_s, float* mask_t, unsigned char* arg_s, unsigned char* arg_t,
+                         int B, int C, int K, int H, int W, void* stream);
+/* Any of the d_* outputs may be NULL (not needed). d_m_* are fully written (zeros off the argmax). */
+int kp_transport_max_bwd(const float* gphi, const float* phi_s, const float* phi_t, const float* mask_s,
+                         const float* mask_t, const unsigned char* arg_s, const unsigned char* arg_t,
+                         float* d_phi_s, float* d_phi_t, float* d_m_s, float* d_m_t,
+                         int B, int C, int K, int H, int W, void* stream);
+
+/* ---- loss and optimiser -------------------------------------------------- */
+/* l2_reconstruction_loss (transporter.py:56-60): loss_sum[0] += sum (x-t)^2*mask (fp64, zeroed by caller);
+ * grad = 2*(x-t)*mask*scale  (scale = 1/numel).  mask may be NULL. */
+int kp_l2_loss(const float* x, const float* t, const float* mask, double* loss_sum, float* grad, float scale,
+               size_t n, void* stream);
+/* torch.optim.Adam step (transporter.py:47,89) over a flat fp32 arena. bc1 = 1-b1^t, bc2 = 1-b2^t. */
+int kp_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
+                 float eps, float bc1, float bc2, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KP_HIP_H */

@@ -1,0 +1,16 @@
+"""keypoints_amd -- MI355X-native (gfx950) Transporter / KeyNet train-step hot path behind the
+`keypoints.models` surface of DuaneNielsen/keypoints.  See DESIGN.md / INTEGRATION.md."""
+from .runtime import default_precision, set_default_precision  # noqa: F401
+from . import models  # noqa: F401
+from .optim import FusedAdam, l2_reconstruction_loss  # noqa: F401
+
+
+def install_as_keypoints():
+    """Alias this package as `keypoints.models.*` so the reference's train scripts import it unchanged."""
+    import sys
+    import types
+    pkg = sys.modules.setdefault('keypoints', types.ModuleType('keypoints'))
+    pkg.models = models
+    sys.modules['keypoints.models'] = models
+    for name in ('functional', 'knn', 'vgg', 'transporter', 'keynet'):
+        sys.modules[f'keypoints.models.{name}'] = getattr(models, name)

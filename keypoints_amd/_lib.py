@@ -1,0 +1,80 @@
+"""ctypes binding of libkp_hip.so (the C ABI declared in include/kp_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or fails to
+load, importing any compute entry point raises.  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C keypoints_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libkp_hip.so')
+
+KP_F32, KP_BF16 = 0, 1
+TAIL_NONE, TAIL_MAXPOOL2, TAIL_UPSAMPLE2 = 0, 1, 2
+
+_p, _i, _f, _z, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
+
+# name -> argument ctypes (all return int unless noted); mirrors include/kp_hip.h one to one
+SIGNATURES = {
+    'kp_nchw_to_nhwc': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'kp_nhwc_grad_to_nchw': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'kp_pack_weights': [_p, _p, _p, _i, _i, _i, _i, _p],
+    'kp_wgrad_unpack': [_p, _p, _i, _i, _i, _p],
+    'kp_conv_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    'kp_conv_wgrad': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'kp_bn_finalize': [_p, _p, _p, _p, _p, _p, _f, _f, _ll, _i, _p],
+    'kp_bn_act_fwd': [_p, _p, _p, _p, _p, _f, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p],
+    'kp_bn_act_bwd_reduce': [_p, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p],
+    'kp_bn_act_bwd_apply': [_p, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'kp_upsample2_bwd': [_p, _i, _p, _i, _i, _i, _i, _i, _p],
+    'kp_head_fwd': [_p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _i, _p],
+    'kp_head_bwd': [_p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'kp_spatial_softmax_fwd': [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'kp_spatial_softmax_bwd': [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    'kp_gaussian_fwd': [_p, _p, _i, _i, _i, _f, _f, _p],
+    'kp_gaussian_bwd': [_p, _p, _p, _i, _i, _i, _f, _f, _p],
+    'kp_point_map_fwd': [_p, _p, _i, _i, _i, _p],
+    'kp_transport_max_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    'kp_transport_max_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    'kp_l2_loss': [_p, _p, _p, _p, _p, _f, _z, _p],
+    'kp_adam_step': [_p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _f, _p],
+}
+PLAIN = {'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
+
+_lib = None
+
+
+class KpError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded CDLL (loads on first use; raises if libkp_hip.so is absent)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KpError(f'{LIB_PATH} not found: build the HIP extension first '
+                          '(make -C keypoints_amd/csrc); there is no CPU fallback')
+        _lib = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.argtypes, fn.restype = args, _i
+        for name, (args, res) in PLAIN.items():
+            fn = getattr(_lib, name)
+            fn.argtypes, fn.restype = args, res
+    return _lib
+
+
+def call(name: str, *args):
+    """Invoke a kp_* entry point; non-zero return -> KpError with the library's message."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise KpError(f'{name} failed ({rc}): {lib().kp_last_error().decode()}')
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,124 @@
+"""Building blocks with the reference's names (keypoints/models/knn.py): Container, Unit,
+SpatialSoftmax, SpatialLogSoftmax, GaussianLike.  `Unit.forward` runs the whole
+pad/conv/BN/activation/pool/upsample stack through libkp_hip.so (unit_engine.py)."""
+from pathlib import Path
+
+import torch
+from torch import nn as nn
+
+from ..runtime import default_precision, require_device
+from ..unit_engine import GradArena, UnitFunction, build_plan
+from .functional import gaussian_like_function, spacial_logsoftmax, spacial_softmax
+
+
+class Container(nn.Module):
+    """Base class of the model assemblies; owns the weight init (knn.py:12-23)."""
+
+    def _initialize_weights(self):
+        # kaiming-normal(fan_out, relu) convs with zero bias, unit-gamma / zero-beta BatchNorm.
+        # Drawn in module order from torch's global RNG, i.e. the same stream as the reference.
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.zeros_(m.bias)
+
+    def forward(self, *input):
+        raise NotImplementedError()
+
+    def save(self, directory):
+        raise NotImplementedError()
+
+    def load(self, directory):
+        raise NotImplementedError()
+
+    def set_precision(self, precision):
+        """'fp32' (strict parity, apex O0) or 'bf16' (mixed precision, fp32 master weights; the O2 role)."""
+        for m in self.modules():
+            if isinstance(m, Unit):
+                m.precision = precision
+        return self
+
+
+class GaussianLike(nn.Module):
+    def __init__(self, sigma=0.1):
+        super().__init__()
+        self.sigma = sigma
+
+    def forward(self, kp, height, width):
+        return gaussian_like_function(kp, height, width, self.sigma)
+
+
+class SpatialSoftmax(nn.Module):
+    def forward(self, heatmap, probs=False):
+        return spacial_softmax(heatmap, probs)
+
+
+class SpatialLogSoftmax(nn.Module):
+    def forward(self, heatmap, probs=False):
+        return spacial_logsoftmax(heatmap, probs)
+
+
+class Unit(nn.Module):
+    """in_block (pad, 3x3 conv, BN, LeakyReLU) -> core -> out_block (1x1 conv, LeakyReLU)."""
+
+    def __init__(self, in_channels, out_channels, core, batch_norm=True):
+        super().__init__()
+        convs = [m for m in core.modules() if isinstance(m, nn.Conv2d)]
+        core_in, core_out = convs[0].in_channels, convs[-1].out_channels
+
+        head = [nn.ReplicationPad2d(1), nn.Conv2d(in_channels, core_in, kernel_size=3, stride=1)]
+        if batch_norm:
+            head.append(nn.BatchNorm2d(core_in))
+        head.append(nn.LeakyReLU(inplace=True))
+        self.in_block = nn.Sequential(*head)
+        self.core = core
+        self.out_block = nn.Sequential(nn.Conv2d(core_out, out_channels, kernel_size=1, stride=1),
+                                       nn.LeakyReLU(inplace=True))
+        self.precision = default_precision()
+        self._plan = None
+        self._arena = None
+        self.after_backward = None   # optional hook(unit): data-parallel gradient reduction hangs here
+
+    # -- HIP execution -------------------------------------------------------------------------
+    def plan(self):
+        if self._plan is None:
+            self._plan = build_plan([self.in_block, self.core, self.out_block])
+        return self._plan
+
+    def grad_arena(self):
+        params = list(self.parameters())
+        if self._arena is None or self._arena.flat.device != params[0].device:
+            self._arena = GradArena(params)
+        return self._arena
+
+    def _after_backward(self):
+        if self.after_backward is not None:
+            self.after_backward(self)
+
+    def forward(self, x):
+        require_device(x)
+        params = list(self.parameters())
+        record = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        return UnitFunction.apply(x, self, record, *params)
+
+    # -- checkpoints: same files / keys as knn.py:143-167 ---------------------------------------
+    def _blocks(self, in_block=True, core=True, out_block=True):
+        return [(n, getattr(self, n)) for n, on in (('in_block', in_block), ('core', core), ('out_block', out_block))
+                if on]
+
+    def save(self, directory):
+        Path(directory).mkdir(parents=True, exist_ok=True)
+        for name, block in self._blocks():
+            torch.save(block.state_dict(), str(Path(directory) / f'{name}.mdl'))
+
+    def load(self, directory, in_block=True, core=True, out_block=True, map_device=None):
+        for name, block in self._blocks(in_block, core, out_block):
+            path = str(Path(directory) / f'{name}.mdl')
+            block.load_state_dict(torch.load(path, map_location=map_device) if map_device else torch.load(path))

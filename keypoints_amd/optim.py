@@ -1,0 +1,114 @@
+"""Loss and optimiser of the train step (transporter.py:47,56-60,79-89) on HIP kernels.
+
+`l2_reconstruction_loss` is the reference's criterion; `FusedAdam` replaces
+``torch.optim.Adam(params, lr=1e-4)`` with one kernel launch per flat parameter arena.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+
+from ._lib import call, ptr
+from .runtime import f32c, require_device, stream_ptr
+
+
+class _L2Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, target, mask):
+        require_device(x, target, mask)
+        x, target = f32c(x), f32c(target)
+        if mask is not None:
+            mask = f32c(mask).expand_as(x).contiguous()
+        n = x.numel()
+        acc = torch.zeros(1, device=x.device, dtype=torch.float64)
+        grad = torch.empty_like(x)
+        call('kp_l2_loss', ptr(x), ptr(target), ptr(mask), ptr(acc), ptr(grad), 1.0 / n, n, stream_ptr())
+        ctx.save_for_backward(grad)
+        return (acc / n).to(torch.float32).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+def l2_reconstruction_loss(x, x_, loss_mask=None):
+    """mean((x - x_)^2 [* loss_mask]); gradient flows to `x` only (x_ is data)."""
+    return _L2Loss.apply(x, x_.detach(), loss_mask)
+
+
+class FusedAdam:
+    """Adam (betas .9/.999, eps 1e-8, no weight decay -- torch.optim.Adam defaults) over flat arenas.
+
+    Parameters are re-homed into one flat fp32 buffer per group of parameters that share a
+    GradArena (one per `knn.Unit`), so a step is one `kp_adam_step` launch per Unit and the
+    gradient buffer is the data-parallel all-reduce bucket.  Loose parameters (not owned by a
+    Unit) get one launch each.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-4, betas=(0.9, 0.999), eps=1e-8, modules=None):
+        self.params: List[torch.nn.Parameter] = [p for p in params]
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+        self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps)]
+        self._units = []
+        self._loose = []
+        self._state = {}
+        if modules is not None:
+            self.bind(modules)
+
+    def bind(self, root: torch.nn.Module) -> 'FusedAdam':
+        """Flatten the parameters of every `Unit` under `root` (call after `.to(device)`)."""
+        from .models.knn import Unit
+        owned = set()
+        wanted = {id(p) for p in self.params}
+        for m in root.modules():
+            if isinstance(m, Unit):
+                ps = [p for p in m.parameters()]
+                if not ps or not all(id(p) in wanted for p in ps):
+                    continue
+                require_device(*ps)
+                flat = torch.empty(sum(p.numel() for p in ps), device=ps[0].device, dtype=torch.float32)
+                off = 0
+                for p in ps:
+                    view = flat[off:off + p.numel()].view_as(p)
+                    view.copy_(p.data)
+                    p.data = view
+                    off += p.numel()
+                m._arena = None   # grad views must be rebuilt against the same ordering
+                self._units.append((m, flat, torch.zeros_like(flat), torch.zeros_like(flat)))
+                owned.update(id(p) for p in ps)
+        self._loose = [p for p in self.params if id(p) not in owned]
+        return self
+
+    def zero_grad(self, set_to_none: bool = False):
+        for m, *_ in self._units:
+            arena = m.grad_arena()
+            arena.flat.zero_()
+            for p in m.parameters():
+                p.grad = arena.views[id(p)]
+        for p in self._loose:
+            if p.grad is not None:
+                p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        if not self._units and not self._loose:
+            self._loose = list(self.params)
+        self.step_count += 1
+        t = self.step_count
+        b1, b2 = self.betas
+        bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+        st = stream_ptr()
+        for m, flat, em, ev in self._units:
+            g = m.grad_arena().flat
+            call('kp_adam_step', ptr(flat), ptr(g), ptr(em), ptr(ev), flat.numel(), self.lr, b1, b2, self.eps, bc1, bc2, st)
+        for p in self._loose:
+            if p.grad is None:
+                continue
+            require_device(p)
+            stt = self._state.setdefault(id(p), (torch.zeros_like(p.data), torch.zeros_like(p.data)))
+            g = f32c(p.grad)
+            call('kp_adam_step', ptr(p.data), ptr(g), ptr(stt[0]), ptr(stt[1]), p.numel(), self.lr, b1, b2, self.eps,
+                 bc1, bc2, st)

@@ -1,0 +1,240 @@
+"""Runs one `knn.Unit` (pad+conv3x3+BN+act stacks with max-pool / bilinear-up tails and a 1x1 head)
+forward and backward entirely through the HIP kernels of libkp_hip.so.
+
+Reference semantics: keypoints/models/knn.py:110-130 (Unit), vgg.py:16-39 (make_layers).
+Data layout in HBM: activations are NHWC in the compute dtype with the
+replicate border physically present, so every convolution -- forward, data-gradient and
+weight-gradient -- is a plain "valid" correlation with no boundary logic:
+
+    a_{l}  [N][H+2][W+2][C]   replicate-padded activation feeding conv l   (written by bn_act_fwd)
+    y_{l}  [N][H][W][K]       conv output before BatchNorm                  (written by conv_fwd)
+    dy_{l} [N][H+4][W+4][K]   dL/dy_l with a zero border of 2               (written by bn_act_bwd_apply)
+    gx_{l} [N][H+2][W+2][C]   dL/da_l over the padded domain                (written by conv_fwd(dy, flipped w))
+
+The adjoint of the replicate pad (folding gx's border onto the edge pixels) happens inside the
+consumer of gx (bn_act_bwd_* of layer l-1).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import call, ptr
+from .runtime import f32c, precision_dtype, require_device, stream_ptr
+
+TAILS = {None: _lib.TAIL_NONE, 'M': _lib.TAIL_MAXPOOL2, 'U': _lib.TAIL_UPSAMPLE2}
+
+
+def _slope_of(act: nn.Module) -> float:
+    if isinstance(act, nn.LeakyReLU):
+        return float(act.negative_slope)
+    if isinstance(act, nn.ReLU):
+        return 0.0
+    raise NotImplementedError(f'activation {type(act).__name__} has no HIP kernel (ReLU / LeakyReLU only)')
+
+
+def build_plan(blocks: List[nn.Sequential]) -> List[dict]:
+    """Group the flat module list of in_block + core + out_block into kernel steps."""
+    mods = [m for b in blocks for m in b]
+    steps, i = [], 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.ReplicationPad2d):
+            conv = mods[i + 1] if i + 1 < len(mods) else None
+            if not (isinstance(conv, nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+                    and conv.padding == (0, 0) and tuple(m.padding) == (1, 1, 1, 1)):
+                raise NotImplementedError('expected ReplicationPad2d(1) + Conv2d(k=3, s=1)')
+            i += 2
+            bn = None
+            if i < len(mods) and isinstance(mods[i], nn.BatchNorm2d):
+                bn = mods[i]; i += 1
+            slope = _slope_of(mods[i]); i += 1
+            tail = None
+            if i < len(mods) and isinstance(mods[i], nn.MaxPool2d):
+                mp = mods[i]
+                if mp.kernel_size not in (2, (2, 2)) or mp.stride not in (2, (2, 2)):
+                    raise NotImplementedError('only MaxPool2d(2, 2) has a HIP kernel')
+                tail = 'M'; i += 1
+            elif i < len(mods) and isinstance(mods[i], (nn.UpsamplingBilinear2d, nn.Upsample)):
+                tail = 'U'; i += 1
+            steps.append(dict(kind='conv3', conv=conv, bn=bn, slope=slope, tail=tail))
+        elif isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1) and i + 2 == len(mods):
+            steps.append(dict(kind='head', conv=m, slope=_slope_of(mods[i + 1])))
+            i += 2
+        else:
+            raise NotImplementedError(f'no HIP kernel sequence for {type(m).__name__} at position {i} of the Unit')
+    if not steps or steps[-1]['kind'] != 'head' or any(s['kind'] == 'head' for s in steps[:-1]):
+        raise NotImplementedError('a Unit must end in Conv2d(1x1) + activation (knn.py:123-125)')
+    return steps
+
+
+class GradArena:
+    """One flat fp32 buffer holding every parameter gradient of a Unit (the DP all-reduce bucket).
+
+    `views[p]` aliases the arena; backward accumulates into the views and installs them as `p.grad`.
+    """
+
+    def __init__(self, params: List[nn.Parameter]):
+        dev = params[0].device
+        self.flat = torch.zeros(sum(p.numel() for p in params), device=dev, dtype=torch.float32)
+        self.views, off = {}, 0
+        for p in params:
+            self.views[id(p)] = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def attach(self, params: List[nn.Parameter]) -> None:
+        stale = [p for p in params if p.grad is not self.views[id(p)]]
+        if len(stale) == len(params):
+            self.flat.zero_()
+        else:
+            for p in stale:
+                self.views[id(p)].zero_()
+        for p in stale:
+            p.grad = self.views[id(p)]
+
+
+def _tail_dims(H, W, tail):
+    if tail == 'M':
+        return H // 2, W // 2
+    if tail == 'U':
+        return 2 * H, 2 * W
+    return H, W
+
+
+class UnitFunction(torch.autograd.Function):
+    """forward(x NCHW fp32) -> out NCHW fp32; parameter gradients are accumulated straight into the
+    Unit's GradArena (returned as None to autograd), the input gradient is returned normally."""
+
+    @staticmethod
+    def forward(ctx, x, unit, record, *params):
+        require_device(x, *params)
+        plan = unit.plan()
+        tdt, code = precision_dtype(unit.precision)
+        st = stream_ptr()
+        dev = x.device
+        x = f32c(x)
+        N, Cin, H, W = x.shape
+        first = plan[0]
+        pad0 = 1 if first['kind'] == 'conv3' else 0
+        a = torch.empty(N, H + 2 * pad0, W + 2 * pad0, Cin, device=dev, dtype=tdt)
+        call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, Cin, H, W, pad0, code, st)
+        saved = []
+        C = Cin
+        for idx, stp in enumerate(plan[:-1]):
+            conv, bn = stp['conv'], stp['bn']
+            K = conv.out_channels
+            if conv.in_channels != C:
+                raise RuntimeError(f'channel mismatch: conv expects {conv.in_channels}, got {C}')
+            wf = torch.empty(K, 3, 3, C, device=dev, dtype=tdt)
+            wd = torch.empty(C, 3, 3, K, device=dev, dtype=tdt) if record else None
+            call('kp_pack_weights', ptr(conv.weight), ptr(wf), ptr(wd), K, C, 3, code, st)
+            y = torch.empty(N, H, W, K, device=dev, dtype=tdt)
+            training = bn is not None and bn.training
+            stats = torch.zeros(2 * K, device=dev, dtype=torch.float64) if training else None
+            call('kp_conv_fwd', ptr(a), ptr(wf), ptr(conv.bias), ptr(y), ptr(stats), N, H + 2, W + 2, C, K, 3, code, st)
+            mean = invstd = None
+            if bn is not None:
+                if training:
+                    mean = torch.empty(K, device=dev, dtype=torch.float32)
+                    invstd = torch.empty(K, device=dev, dtype=torch.float32)
+                    mom = 0.1 if bn.momentum is None else float(bn.momentum)
+                    track = bn.track_running_stats and bn.running_mean is not None
+                    call('kp_bn_finalize', ptr(stats), ptr(mean), ptr(invstd),
+                         ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                         ptr(bn.num_batches_tracked) if track else None, mom, float(bn.eps), N * H * W, K, st)
+                else:
+                    if record:
+                        raise NotImplementedError('backward through eval-mode BatchNorm is not implemented')
+                    mean = bn.running_mean
+                    invstd = torch.rsqrt(bn.running_var + bn.eps)
+            tail = stp['tail']
+            Ho, Wo = _tail_dims(H, W, tail)
+            nxt = plan[idx + 1]
+            out_pad = 1 if nxt['kind'] == 'conv3' else 0
+            a_next = torch.empty(N, Ho + 2 * out_pad, Wo + 2 * out_pad, K, device=dev, dtype=tdt)
+            argmax = torch.empty(N, Ho, Wo, K, device=dev, dtype=torch.uint8) if (tail == 'M' and record) else None
+            call('kp_bn_act_fwd', ptr(y), ptr(mean), ptr(invstd), ptr(bn.weight) if bn is not None else None,
+                 ptr(bn.bias) if bn is not None else None, stp['slope'], TAILS[tail], ptr(a_next), out_pad, ptr(argmax),
+                 N, H, W, K, code, st)
+            if record:
+                saved.append(dict(a=a, y=y, mean=mean, invstd=invstd, argmax=argmax, wd=wd, H=H, W=W, C=C, K=K))
+            a, C, H, W = a_next, K, Ho, Wo
+        head = plan[-1]
+        hconv = head['conv']
+        Kout = hconv.out_channels
+        out = torch.empty(N, Kout, H, W, device=dev, dtype=torch.float32)
+        call('kp_head_fwd', ptr(a), ptr(hconv.weight), ptr(hconv.bias), head['slope'], ptr(out), N, H, W, C, Kout, code, st)
+        if record:
+            ctx.unit, ctx.saved, ctx.head_in, ctx.out = unit, saved, a, out
+            ctx.dims = (N, Cin, x.shape[2], x.shape[3], H, W, C, Kout, pad0)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        unit, saved, a_last, out = ctx.unit, ctx.saved, ctx.head_in, ctx.out
+        N, Cin, H0, W0, Hh, Wh, Ch, Kout, pad0 = ctx.dims
+        plan = unit.plan()
+        tdt, code = precision_dtype(unit.precision)
+        st = stream_ptr()
+        dev = gout.device
+        params = list(unit.parameters())
+        arena = unit.grad_arena()
+        arena.attach(params)
+        gv = arena.views
+        need_x = ctx.needs_input_grad[0]
+
+        gout = f32c(gout)
+        head = plan[-1]
+        hconv = head['conv']
+        has_body = len(plan) > 1
+        g = torch.empty(N, Hh, Wh, Ch, device=dev, dtype=tdt) if (has_body or need_x) else None
+        call('kp_head_bwd', ptr(gout), ptr(out), ptr(a_last), ptr(hconv.weight), head['slope'], ptr(g),
+             ptr(gv[id(hconv.weight)]), ptr(gv[id(hconv.bias)]) if hconv.bias is not None else None,
+             N, Hh, Wh, Ch, Kout, code, st)
+        gp = 0   # border width of g (0 = plain, 1 = padded-domain gradient that still needs folding)
+        for idx in range(len(saved) - 1, -1, -1):
+            stp, sv = plan[idx], saved[idx]
+            conv, bn = stp['conv'], stp['bn']
+            H, W, C, K = sv['H'], sv['W'], sv['C'], sv['K']
+            tail = stp['tail']
+            if tail == 'U':
+                g2 = torch.empty(N, H, W, K, device=dev, dtype=tdt)
+                call('kp_upsample2_bwd', ptr(g), gp, ptr(g2), N, H, W, K, code, st)
+                g, gp, tcode = g2, 0, _lib.TAIL_NONE
+            else:
+                tcode = TAILS[tail]
+            sums = torch.zeros(2 * K, device=dev, dtype=torch.float64)
+            gamma = bn.weight if bn is not None else None
+            beta = bn.bias if bn is not None else None
+            bn_args = (ptr(sv['mean']), ptr(sv['invstd']), ptr(gamma), ptr(beta))
+            call('kp_bn_act_bwd_reduce', ptr(g), gp, tcode, ptr(sv['argmax']), ptr(sv['y']), *bn_args, stp['slope'],
+                 ptr(sums), N, H, W, K, code, st)
+            need_dx = idx > 0 or need_x
+            dp = 2 if need_dx else 0
+            dy = torch.empty(N, H + 2 * dp, W + 2 * dp, K, device=dev, dtype=tdt)
+            if bn is not None:
+                dgam, dbet = ptr(gv[id(bn.weight)]), ptr(gv[id(bn.bias)])
+            else:   # no BN: sum of dy is the conv-bias gradient
+                dgam, dbet = None, (ptr(gv[id(conv.bias)]) if conv.bias is not None else None)
+            call('kp_bn_act_bwd_apply', ptr(g), gp, tcode, ptr(sv['argmax']), ptr(sv['y']), *bn_args, stp['slope'],
+                 ptr(sums), dgam, dbet, ptr(dy), dp, N, H, W, K, code, st)
+            # (conv bias in front of train-mode BN: analytically zero gradient -> its arena slot stays 0)
+            scratch = torch.zeros(K, 3, 3, C, device=dev, dtype=torch.float32)
+            call('kp_conv_wgrad', ptr(sv['a']), ptr(dy), ptr(scratch), N, H, W, C, K, 3, dp, code, st)
+            call('kp_wgrad_unpack', ptr(scratch), ptr(gv[id(conv.weight)]), K, C, 3, st)
+            if need_dx:
+                gx = torch.empty(N, H + 2, W + 2, C, device=dev, dtype=tdt)
+                call('kp_conv_fwd', ptr(dy), ptr(sv['wd']), None, ptr(gx), None, N, H + 4, W + 4, K, C, 3, code, st)
+                g, gp = gx, 1
+            else:
+                g = None
+        dx = None
+        if need_x:
+            dx = torch.empty(N, Cin, H0, W0, device=dev, dtype=torch.float32)
+            call('kp_nhwc_grad_to_nchw', ptr(g), ptr(dx), N, Cin, H0, W0, gp, code, st)
+        ctx.saved = None
+        unit._after_backward()
+        return (dx, None, None) + (None,) * len(params)

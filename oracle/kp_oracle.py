@@ -86,26 +86,51 @@ def unit_plan(core_cfg: List, in_channels: int, out_channels: int, core_slope: f
     return steps
 
 
+def bf16_storage(t: Tensor) -> Tensor:
+    """Straight-through bf16 rounding: models the HIP path's bf16 *storage* of activations / packed
+    weights (keypoints_amd precision 'bf16') while every sum stays fp32, like the kernels."""
+    return t + (t.detach().to(torch.bfloat16).to(t.dtype) - t.detach())
+
+
 def unit_forward(plan: List[dict], P: Params, prefix: str, x: Tensor,
-                 buffers: Optional[Params] = None, training: bool = True) -> Tensor:
-    """`knn.Unit.forward` (knn.py:127-130) on the CPU."""
-    h = x
+                 buffers: Optional[Params] = None, training: bool = True, quant=None) -> Tensor:
+    """`knn.Unit.forward` (knn.py:127-130) on the CPU.
+
+    `quant` (None or `bf16_storage`) rounds exactly where the HIP engine stores in bf16: the layer input,
+    the packed conv weights, the conv output (BatchNorm statistics are taken before that rounding, as in
+    the conv epilogue) and the activation after the pool / upsample tail.  quant=None is the reference."""
+    q = quant if quant is not None else (lambda t: t)
+    h = q(x)
     for st in plan:
         if st['op'] == 'conv3':
             h = F.pad(h, (1, 1, 1, 1), mode='replicate')                      # vgg.py:30
-            h = F.conv2d(h, P[f"{prefix}.{st['key']}.weight"], P[f"{prefix}.{st['key']}.bias"])
+            h = F.conv2d(h, q(P[f"{prefix}.{st['key']}.weight"]), P[f"{prefix}.{st['key']}.bias"])
             bn = f"{prefix}.{st['bn']}"
             rm = buffers[bn + '.running_mean'] if buffers is not None else None
             rv = buffers[bn + '.running_var'] if buffers is not None else None
-            h = F.batch_norm(h, rm, rv, P[bn + '.weight'], P[bn + '.bias'],
-                             training=training or rm is None, momentum=BN_MOMENTUM, eps=BN_EPS)
+            if quant is not None and (training or rm is None):
+                mu = h.mean(dim=(0, 2, 3))
+                var = h.var(dim=(0, 2, 3), unbiased=False)
+                if rm is not None:
+                    n = h.numel() // h.shape[1]
+                    rm.mul_(1 - BN_MOMENTUM).add_(mu.detach(), alpha=BN_MOMENTUM)
+                    rv.mul_(1 - BN_MOMENTUM).add_(var.detach() * n / max(1, n - 1), alpha=BN_MOMENTUM)
+                hq = q(h)
+                h = (hq - mu[None, :, None, None]) * torch.rsqrt(var + BN_EPS)[None, :, None, None] \
+                    * P[bn + '.weight'][None, :, None, None] + P[bn + '.bias'][None, :, None, None]
+            else:
+                h = F.batch_norm(q(h), rm, rv, P[bn + '.weight'], P[bn + '.bias'],
+                                 training=training or rm is None, momentum=BN_MOMENTUM, eps=BN_EPS)
             if buffers is not None and training and bn + '.num_batches_tracked' in buffers:
                 buffers[bn + '.num_batches_tracked'] += 1
             h = F.leaky_relu(h, st['slope']) if st['slope'] > 0 else F.relu(h)
+            nxt = plan[plan.index(st) + 1]['op']
+            if nxt not in ('pool', 'up'):
+                h = q(h)
         elif st['op'] == 'pool':
-            h = F.max_pool2d(h, 2, 2)                                          # vgg.py:24
+            h = q(F.max_pool2d(h, 2, 2))                                       # vgg.py:24
         elif st['op'] == 'up':
-            h = F.interpolate(h, scale_factor=2, mode='bilinear', align_corners=True)  # vgg.py:26
+            h = q(F.interpolate(h, scale_factor=2, mode='bilinear', align_corners=True))  # vgg.py:26
         else:
             h = F.conv2d(h, P[f"{prefix}.{st['key']}.weight"], P[f"{prefix}.{st['key']}.bias"])
             h = F.leaky_relu(h, st['slope'])
@@ -201,23 +226,23 @@ def keynet_plans(model_type: str, in_channels: int, z_channels: int, keypoints: 
     )
 
 
-def transporter_extract(plans, P, x, buffers, training, sigma=0.1):
+def transporter_extract(plans, P, x, buffers, training, sigma=0.1, quant=None):
     """TransporterNet.extract (transporter.py:27-32)."""
-    phi = unit_forward(plans['feature'], P, 'feature', x, buffers, training)
-    heat = unit_forward(plans['keypoint'], P, 'keypoint', x, buffers, training)
+    phi = unit_forward(plans['feature'], P, 'feature', x, buffers, training, quant)
+    heat = unit_forward(plans['keypoint'], P, 'keypoint', x, buffers, training, quant)
     k, p = spatial_logsoftmax(heat)
     m = gaussian_like(k, phi.shape[2], phi.shape[3], sigma)
     return phi, heat, k, p, m
 
 
 def transporter_forward(plans, P: Params, xs: Tensor, xt: Tensor, buffers: Optional[Params] = None,
-                        training: bool = True, combine: str = 'max', sigma: float = 0.1):
+                        training: bool = True, combine: str = 'max', sigma: float = 0.1, quant=None):
     """TransporterNet.forward (transporter.py:34-64); source branch under no_grad."""
     with torch.no_grad():
-        phi_s, _, _, _, m_s = transporter_extract(plans, P, xs, buffers, training, sigma)
-    phi_t, heat_t, k_t, p_t, m_t = transporter_extract(plans, P, xt, buffers, training, sigma)
+        phi_s, _, _, _, m_s = transporter_extract(plans, P, xs, buffers, training, sigma, quant)
+    phi_t, heat_t, k_t, p_t, m_t = transporter_extract(plans, P, xt, buffers, training, sigma, quant)
     phi, mask_s, mask_t = transport(phi_s, phi_t, m_s, m_t, combine)
-    x_t = unit_forward(plans['decoder'], P, 'decoder', phi, buffers, training)
+    x_t = unit_forward(plans['decoder'], P, 'decoder', phi, buffers, training, quant)
     return x_t, phi, k_t, m_t, p_t, heat_t, mask_s, mask_t
 
 
@@ -299,7 +324,7 @@ def adam_update(P: Params, G: Params, state: dict, lr=1e-4, b1=0.9, b2=0.999, ep
 
 
 def transporter_train_step(plans, P: Params, buffers: Params, state: dict, xs: Tensor, xt: Tensor,
-                           loss_mask: Optional[Tensor] = None, combine: str = 'max', lr: float = 1e-4):
+                           loss_mask: Optional[Tensor] = None, combine: str = 'max', lr: float = 1e-4, quant=None):
     """zero_grad -> forward -> L2 loss -> backward -> Adam (transporter.py:79-89).
 
     Returns (loss, outputs, grads); P / buffers / state are updated in place.
@@ -307,7 +332,7 @@ def transporter_train_step(plans, P: Params, buffers: Params, state: dict, xs: T
     for p in P.values():
         p.requires_grad_(True)
         p.grad = None
-    out = transporter_forward(plans, P, xs, xt, buffers, True, combine)
+    out = transporter_forward(plans, P, xs, xt, buffers, True, combine, quant=quant)
     loss = l2_reconstruction_loss(out[0], xt, loss_mask)
     loss.backward()
     G = {n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in P.items()}

@@ -1,0 +1,144 @@
+"""One Pad+Conv3x3+BN(train)+act[+pool|upsample] block and the 1x1 head through the HIP Unit engine,
+against golden vectors produced by the reference's torch modules (tools/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return np.abs(a - b).max() / max(1e-12, np.abs(b).max())
+
+
+def build_block(z, tag, cin, cout, tail, slope, head_out):
+    """A Unit whose in_block is the golden block and whose head is a fixed random 1x1 conv."""
+    from keypoints_amd.models import knn
+    core_mods = []
+    if tail == 'M':
+        core_mods.append(nn.MaxPool2d(2, 2))
+    if tail == 'U':
+        core_mods.append(nn.UpsamplingBilinear2d(scale_factor=2))
+    # Unit wants a conv inside `core` to size its blocks: append one more 3x3 layer (identity-free)
+    core_mods += [nn.ReplicationPad2d(1), nn.Conv2d(cout, cout, 3), nn.BatchNorm2d(cout), nn.ReLU(inplace=True)]
+    unit = knn.Unit(cin, head_out, nn.Sequential(*core_mods))
+    # overwrite the in_block conv (Unit builds in -> core_in = cout)
+    act = nn.LeakyReLU(slope, inplace=True) if slope > 0 else nn.ReLU(inplace=True)
+    unit.in_block[3] = act
+    with torch.no_grad():
+        unit.in_block[1].weight.copy_(torch.tensor(z[f'{tag}.weight']))
+        unit.in_block[1].bias.copy_(torch.tensor(z[f'{tag}.bias']))
+        unit.in_block[2].weight.copy_(torch.tensor(z[f'{tag}.gamma']))
+        unit.in_block[2].bias.copy_(torch.tensor(z[f'{tag}.beta']))
+    unit._plan = None
+    return unit
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('bf16', 3e-2)])
+@pytest.mark.parametrize('tag,cin,cout,tail,slope', [('in3', 3, 64, None, 0.01), ('c64', 32, 64, 'M', 0.01),
+                                                      ('dec', 32, 16, 'U', 0.0), ('odd', 5, 7, None, 0.01)])
+def test_block_against_golden(golden, tag, cin, cout, tail, slope, precision, tol):
+    """Drive the engine op by op (same calls UnitFunction makes) on the golden block and compare the
+    activation, every gradient and the running statistics."""
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import precision_dtype, stream_ptr
+    z = golden('layers.npz')
+    tdt, code = precision_dtype(precision)
+    dev = 'cuda'
+    x = torch.tensor(z[f'{tag}.x'], device=dev)
+    N, C, H, W = x.shape
+    K = cout
+    wt = torch.tensor(z[f'{tag}.weight'], device=dev)
+    bias = torch.tensor(z[f'{tag}.bias'], device=dev)
+    gamma = torch.tensor(z[f'{tag}.gamma'], device=dev)
+    beta = torch.tensor(z[f'{tag}.beta'], device=dev)
+    st = stream_ptr()
+    a = torch.empty(N, H + 2, W + 2, C, device=dev, dtype=tdt)
+    call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, C, H, W, 1, code, st)
+    wf = torch.empty(K, 3, 3, C, device=dev, dtype=tdt)
+    wd = torch.empty(C, 3, 3, K, device=dev, dtype=tdt)
+    call('kp_pack_weights', ptr(wt), ptr(wf), ptr(wd), K, C, 3, code, st)
+    y = torch.empty(N, H, W, K, device=dev, dtype=tdt)
+    stats = torch.zeros(2 * K, device=dev, dtype=torch.float64)
+    call('kp_conv_fwd', ptr(a), ptr(wf), ptr(bias), ptr(y), ptr(stats), N, H + 2, W + 2, C, K, 3, code, st)
+    mean = torch.empty(K, device=dev); invstd = torch.empty(K, device=dev)
+    rm = torch.zeros(K, device=dev); rv = torch.ones(K, device=dev)
+    nbt = torch.zeros((), device=dev, dtype=torch.long)
+    call('kp_bn_finalize', ptr(stats), ptr(mean), ptr(invstd), ptr(rm), ptr(rv), ptr(nbt), 0.1, 1e-5, N * H * W, K, st)
+    tcode = {None: 0, 'M': 1, 'U': 2}[tail]
+    Ho, Wo = (H // 2, W // 2) if tail == 'M' else ((2 * H, 2 * W) if tail == 'U' else (H, W))
+    out = torch.empty(N, Ho, Wo, K, device=dev, dtype=tdt)
+    argmax = torch.empty(N, Ho, Wo, K, device=dev, dtype=torch.uint8) if tail == 'M' else None
+    call('kp_bn_act_fwd', ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), slope, tcode, ptr(out), 0, ptr(argmax),
+         N, H, W, K, code, st)
+    got = out.float().permute(0, 3, 1, 2)
+    assert relerr(got, z[f'{tag}.y']) < tol
+    assert relerr(rm, z[f'{tag}.running_mean']) < max(tol, 1e-5) and relerr(rv, z[f'{tag}.running_var']) < max(tol, 1e-5)
+    assert int(nbt.item()) == 1
+    # padded output replicates its border
+    outp = torch.empty(N, Ho + 2, Wo + 2, K, device=dev, dtype=tdt)
+    call('kp_bn_act_fwd', ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), slope, tcode, ptr(outp), 1, None,
+         N, H, W, K, code, st)
+    ref = torch.nn.functional.pad(out.float().permute(0, 3, 1, 2), (1, 1, 1, 1), mode='replicate').permute(0, 2, 3, 1)
+    assert torch.equal(outp.float(), ref)
+
+    # backward with upstream gradient w (plain, no border)
+    g = torch.tensor(z[f'{tag}.w'], device=dev).permute(0, 2, 3, 1).contiguous().to(tdt)
+    if tail == 'U':
+        g2 = torch.empty(N, H, W, K, device=dev, dtype=tdt)
+        call('kp_upsample2_bwd', ptr(g), 0, ptr(g2), N, H, W, K, code, st)
+        g, tcode_b = g2, 0
+    else:
+        tcode_b = tcode
+    sums = torch.zeros(2 * K, device=dev, dtype=torch.float64)
+    call('kp_bn_act_bwd_reduce', ptr(g), 0, tcode_b, ptr(argmax), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
+         slope, ptr(sums), N, H, W, K, code, st)
+    dgamma = torch.zeros(K, device=dev); dbeta = torch.zeros(K, device=dev)
+    dy = torch.empty(N, H + 4, W + 4, K, device=dev, dtype=tdt)
+    call('kp_bn_act_bwd_apply', ptr(g), 0, tcode_b, ptr(argmax), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
+         slope, ptr(sums), ptr(dgamma), ptr(dbeta), ptr(dy), 2, N, H, W, K, code, st)
+    assert float(dy.float()[:, :2].abs().max()) == 0 and float(dy.float()[:, :, -2:].abs().max()) == 0
+    scratch = torch.zeros(K, 3, 3, C, device=dev)
+    call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, W, C, K, 3, 2, code, st)
+    dw = torch.zeros(K, C, 3, 3, device=dev)
+    call('kp_wgrad_unpack', ptr(scratch), ptr(dw), K, C, 3, st)
+    gx = torch.empty(N, H + 2, W + 2, C, device=dev, dtype=tdt)
+    call('kp_conv_fwd', ptr(dy), ptr(wd), None, ptr(gx), None, N, H + 4, W + 4, K, C, 3, code, st)
+    dx = torch.empty(N, C, H, W, device=dev)
+    call('kp_nhwc_grad_to_nchw', ptr(gx), ptr(dx), N, C, H, W, 1, code, st)
+    gt = tol * 5
+    assert relerr(dgamma, z[f'{tag}.dgamma']) < gt and relerr(dbeta, z[f'{tag}.dbeta']) < gt
+    assert relerr(dw, z[f'{tag}.dweight']) < gt
+    assert relerr(dx, z[f'{tag}.dx']) < gt
+    # conv bias in front of train-mode BN: reference gradient is rounding noise around 0
+    assert np.abs(z[f'{tag}.dbias']).max() < 1e-4 * np.abs(z[f'{tag}.dweight']).max() + 1e-5
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-5), ('bf16', 2e-2)])
+def test_head_against_golden(golden, precision, tol):
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import precision_dtype, stream_ptr
+    z = golden('layers.npz')
+    tdt, code = precision_dtype(precision)
+    dev = 'cuda'
+    x = torch.tensor(z['head.x'], device=dev)
+    N, C, H, W = x.shape
+    K = 5
+    a = torch.empty(N, H, W, C, device=dev, dtype=tdt)
+    st = stream_ptr()
+    call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, C, H, W, 0, code, st)
+    wt = torch.tensor(z['head.weight'], device=dev); b = torch.tensor(z['head.bias'], device=dev)
+    out = torch.empty(N, K, H, W, device=dev)
+    call('kp_head_fwd', ptr(a), ptr(wt), ptr(b), 0.01, ptr(out), N, H, W, C, K, code, st)
+    assert relerr(out, z['head.y']) < tol
+    gout = torch.tensor(z['head.w'], device=dev)
+    dxn = torch.empty(N, H, W, C, device=dev, dtype=tdt)
+    dw = torch.zeros(K, C, device=dev); db = torch.zeros(K, device=dev)
+    call('kp_head_bwd', ptr(gout), ptr(out), ptr(a), ptr(wt), 0.01, ptr(dxn), ptr(dw), ptr(db), N, H, W, C, K, code, st)
+    assert relerr(dxn.float().permute(0, 3, 1, 2), z['head.dx']) < tol
+    assert relerr(dw.view(K, C, 1, 1), z['head.dweight']) < tol and relerr(db, z['head.dbias']) < tol

@@ -1,0 +1,267 @@
+"""Whole-model parity: Transporter / KeyNet forward, loss, every gradient and Adam steps on the HIP path
+vs golden vectors from the reference (tests/golden, tools/make_golden.py) and vs the CPU oracle.
+
+fp32 tolerances follow SURVEY.md 8(c) (about 10x the reference's own fp32-vs-fp64 noise floor):
+  keypoints atol 2e-5, m atol 2.5e-4, x_t <= 1.5e-4 * max|x_t|, loss rtol 1e-5 (F);
+  gradients: rel-L2 <= 1e-3 per tensor on the small nets; on F 128x128 the reference's own fp32
+  gradients sit ~5e-3 from its fp64 run, so there each tensor is judged against the fp64 run with
+  max(3e-3, 8 x that tensor's reference noise); pre-BN conv-bias gradients are exactly 0 here
+  (analytically zero; the reference holds rounding noise there).
+bf16 mode: must track a bf16-storage emulation of the reference (see the test's docstring).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def t2n(a):
+    return a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+
+
+def maxerr(a, b):
+    a, b = t2n(a), t2n(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return np.abs(a - b).max()
+
+
+def rel_l2(a, b):
+    a, b = t2n(a), t2n(b)
+    return np.linalg.norm(a - b) / max(1e-30, np.linalg.norm(b))
+
+
+def pre_bn_bias_names(net):
+    import torch.nn as nn
+    names = set()
+    for mname, m in net.named_modules():
+        if isinstance(m, nn.Sequential):
+            mods = list(m)
+            for i, c in enumerate(mods[:-1]):
+                if isinstance(c, nn.Conv2d) and isinstance(mods[i + 1], nn.BatchNorm2d):
+                    names.add(f'{mname}.{i}.bias')
+    return names
+
+
+@pytest.mark.parametrize('tag,size,K', [('32', 32, 3), ('84', 84, 4)])
+def test_transporter_pong_golden_fp32(golden, tag, size, K):
+    """configs/transporter_pong_grey.yaml architecture (BASELINE config 1 shapes): stored weights, 3 Adam steps."""
+    import keypoints_amd as ka
+    from keypoints_amd.models import transporter
+    z = golden(f'transporter_pong_{tag}.npz')
+    net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, K)
+    sd = {k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith('p0.') or k.startswith('b0.')}
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda()
+    opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
+    xs, xt = torch.tensor(z['xs']).cuda(), torch.tensor(z['xt']).cuda()
+    noise = pre_bn_bias_names(net)
+    for step in range(1, 4):
+        opt.zero_grad()
+        x_t, phi, k, m, (p, q), heat, mask_s, mask_t = net(xs, xt)
+        loss = ka.l2_reconstruction_loss(x_t, xt)
+        loss.backward()
+        if step == 1:
+            scale = np.abs(z['x_t']).max()
+            assert maxerr(x_t, z['x_t']) <= 1.5e-4 * scale
+            assert maxerr(k, z['k']) <= 2e-5 and maxerr(m, z['m']) <= 2.5e-4
+            assert maxerr(p, z['p']) <= 1e-5 and maxerr(q, z['q']) <= 1e-5
+            assert maxerr(heat, z['heatmap']) <= 1.5e-4 * np.abs(z['heatmap']).max()
+            assert maxerr(phi, z['phi']) <= 1.5e-4 * np.abs(z['phi']).max()
+            assert maxerr(mask_s, z['mask_s']) <= 2.5e-4 and maxerr(mask_t, z['mask_t']) <= 2.5e-4
+            for n, prm in net.named_parameters():
+                ref = z['g.' + n]
+                if n in noise:
+                    assert float(prm.grad.abs().max()) == 0.0
+                    assert np.abs(ref).max() <= 1e-5 * max(1.0, np.abs(z['g.' + n.replace('.bias', '.weight')]).max())
+                else:
+                    assert rel_l2(prm.grad, ref) <= 1e-3, n
+        assert abs(loss.item() - float(z[f'loss{step}'])) <= 2e-5 * abs(float(z[f'loss{step}']))
+        opt.step()
+        if step in (1, 3):
+            sd_now = net.state_dict()
+            for key in z.files:
+                if not key.startswith(f'p{step}.') and not key.startswith(f'b{step}.'):
+                    continue
+                name = key[3:]
+                if name in noise:
+                    continue
+                ref = z[key]
+                if name.endswith('num_batches_tracked'):
+                    assert int(sd_now[name].item()) == int(ref)
+                else:
+                    # the reference's pre-BN conv biases random-walk by ~lr per step under Adam (their
+                    # gradient is rounding noise); that drift leaks into running_mean only
+                    tol = 1e-4 if (name.endswith('running_mean') and step > 1) else 2e-5
+                    assert maxerr(sd_now[name], ref) <= tol * max(1.0, np.abs(ref).max()), name
+
+
+def _f_setup(z):
+    from keypoints_amd.models import transporter
+    from oracle import kp_oracle as O
+    plans = O.transporter_plans('F', 3, 64, 10)
+    P, Bf = O.init_params(plans, seed=int(z['seed_params']))
+    chk = float(sum(v.double().abs().sum().item() for v in P.values()))
+    assert abs(chk - float(z['checksum'])) < 1e-6 * chk, 'seeded weights differ from the golden run'
+    net = transporter.make('F', 3, 64, 10)
+    net.load_state_dict({**P, **Bf}, strict=True)
+    g = torch.Generator().manual_seed(int(z['seed_inputs']))
+    xs = torch.rand(2, 3, 128, 128, generator=g)
+    xt = torch.rand(2, 3, 128, 128, generator=g)
+    return plans, P, Bf, net, xs, xt
+
+
+def _grad_errors(net, z, noise):
+    """per tensor: (sampled-entry rel-L2 error, norm error) against the reference run in fp64."""
+    rows = {}
+    for n, prm in net.named_parameters():
+        if n in noise:
+            continue
+        ref = z['g64val.' + n]
+        idx = torch.tensor(z['gidx.' + n]).to(prm.device)
+        got = t2n(prm.grad.flatten()[idx])
+        rows[n] = (np.linalg.norm(got - ref) / max(1e-30, np.linalg.norm(ref)),
+                   abs(float(prm.grad.norm()) - float(z['g64norm.' + n])) / float(z['g64norm.' + n]))
+    return rows
+
+
+def test_transporter_F_128_golden_fp32(golden):
+    """Transporter F 128x128x3 K=10 B=2 (the north-star architecture), strict fp32 mode.  Weights are
+    re-generated from the recorded seed (checksum-guarded); outputs / loss come from the reference in fp32,
+    gradients are judged against the reference run in fp64 with the reference's own fp32 error
+    (gnoise.*, about 5e-3 rel-L2 on this input) as the yardstick."""
+    import keypoints_amd as ka
+    z = golden('transporter_F_128.npz')
+    plans, P, Bf, net, xs, xt = _f_setup(z)
+    net = net.cuda().set_precision('fp32')
+    x_t, phi, k, m, (p, q), heat, mask_s, mask_t = net(xs.cuda(), xt.cuda())
+    loss = ka.l2_reconstruction_loss(x_t, xt.cuda())
+    loss.backward()
+    scale = np.abs(z['x_t']).max()
+    assert maxerr(x_t, z['x_t']) <= 1.5e-4 * scale
+    assert maxerr(k, z['k']) <= 2e-5
+    assert maxerr(m, z['m']) <= 2.5e-4
+    assert maxerr(heat, z['heatmap']) <= 1.5e-4 * np.abs(z['heatmap']).max()
+    assert abs(loss.item() - float(z['loss'])) <= 1e-5 * float(z['loss'])
+    noise = pre_bn_bias_names(net)
+    for n, prm in net.named_parameters():
+        if n in noise:
+            assert float(prm.grad.abs().max()) == 0.0
+    for n, (e_s, e_n) in _grad_errors(net, z, noise).items():
+        tol = max(3e-3, 8 * float(z['gnoise.' + n]))   # 64 sampled entries: a noisy estimator
+        assert e_s <= tol and e_n <= tol, (n, e_s, e_n, tol)
+    sd = net.state_dict()
+    for key in z.files:
+        if key.startswith('buf.'):
+            assert maxerr(sd[key[4:]], z[key]) <= 1e-5 * max(1.0, np.abs(z[key]).max()), key
+
+
+def test_transporter_F_128_bf16_tracks_emulation(golden):
+    """bf16 storage on this 25-layer BN net at B=2 / random init is chaotic: a torch emulation of bf16
+    storage of the *reference* (oracle quant=bf16_storage) already sits 2e-1 rel-L2 from the fp32 reference.
+    The HIP bf16 path must be no worse than that emulation: same distance to the fp32 reference (x_t,
+    keypoints, loss) and the same gradient error against the fp64 reference, within 25 %."""
+    import keypoints_amd as ka
+    from oracle import kp_oracle as O
+    z = golden('transporter_F_128.npz')
+    plans, P, Bf, net, xs, xt = _f_setup(z)
+    net = net.cuda().set_precision('bf16')
+    out = net(xs.cuda(), xt.cuda())
+    loss = ka.l2_reconstruction_loss(out[0], xt.cuda())
+    loss.backward()
+    oP = {k: v.clone() for k, v in P.items()}
+    oB = {k: v.clone() for k, v in Bf.items()}
+    eloss, eout, eG = O.transporter_train_step(plans, oP, oB, {}, xs, xt, quant=O.bf16_storage)
+    ref = z['x_t']
+    hip_e, emu_e = rel_l2(out[0], ref), rel_l2(eout[0], ref)
+    assert hip_e <= 1.25 * emu_e + 1e-3, (hip_e, emu_e)
+    assert maxerr(out[2], z['k']) <= 1.5 * maxerr(eout[2], z['k']) + 2e-3
+    assert abs(loss.item() - float(z['loss'])) <= 1.5 * abs(eloss.item() - float(z['loss'])) + 1e-2 * float(z['loss'])
+    noise = pre_bn_bias_names(net)
+    hip_rows = _grad_errors(net, z, noise)
+    ratios = []
+    for n, (e_s, _) in hip_rows.items():
+        idx = torch.tensor(z['gidx.' + n])
+        emu = np.linalg.norm(t2n(eG[n].flatten()[idx]) - z['g64val.' + n]) / np.linalg.norm(z['g64val.' + n])
+        ratios.append(e_s / max(emu, 1e-3))
+    assert np.median(ratios) <= 1.25 and np.percentile(ratios, 90) <= 2.0, (np.median(ratios), max(ratios))
+
+
+def test_keynet_F_128_golden(golden):
+    """KeyNet F 128x128x3 K=10 B=2 with a loss mask (BASELINE config 3 architecture)."""
+    import types
+    import keypoints_amd as ka
+    from keypoints_amd.models import keynet
+    from oracle import kp_oracle as O
+    z = golden('keynet_F_128.npz')
+    plans = O.keynet_plans('F', 3, 64, 10)
+    P, Bf = O.init_params(plans, seed=int(z['seed_params']))
+    net = keynet.make(types.SimpleNamespace(model_type='F', model_in_channels=3, model_z_channels=64,
+                                            model_keypoints=10, load=None, transfer_load=None))
+    net.load_state_dict({**P, **Bf}, strict=True)
+    net = net.cuda()
+    g = torch.Generator().manual_seed(int(z['seed_inputs']))
+    x = torch.rand(2, 3, 128, 128, generator=g).cuda()
+    x_ = torch.rand(2, 3, 128, 128, generator=g).cuda()
+    mask = (torch.rand(2, 3, 128, 128, generator=g) > 0.1).float().cuda()
+    x_t, zz, k, m, p, heat = net(x, x_)
+    loss = ka.l2_reconstruction_loss(x_t, x_, mask)
+    loss.backward()
+    assert maxerr(x_t, z['x_t']) <= 1.5e-4 * np.abs(z['x_t']).max()
+    assert maxerr(k, z['k']) <= 2e-5 and maxerr(m, z['m']) <= 2.5e-4
+    assert maxerr(zz, z['z']) <= 1.5e-4 * np.abs(z['z']).max()
+    assert abs(loss.item() - float(z['loss'])) <= 1e-5 * float(z['loss'])
+    noise = pre_bn_bias_names(net)
+    for n, (e_s, e_n) in _grad_errors(net, z, noise).items():
+        tol = max(3e-3, 8 * float(z['gnoise.' + n]))   # 64 sampled entries: a noisy estimator
+        assert e_s <= tol and e_n <= tol, (n, e_s, e_n, tol)
+
+
+def test_train_steps_vs_oracle_bf16_pong():
+    """BASELINE config 2 shape (Pong-grey 84x84 K=4, bf16) on a small batch: 3 train steps track the
+    fp32 oracle within mixed-precision error, and the loss decreases identically in sign."""
+    import keypoints_amd as ka
+    from keypoints_amd.models import transporter
+    from oracle import kp_oracle as O
+    torch.manual_seed(3)
+    net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 4)
+    P = {k: v.detach().clone() for k, v in net.named_parameters()}
+    Bf = {k: v.detach().clone() for k, v in net.named_buffers()}
+    net = net.cuda().set_precision('bf16')
+    opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
+    plans = O.transporter_plans('VGG_PONG_LAYERNECK', 1, 16, 4)
+    g = torch.Generator().manual_seed(9)
+    xs = torch.rand(8, 1, 84, 84, generator=g) * 2 - 1
+    xt = torch.rand(8, 1, 84, 84, generator=g) * 2 - 1
+    state = {}
+    for step in range(3):
+        opt.zero_grad()
+        out = net(xs.cuda(), xt.cuda())
+        loss = ka.l2_reconstruction_loss(out[0], xt.cuda())
+        loss.backward()
+        opt.step()
+        oloss, oout, _ = O.transporter_train_step(plans, P, Bf, state, xs, xt)
+        assert abs(loss.item() - oloss.item()) <= 3e-2 * abs(oloss.item())
+        assert maxerr(out[2], oout[2]) <= 5e-3
+        assert maxerr(out[0], oout[0]) <= 3e-2 * float(oout[0].abs().max())
+
+
+def test_full_size_batch_properties():
+    """BASELINE batch sizes (C4: 128 pairs/GPU at 128x128) are beyond what the oracle finishes in
+    seconds, so check size-independent properties: per-sample independence of everything except
+    BatchNorm statistics (eval-mode BN => sample b's outputs do not depend on the rest of the batch),
+    and determinism of the forward pass."""
+    from keypoints_amd.models import transporter
+    torch.manual_seed(0)
+    net = transporter.make('F', 3, 64, 10).cuda().set_precision('bf16')
+    net.eval()
+    g = torch.Generator().manual_seed(5)
+    xs = torch.rand(32, 3, 128, 128, generator=g).cuda()
+    xt = torch.rand(32, 3, 128, 128, generator=g).cuda()
+    with torch.no_grad():
+        full = net(xs, xt)
+        again = net(xs, xt)
+        part = net(xs[8:12], xt[8:12])
+    assert torch.equal(full[0], again[0]) and torch.equal(full[2], again[2])
+    assert torch.equal(full[0][8:12], part[0]) and torch.equal(full[2][8:12], part[2])
+    assert full[2].min() >= 0 and full[2].max() <= 1
