@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark: image-pairs/sec of one full Transporter train step (forward, L2 loss, backward,
+gradient all-reduce, Adam) on synthetic 128x128x3 batches, model F, K=10 (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; weak scaling (the per-GPU batch is fixed at --batch, default 128 = BASELINE config
+"batch 1024 over 8 GPUs").  Rank 0 prints ONE JSON line.  Inputs are resident in HBM before the timed
+region.  `roofline` is measured live with HIP events recorded around the convolution kernels on their
+launch stream (kp_prof_*), `cpu_baseline` times the CPU oracle (oracle/kp_oracle.py, a port of the
+reference's PyTorch CPU path) on a bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3     # fp32 vector / f32-MFMA peak
+FAMILIES = {0: 'conv_valid_generic', 1: 'conv_wgrad_generic', 2: 'conv_mfma_bf16', 3: 'wgrad_mfma_bf16'}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=128, help='image pairs per GPU')
+    ap.add_argument('--size', type=int, default=128)
+    ap.add_argument('--model_type', default='F')
+    ap.add_argument('--model_in_channels', type=int, default=3)
+    ap.add_argument('--model_z_channels', type=int, default=64)
+    ap.add_argument('--model_keypoints', type=int, default=10)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Oracle (CPU port of the reference path) train steps on the host cores: bounded sample."""
+    from oracle import kp_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    plans = O.transporter_plans(args.model_type, args.model_in_channels, args.model_z_channels, args.model_keypoints)
+    P, Bf = O.init_params(plans, seed=0)
+    g = torch.Generator().manual_seed(1234)
+    B = args.cpu_batch
+    xs = torch.rand(B, args.model_in_channels, args.size, args.size, generator=g)
+    xt = torch.rand(B, args.model_in_channels, args.size, args.size, generator=g)
+    state = {}
+    O.transporter_train_step(plans, P, Bf, state, xs, xt)          # warm-up
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        O.transporter_train_step(plans, P, Bf, state, xs, xt)
+    dt = (time.perf_counter() - t0) / args.cpu_steps
+    return dict(value=B / dt, unit='image-pairs/sec', cores=cores, kind='port',
+                sample=f'oracle/kp_oracle.py transporter_train_step fp32, batch {B}, 1 warm-up + {args.cpu_steps} '
+                       f'timed steps, torch CPU {torch.get_num_threads()} threads')
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU fallback)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import keypoints_amd as ka
+    from keypoints_amd import _lib
+    from keypoints_amd.dist import GradReducer
+    from keypoints_amd.models import transporter
+    from oracle import kp_oracle as O   # flop accounting only (conv MACs x 2)
+
+    torch.manual_seed(0)
+    net = transporter.make(args.model_type, args.model_in_channels, args.model_z_channels, args.model_keypoints)
+    net = net.to(dev).set_precision(args.precision)
+    opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
+    reducer = GradReducer(net) if world > 1 else None
+
+    g = torch.Generator().manual_seed(1234 + rank)
+    B = args.batch
+    xs = torch.rand(B, args.model_in_channels, args.size, args.size, generator=g).to(dev)
+    xt = torch.rand(B, args.model_in_channels, args.size, args.size, generator=g).to(dev)
+
+    def step():
+        opt.zero_grad()
+        out = net(xs, xt)
+        loss = ka.l2_reconstruction_loss(out[0], xt)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    _lib.call('kp_prof_enable', 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel-family timing from the HIP events recorded inside the timed region
+    fam = {}
+    for fid, name in FAMILIES.items():
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+        _lib.call('kp_prof_collect', fid, ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(n))
+        if n.value:
+            fam[name] = dict(ms_total=ms.value, launches=n.value, avg_us=1e3 * ms.value / n.value,
+                             tflops=fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0)
+    _lib.call('kp_prof_enable', 0)
+
+    if rank == 0:
+        plans = O.transporter_plans(args.model_type, args.model_in_channels, args.model_z_channels,
+                                    args.model_keypoints)
+        flop_pair = O.conv_flops_per_pair(plans, args.size, args.size)
+        ms_step = 1e3 * elapsed / args.steps
+        value = B * world / (elapsed / args.steps)
+        dom = max(fam.items(), key=lambda kv: kv[1]['ms_total']) if fam else (None, None)
+        peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
+        roofline = dict(bound='mfma', kernel=dom[0], achieved=dom[1]['tflops'] if dom[1] else None, peak=peak,
+                        unit='TFLOP/s', frac=(dom[1]['tflops'] / peak) if dom[1] else None, traffic=None,
+                        avg_launch_us=dom[1]['avg_us'] if dom[1] else None,
+                        launches=dom[1]['launches'] if dom[1] else None,
+                        step_tflops=value / world * flop_pair / 1e12, step_frac=value / world * flop_pair / 1e12 / peak,
+                        kernels=fam)
+        line = dict(metric='image-pairs/sec (train step) Transporter 128x128 K=10', value=value,
+                    unit='image-pairs/sec', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_step,
+                    higher_is_better=True, scaling='weak', vs_baseline=None,
+                    dtype=args.precision if args.precision == 'bf16' else 'f32', data='synthetic',
+                    config=dict(workload=f'Transporter {args.model_type} {args.size}x{args.size}x'
+                                         f'{args.model_in_channels} K={args.model_keypoints}, '
+                                         f'{B} pairs/GPU (BASELINE config 4 shape), fwd+loss+bwd+Adam',
+                                global_batch=B * world, per_gpu_batch=B, parallelism=f'dp{world}',
+                                gflop_per_pair=flop_pair / 1e9, loss=float(loss.item())),
+                    roofline=roofline)
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

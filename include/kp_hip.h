@@ -45,6 +45,18 @@ const char* kp_last_error(void);
 /* number of CUs of the current device (for grid sizing by host code) */
 int kp_device_cus(void);
 
+/* ---- measurement (bench.py roofline leg; not used by the model code) ------- */
+#define KP_PROF_CONV_GENERIC 0   /* fp32-accumulate VALU implicit-GEMM conv (fwd + dgrad) */
+#define KP_PROF_WGRAD_GENERIC 1
+#define KP_PROF_CONV_MFMA 2      /* bf16 MFMA implicit-GEMM conv (fwd + dgrad) */
+#define KP_PROF_WGRAD_MFMA 3
+/* Start (on=1, resets) / stop (on=0) recording a HIP-event pair around every convolution launch,
+ * on the launch stream. */
+int kp_prof_enable(int on);
+/* Synchronise the recorded events of one kernel family and return summed time (ms), algorithmic
+ * FLOPs and launch count since kp_prof_enable(1).  Host-synchronising. */
+int kp_prof_collect(int family, double* ms, double* flops, long long* launches);
+
 /* ---- layout ------------------------------------------------------------ */
 /* NCHW fp32 -> NHWC T with a replicated border of `pad` pixels.
  * Replaces nn.ReplicationPad2d(1) in front of the first conv of a Unit
@@ -68,9 +80,11 @@ int kp_wgrad_unpack(const float* scratch, float* dw, int K, int C, int R, void* 
  * x: [N][Hi][Wi][C] T, w: [K][R][R][C] T, y: [N][Hi-R+1][Wi-R+1][K] T.
  * Forward of nn.Conv2d(k=3) after ReplicationPad2d (vgg.py:30-33, knn.py:115);
  * with x = zero-padded dy and w = the flipped/transposed pack it is the
- * data-gradient of the same layer.  If stats != NULL, stats[0..K) += sum_m y,
- * stats[K..2K) += sum_m y^2 (fp64; BatchNorm batch statistics, vgg.py:35). */
-int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, double* stats,
+ * data-gradient of the same layer.  If stats != NULL it receives the BatchNorm batch statistics
+ * (vgg.py:35) as deterministic partial sums: one row per 64 output pixels,
+ *   stats[row][0][k] = sum_{m in row} y[m][k],  stats[row][1][k] = sum y^2   (fp32, no atomics),
+ * rows = ceil(N*Ho*Wo / 64); kp_bn_finalize reduces the rows in fp64. */
+int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, float* stats,
                 int N, int Hi, int Wi, int C, int K, int R, int dtype, void* stream);
 /* Weight gradient: scratch[k][r][s][c] += sum_{n,p,q} dy[n][p][q][k] * x[n][p+r][q+s][c]
  * x: [N][Ho+R-1][Wo+R-1][C] T; dy: interior of [N][Ho+2*dy_pad][Wo+2*dy_pad][K] T;
@@ -79,9 +93,10 @@ int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, 
                   int dy_pad, int dtype, void* stream);
 
 /* ---- BatchNorm(train) + activation (+ pool / upsample) ----------------- */
-/* stats (from kp_conv_fwd) -> batch mean / 1/sqrt(var+eps); updates running
- * stats with momentum (unbiased var) like nn.BatchNorm2d in train mode. */
-int kp_bn_finalize(const double* stats, float* save_mean, float* save_invstd, float* running_mean,
+/* stats rows (from kp_conv_fwd) -> batch mean / 1/sqrt(var+eps); updates running
+ * stats with momentum (unbiased var) like nn.BatchNorm2d in train mode.  count = N*H*W;
+ * rows = ceil(count/64).  One workgroup per 8 channels, fp64 accumulation. */
+int kp_bn_finalize(const float* stats, float* save_mean, float* save_invstd, float* running_mean,
                    float* running_var, long long* num_batches_tracked, float momentum, float eps, long long count,
                    int C, void* stream);
 /* out = tail(act((y - mean) * invstd * gamma + beta)); act = LeakyReLU(slope) (slope 0 = ReLU).

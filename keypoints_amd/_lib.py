@@ -41,6 +41,8 @@ SIGNATURES = {
     'kp_transport_max_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'kp_l2_loss': [_p, _p, _p, _p, _p, _f, _z, _p],
     'kp_adam_step': [_p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _f, _p],
+    'kp_prof_enable': [_i],
+    'kp_prof_collect': [_i, _p, _p, _p],
 }
 PLAIN = {'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
 

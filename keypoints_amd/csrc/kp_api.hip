@@ -4,10 +4,10 @@
 #include <string.h>
 #include "kp_common.h"
 
-int kp_conv_fwd_generic(const void*, const void*, const float*, void*, double*, int, int, int, int, int, int, int,
+int kp_conv_fwd_generic(const void*, const void*, const float*, void*, float*, int, int, int, int, int, int, int,
                         hipStream_t);
 int kp_conv_wgrad_generic(const void*, const void*, float*, int, int, int, int, int, int, int, int, hipStream_t);
-int kp_conv_fwd_mfma(const void*, const void*, const float*, void*, double*, int, int, int, int, int, int,
+int kp_conv_fwd_mfma(const void*, const void*, const float*, void*, float*, int, int, int, int, int, int,
                      hipStream_t);   // bf16 only; returns KP_E_UNSUPPORTED when the shape is not eligible
 int kp_conv_wgrad_mfma(const void*, const void*, float*, int, int, int, int, int, int, int, hipStream_t);
 
@@ -28,6 +28,34 @@ int kp_check_launch(const char* what) {
     }
     return KP_OK;
 }
+
+// ---- in-library kernel timing (bench.py's roofline leg) -------------------------------------------
+// HIP events are recorded on the launch stream right around the convolution kernels; kp_prof_collect()
+// synchronises them after the timed region and sums time and algorithmic FLOPs per kernel family.
+#include <vector>
+struct ProfRec { int family; double flops; hipEvent_t e0, e1; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_event_pool;
+
+static hipEvent_t prof_event() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
+struct ProfScope {
+    bool on; ProfRec r; hipStream_t st;
+    ProfScope(int family, double flops, hipStream_t s) : on(g_prof_on), st(s) {
+        if (!on) return;
+        r.family = family; r.flops = flops; r.e0 = prof_event(); r.e1 = prof_event();
+        hipEventRecord(r.e0, st);
+    }
+    void done(int family) {
+        if (!on) return;
+        r.family = family;
+        hipEventRecord(r.e1, st);
+        g_prof.push_back(r);
+    }
+};
 
 static int use_mfma() {
     static int v = -1;
@@ -50,16 +78,42 @@ int kp_device_cus(void) {
     return n;
 }
 
-int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, double* stats, int N, int Hi, int Wi, int C,
+int kp_prof_enable(int on) {
+    for (auto& r : g_prof) { g_event_pool.push_back(r.e0); g_event_pool.push_back(r.e1); }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return KP_OK;
+}
+
+int kp_prof_collect(int family, double* ms, double* flops, long long* launches) {
+    double t = 0.0, f = 0.0; long long n = 0;
+    for (auto& r : g_prof) {
+        if (r.family != family) continue;
+        if (hipEventSynchronize(r.e1) != hipSuccess) { kp_set_error("kp_prof_collect: event sync failed"); return KP_E_LAUNCH; }
+        float dt = 0.f;
+        hipEventElapsedTime(&dt, r.e0, r.e1);
+        t += dt; f += r.flops; ++n;
+    }
+    if (ms) *ms = t;
+    if (flops) *flops = f;
+    if (launches) *launches = n;
+    return KP_OK;
+}
+
+int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C,
                 int K, int R, int dtype, void* stream) {
     KP_REQUIRE(x && w && y, "kp_conv_fwd: null pointer");
     KP_REQUIRE(N > 0 && C > 0 && K > 0 && (R == 1 || R == 3) && Hi >= R && Wi >= R, "kp_conv_fwd: bad dims N=%d Hi=%d Wi=%d C=%d K=%d R=%d", N, Hi, Wi, C, K, R);
     KP_REQUIRE(dtype == KP_F32 || dtype == KP_BF16, "kp_conv_fwd: bad dtype %d", dtype);
+    const double flops = 2.0 * N * (double)(Hi - R + 1) * (Wi - R + 1) * C * K * R * R;
+    ProfScope ps(KP_PROF_CONV_GENERIC, flops, (hipStream_t)stream);
     if (dtype == KP_BF16 && use_mfma()) {
         int rc = kp_conv_fwd_mfma(x, w, bias, y, stats, N, Hi, Wi, C, K, R, (hipStream_t)stream);
-        if (rc != KP_E_UNSUPPORTED) return rc;
+        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_MFMA); return rc; }
     }
-    return kp_conv_fwd_generic(x, w, bias, y, stats, N, Hi, Wi, C, K, R, dtype, (hipStream_t)stream);
+    int rc = kp_conv_fwd_generic(x, w, bias, y, stats, N, Hi, Wi, C, K, R, dtype, (hipStream_t)stream);
+    ps.done(KP_PROF_CONV_GENERIC);
+    return rc;
 }
 
 int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R, int dy_pad,
@@ -67,11 +121,15 @@ int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, 
     KP_REQUIRE(x && dy && scratch, "kp_conv_wgrad: null pointer");
     KP_REQUIRE(N > 0 && C > 0 && K > 0 && (R == 1 || R == 3) && Ho > 0 && Wo > 0 && dy_pad >= 0, "kp_conv_wgrad: bad dims");
     KP_REQUIRE(dtype == KP_F32 || dtype == KP_BF16, "kp_conv_wgrad: bad dtype %d", dtype);
+    const double flops = 2.0 * N * (double)Ho * Wo * C * K * R * R;
+    ProfScope ps(KP_PROF_WGRAD_GENERIC, flops, (hipStream_t)stream);
     if (dtype == KP_BF16 && use_mfma()) {
         int rc = kp_conv_wgrad_mfma(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, (hipStream_t)stream);
-        if (rc != KP_E_UNSUPPORTED) return rc;
+        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_WGRAD_MFMA); return rc; }
     }
-    return kp_conv_wgrad_generic(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, dtype, (hipStream_t)stream);
+    int rc = kp_conv_wgrad_generic(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, dtype, (hipStream_t)stream);
+    ps.done(KP_PROF_WGRAD_GENERIC);
+    return rc;
 }
 
 }  // extern "C"

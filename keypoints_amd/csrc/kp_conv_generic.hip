@@ -15,7 +15,7 @@ constexpr int BM = 64, BN = 64, BK = 16, TPB = 256;
 template <typename T, int R>
 __global__ __launch_bounds__(TPB) void conv_valid_generic(const T* __restrict__ x, const T* __restrict__ w,
                                                           const float* __restrict__ bias, T* __restrict__ y,
-                                                          double* __restrict__ stats, int N, int Hi, int Wi, int C,
+                                                          float* __restrict__ partials, int N, int Hi, int Wi, int C,
                                                           int K) {
     const int Ho = Hi - R + 1, Wo = Wi - R + 1;
     const long long M = (long long)N * Ho * Wo;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(TPB) void conv_valid_generic(const T* __restrict__ 
             csq[j] += v * v;
         }
     }
-    if (stats) {
+    if (partials) {   // one row of per-channel (sum, sumsq) per 64-pixel tile: deterministic, no atomics
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             red[0][ty][tx * 4 + j] = csum[j];
@@ -105,11 +105,11 @@ __global__ __launch_bounds__(TPB) void conv_valid_generic(const T* __restrict__ 
         __syncthreads();
         if (tid < 2 * BN) {
             const int which = tid / BN, col = tid % BN;
-            double s = 0.0;
+            float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s += (double)red[which][i][col];
+            for (int i = 0; i < 16; ++i) s += red[which][i][col];
             const int k = k0 + col;
-            if (k < K) atomicAdd(stats + which * K + k, s);
+            if (k < K) partials[((long long)blockIdx.x * 2 + which) * K + k] = s;
         }
     }
 }
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(TPB) void conv_wgrad_generic(const T* __restrict__ 
 }
 
 template <typename T>
-int launch_fwd(const void* x, const void* w, const float* bias, void* y, double* stats, int N, int Hi, int Wi, int C,
+int launch_fwd(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C,
                int K, int R, hipStream_t st) {
     const long long M = (long long)N * (Hi - R + 1) * (Wi - R + 1);
     dim3 grid(cdiv(M, BM), cdiv(K, BN));
@@ -224,7 +224,7 @@ int launch_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, i
 
 }  // namespace
 
-int kp_conv_fwd_generic(const void* x, const void* w, const float* bias, void* y, double* stats, int N, int Hi, int Wi,
+int kp_conv_fwd_generic(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi,
                         int C, int K, int R, int dtype, hipStream_t st) {
     return dtype == KP_F32 ? launch_fwd<float>(x, w, bias, y, stats, N, Hi, Wi, C, K, R, st)
                            : launch_fwd<bf16_t>(x, w, bias, y, stats, N, Hi, Wi, C, K, R, st);

@@ -1,11 +1,245 @@
-// bf16 MFMA implicit-GEMM convolution kernels (gfx950).  Placeholder until the tiled kernels land:
-// every shape is reported unsupported so kp_conv_* falls through to the generic kernels.
+// bf16 MFMA implicit-GEMM convolution for gfx950 (CDNA4): forward / data-gradient ("valid" 3x3
+// correlation over a physically padded NHWC image) and weight-gradient.
+//
+// Forward / dgrad GEMM view:   Y[m][k] = sum_{tap,c} X[pix(m)+tap][c] * W[k][tap][c]
+//   M = N*Ho*Wo pixels, N = K output channels, reduction = 9*C.
+// Workgroup tile 128 pixels x BN channels (BN = 128 or 64), reduction step BK = 64 channels of one tap,
+// 4 wavefronts in a 2x2 layout (wave tile 64 pixels x BN/2 channels), v_mfma_f32_32x32x16_bf16.
+// Operands are swapped (MFMA "A" = weights, "B" = pixels) so that a lane's accumulator registers hold
+// 4 *consecutive output channels* of one pixel -> 8-byte packed bf16 stores into the NHWC output.
+// Both tiles go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double buffered.
+// LDS rows are 128 B (64 bf16); the 16-B slot index is XOR-swizzled with (row>>1)&7, applied on the
+// per-lane *source* address (the LDS-DMA destination is lane-linear) and on the ds_read_b128 address,
+// which makes every ds_read_b128 lane group hit 16 distinct 16-B bank slots (conflict-free).
 #include "kp_common.h"
 
-int kp_conv_fwd_mfma(const void*, const void*, const float*, void*, double*, int, int, int, int, int, int,
-                     hipStream_t) {
-    return KP_E_UNSUPPORTED;
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int BM = 128, BK = 64, TPB = 256;
+constexpr int ROWB = BK * 2;   // bytes per LDS row
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    // 16 B per lane: LDS destination = wave-uniform base + lane*16
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_wave_base, 16, 0, 0);
 }
+
+__device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
+
+// halving butterfly: 16 per-lane values -> each lane ends with the sum over its 32-lane half of ONE value.
+// Returns that sum; `reg` receives which of the 16 inputs it belongs to.
+__device__ __forceinline__ float reduce16_over32(float (&v)[16], int lane, int& reg) {
+    float a[8];
+    const bool b4 = lane & 16;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float keep = b4 ? v[i + 8] : v[i], send = b4 ? v[i] : v[i + 8];
+        a[i] = keep + __shfl_xor(send, 16, 64);
+    }
+    float b[4];
+    const bool b3 = lane & 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b3 ? a[i + 4] : a[i], send = b3 ? a[i] : a[i + 4];
+        b[i] = keep + __shfl_xor(send, 8, 64);
+    }
+    float c[2];
+    const bool b2 = lane & 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b2 ? b[i + 2] : b[i], send = b2 ? b[i] : b[i + 2];
+        c[i] = keep + __shfl_xor(send, 4, 64);
+    }
+    const bool b1 = lane & 2;
+    float d = (b1 ? c[1] : c[0]) + __shfl_xor(b1 ? c[0] : c[1], 2, 64);
+    d += __shfl_xor(d, 1, 64);
+    reg = (b4 ? 8 : 0) | (b3 ? 4 : 0) | (b2 ? 2 : 0) | (b1 ? 1 : 0);
+    return d;
+}
+
+template <int BN>
+__global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                         const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                         float* __restrict__ partials, int N, int Hi, int Wi, int C,
+                                                         int K, int mtiles, int ktiles) {
+    constexpr int WN = BN / 2;            // channels per wave
+    constexpr int TN = WN / 32;           // 32-channel MFMA tiles per wave (2 or 1)
+    constexpr int XBYTES = BM * ROWB, WBYTES = BN * ROWB, STAGE = XBYTES + WBYTES;
+    constexpr int XI = BM / 32, WI = BN / 32;   // glds instructions per wave per stage
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int Ho = Hi - 2, Wo = Wi - 2;
+    const long long M = (long long)N * Ho * Wo;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile order: the dispatcher round-robins workgroups over the 8 XCDs; give each XCD a
+    // contiguous run of (m-tile, k-tile) pairs with the k-tile fastest so the X rows stay in its L2.
+    const int nwg = gridDim.x;
+    int tile;
+    {
+        const int b = blockIdx.x, q = nwg / 8, r = nwg % 8, xcd = b % 8, i = b / 8;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int mt = tile / ktiles, kt = tile % ktiles;
+    const long long m0 = (long long)mt * BM;
+    const int k0 = kt * BN;
+
+    // ---- loader state: per instruction j the lane's global row pointer (swizzled slot folded in)
+    const int lrow8 = lane >> 3, lslot = lane & 7;
+    const unsigned char* xsrc[XI];
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+        const int row = (j * 4 + wave) * 8 + lrow8;
+        long long m = m0 + row;
+        if (m >= M) m = M - 1;   // tail rows: load something valid, masked at the store
+        const int q = (int)(m % Wo);
+        const long long t = m / Wo;
+        const int p = (int)(t % Ho);
+        const long long n = t / Ho;
+        xsrc[j] = (const unsigned char*)x + (((n * Hi + p) * Wi + q) * (long long)C + swz(row, lslot) * 8) * 2;
+    }
+    const unsigned char* wsrc[WI];
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+        const int row = (j * 4 + wave) * 8 + lrow8;
+        wsrc[j] = (const unsigned char*)w + (((long long)(k0 + row) * 9) * C + swz(row, lslot) * 8) * 2;
+    }
+
+    auto stage = [&](int buf, int tap, int c0) {
+        unsigned char* sx = smem + buf * STAGE;
+        unsigned char* sw = sx + XBYTES;
+        const long long xo = (((long long)(tap / 3) * Wi + (tap % 3)) * C + c0) * 2;
+        const long long wo = ((long long)tap * C + c0) * 2;
+#pragma unroll
+        for (int j = 0; j < XI; ++j) glds16(xsrc[j] + xo, sx + (j * 4 + wave) * 8 * ROWB);
+#pragma unroll
+        for (int j = 0; j < WI; ++j) glds16(wsrc[j] + wo, sw + (j * 4 + wave) * 8 * ROWB);
+    };
+
+    f32x16 acc[TN][2];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    // fragment read offsets (bytes within a stage buffer), one per 32-row tile; kk adds 2 slots
+    const int fr = lane & 31, fh = lane >> 5;
+    int xoff[2], woff[TN];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) xoff[b] = (wm * 64 + b * 32 + fr) * ROWB;
+#pragma unroll
+    for (int a = 0; a < TN; ++a) woff[a] = XBYTES + (wn * WN + a * 32 + fr) * ROWB;
+    const int xsw[2] = {((wm * 64 + fr) >> 1) & 7, ((wm * 64 + 32 + fr) >> 1) & 7};
+    int wsw[TN];
+#pragma unroll
+    for (int a = 0; a < TN; ++a) wsw[a] = ((wn * WN + a * 32 + fr) >> 1) & 7;
+
+    const int csteps = C / BK, T = 9 * csteps;
+    stage(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int tap = 0, cs = 0;
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        int ntap = tap, ncs = cs + 1;
+        if (ncs == csteps) { ncs = 0; ntap = tap + 1; }
+        if (t + 1 < T) stage(buf ^ 1, ntap, ncs * BK);
+        const unsigned char* sb = smem + buf * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 xf[2], wf[TN];
+            const int ls = kk * 2 + fh;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) xf[b] = *(const bf16x8*)(sb + xoff[b] + ((ls ^ xsw[b]) << 4));
+#pragma unroll
+            for (int a = 0; a < TN; ++a) wf[a] = *(const bf16x8*)(sb + woff[a] + ((ls ^ wsw[a]) << 4));
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        tap = ntap; cs = ncs;
+    }
+
+    // ---- epilogue: D[k_out][pixel]; lane: pixel = fr, k_out = 8*(reg>>2) + 4*fh + (reg&3)
+    const long long prow = m0 / 64 + wm;   // statistics row of this wave (64 pixels)
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+        const int kb = k0 + wn * WN + a * 32;
+        float s[16], sq[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = sq[i] = 0.f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const long long m = m0 + wm * 64 + b * 32 + fr;
+            const bool ok = m < M;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int kq = kb + 8 * g + 4 * fh;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[a][b][g * 4 + e] + (bias ? bias[kq + e] : 0.f);
+                    if (ok) { s[g * 4 + e] += v[e]; sq[g * 4 + e] += v[e] * v[e]; }
+                }
+                if (ok) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                    pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(y + m * K + kq) = pk;
+                }
+            }
+        }
+        if (partials && m0 + wm * 64 < M) {
+            int r1, r2;
+            const float ts = reduce16_over32(s, lane, r1);
+            const float tq = reduce16_over32(sq, lane, r2);
+            if ((lane & 1) == 0) {
+                const int k = kb + 8 * (r1 >> 2) + 4 * fh + (r1 & 3);
+                partials[(prow * 2 + 0) * K + k] = ts;
+                partials[(prow * 2 + 1) * K + k] = tq;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int kp_conv_fwd_mfma(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi,
+                     int C, int K, int R, hipStream_t st) {
+    if (R != 3 || C % BK != 0 || K % 64 != 0) return KP_E_UNSUPPORTED;
+    const long long M = (long long)N * (Hi - 2) * (Wi - 2);
+    const long long mtiles = (M + BM - 1) / BM;
+    // statistics rows are per 64 pixels: a half-empty last tile would leave the odd row unwritten
+    if (stats && (M % 64) != 0) return KP_E_UNSUPPORTED;
+    if (K % 128 == 0) {
+        const int ktiles = K / 128;
+        if (mtiles * ktiles > 0x7fffffffLL) return KP_E_UNSUPPORTED;
+        conv3x3_mfma_k<128><<<(unsigned)(mtiles * ktiles), TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias,
+                                                                       (bf16_t*)y, stats, N, Hi, Wi, C, K,
+                                                                       (int)mtiles, ktiles);
+    } else {
+        const int ktiles = K / 64;
+        if (mtiles * ktiles > 0x7fffffffLL) return KP_E_UNSUPPORTED;
+        conv3x3_mfma_k<64><<<(unsigned)(mtiles * ktiles), TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias,
+                                                                      (bf16_t*)y, stats, N, Hi, Wi, C, K,
+                                                                      (int)mtiles, ktiles);
+    }
+    return kp_check_launch("conv3x3_mfma");
+}
+
 int kp_conv_wgrad_mfma(const void*, const void*, float*, int, int, int, int, int, int, int, hipStream_t) {
     return KP_E_UNSUPPORTED;
 }

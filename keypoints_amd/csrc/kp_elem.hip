@@ -79,12 +79,29 @@ __global__ void wgrad_unpack_k(const float* __restrict__ scratch, float* __restr
 }
 
 // ---------------------------------------------------------------- BatchNorm
-__global__ void bn_finalize_k(const double* __restrict__ stats, float* __restrict__ mean, float* __restrict__ invstd,
-                              float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt,
-                              float momentum, float eps, long long count, int C) {
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const double mu = stats[c] / (double)count;
-        double var = stats[C + c] / (double)count - mu * mu;
+__global__ __launch_bounds__(TPB) void bn_finalize_k(const float* __restrict__ partials, float* __restrict__ mean,
+                                                     float* __restrict__ invstd, float* __restrict__ rmean,
+                                                     float* __restrict__ rvar, long long* __restrict__ nbt,
+                                                     float momentum, float eps, long long count, long long rows,
+                                                     int C) {
+    // block = 8 channels x 32 row-lanes; partials[row][2][C]
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (long long r = rl; r < rows; r += 32) {
+            s += (double)partials[(r * 2 + 0) * C + c];
+            q += (double)partials[(r * 2 + 1) * C + c];
+        }
+    __shared__ double red[2][32][8];
+    red[0][rl][cl] = s;
+    red[1][rl][cl] = q;
+    __syncthreads();
+    if (threadIdx.x < 8 && c < C) {
+        double ss = 0.0, qq = 0.0;
+        for (int i = 0; i < 32; ++i) { ss += red[0][i][cl]; qq += red[1][i][cl]; }
+        const double mu = ss / (double)count;
+        double var = qq / (double)count - mu * mu;
         if (var < 0.0) var = 0.0;
         mean[c] = (float)mu;
         invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -94,7 +111,7 @@ __global__ void bn_finalize_k(const double* __restrict__ stats, float* __restric
             rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
         }
     }
-    if (nbt && threadIdx.x == 0) *nbt += 1;
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
 }
 
 struct BnP {
@@ -564,11 +581,12 @@ int kp_wgrad_unpack(const float* scratch, float* dw, int K, int C, int R, void* 
     return kp_check_launch("wgrad_unpack");
 }
 
-int kp_bn_finalize(const double* stats, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+int kp_bn_finalize(const float* stats, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
                    long long* num_batches_tracked, float momentum, float eps, long long count, int C, void* stream) {
     KP_REQUIRE(C > 0 && count > 0, "kp_bn_finalize: bad dims");
-    bn_finalize_k<<<1, TPB, 0, (hipStream_t)stream>>>(stats, save_mean, save_invstd, running_mean, running_var,
-                                                      num_batches_tracked, momentum, eps, count, C);
+    bn_finalize_k<<<cdiv(C, 8), TPB, 0, (hipStream_t)stream>>>(stats, save_mean, save_invstd, running_mean, running_var,
+                                                               num_batches_tracked, momentum, eps, count,
+                                                               (count + 63) / 64, C);
     return kp_check_launch("bn_finalize");
 }
 

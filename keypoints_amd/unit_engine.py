@@ -133,7 +133,7 @@ class UnitFunction(torch.autograd.Function):
             call('kp_pack_weights', ptr(conv.weight), ptr(wf), ptr(wd), K, C, 3, code, st)
             y = torch.empty(N, H, W, K, device=dev, dtype=tdt)
             training = bn is not None and bn.training
-            stats = torch.zeros(2 * K, device=dev, dtype=torch.float64) if training else None
+            stats = torch.empty((N * H * W + 63) // 64, 2, K, device=dev, dtype=torch.float32) if training else None
             call('kp_conv_fwd', ptr(a), ptr(wf), ptr(conv.bias), ptr(y), ptr(stats), N, H + 2, W + 2, C, K, 3, code, st)
             mean = invstd = None
             if bn is not None:

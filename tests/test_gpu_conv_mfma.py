@@ -1,0 +1,53 @@
+"""bf16 MFMA implicit-GEMM convolution kernels vs a torch fp32 CPU convolution of the same bf16-rounded
+operands (tolerance: fp32 accumulation-order noise + one bf16 rounding of the output)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # N, Ho, Wo, C, K, with_stats
+    (2, 16, 16, 64, 64, True), (2, 8, 8, 128, 128, True), (1, 32, 32, 64, 256, True),
+    (1, 8, 24, 64, 128, True),          # M = 192: masked half tile
+    (3, 18, 18, 128, 64, False),        # dgrad-like: M % 64 != 0, no bias / stats
+    (1, 16, 16, 512, 512, True), (2, 130, 130, 64, 128, False),
+]
+
+
+@pytest.mark.parametrize('N,Ho,Wo,C,K,with_stats', SHAPES)
+def test_conv_fwd_mfma(N, Ho, Wo, C, K, with_stats):
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    g = torch.Generator().manual_seed(N * 1000 + C + K)
+    x = torch.randn(N, Ho + 2, Wo + 2, C, generator=g).bfloat16()
+    w = (torch.randn(K, 3, 3, C, generator=g) * (2.0 / (9 * C)) ** 0.5).bfloat16()
+    bias = torch.randn(K, generator=g) if with_stats else None
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias).permute(0, 2, 3, 1).contiguous()
+    xd, wd = x.cuda(), w.cuda()
+    bd = bias.cuda() if bias is not None else None
+    y = torch.full((N, Ho, Wo, K), float('nan'), device='cuda', dtype=torch.bfloat16)
+    rows = (N * Ho * Wo + 63) // 64
+    stats = torch.full((rows, 2, K), float('nan'), device='cuda') if with_stats else None
+    st = stream_ptr()
+    call('kp_prof_enable', 1)
+    call('kp_conv_fwd', ptr(xd), ptr(wd), ptr(bd), ptr(y), ptr(stats), N, Ho + 2, Wo + 2, C, K, 3, _lib.KP_BF16, st)
+    import ctypes
+    n = ctypes.c_longlong()
+    call('kp_prof_collect', 2, None, None, ctypes.addressof(n))
+    call('kp_prof_enable', 0)
+    assert n.value == 1, 'the MFMA kernel did not take this shape'
+    got = y.float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    assert err <= 1e-2 * ref.abs().max().item() + 1e-3, err
+    # tighter: compare with the bf16 rounding of the reference
+    close = (got - ref.bfloat16().float()).abs() <= 2 ** -7 * ref.abs() + 1e-3
+    assert close.float().mean().item() > 0.999
+    if with_stats:
+        s = stats.double().sum(0).cpu()
+        assert torch.isfinite(s).all()
+        flat = ref.double().reshape(-1, K)
+        assert (s[0] - flat.sum(0)).abs().max().item() <= 1e-3 * flat.abs().sum(0).max().item()
+        assert (s[1] - (flat ** 2).sum(0)).abs().max().item() <= 1e-3 * (flat ** 2).sum(0).max().item()

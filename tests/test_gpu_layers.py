@@ -64,7 +64,7 @@ def test_block_against_golden(golden, tag, cin, cout, tail, slope, precision, to
     wd = torch.empty(C, 3, 3, K, device=dev, dtype=tdt)
     call('kp_pack_weights', ptr(wt), ptr(wf), ptr(wd), K, C, 3, code, st)
     y = torch.empty(N, H, W, K, device=dev, dtype=tdt)
-    stats = torch.zeros(2 * K, device=dev, dtype=torch.float64)
+    stats = torch.empty((N * H * W + 63) // 64, 2, K, device=dev, dtype=torch.float32)
     call('kp_conv_fwd', ptr(a), ptr(wf), ptr(bias), ptr(y), ptr(stats), N, H + 2, W + 2, C, K, 3, code, st)
     mean = torch.empty(K, device=dev); invstd = torch.empty(K, device=dev)
     rm = torch.zeros(K, device=dev); rv = torch.ones(K, device=dev)
