@@ -43,15 +43,27 @@ def parse():
     ap.add_argument('--model_keypoints', type=int, default=10)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=8)
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-batch', type=int, default=16)
+    ap.add_argument('--cpu-steps', type=int, default=3)
     return ap.parse_args()
+
+
+def usable_cores() -> int:
+    """Host cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def cpu_baseline(args):
     """Oracle (CPU port of the reference path) train steps on the host cores: bounded sample."""
     from oracle import kp_oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     plans = O.transporter_plans(args.model_type, args.model_in_channels, args.model_z_channels, args.model_keypoints)
     P, Bf = O.init_params(plans, seed=0)

@@ -240,6 +240,3 @@ int kp_conv_fwd_mfma(const void* x, const void* w, const float* bias, void* y, f
     return kp_check_launch("conv3x3_mfma");
 }
 
-int kp_conv_wgrad_mfma(const void*, const void*, float*, int, int, int, int, int, int, int, hipStream_t) {
-    return KP_E_UNSUPPORTED;
-}

@@ -51,3 +51,40 @@ def test_conv_fwd_mfma(N, Ho, Wo, C, K, with_stats):
         flat = ref.double().reshape(-1, K)
         assert (s[0] - flat.sum(0)).abs().max().item() <= 1e-3 * flat.abs().sum(0).max().item()
         assert (s[1] - (flat ** 2).sum(0)).abs().max().item() <= 1e-3 * (flat ** 2).sum(0).max().item()
+
+
+WG_SHAPES = [  # N, Ho, Wo, C, K, dy_pad
+    (2, 16, 16, 64, 64, 2), (2, 8, 8, 128, 128, 2), (1, 32, 32, 64, 128, 0), (2, 16, 16, 128, 64, 2),
+    (4, 16, 16, 256, 512, 2), (1, 128, 128, 64, 128, 2),
+]
+
+
+@pytest.mark.parametrize('N,Ho,Wo,C,K,dp', WG_SHAPES)
+def test_conv_wgrad_mfma(N, Ho, Wo, C, K, dp):
+    import ctypes
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    g = torch.Generator().manual_seed(N * 77 + C + K)
+    x = torch.randn(N, Ho + 2, Wo + 2, C, generator=g).bfloat16()
+    dyi = torch.randn(N, Ho, Wo, K, generator=g).bfloat16()
+    dy = torch.zeros(N, Ho + 2 * dp, Wo + 2 * dp, K, dtype=torch.bfloat16)
+    dy[:, dp:dp + Ho, dp:dp + Wo] = dyi
+    # reference: dW[k][r][s][c] = sum dy[n,p,q,k] * x[n,p+r,q+s,c]
+    xf, df = x.double(), dyi.double()
+    ref = torch.zeros(K, 3, 3, C, dtype=torch.float64)
+    for r in range(3):
+        for s in range(3):
+            ref[:, r, s, :] = torch.einsum('npqk,npqc->kc', df, xf[:, r:r + Ho, s:s + Wo])
+    scratch = torch.zeros(K, 3, 3, C, device='cuda')
+    xd, dyd = x.cuda(), dy.cuda()   # keep alive: ptr() of a temporary would dangle
+    call('kp_prof_enable', 1)
+    call('kp_conv_wgrad', ptr(xd), ptr(dyd), ptr(scratch), N, Ho, Wo, C, K, 3, dp, _lib.KP_BF16, stream_ptr())
+    n = ctypes.c_longlong()
+    call('kp_prof_collect', 3, None, None, ctypes.addressof(n))
+    call('kp_prof_enable', 0)
+    assert n.value == 1, 'the MFMA wgrad kernel did not take this shape'
+    got = scratch.double().cpu()
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-5 * ref.abs().max().item() * (N * Ho * Wo) ** 0.5 + 1e-4, (err, ref.abs().max().item())
+    assert ((got - ref).norm() / ref.norm()).item() < 1e-5
