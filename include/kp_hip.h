@@ -93,10 +93,12 @@ int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, 
                   int dy_pad, int dtype, void* stream);
 
 /* ---- BatchNorm(train) + activation (+ pool / upsample) ----------------- */
-/* stats rows (from kp_conv_fwd) -> batch mean / 1/sqrt(var+eps); updates running
- * stats with momentum (unbiased var) like nn.BatchNorm2d in train mode.  count = N*H*W;
- * rows = ceil(count/64).  One workgroup per 8 channels, fp64 accumulation. */
-int kp_bn_finalize(const float* stats, float* save_mean, float* save_invstd, float* running_mean,
+/* fp64 workspace size (in doubles) needed by kp_bn_finalize / kp_bn_bwd_finalize for C channels. */
+int kp_bn_ws_doubles(int C);
+/* stats rows (from kp_conv_fwd) -> batch mean / 1/sqrt(var+eps); updates running stats with momentum
+ * (unbiased var) like nn.BatchNorm2d in train mode.  count = N*H*W; rows = ceil(count/64).
+ * Two-stage deterministic fp64 reduction through `ws` (kp_bn_ws_doubles(C) doubles). */
+int kp_bn_finalize(const float* stats, double* ws, float* save_mean, float* save_invstd, float* running_mean,
                    float* running_var, long long* num_batches_tracked, float momentum, float eps, long long count,
                    int C, void* stream);
 /* out = tail(act((y - mean) * invstd * gamma + beta)); act = LeakyReLU(slope) (slope 0 = ReLU).
@@ -107,19 +109,23 @@ int kp_bn_finalize(const float* stats, float* save_mean, float* save_invstd, flo
 int kp_bn_act_fwd(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                   float slope, int tail, void* out, int out_pad, unsigned char* argmax,
                   int N, int H, int W, int C, int dtype, void* stream);
-/* Backward, pass 1: sums[0..C) += sum g*act'(z), sums[C..2C) += sum g*act'(z)*xhat  (fp64, zeroed by caller).
+/* Backward, pass 1: per image row r = (n,h): partials[r][0][c] = sum_w g*act'(z), partials[r][1][c] =
+ * sum_w g*act'(z)*xhat  (fp32 [N*H][2][C], fully written, no atomics).
  * The incoming gradient g w.r.t. the activation output of this layer is read through `gsrc`:
  *   tail none    : gsrc = [N][H+2gp][W+2gp][C] T, gp in {0,1}; gp=1 folds the border (adjoint of replicate pad)
  *   tail maxpool2: gsrc = [N][H/2+2gp][W/2+2gp][C] T routed through argmax
  *   (upsample: run kp_upsample2_bwd first, then tail none / gp = 0). */
 int kp_bn_act_bwd_reduce(const void* gsrc, int gp, int tail, const unsigned char* argmax, const void* y,
                          const float* mean, const float* invstd, const float* gamma, const float* beta,
-                         float slope, double* sums, int N, int H, int W, int C, int dtype, void* stream);
+                         float slope, float* partials, int N, int H, int W, int C, int dtype, void* stream);
+/* partials -> sums[0..C) = dbeta, sums[C..2C) = dgamma (fp32, overwritten); dbeta[] += , dgamma[] += if non-NULL. */
+int kp_bn_bwd_finalize(const float* partials, double* ws, long long rows, int C, float* sums, float* dgamma,
+                       float* dbeta, void* stream);
 /* Backward, pass 2: dy = gamma*invstd*(ghat - dbeta/M - xhat*dgamma/M) written into
- * [N][H+2dp][W+2dp][C] T with a ZERO border of dp pixels; dgamma/dbeta (fp32) += sums. */
+ * [N][H+2dp][W+2dp][C] T with a ZERO border of dp pixels. */
 int kp_bn_act_bwd_apply(const void* gsrc, int gp, int tail, const unsigned char* argmax, const void* y,
                         const float* mean, const float* invstd, const float* gamma, const float* beta,
-                        float slope, const double* sums, float* dgamma, float* dbeta, void* dy, int dp,
+                        float slope, const float* sums, void* dy, int dp,
                         int N, int H, int W, int C, int dtype, void* stream);
 /* Adjoint of bilinear x2 (align_corners=True): gsrc = [N][2H+2gp][2W+2gp][C] T (folded if gp=1)
  * -> g [N][H][W][C] T. */

@@ -25,10 +25,11 @@ SIGNATURES = {
     'kp_wgrad_unpack': [_p, _p, _i, _i, _i, _p],
     'kp_conv_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'kp_conv_wgrad': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
-    'kp_bn_finalize': [_p, _p, _p, _p, _p, _p, _f, _f, _ll, _i, _p],
+    'kp_bn_finalize': [_p, _p, _p, _p, _p, _p, _p, _f, _f, _ll, _i, _p],
     'kp_bn_act_fwd': [_p, _p, _p, _p, _p, _f, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p],
     'kp_bn_act_bwd_reduce': [_p, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p],
-    'kp_bn_act_bwd_apply': [_p, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'kp_bn_bwd_finalize': [_p, _p, _ll, _i, _p, _p, _p, _p],
+    'kp_bn_act_bwd_apply': [_p, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'kp_upsample2_bwd': [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     'kp_head_fwd': [_p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _i, _p],
     'kp_head_bwd': [_p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -44,7 +45,7 @@ SIGNATURES = {
     'kp_prof_enable': [_i],
     'kp_prof_collect': [_i, _p, _p, _p],
 }
-PLAIN = {'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
+PLAIN = {'kp_bn_ws_doubles': ([_i], _i), 'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
 
 _lib = None
 

@@ -1,5 +1,5 @@
-// HBM-bound kernels around the convolutions: layout changes, weight packs, BatchNorm(train) +
-// activation (+ max-pool / bilinear x2) forward and backward, the 1x1 head, L2 loss and Adam.
+// Small kernels around the convolutions: layout changes, weight packs, the 1x1 head, L2 loss and Adam
+// (BatchNorm / activation / pool / upsample live in kp_bn.hip).
 // Reference semantics: keypoints/models/vgg.py:16-39, knn.py:110-130, transporter.py:47,56-60.
 #include "kp_common.h"
 
@@ -76,323 +76,6 @@ __global__ void wgrad_unpack_k(const float* __restrict__ scratch, float* __restr
     const int c = (int)((t / ((long long)R * R)) % C);
     const int k = (int)(t / ((long long)R * R * C));
     dw[t] += scratch[(((long long)k * R + r) * R + s) * C + c];
-}
-
-// ---------------------------------------------------------------- BatchNorm
-__global__ __launch_bounds__(TPB) void bn_finalize_k(const float* __restrict__ partials, float* __restrict__ mean,
-                                                     float* __restrict__ invstd, float* __restrict__ rmean,
-                                                     float* __restrict__ rvar, long long* __restrict__ nbt,
-                                                     float momentum, float eps, long long count, long long rows,
-                                                     int C) {
-    // block = 8 channels x 32 row-lanes; partials[row][2][C]
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
-    const int c = blockIdx.x * 8 + cl;
-    double s = 0.0, q = 0.0;
-    if (c < C)
-        for (long long r = rl; r < rows; r += 32) {
-            s += (double)partials[(r * 2 + 0) * C + c];
-            q += (double)partials[(r * 2 + 1) * C + c];
-        }
-    __shared__ double red[2][32][8];
-    red[0][rl][cl] = s;
-    red[1][rl][cl] = q;
-    __syncthreads();
-    if (threadIdx.x < 8 && c < C) {
-        double ss = 0.0, qq = 0.0;
-        for (int i = 0; i < 32; ++i) { ss += red[0][i][cl]; qq += red[1][i][cl]; }
-        const double mu = ss / (double)count;
-        double var = qq / (double)count - mu * mu;
-        if (var < 0.0) var = 0.0;
-        mean[c] = (float)mu;
-        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mu;
-        if (rvar) {
-            const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
-            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
-        }
-    }
-    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
-}
-
-struct BnP {
-    const float *mean, *invstd, *gamma, *beta;
-};
-
-template <int V>
-struct BnC {   // per-thread channel constants
-    float mu[V], is[V], ga[V], be[V];
-    bool affine;
-    __device__ __forceinline__ void load(const BnP& b, int c) {
-        affine = b.mean != nullptr;
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-            mu[v] = affine ? b.mean[c + v] : 0.f;
-            is[v] = affine ? b.invstd[c + v] : 1.f;
-            ga[v] = affine ? b.gamma[c + v] : 1.f;
-            be[v] = affine ? b.beta[c + v] : 0.f;
-        }
-    }
-    __device__ __forceinline__ float z(float y, int v) const { return affine ? (y - mu[v]) * is[v] * ga[v] + be[v] : y; }
-    __device__ __forceinline__ float xhat(float y, int v) const { return (y - mu[v]) * is[v]; }
-};
-
-template <typename T, int V>
-__device__ __forceinline__ void ldv(const T* p, float (&o)[V]) {
-    if constexpr (V == 4) ld4<T>(p, o);
-    else o[0] = ld<T>(p);
-}
-template <typename T, int V>
-__device__ __forceinline__ void stv(T* p, const float (&o)[V]) {
-    if constexpr (V == 4) st4<T>(p, o);
-    else st<T>(p, o[0]);
-}
-
-// torch's upsample_bilinear2d(align_corners=True) source index / lambda for output index o
-__device__ __forceinline__ void bilin(int o, int in_size, int out_size, int& i0, int& ip, float& l0, float& l1) {
-    const float scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
-    const float r = scale * (float)o;
-    i0 = (int)r;
-    ip = (i0 < in_size - 1) ? 1 : 0;
-    l1 = r - (float)i0;
-    l0 = 1.f - l1;
-}
-
-template <typename T, int V>
-__global__ void bn_act_fwd_k(const T* __restrict__ y, BnP bn, float slope, int tail, T* __restrict__ out, int p,
-                             unsigned char* __restrict__ argmax, int N, int H, int W, int C) {
-    const int Ho = tail == KP_TAIL_MAXPOOL2 ? H / 2 : (tail == KP_TAIL_UPSAMPLE2 ? 2 * H : H);
-    const int Wo = tail == KP_TAIL_MAXPOOL2 ? W / 2 : (tail == KP_TAIL_UPSAMPLE2 ? 2 * W : W);
-    const int Hp = Ho + 2 * p, Wp = Wo + 2 * p, CV = C / V;
-    const long long total = (long long)N * Hp * Wp * CV;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const int c = (int)(t % CV) * V;
-    long long r = t / CV;
-    const int j = (int)(r % Wp); r /= Wp;
-    const int i = (int)(r % Hp);
-    const int n = (int)(r / Hp);
-    const int oh = clampi(i - p, 0, Ho - 1), ow = clampi(j - p, 0, Wo - 1);
-    BnC<V> k; k.load(bn, c);
-    float res[V];
-    const T* yn = y + (long long)n * H * W * C + c;
-    if (tail == KP_TAIL_NONE) {
-        float v[V]; ldv<T, V>(yn + ((long long)oh * W + ow) * C, v);
-#pragma unroll
-        for (int e = 0; e < V; ++e) res[e] = act_fwd(k.z(v[e], e), slope);
-    } else if (tail == KP_TAIL_MAXPOOL2) {
-        int best[V];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float v[V]; ldv<T, V>(yn + ((long long)(2 * oh + (q >> 1)) * W + 2 * ow + (q & 1)) * C, v);
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                // compare what the next layer will actually see (storage precision)
-                float a = act_fwd(k.z(v[e], e), slope);
-                if constexpr (sizeof(T) == 2) a = bf2f(f2bf(a));
-                if (q == 0 || a > res[e] || a != a) { res[e] = a; best[e] = q; }
-            }
-        }
-        if (argmax && i - p == oh && j - p == ow) {
-#pragma unroll
-            for (int e = 0; e < V; ++e) argmax[(((long long)n * Ho + oh) * Wo + ow) * C + c + e] = (unsigned char)best[e];
-        }
-    } else {
-        int h0, hp, w0, wp; float lh0, lh1, lw0, lw1;
-        bilin(oh, H, Ho, h0, hp, lh0, lh1);
-        bilin(ow, W, Wo, w0, wp, lw0, lw1);
-        float v00[V], v01[V], v10[V], v11[V];
-        ldv<T, V>(yn + ((long long)h0 * W + w0) * C, v00);
-        ldv<T, V>(yn + ((long long)h0 * W + w0 + wp) * C, v01);
-        ldv<T, V>(yn + ((long long)(h0 + hp) * W + w0) * C, v10);
-        ldv<T, V>(yn + ((long long)(h0 + hp) * W + w0 + wp) * C, v11);
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const float a00 = act_fwd(k.z(v00[e], e), slope), a01 = act_fwd(k.z(v01[e], e), slope);
-            const float a10 = act_fwd(k.z(v10[e], e), slope), a11 = act_fwd(k.z(v11[e], e), slope);
-            res[e] = lh0 * (lw0 * a00 + lw1 * a01) + lh1 * (lw0 * a10 + lw1 * a11);
-        }
-    }
-    stv<T, V>(out + t * V, res);
-}
-
-// incoming gradient w.r.t. this layer's activation output at pre-tail pixel (n,h,w), channels c..c+V
-template <typename T, int V>
-__device__ __forceinline__ void load_g(const T* __restrict__ gsrc, int gp, int tail,
-                                       const unsigned char* __restrict__ argmax, int n, int h, int w, int c, int H,
-                                       int W, int C, float (&g)[V]) {
-#pragma unroll
-    for (int e = 0; e < V; ++e) g[e] = 0.f;
-    int Hs = H, Ws = W, sh = h, sw = w;
-    bool take[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) take[e] = true;
-    if (tail == KP_TAIL_MAXPOOL2) {
-        Hs = H / 2; Ws = W / 2; sh = h >> 1; sw = w >> 1;
-        if (sh >= Hs || sw >= Ws) return;
-        const int pos = ((h & 1) << 1) | (w & 1);
-        bool any = false;
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-            take[e] = argmax[(((long long)n * Hs + sh) * Ws + sw) * C + c + e] == pos;
-            any |= take[e];
-        }
-        if (!any) return;
-    }
-    const int Hp = Hs + 2 * gp, Wp = Ws + 2 * gp;
-    int ilo, ihi, jlo, jhi;
-    fold_range(sh, Hs, gp, ilo, ihi);
-    fold_range(sw, Ws, gp, jlo, jhi);
-    for (int i = ilo; i <= ihi; ++i)
-        for (int j = jlo; j <= jhi; ++j) {
-            float v[V]; ldv<T, V>(gsrc + (((long long)n * Hp + i) * Wp + j) * C + c, v);
-#pragma unroll
-            for (int e = 0; e < V; ++e) g[e] += v[e];
-        }
-#pragma unroll
-    for (int e = 0; e < V; ++e) if (!take[e]) g[e] = 0.f;
-}
-
-template <typename T, int V>
-__global__ __launch_bounds__(TPB) void bn_bwd_reduce_k(const T* __restrict__ gsrc, int gp, int tail,
-                                                       const unsigned char* __restrict__ argmax,
-                                                       const T* __restrict__ y, BnP bn, float slope,
-                                                       double* __restrict__ sums, int N, int H, int W, int C,
-                                                       int pix_per_block) {
-    const int CV = C / V;
-    const int cols = CV < TPB ? CV : TPB, rows = TPB / cols;
-    const int col = threadIdx.x % cols, row = threadIdx.x / cols;
-    const long long M = (long long)N * H * W;
-    const long long mbeg = (long long)blockIdx.x * pix_per_block;
-    const long long mend = mbeg + pix_per_block < M ? mbeg + pix_per_block : M;
-    extern __shared__ double red[];   // [rows][2*V] per col chunk
-    for (int cv = col; cv < CV; cv += cols) {
-        const int c = cv * V;
-        BnC<V> k; k.load(bn, c);
-        float sb[V], sg[V];
-#pragma unroll
-        for (int e = 0; e < V; ++e) sb[e] = sg[e] = 0.f;
-        if (row < rows) {
-            for (long long m = mbeg + row; m < mend; m += rows) {
-                const int w = (int)(m % W);
-                const int h = (int)((m / W) % H);
-                const int n = (int)(m / ((long long)W * H));
-                float g[V], yv[V];
-                load_g<T, V>(gsrc, gp, tail, argmax, n, h, w, c, H, W, C, g);
-                ldv<T, V>(y + m * C + c, yv);
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    const float gh = g[e] * act_grad(k.z(yv[e], e), slope);
-                    sb[e] += gh;
-                    sg[e] += gh * k.xhat(yv[e], e);
-                }
-            }
-        }
-        // reduce over rows through LDS
-        __syncthreads();
-        if (row < rows) {
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                red[((row * cols + col) * V + e) * 2 + 0] = (double)sb[e];
-                red[((row * cols + col) * V + e) * 2 + 1] = (double)sg[e];
-            }
-        }
-        __syncthreads();
-        if (row == 0) {
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                double a = 0.0, b = 0.0;
-                for (int r2 = 0; r2 < rows; ++r2) {
-                    a += red[((r2 * cols + col) * V + e) * 2 + 0];
-                    b += red[((r2 * cols + col) * V + e) * 2 + 1];
-                }
-                atomicAdd(sums + c + e, a);
-                atomicAdd(sums + C + c + e, b);
-            }
-        }
-    }
-}
-
-template <typename T, int V>
-__global__ void bn_bwd_apply_k(const T* __restrict__ gsrc, int gp, int tail, const unsigned char* __restrict__ argmax,
-                               const T* __restrict__ y, BnP bn, float slope, const double* __restrict__ sums,
-                               float* __restrict__ dgamma, float* __restrict__ dbeta, T* __restrict__ dy, int dp,
-                               int N, int H, int W, int C) {
-    const int Hp = H + 2 * dp, Wp = W + 2 * dp, CV = C / V;
-    const long long total = (long long)N * Hp * Wp * CV;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x == 0 && sums != nullptr) {
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            if (dbeta) dbeta[c] += (float)sums[c];
-            if (dgamma) dgamma[c] += (float)sums[C + c];
-        }
-    }
-    if (t >= total) return;
-    const int c = (int)(t % CV) * V;
-    long long r = t / CV;
-    const int j = (int)(r % Wp); r /= Wp;
-    const int i = (int)(r % Hp);
-    const int n = (int)(r / Hp);
-    const int h = i - dp, w = j - dp;
-    float res[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) res[e] = 0.f;
-    if (h >= 0 && h < H && w >= 0 && w < W) {
-        BnC<V> k; k.load(bn, c);
-        float g[V], yv[V];
-        load_g<T, V>(gsrc, gp, tail, argmax, n, h, w, c, H, W, C, g);
-        ldv<T, V>(y + (((long long)n * H + h) * W + w) * C + c, yv);
-        const float invM = 1.0f / (float)((long long)N * H * W);
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const float gh = g[e] * act_grad(k.z(yv[e], e), slope);
-            if (k.affine) {
-                const float db = (float)sums[c + e], dg = (float)sums[C + c + e];
-                res[e] = k.ga[e] * k.is[e] * (gh - db * invM - k.xhat(yv[e], e) * dg * invM);
-            } else {
-                res[e] = gh;
-            }
-        }
-    }
-    stv<T, V>(dy + t * V, res);
-}
-
-template <typename T, int V>
-__global__ void upsample2_bwd_k(const T* __restrict__ gsrc, int gp, T* __restrict__ g, int N, int H, int W, int C) {
-    const int CV = C / V, Ho = 2 * H, Wo = 2 * W, Hp = Ho + 2 * gp, Wp = Wo + 2 * gp;
-    const long long total = (long long)N * H * W * CV;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const int c = (int)(t % CV) * V;
-    long long r = t / CV;
-    const int w = (int)(r % W); r /= W;
-    const int h = (int)(r % H);
-    const int n = (int)(r / H);
-    float acc[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) acc[e] = 0.f;
-    const int i_lo = 2 * h - 2 < 0 ? 0 : 2 * h - 2, i_hi = 2 * h + 2 > Ho - 1 ? Ho - 1 : 2 * h + 2;
-    const int j_lo = 2 * w - 2 < 0 ? 0 : 2 * w - 2, j_hi = 2 * w + 2 > Wo - 1 ? Wo - 1 : 2 * w + 2;
-    for (int i = i_lo; i <= i_hi; ++i) {
-        int h0, hp; float lh0, lh1;
-        bilin(i, H, Ho, h0, hp, lh0, lh1);
-        const float wh = (h0 == h ? lh0 : 0.f) + (h0 + hp == h ? lh1 : 0.f);
-        if (wh == 0.f) continue;
-        int ilo, ihi; fold_range(i, Ho, gp, ilo, ihi);
-        for (int j = j_lo; j <= j_hi; ++j) {
-            int w0, wp; float lw0, lw1;
-            bilin(j, W, Wo, w0, wp, lw0, lw1);
-            const float ww = (w0 == w ? lw0 : 0.f) + (w0 + wp == w ? lw1 : 0.f);
-            if (ww == 0.f) continue;
-            int jlo, jhi; fold_range(j, Wo, gp, jlo, jhi);
-            for (int a = ilo; a <= ihi; ++a)
-                for (int b = jlo; b <= jhi; ++b) {
-                    float v[V]; ldv<T, V>(gsrc + (((long long)n * Hp + a) * Wp + b) * C + c, v);
-#pragma unroll
-                    for (int e = 0; e < V; ++e) acc[e] += wh * ww * v[e];
-                }
-        }
-    }
-    stv<T, V>(g + t * V, acc);
 }
 
 // ---------------------------------------------------------------- 1x1 head
@@ -579,79 +262,6 @@ int kp_wgrad_unpack(const float* scratch, float* dw, int K, int C, int R, void* 
     const long long total = (long long)K * C * R * R;
     wgrad_unpack_k<<<cdiv(total, TPB), TPB, 0, (hipStream_t)stream>>>(scratch, dw, K, C, R);
     return kp_check_launch("wgrad_unpack");
-}
-
-int kp_bn_finalize(const float* stats, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
-                   long long* num_batches_tracked, float momentum, float eps, long long count, int C, void* stream) {
-    KP_REQUIRE(C > 0 && count > 0, "kp_bn_finalize: bad dims");
-    bn_finalize_k<<<cdiv(C, 8), TPB, 0, (hipStream_t)stream>>>(stats, save_mean, save_invstd, running_mean, running_var,
-                                                               num_batches_tracked, momentum, eps, count,
-                                                               (count + 63) / 64, C);
-    return kp_check_launch("bn_finalize");
-}
-
-int kp_bn_act_fwd(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                  float slope, int tail, void* out, int out_pad, unsigned char* argmax, int N, int H, int W, int C,
-                  int dtype, void* stream) {
-    KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && out_pad >= 0 && tail >= 0 && tail <= 2, "kp_bn_act_fwd: bad dims");
-    KP_REQUIRE(tail != KP_TAIL_MAXPOOL2 || (H >= 2 && W >= 2), "kp_bn_act_fwd: maxpool needs H,W >= 2");
-    const int Ho = tail == KP_TAIL_MAXPOOL2 ? H / 2 : (tail == KP_TAIL_UPSAMPLE2 ? 2 * H : H);
-    const int Wo = tail == KP_TAIL_MAXPOOL2 ? W / 2 : (tail == KP_TAIL_UPSAMPLE2 ? 2 * W : W);
-    BnP bn{mean, invstd, gamma, beta};
-    const long long pix = (long long)N * (Ho + 2 * out_pad) * (Wo + 2 * out_pad);
-    hipStream_t st = (hipStream_t)stream;
-    if (C % 4 == 0)
-        DISPATCH_T(dtype, bn_act_fwd_k<T, 4><<<cdiv(pix * (C / 4), TPB), TPB, 0, st>>>((const T*)y, bn, slope, tail, (T*)out, out_pad, argmax, N, H, W, C));
-    else
-        DISPATCH_T(dtype, bn_act_fwd_k<T, 1><<<cdiv(pix * C, TPB), TPB, 0, st>>>((const T*)y, bn, slope, tail, (T*)out, out_pad, argmax, N, H, W, C));
-    return kp_check_launch("bn_act_fwd");
-}
-
-int kp_bn_act_bwd_reduce(const void* gsrc, int gp, int tail, const unsigned char* argmax, const void* y,
-                         const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
-                         double* sums, int N, int H, int W, int C, int dtype, void* stream) {
-    KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && gp >= 0 && (tail == 0 || tail == 1), "kp_bn_act_bwd_reduce: bad args");
-    KP_REQUIRE(tail == 0 || argmax != nullptr, "kp_bn_act_bwd_reduce: maxpool needs argmax");
-    KP_REQUIRE((C % 4 == 0 ? C / 4 : C) <= TPB, "kp_bn_act_bwd_reduce: C too large (<= 1024, or <= 256 if C %% 4 != 0)");
-    BnP bn{mean, invstd, gamma, beta};
-    const long long M = (long long)N * H * W;
-    long long ppb = (M + 1023) / 1024;
-    if (ppb < 64) ppb = 64;
-    const unsigned grid = cdiv(M, ppb);
-    hipStream_t st = (hipStream_t)stream;
-    const int V = (C % 4 == 0) ? 4 : 1;
-    const size_t smem = (size_t)TPB * V * 2 * sizeof(double);
-    if (V == 4)
-        DISPATCH_T(dtype, bn_bwd_reduce_k<T, 4><<<grid, TPB, smem, st>>>((const T*)gsrc, gp, tail, argmax, (const T*)y, bn, slope, sums, N, H, W, C, (int)ppb));
-    else
-        DISPATCH_T(dtype, bn_bwd_reduce_k<T, 1><<<grid, TPB, smem, st>>>((const T*)gsrc, gp, tail, argmax, (const T*)y, bn, slope, sums, N, H, W, C, (int)ppb));
-    return kp_check_launch("bn_bwd_reduce");
-}
-
-int kp_bn_act_bwd_apply(const void* gsrc, int gp, int tail, const unsigned char* argmax, const void* y,
-                        const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
-                        const double* sums, float* dgamma, float* dbeta, void* dy, int dp, int N, int H, int W, int C,
-                        int dtype, void* stream) {
-    KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && gp >= 0 && dp >= 0 && (tail == 0 || tail == 1), "kp_bn_act_bwd_apply: bad args");
-    BnP bn{mean, invstd, gamma, beta};
-    const long long pix = (long long)N * (H + 2 * dp) * (W + 2 * dp);
-    hipStream_t st = (hipStream_t)stream;
-    if (C % 4 == 0)
-        DISPATCH_T(dtype, bn_bwd_apply_k<T, 4><<<cdiv(pix * (C / 4), TPB), TPB, 0, st>>>((const T*)gsrc, gp, tail, argmax, (const T*)y, bn, slope, sums, dgamma, dbeta, (T*)dy, dp, N, H, W, C));
-    else
-        DISPATCH_T(dtype, bn_bwd_apply_k<T, 1><<<cdiv(pix * C, TPB), TPB, 0, st>>>((const T*)gsrc, gp, tail, argmax, (const T*)y, bn, slope, sums, dgamma, dbeta, (T*)dy, dp, N, H, W, C));
-    return kp_check_launch("bn_bwd_apply");
-}
-
-int kp_upsample2_bwd(const void* gsrc, int gp, void* g, int N, int H, int W, int C, int dtype, void* stream) {
-    KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && gp >= 0, "kp_upsample2_bwd: bad dims");
-    const long long pix = (long long)N * H * W;
-    hipStream_t st = (hipStream_t)stream;
-    if (C % 4 == 0)
-        DISPATCH_T(dtype, upsample2_bwd_k<T, 4><<<cdiv(pix * (C / 4), TPB), TPB, 0, st>>>((const T*)gsrc, gp, (T*)g, N, H, W, C));
-    else
-        DISPATCH_T(dtype, upsample2_bwd_k<T, 1><<<cdiv(pix * C, TPB), TPB, 0, st>>>((const T*)gsrc, gp, (T*)g, N, H, W, C));
-    return kp_check_launch("upsample2_bwd");
 }
 
 int kp_head_fwd(const void* x, const float* w, const float* bias, float slope, float* out, int N, int H, int W, int C,

@@ -142,7 +142,8 @@ class UnitFunction(torch.autograd.Function):
                     invstd = torch.empty(K, device=dev, dtype=torch.float32)
                     mom = 0.1 if bn.momentum is None else float(bn.momentum)
                     track = bn.track_running_stats and bn.running_mean is not None
-                    call('kp_bn_finalize', ptr(stats), ptr(mean), ptr(invstd),
+                    ws = torch.empty(128 * K, device=dev, dtype=torch.float64)
+                    call('kp_bn_finalize', ptr(stats), ptr(ws), ptr(mean), ptr(invstd),
                          ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
                          ptr(bn.num_batches_tracked) if track else None, mom, float(bn.eps), N * H * W, K, st)
                 else:
@@ -206,21 +207,24 @@ class UnitFunction(torch.autograd.Function):
                 g, gp, tcode = g2, 0, _lib.TAIL_NONE
             else:
                 tcode = TAILS[tail]
-            sums = torch.zeros(2 * K, device=dev, dtype=torch.float64)
+            partials = torch.empty(N * H, 2, K, device=dev, dtype=torch.float32)
             gamma = bn.weight if bn is not None else None
             beta = bn.bias if bn is not None else None
             bn_args = (ptr(sv['mean']), ptr(sv['invstd']), ptr(gamma), ptr(beta))
             call('kp_bn_act_bwd_reduce', ptr(g), gp, tcode, ptr(sv['argmax']), ptr(sv['y']), *bn_args, stp['slope'],
-                 ptr(sums), N, H, W, K, code, st)
-            need_dx = idx > 0 or need_x
-            dp = 2 if need_dx else 0
-            dy = torch.empty(N, H + 2 * dp, W + 2 * dp, K, device=dev, dtype=tdt)
+                 ptr(partials), N, H, W, K, code, st)
             if bn is not None:
                 dgam, dbet = ptr(gv[id(bn.weight)]), ptr(gv[id(bn.bias)])
             else:   # no BN: sum of dy is the conv-bias gradient
                 dgam, dbet = None, (ptr(gv[id(conv.bias)]) if conv.bias is not None else None)
+            sums = torch.empty(2 * K, device=dev, dtype=torch.float32)
+            ws = torch.empty(128 * K, device=dev, dtype=torch.float64)
+            call('kp_bn_bwd_finalize', ptr(partials), ptr(ws), N * H, K, ptr(sums), dgam, dbet, st)
+            need_dx = idx > 0 or need_x
+            dp = 2 if need_dx else 0
+            dy = torch.empty(N, H + 2 * dp, W + 2 * dp, K, device=dev, dtype=tdt)
             call('kp_bn_act_bwd_apply', ptr(g), gp, tcode, ptr(sv['argmax']), ptr(sv['y']), *bn_args, stp['slope'],
-                 ptr(sums), dgam, dbet, ptr(dy), dp, N, H, W, K, code, st)
+                 ptr(sums), ptr(dy), dp, N, H, W, K, code, st)
             # (conv bias in front of train-mode BN: analytically zero gradient -> its arena slot stays 0)
             scratch = torch.zeros(K, 3, 3, C, device=dev, dtype=torch.float32)
             call('kp_conv_wgrad', ptr(sv['a']), ptr(dy), ptr(scratch), N, H, W, C, K, 3, dp, code, st)

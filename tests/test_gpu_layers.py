@@ -15,29 +15,6 @@ def relerr(a, b):
     return np.abs(a - b).max() / max(1e-12, np.abs(b).max())
 
 
-def build_block(z, tag, cin, cout, tail, slope, head_out):
-    """A Unit whose in_block is the golden block and whose head is a fixed random 1x1 conv."""
-    from keypoints_amd.models import knn
-    core_mods = []
-    if tail == 'M':
-        core_mods.append(nn.MaxPool2d(2, 2))
-    if tail == 'U':
-        core_mods.append(nn.UpsamplingBilinear2d(scale_factor=2))
-    # Unit wants a conv inside `core` to size its blocks: append one more 3x3 layer (identity-free)
-    core_mods += [nn.ReplicationPad2d(1), nn.Conv2d(cout, cout, 3), nn.BatchNorm2d(cout), nn.ReLU(inplace=True)]
-    unit = knn.Unit(cin, head_out, nn.Sequential(*core_mods))
-    # overwrite the in_block conv (Unit builds in -> core_in = cout)
-    act = nn.LeakyReLU(slope, inplace=True) if slope > 0 else nn.ReLU(inplace=True)
-    unit.in_block[3] = act
-    with torch.no_grad():
-        unit.in_block[1].weight.copy_(torch.tensor(z[f'{tag}.weight']))
-        unit.in_block[1].bias.copy_(torch.tensor(z[f'{tag}.bias']))
-        unit.in_block[2].weight.copy_(torch.tensor(z[f'{tag}.gamma']))
-        unit.in_block[2].bias.copy_(torch.tensor(z[f'{tag}.beta']))
-    unit._plan = None
-    return unit
-
-
 @pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('bf16', 3e-2)])
 @pytest.mark.parametrize('tag,cin,cout,tail,slope', [('in3', 3, 64, None, 0.01), ('c64', 32, 64, 'M', 0.01),
                                                       ('dec', 32, 16, 'U', 0.0), ('odd', 5, 7, None, 0.01)])
@@ -69,7 +46,8 @@ def test_block_against_golden(golden, tag, cin, cout, tail, slope, precision, to
     mean = torch.empty(K, device=dev); invstd = torch.empty(K, device=dev)
     rm = torch.zeros(K, device=dev); rv = torch.ones(K, device=dev)
     nbt = torch.zeros((), device=dev, dtype=torch.long)
-    call('kp_bn_finalize', ptr(stats), ptr(mean), ptr(invstd), ptr(rm), ptr(rv), ptr(nbt), 0.1, 1e-5, N * H * W, K, st)
+    ws = torch.empty(128 * K, device=dev, dtype=torch.float64)
+    call('kp_bn_finalize', ptr(stats), ptr(ws), ptr(mean), ptr(invstd), ptr(rm), ptr(rv), ptr(nbt), 0.1, 1e-5, N * H * W, K, st)
     tcode = {None: 0, 'M': 1, 'U': 2}[tail]
     Ho, Wo = (H // 2, W // 2) if tail == 'M' else ((2 * H, 2 * W) if tail == 'U' else (H, W))
     out = torch.empty(N, Ho, Wo, K, device=dev, dtype=tdt)
@@ -95,13 +73,15 @@ def test_block_against_golden(golden, tag, cin, cout, tail, slope, precision, to
         g, tcode_b = g2, 0
     else:
         tcode_b = tcode
-    sums = torch.zeros(2 * K, device=dev, dtype=torch.float64)
+    partials = torch.empty(N * H, 2, K, device=dev)
     call('kp_bn_act_bwd_reduce', ptr(g), 0, tcode_b, ptr(argmax), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
-         slope, ptr(sums), N, H, W, K, code, st)
+         slope, ptr(partials), N, H, W, K, code, st)
     dgamma = torch.zeros(K, device=dev); dbeta = torch.zeros(K, device=dev)
+    sums = torch.empty(2 * K, device=dev)
+    call('kp_bn_bwd_finalize', ptr(partials), ptr(ws), N * H, K, ptr(sums), ptr(dgamma), ptr(dbeta), st)
     dy = torch.empty(N, H + 4, W + 4, K, device=dev, dtype=tdt)
     call('kp_bn_act_bwd_apply', ptr(g), 0, tcode_b, ptr(argmax), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
-         slope, ptr(sums), ptr(dgamma), ptr(dbeta), ptr(dy), 2, N, H, W, K, code, st)
+         slope, ptr(sums), ptr(dy), 2, N, H, W, K, code, st)
     assert float(dy.float()[:, :2].abs().max()) == 0 and float(dy.float()[:, :, -2:].abs().max()) == 0
     scratch = torch.zeros(K, 3, 3, C, device=dev)
     call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, W, C, K, 3, 2, code, st)
