@@ -1,0 +1,62 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient reduction used for N > 1 GPUs
+(keypoints_amd/dist.py).  On the GPU box the same code runs over RCCL (backend 'nccl')."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from keypoints_amd.dist import GradReducer
+        from keypoints_amd.models import transporter
+        torch.manual_seed(100 + rank)                      # deliberately different init per rank
+        net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 3)
+        red = GradReducer(net)                              # broadcasts rank 0's parameters + buffers
+        w0 = net.feature.in_block[1].weight.detach().clone()
+        ref = [torch.empty_like(w0) for _ in range(world)]
+        dist.all_gather(ref, w0)
+        same_init = all(torch.equal(ref[0], r) for r in ref)
+        # emulate the end of each Unit's backward: arenas hold rank-dependent gradients
+        units = [net.decoder, net.keypoint, net.feature]    # backward order
+        for i, u in enumerate(units):
+            arena = u.grad_arena()
+            arena.attach(list(u.parameters()))
+            arena.flat.copy_(torch.arange(arena.flat.numel(), dtype=torch.float32) * (rank + 1) + i)
+            u._after_backward()                             # fires the async all-reduce of this bucket
+        red.finish()
+        ok = True
+        for i, u in enumerate(units):
+            n = u.grad_arena().flat.numel()
+            expect = torch.arange(n, dtype=torch.float32) * (sum(range(1, world + 1)) / world) + i
+            ok = ok and torch.allclose(u.grad_arena().flat, expect, rtol=1e-6, atol=1e-6)
+            ok = ok and all(p.grad is u.grad_arena().views[id(p)] for p in u.parameters())
+        q.put((rank, same_init, ok, len(red._pending)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same_init, ok, pending in res:
+        assert same_init, f'rank {rank}: parameters not broadcast from rank 0'
+        assert ok, f'rank {rank}: averaged gradient arena mismatch'
+        assert pending == 0

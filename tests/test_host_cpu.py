@@ -1,0 +1,150 @@
+"""CPU: host-side logic of the drop-in surface and the C-ABI library (load + exported symbols only; no
+compute call is made without a GPU)."""
+import ctypes
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, 'include', 'kp_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(kp_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from keypoints_amd import _lib
+    names = header_functions()
+    assert len(names) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    bound = set(_lib.SIGNATURES) | set(_lib.PLAIN)
+    assert set(names) == bound, (set(names) ^ bound)
+    assert _lib.lib().kp_version() >= 100
+
+
+def test_no_oracle_import_in_product():
+    """The product path must never route through the oracle / a CPU fallback."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'keypoints_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.replace('no oracle', ''), f
+
+
+def test_cpu_tensors_fail_loudly():
+    from keypoints_amd.models import functional as MF, transporter
+    net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 3)
+    with pytest.raises(RuntimeError, match='HIP device'):
+        net(torch.zeros(2, 1, 32, 32), torch.zeros(2, 1, 32, 32))
+    with pytest.raises(RuntimeError, match='HIP device'):
+        MF.spacial_logsoftmax(torch.zeros(1, 2, 8, 8))
+    with pytest.raises(RuntimeError, match='HIP device'):
+        MF.gaussian_like_function(torch.zeros(1, 2, 2), 8, 8)
+
+
+def test_same_seed_same_init_and_keys_as_reference(golden):
+    """transporter.make draws the reference's RNG stream: same torch seed -> identical initial weights,
+    and the state_dict keys / parameter count are the reference's (checkpoint compatibility)."""
+    from keypoints_amd.models import transporter
+    z = golden('init_check.npz')
+    for tag, args in (('pong', ('VGG_PONG_LAYERNECK', 1, 16, 3)), ('F', ('F', 3, 64, 10))):
+        torch.manual_seed(1234)
+        net = transporter.make(*args)
+        assert list(net.state_dict().keys()) == list(z[f'{tag}.keys'])
+        assert sum(p.numel() for p in net.parameters()) == int(z[f'{tag}.nparams'])
+        for n, p in net.named_parameters():
+            assert abs(p.detach().double().sum().item() - float(z[f'{tag}.sum.{n}'])) < 1e-9
+            assert abs(p.detach().double().abs().sum().item() - float(z[f'{tag}.abs.{n}'])) < 1e-9
+    assert sum(p.numel() for p in transporter.make('F', 3, 64, 10).parameters()) == 24468813
+
+
+def test_plan_of_model_F():
+    from keypoints_amd.models import transporter
+    net = transporter.make('F', 3, 64, 10)
+    enc = net.feature.plan()
+    assert [s['kind'] for s in enc] == ['conv3'] * 8 + ['head']
+    assert [s.get('tail') for s in enc[:-1]] == [None, 'M', None, 'M', None, 'M', None, None]
+    assert all(abs(s['slope'] - 0.01) < 1e-9 for s in enc)
+    dec = net.decoder.plan()
+    assert [s.get('tail') for s in dec[:-1]] == [None, 'U', None, 'U', None, 'U', None, None]
+    assert dec[0]['slope'] == 0.01 and all(s['slope'] == 0.0 for s in dec[1:-1]) and dec[-1]['slope'] == 0.01
+    assert [s['conv'].out_channels for s in dec] == [512, 512, 256, 256, 256, 256, 128, 64, 3]
+
+
+def test_keynet_make_and_decoder_width():
+    from keypoints_amd.models import keynet
+    args = types.SimpleNamespace(model_type='F', model_in_channels=3, model_z_channels=64, model_keypoints=10,
+                                 load=None, transfer_load=None)
+    net = keynet.make(args)
+    assert net.decoder.in_block[1].in_channels == 74
+    assert sum(p.numel() for p in net.parameters()) == 24514893
+
+
+def test_unsupported_structures_raise():
+    from keypoints_amd.models import knn, vgg
+    with pytest.raises(NotImplementedError):
+        vgg.make_layers(vgg.vgg_cfg['F'], co_ord_conv=True)
+    core = nn.Sequential(nn.ReplicationPad2d(1), nn.Conv2d(8, 8, 3), nn.BatchNorm2d(8), nn.Tanh())
+    with pytest.raises(NotImplementedError):
+        knn.Unit(3, 4, core).plan()
+
+
+def test_checkpoint_layout_roundtrip(tmp_path):
+    """save()/load() write the reference's files: <dir>/{encoder,keypoint,decoder}/{in_block,core,out_block}.mdl
+    holding nn.Sequential state_dicts (knn.py:143-167, transporter.py:66-80)."""
+    from keypoints_amd.models import transporter
+    torch.manual_seed(1)
+    a = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 3)
+    a.save(str(tmp_path / 'ck'))
+    for unit in ('encoder', 'keypoint', 'decoder'):
+        for blk in ('in_block', 'core', 'out_block'):
+            assert (tmp_path / 'ck' / unit / f'{blk}.mdl').exists()
+    sd = torch.load(str(tmp_path / 'ck' / 'encoder' / 'in_block.mdl'))
+    assert list(sd.keys()) == ['1.weight', '1.bias', '2.weight', '2.bias', '2.running_mean', '2.running_var',
+                               '2.num_batches_tracked']
+    torch.manual_seed(2)
+    b = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 3, load=str(tmp_path / 'ck'))
+    for (n1, p1), (_, p2) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(p1, p2), n1
+    c = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 3)
+    c.load_from_autoencoder(str(tmp_path / 'ck'))   # re-uses encoder in_block+core for the keypoint net
+    assert torch.equal(c.keypoint.in_block[1].weight, a.feature.in_block[1].weight)
+
+
+def test_install_as_keypoints_alias():
+    import sys
+    import keypoints_amd as ka
+    saved = {k: v for k, v in sys.modules.items() if k == 'keypoints' or k.startswith('keypoints.')}
+    try:
+        ka.install_as_keypoints()
+        from keypoints.models import transporter as T   # noqa: the reference's import line
+        assert T is ka.models.transporter
+    finally:
+        for k in [k for k in sys.modules if k == 'keypoints' or k.startswith('keypoints.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_grad_arena_views_and_attach():
+    from keypoints_amd.models import transporter
+    net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 3)
+    u = net.decoder
+    arena = u.grad_arena()
+    params = list(u.parameters())
+    assert arena.flat.numel() == sum(p.numel() for p in params)
+    arena.flat.fill_(3.0)
+    arena.attach(params)                      # nothing attached yet -> whole arena zeroed
+    assert float(arena.flat.abs().max()) == 0 and all(p.grad is arena.views[id(p)] for p in params)
+    arena.views[id(params[0])].fill_(2.0)
+    params[1].grad = None
+    arena.attach(params)                      # only the detached slot is re-zeroed
+    assert float(params[0].grad.min()) == 2.0 and float(params[1].grad.abs().max()) == 0
