@@ -45,6 +45,10 @@ const char* kp_last_error(void);
 /* number of CUs of the current device (for grid sizing by host code) */
 int kp_device_cus(void);
 
+/* Tuning switches for A/B measurements (not needed in normal use). */
+#define KP_CFG_CONV_PATCH 0   /* 1 (default): LDS-patch 3x3 kernel where eligible; 0: linear implicit-GEMM kernel */
+int kp_config(int key, int value);
+
 /* ---- measurement (bench.py roofline leg; not used by the model code) ------- */
 #define KP_PROF_CONV_GENERIC 0   /* fp32-accumulate VALU implicit-GEMM conv (fwd + dgrad) */
 #define KP_PROF_WGRAD_GENERIC 1

@@ -43,6 +43,7 @@ SIGNATURES = {
     'kp_l2_loss': [_p, _p, _p, _p, _p, _f, _z, _p],
     'kp_adam_step': [_p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _f, _p],
     'kp_prof_enable': [_i],
+    'kp_config': [_i, _i],
     'kp_prof_collect': [_i, _p, _p, _p],
 }
 PLAIN = {'kp_bn_ws_doubles': ([_i], _i), 'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}

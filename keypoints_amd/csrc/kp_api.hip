@@ -78,6 +78,13 @@ int kp_device_cus(void) {
     return n;
 }
 
+extern int g_kp_conv_patch;
+int kp_config(int key, int value) {
+    if (key == KP_CFG_CONV_PATCH) { g_kp_conv_patch = value ? 1 : 0; return KP_OK; }
+    kp_set_error("kp_config: unknown key %d", key);
+    return KP_E_ARG;
+}
+
 int kp_prof_enable(int on) {
     for (auto& r : g_prof) { g_event_pool.push_back(r.e0); g_event_pool.push_back(r.e1); }
     g_prof.clear();

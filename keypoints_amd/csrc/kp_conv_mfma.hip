@@ -11,6 +11,7 @@
 // LDS rows are 128 B (64 bf16); the 16-B slot index is XOR-swizzled with (row>>1)&7, applied on the
 // per-lane *source* address (the LDS-DMA destination is lane-linear) and on the ds_read_b128 address,
 // which makes every ds_read_b128 lane group hit 16 distinct 16-B bank slots (conflict-free).
+#include <stdlib.h>
 #include "kp_common.h"
 
 namespace {
@@ -62,7 +63,27 @@ __device__ __forceinline__ float reduce16_over32(float (&v)[16], int lane, int& 
     return d;
 }
 
-template <int BN>
+// Output pixel m -> (image n, row p, col q).  RING = false: all Ho x Wo pixels in row-major order.
+// RING = true: only the 1-pixel border ring of the output (2*Wo + 2*(Ho-2) pixels per image): used for the
+// data-gradient, whose interior is computed by the LDS-patch kernel (kp_conv_patch.hip) in exact 16x16 tiles.
+template <bool RING>
+__device__ __forceinline__ void pix_decode(long long m, int Ho, int Wo, long long& n, int& p, int& q) {
+    if (!RING) {
+        q = (int)(m % Wo);
+        const long long t = m / Wo;
+        p = (int)(t % Ho);
+        n = t / Ho;
+    } else {
+        const int RP = 2 * Wo + 2 * (Ho - 2);
+        n = m / RP;
+        const int r = (int)(m % RP);
+        if (r < Wo) { p = 0; q = r; }
+        else if (r < 2 * Wo) { p = Ho - 1; q = r - Wo; }
+        else { const int r2 = r - 2 * Wo; p = 1 + (r2 >> 1); q = (r2 & 1) ? Wo - 1 : 0; }
+    }
+}
+
+template <int BN, bool RING>
 __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                          const float* __restrict__ bias, bf16_t* __restrict__ y,
                                                          float* __restrict__ partials, int N, int Hi, int Wi, int C,
@@ -74,7 +95,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restric
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
     const int Ho = Hi - 2, Wo = Wi - 2;
-    const long long M = (long long)N * Ho * Wo;
+    const long long M = RING ? (long long)N * (2 * Wo + 2 * (Ho - 2)) : (long long)N * Ho * Wo;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -98,10 +119,8 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restric
         const int row = (j * 4 + wave) * 8 + lrow8;
         long long m = m0 + row;
         if (m >= M) m = M - 1;   // tail rows: load something valid, masked at the store
-        const int q = (int)(m % Wo);
-        const long long t = m / Wo;
-        const int p = (int)(t % Ho);
-        const long long n = t / Ho;
+        long long n; int p, q;
+        pix_decode<RING>(m, Ho, Wo, n, p, q);
         xsrc[j] = (const unsigned char*)x + (((n * Hi + p) * Wi + q) * (long long)C + swz(row, lslot) * 8) * 2;
     }
     const unsigned char* wsrc[WI];
@@ -185,6 +204,12 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restric
         for (int b = 0; b < 2; ++b) {
             const long long m = m0 + wm * 64 + b * 32 + fr;
             const bool ok = m < M;
+            long long opix = m;
+            if (RING && ok) {
+                long long n; int p, q;
+                pix_decode<true>(m, Ho, Wo, n, p, q);
+                opix = (n * Ho + p) * Wo + q;
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int kq = kb + 8 * g + 4 * fh;
@@ -198,7 +223,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restric
                     uint2 pk;
                     pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
                     pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                    *reinterpret_cast<uint2*>(y + m * K + kq) = pk;
+                    *reinterpret_cast<uint2*>(y + opix * K + kq) = pk;
                 }
             }
         }
@@ -217,26 +242,55 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restric
 
 }  // namespace
 
-int kp_conv_fwd_mfma(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi,
-                     int C, int K, int R, hipStream_t st) {
-    if (R != 3 || C % BK != 0 || K % 64 != 0) return KP_E_UNSUPPORTED;
-    const long long M = (long long)N * (Hi - 2) * (Wi - 2);
+int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hib,
+                         int Wib, int ioff, int Hob, int Wob, int ooff, int H, int W, int C, int K, hipStream_t st);
+
+template <bool RING>
+static int launch_linear(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi,
+                         int C, int K, hipStream_t st) {
+    const int Ho = Hi - 2, Wo = Wi - 2;
+    const long long M = RING ? (long long)N * (2 * Wo + 2 * (Ho - 2)) : (long long)N * Ho * Wo;
     const long long mtiles = (M + BM - 1) / BM;
     // statistics rows are per 64 pixels: a half-empty last tile would leave the odd row unwritten
-    if (stats && (M % 64) != 0) return KP_E_UNSUPPORTED;
-    if (K % 128 == 0) {
-        const int ktiles = K / 128;
-        if (mtiles * ktiles > 0x7fffffffLL) return KP_E_UNSUPPORTED;
-        conv3x3_mfma_k<128><<<(unsigned)(mtiles * ktiles), TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias,
-                                                                       (bf16_t*)y, stats, N, Hi, Wi, C, K,
-                                                                       (int)mtiles, ktiles);
-    } else {
-        const int ktiles = K / 64;
-        if (mtiles * ktiles > 0x7fffffffLL) return KP_E_UNSUPPORTED;
-        conv3x3_mfma_k<64><<<(unsigned)(mtiles * ktiles), TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias,
-                                                                      (bf16_t*)y, stats, N, Hi, Wi, C, K,
-                                                                      (int)mtiles, ktiles);
-    }
+    if (stats && (RING || (M % 64) != 0)) return KP_E_UNSUPPORTED;
+    const int bn = (K % 128 == 0) ? 128 : 64;
+    const int ktiles = K / bn;
+    if (mtiles * ktiles > 0x7fffffffLL) return KP_E_UNSUPPORTED;
+    const unsigned grid = (unsigned)(mtiles * ktiles);
+    if (bn == 128)
+        conv3x3_mfma_k<128, RING><<<grid, TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, stats, N, Hi,
+                                                       Wi, C, K, (int)mtiles, ktiles);
+    else
+        conv3x3_mfma_k<64, RING><<<grid, TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, stats, N, Hi,
+                                                      Wi, C, K, (int)mtiles, ktiles);
     return kp_check_launch("conv3x3_mfma");
 }
 
+int g_kp_conv_patch = -1;   // kp_config(KP_CFG_CONV_PATCH, v); -1 = read KP_CONV_PATCH from the environment once
+static int patch_mode() {   // 0 forces the linear implicit-GEMM kernel (A/B measurements)
+    if (g_kp_conv_patch < 0) {
+        const char* e = getenv("KP_CONV_PATCH");
+        g_kp_conv_patch = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_kp_conv_patch;
+}
+
+// Dispatch: (a) output a multiple of 16x16 -> LDS-patch kernel; (b) output = 16x16 multiple + a 1-pixel ring
+// (the data-gradient over the padded domain) -> patch kernel on the interior + linear kernel on the ring;
+// (c) anything else -> linear implicit-GEMM kernel.
+int kp_conv_fwd_mfma(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi,
+                     int C, int K, int R, hipStream_t st) {
+    if (R != 3 || C % BK != 0 || K % 64 != 0) return KP_E_UNSUPPORTED;
+    const int Ho = Hi - 2, Wo = Wi - 2;
+    if (patch_mode()) {
+        if (Ho % 16 == 0 && Wo % 16 == 0) {
+            int rc = kp_conv_patch_launch(x, w, bias, y, stats, N, Hi, Wi, 0, Ho, Wo, 0, Ho, Wo, C, K, st);
+            if (rc != KP_E_UNSUPPORTED) return rc;
+        } else if (!stats && Ho > 2 && Wo > 2 && (Ho - 2) % 16 == 0 && (Wo - 2) % 16 == 0) {
+            int rc = kp_conv_patch_launch(x, w, bias, y, nullptr, N, Hi, Wi, 1, Ho, Wo, 1, Ho - 2, Wo - 2, C, K, st);
+            if (rc == KP_OK) return launch_linear<true>(x, w, bias, y, nullptr, N, Hi, Wi, C, K, st);
+            if (rc != KP_E_UNSUPPORTED) return rc;
+        }
+    }
+    return launch_linear<false>(x, w, bias, y, stats, N, Hi, Wi, C, K, st);
+}

@@ -12,6 +12,9 @@ SHAPES = [  # N, Ho, Wo, C, K, with_stats
     (1, 8, 24, 64, 128, True),          # M = 192: masked half tile
     (3, 18, 18, 128, 64, False),        # dgrad-like: M % 64 != 0, no bias / stats
     (1, 16, 16, 512, 512, True), (2, 130, 130, 64, 128, False),
+    # LDS-patch kernel: 16x16-tileable outputs, and 16x16 interior + ring (data-gradient domain)
+    (2, 32, 32, 128, 256, True), (1, 64, 64, 256, 128, True), (3, 16, 16, 64, 512, True),
+    (2, 34, 34, 256, 256, False), (1, 66, 66, 128, 64, False), (2, 18, 18, 512, 128, False),
 ]
 
 
