@@ -1,0 +1,224 @@
+// First layer of a Unit: Conv2d(Cin <= 4 -> K, 3x3) over the replicate-padded input image
+// (knn.py:115: in_block = ReplicationPad2d(1), Conv2d(in_channels, core_in, 3), BN, LeakyReLU).
+// With Cin = 3 the reduction is only 27 deep: 0.03 GMAC per image against 128 B of output per pixel, so both
+// the forward and the weight-gradient are HBM-bound (write / read of the [N][H][W][K] bf16 tensor) and are
+// written as VALU kernels shaped for coalesced 16-byte access rather than as MFMA GEMMs.
+//
+// forward : one thread per output pixel, 8 output channels at a time; weights are fp32 in LDS and read at
+//           wave-uniform addresses (LDS broadcast); results go through a swizzled per-wave LDS tile so that
+//           the global stores are whole 1-KiB runs; BatchNorm partial sums per 64 pixels by a halving butterfly.
+// wgrad   : one lane per output channel k; a wavefront walks the pixels of an image row, reading dy[pixel][k]
+//           coalesced and the 3x3xCin input window (fp32 in LDS, 16-byte aligned pixels) at uniform addresses;
+//           27 accumulators per lane, block reduction in LDS, fp32 atomics into the zeroed scratch.
+#include "kp_common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+// 8 per-lane values -> each lane gets the sum over all 64 lanes of ONE of them (index returned in idx)
+__device__ __forceinline__ float reduce8_over64(const float (&v)[8], int lane, int& idx) {
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+    float a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b5 ? v[i + 4] : v[i], send = b5 ? v[i] : v[i + 4];
+        a[i] = keep + __shfl_xor(send, 32, 64);
+    }
+    float b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b4 ? a[i + 2] : a[i], send = b4 ? a[i] : a[i + 2];
+        b[i] = keep + __shfl_xor(send, 16, 64);
+    }
+    float d = (b3 ? b[1] : b[0]) + __shfl_xor(b3 ? b[0] : b[1], 8, 64);
+    d += __shfl_xor(d, 4, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 1, 64);
+    idx = (b5 ? 4 : 0) | (b4 ? 2 : 0) | (b3 ? 1 : 0);
+    return d;
+}
+
+template <int CIN>
+__global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                         const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                         float* __restrict__ partials, int Hi, int Wi, int K,
+                                                         long long M) {
+    constexpr int J = 9 * CIN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* wl = reinterpret_cast<float*>(smem);                           // [J][K] fp32
+    unsigned char* stage = smem + (size_t)J * K * sizeof(float);         // [4 waves][64 px][K] bf16, swizzled
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Ho = Hi - 2, Wo = Wi - 2;
+    for (int i = tid; i < J * K; i += TPB) {   // w is [K][J] -> wl[j][k]
+        const int k = i / J, j = i - k * J;
+        wl[j * K + k] = bf2f(w[i]);
+    }
+    __syncthreads();
+    const long long m_wave = (long long)blockIdx.x * TPB + wave * 64;
+    if (m_wave >= M) return;                   // M % 64 == 0: wavefronts are all-or-nothing
+    const long long m = m_wave + lane;
+    const int q = (int)(m % Wo);
+    const long long t = m / Wo;
+    const int p = (int)(t % Ho);
+    const long long n = t / Ho;
+    float xin[J];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const bf16_t* xr = x + ((n * Hi + p + r) * Wi + q) * CIN;
+#pragma unroll
+        for (int i = 0; i < 3 * CIN; ++i) xin[r * 3 * CIN + i] = bf2f(xr[i]);
+    }
+    const int CP = K >> 3;                     // 16-byte chunks per pixel
+    unsigned char* st = stage + (size_t)wave * 64 * K * 2;
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[k0 + e] : 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float4 w0 = *reinterpret_cast<const float4*>(wl + j * K + k0);
+            const float4 w1 = *reinterpret_cast<const float4*>(wl + j * K + k0 + 4);
+            acc[0] = fmaf(xin[j], w0.x, acc[0]); acc[1] = fmaf(xin[j], w0.y, acc[1]);
+            acc[2] = fmaf(xin[j], w0.z, acc[2]); acc[3] = fmaf(xin[j], w0.w, acc[3]);
+            acc[4] = fmaf(xin[j], w1.x, acc[4]); acc[5] = fmaf(xin[j], w1.y, acc[5]);
+            acc[6] = fmaf(xin[j], w1.z, acc[6]); acc[7] = fmaf(xin[j], w1.w, acc[7]);
+        }
+        if (partials) {
+            float sq[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sq[e] = acc[e] * acc[e];
+            int i1, i2;
+            const float ts = reduce8_over64(acc, lane, i1);
+            const float tq = reduce8_over64(sq, lane, i2);
+            if ((lane & 7) == 0) {
+                const long long row = m_wave >> 6;
+                partials[(row * 2 + 0) * K + k0 + i1] = ts;
+                partials[(row * 2 + 1) * K + k0 + i1] = tq;
+            }
+        }
+        uint4 pk;
+        pk.x = (uint32_t)f2bf(acc[0]) | ((uint32_t)f2bf(acc[1]) << 16);
+        pk.y = (uint32_t)f2bf(acc[2]) | ((uint32_t)f2bf(acc[3]) << 16);
+        pk.z = (uint32_t)f2bf(acc[4]) | ((uint32_t)f2bf(acc[5]) << 16);
+        pk.w = (uint32_t)f2bf(acc[6]) | ((uint32_t)f2bf(acc[7]) << 16);
+        const int ch = k0 >> 3;
+        *reinterpret_cast<uint4*>(st + (size_t)lane * K * 2 + ((ch ^ (lane & (CP - 1))) << 4)) = pk;
+    }
+    // coalesced write-out: chunk id = i*64 + lane -> (pixel id / CP, chunk id % CP)
+    bf16_t* yw = y + m_wave * K;
+    for (int id = lane; id < 64 * CP; id += 64) {
+        const int px = id / CP, ch = id - px * CP;
+        const uint4 v = *reinterpret_cast<const uint4*>(st + (size_t)px * K * 2 + ((ch ^ (px & (CP - 1))) << 4));
+        *reinterpret_cast<uint4*>(yw + (size_t)id * 8) = v;
+    }
+}
+
+// scratch[k][tap][c] += sum_pixels dy[pixel][k] * x[pixel + tap][c]
+template <int CIN>
+__global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                           float* __restrict__ scratch, int Ho, int Wo, int K,
+                                                           int dy_pad, long long total_rows, int rows_per_block) {
+    constexpr int J = 9 * CIN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Hi = Ho + 2, Wi = Wo + 2, Hd = Ho + 2 * dy_pad, Wd = Wo + 2 * dy_pad;
+    const int rowf = Wi * 4;                                  // floats per staged input row (pixel = 4 floats)
+    float* xw = reinterpret_cast<float*>(smem) + (size_t)wave * 3 * rowf;   // this wave's 3 input rows
+    const int KS = 64 / K;                                    // pixel streams per wavefront (K = 16, 32, 64)
+    const int k = lane % K, stream = lane / K;
+
+    float acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[j] = 0.f;
+
+    const long long row0 = (long long)blockIdx.x * rows_per_block;
+    for (int rr = wave; rr < rows_per_block; rr += 4) {
+        const long long row = row0 + rr;
+        if (row >= total_rows) break;
+        const int p = (int)(row % Ho);
+        const long long n = row / Ho;
+        // stage input rows p..p+2 as fp32, 4 floats per pixel (channels >= CIN are never read)
+        const bf16_t* xr = x + ((n * Hi + p) * Wi) * CIN;
+        for (int i = lane; i < 3 * Wi * CIN; i += 64) {
+            const int r = i / (Wi * CIN), rem = i - r * (Wi * CIN);
+            const int px = rem / CIN, c = rem - px * CIN;
+            xw[r * rowf + px * 4 + c] = bf2f(xr[i]);
+        }
+        const bf16_t* dr = dy + (((n * Hd + p + dy_pad) * Wd) + dy_pad) * (long long)K + k;
+#pragma unroll 4
+        for (int q = stream; q < Wo; q += KS) {
+            const float d = bf2f(dr[(long long)q * K]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const float4 v = *reinterpret_cast<const float4*>(xw + r * rowf + (q + s) * 4);
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int c = 0; c < CIN; ++c) acc[(r * 3 + s) * CIN + c] = fmaf(d, vv[c], acc[(r * 3 + s) * CIN + c]);
+                }
+        }
+    }
+    // fold the pixel streams (lanes k, k+K, ...), then the 4 wavefronts, then one atomic per (k, j) per block
+    for (int o = K; o < 64; o <<= 1)
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+    __syncthreads();                                          // everyone is done with the staged rows
+    float* red = reinterpret_cast<float*>(smem);              // [4][K][J]
+    if (stream == 0)
+#pragma unroll
+        for (int j = 0; j < J; ++j) red[(wave * K + k) * J + j] = acc[j];
+    __syncthreads();
+    for (int i = tid; i < K * J; i += TPB) {
+        const float s = red[i] + red[K * J + i] + red[2 * K * J + i] + red[3 * K * J + i];
+        unsafeAtomicAdd(scratch + i, s);                      // scratch is [K][9][CIN] = [K][J]
+    }
+}
+
+}  // namespace
+
+int kp_conv_first_fwd(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi,
+                      int C, int K, hipStream_t st) {
+    const long long M = (long long)N * (Hi - 2) * (Wi - 2);
+    const int CP = K / 8;
+    if (C < 1 || C > 4 || K % 8 != 0 || K > 128 || (CP & (CP - 1)) != 0 || M % 64 != 0) return KP_E_UNSUPPORTED;
+    const size_t lds = (size_t)9 * C * K * sizeof(float) + (size_t)4 * 64 * K * 2;
+    const unsigned grid = (unsigned)((M + TPB - 1) / TPB);
+#define KP_FIRST_FWD(CINv)                                                                                          \
+    conv3_first_fwd_k<CINv><<<grid, TPB, lds, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, stats, Hi, \
+                                                    Wi, K, M)
+    switch (C) {
+        case 1: KP_FIRST_FWD(1); break;
+        case 2: KP_FIRST_FWD(2); break;
+        case 3: KP_FIRST_FWD(3); break;
+        default: KP_FIRST_FWD(4); break;
+    }
+#undef KP_FIRST_FWD
+    return kp_check_launch("conv3_first_fwd");
+}
+
+int kp_conv_first_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K,
+                        int dy_pad, hipStream_t st) {
+    if (C < 1 || C > 4 || !(K == 16 || K == 32 || K == 64)) return KP_E_UNSUPPORTED;
+    const long long rows = (long long)N * Ho;
+    int rpb = (int)((rows + 1023) / 1024);
+    if (rpb < 4) rpb = 4;
+    rpb = (rpb + 3) / 4 * 4;
+    const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
+    size_t lds = (size_t)4 * 3 * (Wo + 2) * 4 * sizeof(float);
+    const size_t red = (size_t)4 * K * 9 * C * sizeof(float);
+    if (red > lds) lds = red;
+    if (lds > 64 * 1024) return KP_E_UNSUPPORTED;
+#define KP_FIRST_WG(CINv)                                                                                        \
+    conv3_first_wgrad_k<CINv><<<grid, TPB, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, scratch, Ho, Wo, K,    \
+                                                      dy_pad, rows, rpb)
+    switch (C) {
+        case 1: KP_FIRST_WG(1); break;
+        case 2: KP_FIRST_WG(2); break;
+        case 3: KP_FIRST_WG(3); break;
+        default: KP_FIRST_WG(4); break;
+    }
+#undef KP_FIRST_WG
+    return kp_check_launch("conv3_first_wgrad");
+}

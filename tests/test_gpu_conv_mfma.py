@@ -91,3 +91,59 @@ def test_conv_wgrad_mfma(N, Ho, Wo, C, K, dp):
     err = (got - ref).abs().max().item()
     assert err <= 2e-5 * ref.abs().max().item() * (N * Ho * Wo) ** 0.5 + 1e-4, (err, ref.abs().max().item())
     assert ((got - ref).norm() / ref.norm()).item() < 1e-5
+
+
+FIRST_SHAPES = [  # N, Ho, Wo, C, K
+    (2, 32, 32, 3, 64), (1, 16, 16, 1, 16), (2, 128, 128, 3, 64), (3, 16, 48, 3, 32), (1, 8, 8, 4, 64),
+]
+
+
+@pytest.mark.parametrize('N,Ho,Wo,C,K', FIRST_SHAPES)
+def test_conv_first_layer(N, Ho, Wo, C, K):
+    """Cin <= 4 first-layer kernels (kp_conv_first.hip): forward + BN partial sums + weight gradient."""
+    import ctypes
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    g = torch.Generator().manual_seed(N * 31 + C * 7 + K)
+    x = torch.randn(N, Ho + 2, Wo + 2, C, generator=g).bfloat16()
+    w = (torch.randn(K, 3, 3, C, generator=g) * (2.0 / (9 * C)) ** 0.5).bfloat16()
+    bias = torch.randn(K, generator=g)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias).permute(0, 2, 3, 1).contiguous()
+    xd, wd, bd = x.cuda(), w.cuda(), bias.cuda()
+    y = torch.full((N, Ho, Wo, K), float('nan'), device='cuda', dtype=torch.bfloat16)
+    rows = N * Ho * Wo // 64
+    stats = torch.full((rows, 2, K), float('nan'), device='cuda')
+    st = stream_ptr()
+    n = ctypes.c_longlong()
+    call('kp_prof_enable', 1)
+    call('kp_conv_fwd', ptr(xd), ptr(wd), ptr(bd), ptr(y), ptr(stats), N, Ho + 2, Wo + 2, C, K, 3, _lib.KP_BF16, st)
+    call('kp_prof_collect', 4, None, None, ctypes.addressof(n))
+    assert n.value == 1, 'the first-layer kernel did not take this shape'
+    got = y.float().cpu()
+    assert torch.isfinite(got).all()
+    close = (got - ref.bfloat16().float()).abs() <= 2 ** -7 * ref.abs() + 1e-3
+    assert close.float().mean().item() > 0.9995
+    s = stats.double().sum(0).cpu()
+    flat = ref.double().reshape(-1, K)
+    assert (s[0] - flat.sum(0)).abs().max().item() <= 1e-4 * flat.abs().sum(0).max().item()
+    assert (s[1] - (flat ** 2).sum(0)).abs().max().item() <= 1e-4 * (flat ** 2).sum(0).max().item()
+
+    for dp in (0, 2):
+        dyi = torch.randn(N, Ho, Wo, K, generator=g).bfloat16()
+        dy = torch.zeros(N, Ho + 2 * dp, Wo + 2 * dp, K, dtype=torch.bfloat16)
+        dy[:, dp:dp + Ho, dp:dp + Wo] = dyi
+        xf, df = x.double(), dyi.double()
+        wref = torch.zeros(K, 3, 3, C, dtype=torch.float64)
+        for r in range(3):
+            for s_ in range(3):
+                wref[:, r, s_, :] = torch.einsum('npqk,npqc->kc', df, xf[:, r:r + Ho, s_:s_ + Wo])
+        scratch = torch.zeros(K, 3, 3, C, device='cuda')
+        dyd = dy.cuda()
+        call('kp_prof_enable', 1)
+        call('kp_conv_wgrad', ptr(xd), ptr(dyd), ptr(scratch), N, Ho, Wo, C, K, 3, dp, _lib.KP_BF16, st)
+        call('kp_prof_collect', 4, None, None, ctypes.addressof(n))
+        assert n.value == 1, 'the first-layer wgrad kernel did not take this shape'
+        gotw = scratch.double().cpu()
+        assert ((gotw - wref).norm() / wref.norm()).item() < 1e-5
+    call('kp_prof_enable', 0)

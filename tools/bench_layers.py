@@ -91,6 +91,22 @@ def main():
         t[1] += nw * tw
         print(f'{name:<20}' + ''.join(f'{c:9.0f}' for c in cols) + f'{flops / tw / 1e12:9.0f}')
         del a, wf, wd, y, stats, dy, gx, scratch
+    if not args.only or 'first' in args.only:
+        C, K, H = 3, 64, 128
+        a = (torch.randn(N, H + 2, H + 2, C, device='cuda') * 0.5).to(bf)
+        wf = (torch.randn(K, 3, 3, C, device='cuda') * 0.2).to(bf)
+        bias = torch.zeros(K, device='cuda')
+        y = torch.empty(N, H, H, K, device='cuda', dtype=bf)
+        stats = torch.empty(N * H * H // 64, 2, K, device='cuda')
+        dy = (torch.randn(N, H, H, K, device='cuda') * 0.5).to(bf)
+        scratch = torch.zeros(K, 3, 3, C, device='cuda')
+        tf = timed(lambda: call('kp_conv_fwd', ptr(a), ptr(wf), ptr(bias), ptr(y), ptr(stats), N, H + 2, H + 2, C, K, 3,
+                                _lib.KP_BF16, st), args.reps)
+        tw = timed(lambda: call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, H, C, K, 3, 0, _lib.KP_BF16, st),
+                   args.reps)
+        gb = N * H * H * K * 2 / 1e9
+        print(f'first 3>64 @128: fwd {tf * 1e6:7.0f} us ({gb / tf:6.0f} GB/s written)   wgrad {tw * 1e6:7.0f} us '
+              f'({gb / tw:6.0f} GB/s read)   x4 fwd + x2 wgrad per step = {(4 * tf + 2 * tw) * 1e3:.2f} ms')
     for k, (f, t) in tot.items():
         print(f'total {k}: {t * 1e3:8.2f} ms/step-equivalent   {f / t / 1e12:7.0f} TFLOP/s')
 
