@@ -47,7 +47,10 @@ int kp_device_cus(void);
 
 /* Tuning switches for A/B measurements (not needed in normal use). */
 #define KP_CFG_CONV_PATCH 0   /* 1 (default): LDS-patch 3x3 kernel where eligible; 0: linear implicit-GEMM kernel */
+#define KP_CFG_DEBUG 1        /* ablation mask for kernel measurements (0 = normal operation) */
 int kp_config(int key, int value);
+#define KP_CFG_TRACE 2        /* device buffer of 512 int64: s_memtime stamps of workgroup 0 of the patch conv kernel */
+int kp_config_ptr(int key, void* value);
 
 /* ---- measurement (bench.py roofline leg; not used by the model code) ------- */
 #define KP_PROF_CONV_GENERIC 0   /* fp32-accumulate VALU implicit-GEMM conv (fwd + dgrad) */

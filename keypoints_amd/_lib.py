@@ -44,6 +44,7 @@ SIGNATURES = {
     'kp_adam_step': [_p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _f, _p],
     'kp_prof_enable': [_i],
     'kp_config': [_i, _i],
+    'kp_config_ptr': [_i, _p],
     'kp_prof_collect': [_i, _p, _p, _p],
 }
 PLAIN = {'kp_bn_ws_doubles': ([_i], _i), 'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}

@@ -14,6 +14,8 @@ int kp_conv_first_fwd(const void*, const void*, const float*, void*, float*, int
 int kp_conv_first_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 
 static thread_local char g_err[512] = "";
+long long* g_kp_trace = nullptr;   // kp_config_ptr(KP_CFG_TRACE, dev_ptr): s_memtime trace buffer (512 x i64) or NULL
+int g_kp_debug = 0;   // kp_config(KP_CFG_DEBUG, mask): kernel ablation switches for measurements
 
 void kp_set_error(const char* fmt, ...) {
     va_list ap;
@@ -68,6 +70,8 @@ static int use_mfma() {
     return v;
 }
 
+extern int g_kp_conv_patch;
+
 extern "C" {
 
 int kp_version(void) { return 100; }
@@ -80,10 +84,16 @@ int kp_device_cus(void) {
     return n;
 }
 
-extern int g_kp_conv_patch;
 int kp_config(int key, int value) {
     if (key == KP_CFG_CONV_PATCH) { g_kp_conv_patch = value ? 1 : 0; return KP_OK; }
+    if (key == KP_CFG_DEBUG) { g_kp_debug = value; return KP_OK; }
     kp_set_error("kp_config: unknown key %d", key);
+    return KP_E_ARG;
+}
+
+int kp_config_ptr(int key, void* value) {
+    if (key == KP_CFG_TRACE) { g_kp_trace = (long long*)value; return KP_OK; }
+    kp_set_error("kp_config_ptr: unknown key %d", key);
     return KP_E_ARG;
 }
 

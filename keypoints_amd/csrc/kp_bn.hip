@@ -35,10 +35,10 @@ template <> struct Vec<bf16_t, 8> {
     }
     static __device__ __forceinline__ void st(bf16_t* p, const float (&o)[8]) {
         uint4 v;
-        v.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-        v.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
-        v.z = (uint32_t)f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16);
-        v.w = (uint32_t)f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
+        v.x = pack_bf16x2(o[0], o[1]);
+        v.y = pack_bf16x2(o[2], o[3]);
+        v.z = pack_bf16x2(o[4], o[5]);
+        v.w = pack_bf16x2(o[6], o[7]);
         *reinterpret_cast<uint4*>(p) = v;
     }
 };

@@ -8,11 +8,14 @@
 typedef uint16_t bf16_t;   // raw bfloat16 bits
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                             // round to nearest even
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32), which hipcc
+// selects for __bf16 casts -- one instruction per PAIR instead of ~8 VALU ops per value.
+typedef __bf16 kp_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float kp_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const kp_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, kp_bf16x2));
 }
 
 template <typename T> __device__ __forceinline__ float ld(const T* p);
@@ -39,8 +42,8 @@ template <> __device__ __forceinline__ void st4<float>(float* p, const float (&o
 }
 template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (&o)[4]) {
     uint2 v;
-    v.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-    v.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+    v.x = pack_bf16x2(o[0], o[1]);
+    v.y = pack_bf16x2(o[2], o[3]);
     *reinterpret_cast<uint2*>(p) = v;
 }
 

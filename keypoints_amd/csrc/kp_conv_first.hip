@@ -98,10 +98,10 @@ __global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const bf16_t* __restric
             }
         }
         uint4 pk;
-        pk.x = (uint32_t)f2bf(acc[0]) | ((uint32_t)f2bf(acc[1]) << 16);
-        pk.y = (uint32_t)f2bf(acc[2]) | ((uint32_t)f2bf(acc[3]) << 16);
-        pk.z = (uint32_t)f2bf(acc[4]) | ((uint32_t)f2bf(acc[5]) << 16);
-        pk.w = (uint32_t)f2bf(acc[6]) | ((uint32_t)f2bf(acc[7]) << 16);
+        pk.x = pack_bf16x2(acc[0], acc[1]);
+        pk.y = pack_bf16x2(acc[2], acc[3]);
+        pk.z = pack_bf16x2(acc[4], acc[5]);
+        pk.w = pack_bf16x2(acc[6], acc[7]);
         const int ch = k0 >> 3;
         *reinterpret_cast<uint4*>(st + (size_t)lane * K * 2 + ((ch ^ (lane & (CP - 1))) << 4)) = pk;
     }

@@ -221,8 +221,8 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restric
                 }
                 if (ok) {
                     uint2 pk;
-                    pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                    pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
                     *reinterpret_cast<uint2*>(y + opix * K + kq) = pk;
                 }
             }

@@ -45,7 +45,8 @@ __device__ __forceinline__ void wait_vm_n(int n) {   // n is wave-uniform
         case 0: wait_vm<0>(); break;
         case 1: wait_vm<1>(); break;
         case 2: wait_vm<2>(); break;
-        default: wait_vm<3>(); break;
+        case 3: wait_vm<3>(); break;
+        default: wait_vm<4>(); break;
     }
 }
 
@@ -54,32 +55,37 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wav
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
-// halving butterfly: 16 per-lane values -> each lane ends with the sum over its 32-lane half of ONE value.
+// Halving butterfly: 16 per-lane values -> each lane ends with the sum over its 32-lane half of ONE value
+// (index returned in `reg`).  All exchanges are VALU cross-lane ops (v_permlane16_swap, DPP row_ror / half-mirror /
+// quad_perm) -- no ds_bpermute round trips through the LDS, whose latency used to dominate the epilogue.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float reduce16_over32(float (&v)[16], int lane, int& reg) {
     float a[8];
-    const bool b4 = lane & 16;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float keep = b4 ? v[i + 8] : v[i], send = b4 ? v[i] : v[i + 8];
-        a[i] = keep + __shfl_xor(send, 16, 64);
+    for (int i = 0; i < 8; ++i) {   // rows of 16 lanes: odd rows of v[i] <-> even rows of v[i+8]
+        // (inline asm: the builtin's second result comes back equal to the first with this hipcc; the s_nop covers
+        //  the VALU-write -> permlane-read hazard that the compiler does not pad inside asm)
+        float lo = v[i], hi = v[i + 8];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+        a[i] = lo + hi;
     }
+    const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
     float b[4];
-    const bool b3 = lane & 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i) {   // partner = lane ^ 8 (row_ror:8)
         const float keep = b3 ? a[i + 4] : a[i], send = b3 ? a[i] : a[i + 4];
-        b[i] = keep + __shfl_xor(send, 8, 64);
+        b[i] = keep + dpp_mov<0x128>(send);
     }
     float c[2];
-    const bool b2 = lane & 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i) {   // partner = lane ^ 7 (row_half_mirror): opposite bit 2
         const float keep = b2 ? b[i + 2] : b[i], send = b2 ? b[i] : b[i + 2];
-        c[i] = keep + __shfl_xor(send, 4, 64);
+        c[i] = keep + dpp_mov<0x141>(send);
     }
-    const bool b1 = lane & 2;
-    float d = (b1 ? c[1] : c[0]) + __shfl_xor(b1 ? c[0] : c[1], 2, 64);
-    d += __shfl_xor(d, 1, 64);
+    float d = (b1 ? c[1] : c[0]) + dpp_mov<0x4E>(b1 ? c[0] : c[1]);   // partner = lane ^ 2
+    d += dpp_mov<0xB1>(d);                                              // partner = lane ^ 1
     reg = (b4 ? 8 : 0) | (b3 ? 4 : 0) | (b2 ? 2 : 0) | (b1 ? 1 : 0);
     return d;
 }
@@ -89,9 +95,18 @@ struct PatchArgs {
     int Hib, Wib, ioff;   // input buffer rows / cols, offset of the tile domain's patch origin in it
     int Hob, Wob, ooff;   // output buffer rows / cols, offset of the tile domain in it
     int H, W;             // tile domain (multiples of 16)
-    int C, K, ktiles;
+    int C, K, ktiles, ntiles, dbg;
+    long long* trace;     // optional: s_memtime stamps of workgroup 0 / wave 0 (512 entries), measurement only
 };
 
+// Persistent workgroups: the (tile, 64-channel chunk, tap) steps of all tiles of a workgroup form ONE software
+// pipeline, so the HBM latency of a tile's first patch / weights and the epilogue stores of the previous tile
+// overlap.  Step t (8 or 16 MFMA per wave, reduction slices kk = 0..3 of 16 channels):
+//     MFMA kk=0,1 (fragments already in registers)  ||  ds_read fragments kk=2,3 of step t
+//     s_waitcnt vmcnt(#DMA issued after the previous barrier); s_barrier      <- weights of step t+1 landed
+//     issue DMA: weight tile of step t+3 -> ring slot t%3 (its last reader was the first half of step t),
+//                one slice of the next chunk's patch
+//     MFMA kk=2,3                                    ||  ds_read fragments kk=0,1 of step t+1
 template <int BN>
 __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     constexpr int WBYTES = BN * ROWB;
@@ -99,31 +114,45 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     constexpr int WN = BN / 2;            // channels per wave
     constexpr int TN = WN / 32;           // 32-channel MFMA tiles per wave
     constexpr int OFF_W = 2 * PBYTES, OFF_DUMMY = OFF_W + NWBUF * WBYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_DUMMY + 1024];
+    constexpr int OFF_BIAS = OFF_DUMMY + 1024;            // [8 waves][64] fp32: each wave's own output-channel biases
+    constexpr int OFF_TRACE = OFF_BIAS + NWAVE * 64 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_TRACE + 4096];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int C = A.C, K = A.K;
 
-    // XCD-aware tile order: consecutive tile ids (k-tile fastest) stay on one XCD so its L2 keeps the patch
-    int tile;
-    {
-        const int nwg = gridDim.x, b = blockIdx.x, q = nwg / 8, r = nwg % 8, xcd = b % 8, i = b / 8;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-    }
-    const int kt = tile % A.ktiles, pt = tile / A.ktiles;
+    // ---- persistent tile list: XCD x owns tile ids [x*Q, (x+1)*Q) (k-tile fastest), its workgroups take them
+    //      round-robin, so the workgroups of an XCD work on neighbouring tiles at the same time (L2 reuse)
+    const int per_xcd = gridDim.x >> 3, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int Q = (A.ntiles + 7) >> 3;
+    const int tile_hi = (xcd + 1) * Q < A.ntiles ? (xcd + 1) * Q : A.ntiles;
+    int tile = xcd * Q + jb;
+    if (tile >= tile_hi) return;
     const int tiles_x = A.W / TS, tiles_y = A.H / TS;
-    const int txi = pt % tiles_x, tyi = (pt / tiles_x) % tiles_y, n = pt / (tiles_x * tiles_y);
-    const int oy0 = tyi * TS, ox0 = txi * TS, k0 = kt * BN;
 
-    // ---- DMA descriptors and per-lane offsets -----------------------------------------------------------
-    const unsigned char* xbase = (const unsigned char*)A.x +
-        ((((long long)n * A.Hib + oy0 + A.ioff) * A.Wib) + ox0 + A.ioff) * (long long)C * 2;
-    const unsigned char* wbase = (const unsigned char*)A.w + (long long)k0 * 9 * C * 2;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, 0x7ffffffe, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, 0x7ffffffe, 0x00020000);
+    struct TileRef { int n, oy0, ox0, k0, pt; };
+    auto decode = [&](int id) {
+        TileRef t;
+        const int kt = id % A.ktiles;
+        t.pt = id / A.ktiles;
+        const int txi = t.pt % tiles_x, tyi = (t.pt / tiles_x) % tiles_y;
+        t.n = t.pt / (tiles_x * tiles_y);
+        t.oy0 = tyi * TS; t.ox0 = txi * TS; t.k0 = kt * BN;
+        return t;
+    };
+    auto x_rsrc = [&](const TileRef& t) {
+        const unsigned char* xbase = (const unsigned char*)A.x +
+            ((((long long)t.n * A.Hib + t.oy0 + A.ioff) * A.Wib) + t.ox0 + A.ioff) * (long long)C * 2;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, 0x7ffffffe, 0x00020000);
+    };
+    auto w_rsrc = [&](const TileRef& t) {
+        const unsigned char* wbase = (const unsigned char*)A.w + (long long)t.k0 * 9 * C * 2;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, 0x7ffffffe, 0x00020000);
+    };
 
+    // ---- per-lane DMA offsets (tile independent) --------------------------------------------------------
     const int lrow8 = lane >> 3, lslot = lane & 7;
     int pvoff[PSLICES];   // patch: instruction ii = j*8 + wave covers patch pixels ii*8 .. ii*8+7
 #pragma unroll
@@ -139,14 +168,13 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         const int row = (j * NWAVE + wave) * 8 + lrow8;
         wvoff[j] = row * 9 * C * 2 + ((lslot ^ ((row >> 1) & 7)) << 4);
     }
-
-    auto issue_w = [&](int buf, int tap, int c0) {
+    auto issue_w = [&](const __amdgpu_buffer_rsrc_t& wr, int buf, int tap, int c0) {
         unsigned char* dst = smem + OFF_W + buf * WBYTES;
         const int soff = (tap * C + c0) * 2;
 #pragma unroll
         for (int j = 0; j < NWI; ++j) dma16(wr, dst + (j * NWAVE + wave) * 1024, wvoff[j], soff);
     };
-    auto issue_p = [&](int pbuf, int j, int c0) {   // j compile-time after unrolling
+    auto issue_p = [&](const __amdgpu_buffer_rsrc_t& xr, int pbuf, int j, int c0) {   // j compile-time
         const int ii = j * NWAVE + wave;
         unsigned char* dst = (ii < PINSTR) ? smem + pbuf * PBYTES + ii * 1024 : smem + OFF_DUMMY;
         dma16(xr, dst, pvoff[j], c0 * 2);
@@ -169,105 +197,224 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         ws16[a] = (fh ^ ((row >> 1) & 7)) << 4;
     }
 
+    struct Frag { bf16x8 x[2]; bf16x8 w[TN]; };
+    auto load_frag = [&](Frag& f, const unsigned char* xb, const unsigned char* wb, int s, int kk) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) f.x[b] = *(const bf16x8*)(xb + xoff[b] + (xs16[s] ^ (kk << 5)));
+#pragma unroll
+        for (int a = 0; a < TN; ++a) f.w[a] = *(const bf16x8*)(wb + woff[a] + (ws16[a] ^ (kk << 5)));
+    };
+
     f32x16 acc[TN][2];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int a = 0; a < TN; ++a)
+        for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[a], f.x[b], acc[a][b], 0, 0, 0);
+    };
 
-    const int nchunks = C / 64, T = nchunks * 9;
-
-    // ---- prologue: patch of chunk 0, weight tiles of steps 0 and 1 ------------------------------------------
+    // epilogue: D[k_out][pixel]; lane: pixel = fr of fragment b, k_out = 8*(reg>>2) + 4*fh + (reg&3).
+    // The wave's 32-pixel x WN-channel fragments go through a wave-private, XOR-swizzled staging tile in the
+    // patch buffer that the finished chunk no longer needs, and leave as 16-byte lanes over whole 128-byte
+    // (64-byte for BN = 64) runs per pixel: 8x fewer cache lines per store instruction than storing straight
+    // from the MFMA layout.
+    constexpr int CPP = WN / 8;            // 16-byte chunks per pixel (this wave's channels)
+    auto epilogue = [&](const TileRef& t, int free_pb) {
+        unsigned char* stg = smem + free_pb * PBYTES + wave * (32 * WN * 2);
+        const long long prow = (long long)t.pt * 4 + wm;   // statistics row of this wave (64 pixels)
+        float sm[TN][16], sq[TN][16];
 #pragma unroll
-    for (int j = 0; j < PSLICES; ++j) issue_p(0, j, 0);
-    issue_w(0, 0, 0);
-    issue_w(1, 1, 0);   // T >= 9
-    wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const unsigned char* pb = smem + (ch & 1) * PBYTES;
-        const int npb = (ch + 1) & 1;
-        const bool more_p = ch + 1 < nchunks;
+        for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int t = ch * 9 + tap;
-            // -- issue: weight tile of step t+2, one slice of the next chunk's patch
-            int issued = 0;
-            if (t + 2 < T) {
-                const int tap2 = (tap + 2) % 9;
-                const int c2 = (tap + 2 >= 9 ? ch + 1 : ch) * 64;
-                issue_w((tap + 2) % NWBUF, tap2, c2);
-                issued += NWI;
-            }
-            if (tap < PSLICES && more_p) {
-                issue_p(npb, tap, (ch + 1) * 64);
-                issued += 1;
-            }
-            // -- compute step t from patch pb (shift r,s) and weight buffer tap % 3
-            const int r = tap / 3, s = tap % 3;
-            const unsigned char* xb = pb + (r * PW + s) * ROWB;
-            const unsigned char* wb = smem + OFF_W + (tap % NWBUF) * WBYTES;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                bf16x8 xf[2], wf[TN];
-#pragma unroll
-                for (int b = 0; b < 2; ++b) xf[b] = *(const bf16x8*)(xb + xoff[b] + (xs16[s] ^ (kk << 5)));
-#pragma unroll
-                for (int a = 0; a < TN; ++a) wf[a] = *(const bf16x8*)(wb + woff[a] + (ws16[a] ^ (kk << 5)));
-#pragma unroll
-                for (int a = 0; a < TN; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
-            }
-            // -- everything older than this step's DMA has landed (weights of step t+1, earlier patch slices)
-            wait_vm_n(issued);
-            __builtin_amdgcn_s_barrier();
-        }
-    }
-
-    // ---- epilogue: D[k_out][pixel]; lane: pixel = fr of fragment b, k_out = 8*(reg>>2) + 4*fh + (reg&3)
-    const long long prow = (long long)pt * 4 + wm;   // statistics row of this wave (64 pixels)
-#pragma unroll
-    for (int a = 0; a < TN; ++a) {
-        const int kb = k0 + wn * WN + a * 32;
-        float sm[16], sq[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sm[i] = sq[i] = 0.f;
+            for (int i = 0; i < 16; ++i) sm[a][i] = sq[a][i] = 0.f;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int oy = oy0 + wm * 4 + b * 2 + (fr >> 4) + A.ooff, ox = ox0 + ftx + A.ooff;
-            bf16_t* yp = A.y + (((long long)n * A.Hob + oy) * A.Wob + ox) * K;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int kq = kb + 8 * g + 4 * fh;
-                float v[4];
+            for (int a = 0; a < TN; ++a) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[a][b][g * 4 + e] + (A.bias ? A.bias[kq + e] : 0.f);
-                    sm[g * 4 + e] += v[e];
-                    sq[g * 4 + e] += v[e] * v[e];
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bq = *reinterpret_cast<const float4*>(smem + OFF_BIAS + (wave * 64 + a * 32 + 8 * g + 4 * fh) * 4);
+                    const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[a][b][g * 4 + e] + bv[e];
+                        sm[a][g * 4 + e] += v[e];
+                        sq[a][g * 4 + e] += v[e] * v[e];
+                    }
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    const int chunk = a * 4 + g;
+                    *reinterpret_cast<uint2*>(stg + fr * (WN * 2) + ((chunk ^ (fr & (CPP - 1))) << 4) + fh * 8) = pk;
                 }
-                uint2 pk;
-                pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                *reinterpret_cast<uint2*>(yp + kq) = pk;
+            }
+            if (!(A.dbg & 1)) {
+#pragma unroll
+                for (int i = 0; i < 32 * CPP / 64; ++i) {
+                    const int id = i * 64 + lane, px = id / CPP, c16 = id % CPP;
+                    const uint4 vv = *reinterpret_cast<const uint4*>(stg + px * (WN * 2) + ((c16 ^ (px & (CPP - 1))) << 4));
+                    const int oy = t.oy0 + wm * 4 + b * 2 + (px >> 4) + A.ooff, ox = t.ox0 + (px & 15) + A.ooff;
+                    bf16_t* yp = A.y + (((long long)t.n * A.Hob + oy) * A.Wob + ox) * K + t.k0 + wn * WN + c16 * 8;
+                    *reinterpret_cast<uint4*>(yp) = vv;
+                }
             }
         }
-        if (A.partials) {
-            int r1, r2;
-            const float ts = reduce16_over32(sm, lane, r1);
-            const float tq = reduce16_over32(sq, lane, r2);
-            if ((lane & 1) == 0) {
-                const int k = kb + 8 * (r1 >> 2) + 4 * fh + (r1 & 3);
-                A.partials[(prow * 2 + 0) * K + k] = ts;
-                A.partials[(prow * 2 + 1) * K + k] = tq;
+        if (A.partials && !(A.dbg & 2)) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int kb = t.k0 + wn * WN + a * 32;
+                int r1, r2;
+                const float ts = reduce16_over32(sm[a], lane, r1);
+                const float tq = reduce16_over32(sq[a], lane, r2);
+                if ((lane & 1) == 0) {
+                    const int k = kb + 8 * (r1 >> 2) + 4 * fh + (r1 & 3);
+                    A.partials[(prow * 2 + 0) * K + k] = ts;
+                    A.partials[(prow * 2 + 1) * K + k] = tq;
+                }
             }
         }
+    };
+
+    const bool tracing = A.trace != nullptr && blockIdx.x == 0 && wave == 0;
+    int tri = 0;
+    auto stamp = [&]() {
+        if (tracing) {
+            const long long now = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && tri < 512) reinterpret_cast<long long*>(smem + OFF_TRACE)[tri] = now;
+            ++tri;
+        }
+    };
+    const int nchunks = C / 64;
+    TileRef cur = decode(tile);
+    __amdgpu_buffer_rsrc_t xr = x_rsrc(cur), wr = w_rsrc(cur);
+    // this wave's WN output-channel biases -> its private LDS slot (read back in the epilogue with lgkmcnt only,
+    // so the epilogue never waits on vmcnt behind its own stores)
+    auto load_bias = [&](const TileRef& t) {
+        if (lane < WN) {
+            const float bvl = A.bias ? A.bias[t.k0 + wn * WN + lane] : 0.f;
+            reinterpret_cast<float*>(smem + OFF_BIAS)[wave * 64 + lane] = bvl;
+        }
+    };
+    load_bias(cur);
+
+    // ---- prologue: patch of chunk 0, weight tiles of steps 0..2 of the first tile -------------------------
+#pragma unroll
+    for (int j = 0; j < PSLICES; ++j) issue_p(xr, 0, j, 0);
+    issue_w(wr, 0, 0, 0);
+    issue_w(wr, 1, 1, 0);
+    issue_w(wr, 2, 2, 0);
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    Frag f0, f1, f2, f3;
+    load_frag(f0, smem, smem + OFF_W, 0, 0);
+    load_frag(f1, smem, smem + OFF_W, 0, 1);
+    zero_acc();
+    int pend = 0;      // DMA instructions issued after the previous barrier (still allowed in flight at the next)
+    int pbi = 0;       // patch buffer of the current chunk
+    bool after_epi = false;
+
+    while (true) {
+        const int ntile_id = tile + per_xcd;
+        const bool has_next = ntile_id < tile_hi;
+        TileRef nxt = cur;
+        __amdgpu_buffer_rsrc_t xrn = xr, wrn = wr;
+        if (has_next) { nxt = decode(ntile_id); xrn = x_rsrc(nxt); wrn = w_rsrc(nxt); }
+
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const unsigned char* pb = smem + pbi * PBYTES;
+            const unsigned char* npb = smem + (pbi ^ 1) * PBYTES;
+            const bool last_ch = ch + 1 == nchunks;
+            const bool more_p = !last_ch || has_next;          // is there a "next chunk" to prefetch a patch for
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int r = tap / 3, s = tap % 3;
+                const unsigned char* xb = pb + (r * PW + s) * ROWB;
+                const unsigned char* wb = smem + OFF_W + (tap % NWBUF) * WBYTES;
+                constexpr int dummy_c = 0; (void)dummy_c;
+                const int ntap = (tap + 1) % 9, nr = ntap / 3, ns = ntap % 3;
+                const unsigned char* nxb = (tap == 8 ? npb : pb) + (nr * PW + ns) * ROWB;
+                const unsigned char* nwb = smem + OFF_W + ((tap + 1) % NWBUF) * WBYTES;
+
+                // -- first half: kk = 0,1 from registers; fetch kk = 2,3
+                mma(f0);
+                load_frag(f2, xb, wb, s, 2);
+                mma(f1);
+                load_frag(f3, xb, wb, s, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                stamp();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done reading ring slot tap%3
+                stamp();
+                // weights of step t+1 (+ older patch slices) landed; right after an epilogue everything older
+                // was already drained, and its stores must not be waited for here
+                if (!(tap == 0 && after_epi)) wait_vm_n(pend);
+                stamp();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                stamp();
+                __builtin_amdgcn_sched_barrier(0);
+
+                // -- second half: kk = 2 first (keeps the matrix pipe fed while the DMA instructions issue)
+                mma(f2);
+                __builtin_amdgcn_sched_barrier(0);
+                // -- issue: weight tile of step t+3 into the slot just released, one slice of the next patch.
+                //    The last step of a tile defers this until after the epilogue (see below).
+                pend = 0;
+                const bool defer = tap == 8 && last_ch;
+                if (!defer) {
+                    const int tap3 = (tap + 3) % 9;
+                    const bool wrap = tap + 3 >= 9;
+                    if (!wrap || !last_ch) {
+                        issue_w(wr, tap % NWBUF, tap3, (wrap ? ch + 1 : ch) * 64);
+                        pend += NWI;
+                    } else if (has_next) {
+                        issue_w(wrn, tap % NWBUF, tap3, 0);
+                        pend += NWI;
+                    }
+                }
+                if (tap < PSLICES && more_p) {
+                    if (!last_ch) issue_p(xr, pbi ^ 1, tap, (ch + 1) * 64);
+                    else issue_p(xrn, pbi ^ 1, tap, 0);
+                    pend += 1;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                load_frag(f0, nxb, nwb, ns, 0);
+                mma(f3);
+                load_frag(f1, nxb, nwb, ns, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            pbi ^= 1;
+            after_epi = false;
+        }
+        // tile switch: drain the DMA queue (everything in it was issued >= half a step ago), store the tile,
+        // then issue the weight tile that the last step deferred.  The next barrier does not wait (after_epi);
+        // the one after it retires these stores together with the DMA.
+        stamp();
+        wait_vm<0>();
+        stamp();
+        epilogue(cur, pbi ^ 1);   // pbi = buffer of the NEXT tile's first patch; the other one is free
+        stamp();
+        if (!has_next) break;
+        if (nxt.k0 != cur.k0) load_bias(nxt);   // read again only at the next epilogue (many barriers later)
+        issue_w(wrn, 8 % NWBUF, 2, 0);
+        pend = NWI;
+        after_epi = true;
+        zero_acc();
+        tile = ntile_id; cur = nxt; xr = xrn; wr = wrn;
     }
+    if (tracing && lane == 0)
+        for (int i = 0; i < 512; ++i) A.trace[i] = i < tri ? reinterpret_cast<long long*>(smem + OFF_TRACE)[i] : 0;
 }
 
 }  // namespace
@@ -285,15 +432,20 @@ int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* 
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.partials = stats;
     a.Hib = Hib; a.Wib = Wib; a.ioff = ioff; a.Hob = Hob; a.Wob = Wob; a.ooff = ooff; a.H = H; a.W = W;
     a.C = C; a.K = K;
+    { extern int g_kp_debug; extern long long* g_kp_trace; a.dbg = g_kp_debug; a.trace = g_kp_trace; }
     const long long ptiles = (long long)N * (H / TS) * (W / TS);
-    if (K % 128 == 0) {
-        a.ktiles = K / 128;
-        if (ptiles * a.ktiles > 0x7fffffffLL) return KP_E_UNSUPPORTED;
-        conv3x3_patch_k<128><<<(unsigned)(ptiles * a.ktiles), TPB, 0, st>>>(a);
-    } else {
-        a.ktiles = K / 64;
-        if (ptiles * a.ktiles > 0x7fffffffLL) return KP_E_UNSUPPORTED;
-        conv3x3_patch_k<64><<<(unsigned)(ptiles * a.ktiles), TPB, 0, st>>>(a);
-    }
+    const int bn = (K % 128 == 0) ? 128 : 64;
+    a.ktiles = K / bn;
+    if (ptiles * a.ktiles > 0x7fffffffLL) return KP_E_UNSUPPORTED;
+    a.ntiles = (int)(ptiles * a.ktiles);
+    static int cus = 0;
+    if (!cus) { cus = kp_device_cus(); if (cus <= 0) cus = 256; }
+    // one persistent workgroup per CU (134 KB of LDS each), a multiple of the 8 XCDs
+    int grid = (cus / 8) * 8;
+    if (grid < 8) grid = 8;
+    const int need = ((a.ntiles + 7) / 8) * 8;
+    if (grid > need) grid = need;
+    if (bn == 128) conv3x3_patch_k<128><<<grid, TPB, 0, st>>>(a);
+    else conv3x3_patch_k<64><<<grid, TPB, 0, st>>>(a);
     return kp_check_launch("conv3x3_patch");
 }
