@@ -59,6 +59,9 @@ def test_conv_fwd_mfma(N, Ho, Wo, C, K, with_stats):
 WG_SHAPES = [  # N, Ho, Wo, C, K, dy_pad
     (2, 16, 16, 64, 64, 2), (2, 8, 8, 128, 128, 2), (1, 32, 32, 64, 128, 0), (2, 16, 16, 128, 64, 2),
     (4, 16, 16, 256, 512, 2), (1, 128, 128, 64, 128, 2),
+    # tap-reuse kernel (kp_wgrad_patch.hip): (128 x 64) and (64 x 128) gradient blocks, odd split counts
+    (3, 32, 32, 128, 128, 2), (2, 16, 32, 128, 64, 2), (1, 64, 64, 256, 64, 0), (5, 16, 16, 64, 512, 2),
+    (2, 24, 48, 64, 128, 2),
 ]
 
 

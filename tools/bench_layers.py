@@ -84,6 +84,12 @@ def main():
             t[0] += nf * flops + nd * flops   # algorithmic (interior) flops
             t[1] += nf * tf + nd * td
         call('kp_config', 0, 1)
+        if args.ab:
+            call('kp_config', 3, 0)
+            tw0 = timed(lambda: call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, W, C, K, 3, 2, _lib.KP_BF16, st),
+                        args.reps)
+            cols.append(flops / tw0 / 1e12)
+            call('kp_config', 3, 1)
         tw = timed(lambda: call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, W, C, K, 3, 2, _lib.KP_BF16, st),
                    args.reps)
         t = tot.setdefault('wgrad', [0.0, 0.0])
