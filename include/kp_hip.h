@@ -50,6 +50,7 @@ int kp_device_cus(void);
 #define KP_CFG_DEBUG 1        /* ablation mask for kernel measurements (0 = normal operation) */
 int kp_config(int key, int value);
 #define KP_CFG_WGRAD_PATCH 3  /* 1 (default): tap-reuse weight-gradient kernel where eligible; 0: per-tap kernel */
+#define KP_CFG_BN_FAST 4      /* 1 (default): multi-row unrolled bf16 BatchNorm/activation kernels; 0: general kernels */
 #define KP_CFG_TRACE 2        /* device buffer of 512 int64: s_memtime stamps of workgroup 0 of the patch conv kernel */
 int kp_config_ptr(int key, void* value);
 

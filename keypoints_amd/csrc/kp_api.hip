@@ -17,6 +17,7 @@ int kp_conv_first_wgrad(const void*, const void*, float*, int, int, int, int, in
 static thread_local char g_err[512] = "";
 long long* g_kp_trace = nullptr;   // kp_config_ptr(KP_CFG_TRACE, dev_ptr): s_memtime trace buffer (512 x i64) or NULL
 int g_kp_wgrad_patch = 1;   // kp_config(KP_CFG_WGRAD_PATCH, v)
+int g_kp_bn_fast = 1;       // kp_config(KP_CFG_BN_FAST, v)
 int g_kp_debug = 0;   // kp_config(KP_CFG_DEBUG, mask): kernel ablation switches for measurements
 
 void kp_set_error(const char* fmt, ...) {
@@ -89,6 +90,7 @@ int kp_device_cus(void) {
 int kp_config(int key, int value) {
     if (key == KP_CFG_CONV_PATCH) { g_kp_conv_patch = value ? 1 : 0; return KP_OK; }
     if (key == KP_CFG_DEBUG) { g_kp_debug = value; return KP_OK; }
+    if (key == KP_CFG_BN_FAST) { g_kp_bn_fast = value ? 1 : 0; return KP_OK; }
     if (key == KP_CFG_WGRAD_PATCH) { g_kp_wgrad_patch = value ? 1 : 0; return KP_OK; }
     kp_set_error("kp_config: unknown key %d", key);
     return KP_E_ARG;

@@ -431,6 +431,12 @@ static int reduce_rows(const float* partials, double* ws, long long rows, int C2
     return kp_check_launch("reduce_rows");
 }
 
+int kp_bn_act_fwd_fast(const void*, const float*, const float*, const float*, const float*, float, int, void*, int, int,
+                       int, int, int, hipStream_t);
+int kp_bn_bwd_fast(int, const void*, int, int, const unsigned char*, const void*, const float*, const float*,
+                   const float*, const float*, float, float*, const float*, void*, int, int, int, int, int, hipStream_t);
+extern int g_kp_bn_fast;
+
 extern "C" {
 
 int kp_bn_ws_doubles(int C) { return RED_R * 2 * C; }
@@ -456,6 +462,10 @@ int kp_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
     BnP bn{mean, invstd, gamma, beta};
     const unsigned grid = (unsigned)((long long)N * (Ho + 2 * out_pad));
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == KP_BF16 && g_kp_bn_fast) {
+        int rc = kp_bn_act_fwd_fast(y, mean, invstd, gamma, beta, slope, tail, out, out_pad, N, H, W, C, st);
+        if (rc != KP_E_UNSUPPORTED) return rc;
+    }
     KP_BN_DISPATCH(dtype, C, (bn_act_fwd_k<T, V><<<grid, TPB, 0, st>>>((const T*)y, bn, slope, tail, (T*)out, out_pad, argmax, H, W, C)));
     return kp_check_launch("bn_act_fwd");
 }
@@ -468,6 +478,11 @@ int kp_bn_act_bwd_reduce(const void* gsrc, int gp, int tail, const unsigned char
     BnP bn{mean, invstd, gamma, beta};
     const unsigned grid = (unsigned)((long long)N * H);
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == KP_BF16 && g_kp_bn_fast) {
+        int rc = kp_bn_bwd_fast(0, gsrc, gp, tail, argmax, y, mean, invstd, gamma, beta, slope, partials, nullptr, nullptr,
+                                0, N, H, W, C, st);
+        if (rc != KP_E_UNSUPPORTED) return rc;
+    }
     KP_BN_DISPATCH(dtype, C, (bn_bwd_reduce_k<T, V><<<grid, TPB, (size_t)TPB * 2 * V * sizeof(float), st>>>((const T*)gsrc, gp, tail, argmax, (const T*)y, bn, slope, partials, H, W, C)));
     return kp_check_launch("bn_bwd_reduce");
 }
@@ -490,6 +505,11 @@ int kp_bn_act_bwd_apply(const void* gsrc, int gp, int tail, const unsigned char*
     BnP bn{mean, invstd, gamma, beta};
     const unsigned grid = (unsigned)((long long)N * (H + 2 * dp));
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == KP_BF16 && g_kp_bn_fast) {
+        int rc = kp_bn_bwd_fast(1, gsrc, gp, tail, argmax, y, mean, invstd, gamma, beta, slope, nullptr, sums, dy, dp, N,
+                                H, W, C, st);
+        if (rc != KP_E_UNSUPPORTED) return rc;
+    }
     KP_BN_DISPATCH(dtype, C, (bn_bwd_apply_k<T, V><<<grid, TPB, 0, st>>>((const T*)gsrc, gp, tail, argmax, (const T*)y, bn, slope, sums, (T*)dy, dp, N, H, W, C)));
     return kp_check_launch("bn_bwd_apply");
 }

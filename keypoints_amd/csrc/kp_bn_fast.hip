@@ -1,0 +1,295 @@
+// Fast bf16 paths of the BatchNorm(train) + activation passes (kp_bn.hip holds the general kernels and the
+// entry points; this file is their HBM-roofline version for the shapes the networks actually run).
+//
+// Same mapping idea as kp_bn.hip -- a thread owns ONE 16-byte channel vector (8 bf16) and walks pixels, so the
+// per-channel constants live in registers -- but shaped for bandwidth:
+//   * a workgroup takes several image rows (>= 16 vectors per thread), not one;
+//   * the pixel loop is unrolled by 4 with all loads issued before the first use (4-8 x 16 B in flight per lane);
+//   * tail / border-width are template parameters; the replicate-pad adjoint ("fold") of an incoming gradient
+//     is one unconditional centre load plus a rare edge path;
+//   * the backward reduction leaves ONE partial row per workgroup (the other rows of its range are zeroed),
+//     which also shortens the fp64 column reduction that follows.
+// Arithmetic is expression-for-expression the same as the general kernels (only the summation order of the
+// fold at image edges differs).
+#include "kp_common.h"
+
+namespace {
+
+constexpr int TPB = 256, V = 8, UNR = 4;
+
+struct BnP {
+    const float *mean, *invstd, *gamma, *beta;
+};
+
+struct BnC {
+    float mu[V], is[V], ga[V], be[V];
+    bool affine;
+    __device__ __forceinline__ void load(const BnP& b, int c) {
+        affine = b.mean != nullptr;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            mu[v] = affine ? b.mean[c + v] : 0.f;
+            is[v] = affine ? b.invstd[c + v] : 1.f;
+            ga[v] = affine ? b.gamma[c + v] : 1.f;
+            be[v] = affine ? b.beta[c + v] : 0.f;
+        }
+    }
+    __device__ __forceinline__ float z(float y, int v) const { return affine ? (y - mu[v]) * is[v] * ga[v] + be[v] : y; }
+    __device__ __forceinline__ float xhat(float y, int v) const { return (y - mu[v]) * is[v]; }
+};
+
+__device__ __forceinline__ void unpack8(const uint4 v, float (&o)[V]) {
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&o)[V]) {
+    uint4 v;
+    v.x = pack_bf16x2(o[0], o[1]); v.y = pack_bf16x2(o[2], o[3]);
+    v.z = pack_bf16x2(o[4], o[5]); v.w = pack_bf16x2(o[6], o[7]);
+    return v;
+}
+__device__ __forceinline__ uint4 ldv(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void stv(bf16_t* p, const uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- forward, tail none: out[n][i][j] = act(bn(y[n][clamp(i-p)][clamp(j-p)])) ------------------------------
+__global__ __launch_bounds__(TPB) void bn_act_fwd_none_fast_k(const bf16_t* __restrict__ y, BnP bn, float slope,
+                                                              bf16_t* __restrict__ out, int p, int H, int W, int C,
+                                                              long long total_rows, int rpb) {
+    const int CV = C / V, Hp = H + 2 * p, Wp = W + 2 * p;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
+    const int c = cv * V;
+    BnC k; k.load(bn, c);
+    const long long r0 = (long long)blockIdx.x * rpb;
+    for (int rr = 0; rr < rpb; ++rr) {
+        const long long row = r0 + rr;
+        if (row >= total_rows) break;
+        const long long n = row / Hp;
+        const int i = (int)(row - n * Hp);
+        const int oh = clampi(i - p, 0, H - 1);
+        const bf16_t* yr = y + ((n * H + oh) * W) * (long long)C + c;
+        bf16_t* orow = out + row * Wp * (long long)C + c;
+        for (int j0 = pl; j0 < Wp; j0 += UNR * npl) {
+            uint4 raw[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int j = j0 + u * npl;
+                if (j < Wp) raw[u] = ldv(yr + (long long)clampi(j - p, 0, W - 1) * C);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int j = j0 + u * npl;
+                if (j < Wp) {
+                    float v[V], res[V];
+                    unpack8(raw[u], v);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) res[e] = act_fwd(k.z(v[e], e), slope);
+                    stv(orow + (long long)j * C, pack8(res));
+                }
+            }
+        }
+    }
+}
+
+// ---- backward ---------------------------------------------------------------------------------------------
+// Incoming gradient for pre-tail pixel (h, w): TAIL none -> source pixel (h, w); TAIL pool -> source pixel
+// (h/2, w/2) taken only where argmax == position.  GP = 1: the source is a padded-domain gradient
+// [Hs+2][Ws+2] whose border ring folds onto the edge pixels.
+template <int GP>
+__device__ __forceinline__ const bf16_t* g_centre(const bf16_t* gsrc, long long n, int sh, int sw, int Hs, int Ws, int C) {
+    return gsrc + ((n * (Hs + 2 * GP) + sh + GP) * (Ws + 2 * GP) + sw + GP) * (long long)C;
+}
+// adds the ring neighbours of an edge pixel (everything in the fold range except the centre)
+__device__ __forceinline__ void g_edge_add(const bf16_t* gsrc, long long n, int sh, int sw, int Hs, int Ws, int C, int c,
+                                           float (&g)[V]) {
+    const int ilo = (sh == 0) ? 0 : sh + 1, ihi = (sh == Hs - 1) ? Hs + 1 : sh + 1;
+    const int jlo = (sw == 0) ? 0 : sw + 1, jhi = (sw == Ws - 1) ? Ws + 1 : sw + 1;
+    for (int i = ilo; i <= ihi; ++i)
+        for (int j = jlo; j <= jhi; ++j) {
+            if (i == sh + 1 && j == sw + 1) continue;
+            float v[V];
+            unpack8(ldv(gsrc + ((n * (Hs + 2) + i) * (Ws + 2) + j) * (long long)C + c), v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) g[e] += v[e];
+        }
+}
+// MODE 0: per-workgroup partial sums of (ghat, ghat*xhat).  MODE 1: dy = gamma*invstd*(ghat - db - xhat*dg).
+// Rows: MODE 0 iterates the N*H pre-tail rows; MODE 1 iterates the N*(H+2dp) output rows (border rows zeroed).
+template <int POOL, int GP, int MODE>
+__global__ __launch_bounds__(TPB) void bn_bwd_fast_k(const bf16_t* __restrict__ gsrc, const unsigned char* __restrict__ argmax,
+                                                     const bf16_t* __restrict__ y, BnP bn, float slope,
+                                                     float* __restrict__ partials, const float* __restrict__ sums,
+                                                     bf16_t* __restrict__ dy, int dp, int N, int H, int W, int C,
+                                                     long long total_rows, int rpb) {
+    const int CV = C / V;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
+    const int c = cv * V;
+    const int Hs = POOL ? H / 2 : H, Ws = POOL ? W / 2 : W;
+    const int Hp = H + 2 * dp, Wp = W + 2 * dp;
+    BnC k; k.load(bn, c);
+    float sb[V], sg[V], db[V], dg[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) sb[e] = sg[e] = db[e] = dg[e] = 0.f;
+    if (MODE == 1) {
+        const float invM = 1.0f / (float)((long long)N * H * W);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            db[e] = k.affine ? sums[c + e] * invM : 0.f;
+            dg[e] = k.affine ? sums[C + c + e] * invM : 0.f;
+        }
+    }
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    const long long r0 = (long long)blockIdx.x * rpb;
+    for (int rr = 0; rr < rpb; ++rr) {
+        const long long row = r0 + rr;
+        if (row >= total_rows) break;
+        long long n; int h;
+        bf16_t* drow = nullptr;
+        if (MODE == 1) {
+            n = row / Hp;
+            h = (int)(row - n * Hp) - dp;
+            drow = dy + row * Wp * (long long)C + c;
+            if (h < 0 || h >= H) {   // zero border row
+                for (int j = pl; j < Wp; j += npl) stv(drow + (long long)j * C, zero4);
+                continue;
+            }
+            for (int j = pl; j < dp; j += npl) {   // zero border columns
+                stv(drow + (long long)j * C, zero4);
+                stv(drow + (long long)(W + dp + j) * C, zero4);
+            }
+        } else {
+            n = row / H;
+            h = (int)(row - n * H);
+        }
+        const int sh = POOL ? (h >> 1) : h;
+        const bool hedge = GP && (sh == 0 || sh == Hs - 1);
+        const bf16_t* yr = y + ((n * H + h) * W) * (long long)C + c;
+        for (int w0 = pl; w0 < W; w0 += UNR * npl) {
+            uint4 graw[UNR], yraw[UNR];
+            uint2 amraw[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int w = w0 + u * npl;
+                if (w < W) {
+                    const int sw = POOL ? (w >> 1) : w;
+                    graw[u] = ldv(g_centre<GP>(gsrc, n, sh, sw, Hs, Ws, C) + c);
+                    yraw[u] = ldv(yr + (long long)w * C);
+                    if (POOL) amraw[u] = *reinterpret_cast<const uint2*>(argmax + ((n * Hs + sh) * Ws + sw) * (long long)C + c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int w = w0 + u * npl;
+                if (w < W) {
+                    const int sw = POOL ? (w >> 1) : w;
+                    float g[V], yv[V];
+                    unpack8(graw[u], g);
+                    unpack8(yraw[u], yv);
+                    if (GP && (hedge || sw == 0 || sw == Ws - 1)) g_edge_add(gsrc, n, sh, sw, Hs, Ws, C, c, g);
+                    if (POOL) {
+                        const unsigned pos = ((h & 1) << 1) | (w & 1);
+                        unsigned take = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            take |= (((amraw[u].x >> (8 * e)) & 0xffu) == pos) ? (1u << e) : 0u;
+                            take |= (((amraw[u].y >> (8 * e)) & 0xffu) == pos) ? (1u << (e + 4)) : 0u;
+                        }
+#pragma unroll
+                        for (int e = 0; e < V; ++e) if (!((take >> e) & 1u)) g[e] = 0.f;
+                    }
+                    if (MODE == 0) {
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            const float gh = g[e] * act_grad(k.z(yv[e], e), slope);
+                            sb[e] += gh;
+                            sg[e] += gh * k.xhat(yv[e], e);
+                        }
+                    } else {
+                        float res[V];
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            const float gh = g[e] * act_grad(k.z(yv[e], e), slope);
+                            res[e] = k.affine ? k.ga[e] * k.is[e] * (gh - db[e] - k.xhat(yv[e], e) * dg[e]) : gh;
+                        }
+                        stv(drow + (long long)(w + dp) * C, pack8(res));
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == 0) {
+        // workgroup reduction over the pixel lanes -> partial row r0; rows r0+1 .. r0+rpb-1 are zeroed
+        __shared__ float red[TPB * 2 * V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            red[(pl * CV + cv) * 2 * V + e] = sb[e];
+            red[(pl * CV + cv) * 2 * V + V + e] = sg[e];
+        }
+        __syncthreads();
+        if (pl == 0) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float a = 0.f, b = 0.f;
+                for (int r2 = 0; r2 < npl; ++r2) {
+                    a += red[(r2 * CV + cv) * 2 * V + e];
+                    b += red[(r2 * CV + cv) * 2 * V + V + e];
+                }
+                partials[(r0 * 2 + 0) * C + c + e] = a;
+                partials[(r0 * 2 + 1) * C + c + e] = b;
+            }
+        }
+        for (int rr = 1; rr < rpb && r0 + rr < total_rows; ++rr)
+            for (int i = threadIdx.x; i < 2 * C; i += TPB) partials[(r0 + rr) * 2 * C + i] = 0.f;
+    }
+}
+
+bool fast_shape(int C) { return C % V == 0 && (C / V) <= TPB && TPB % (C / V) == 0; }
+
+int rows_per_block(long long total_rows, int vec_per_row, int cus) {
+    // >= 16 vectors per thread, but keep >= ~4 workgroups per CU
+    int rpb = (16 * TPB + vec_per_row - 1) / vec_per_row;
+    if (rpb < 1) rpb = 1;
+    const long long max_rpb = total_rows / ((long long)cus * 4);
+    if (rpb > max_rpb) rpb = (int)(max_rpb > 1 ? max_rpb : 1);
+    return rpb;
+}
+
+}  // namespace
+
+int kp_bn_act_fwd_fast(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                       float slope, int tail, void* out, int out_pad, int N, int H, int W, int C, hipStream_t st) {
+    if (tail != KP_TAIL_NONE || !fast_shape(C)) return KP_E_UNSUPPORTED;
+    BnP bn{mean, invstd, gamma, beta};
+    const long long rows = (long long)N * (H + 2 * out_pad);
+    const int rpb = rows_per_block(rows, (W + 2 * out_pad) * (C / V), kp_device_cus());
+    const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
+    bn_act_fwd_none_fast_k<<<grid, TPB, 0, st>>>((const bf16_t*)y, bn, slope, (bf16_t*)out, out_pad, H, W, C, rows, rpb);
+    return kp_check_launch("bn_act_fwd_fast");
+}
+
+// mode 0: reduce (partials [N*H][2][C], fully written); mode 1: apply
+int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned char* argmax, const void* y,
+                   const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                   float* partials, const float* sums, void* dy, int dp, int N, int H, int W, int C, hipStream_t st) {
+    if (!(tail == KP_TAIL_NONE || tail == KP_TAIL_MAXPOOL2) || gp < 0 || gp > 1 || !fast_shape(C)) return KP_E_UNSUPPORTED;
+    if (tail == KP_TAIL_MAXPOOL2 && ((H | W) & 1)) return KP_E_UNSUPPORTED;
+    BnP bn{mean, invstd, gamma, beta};
+    const long long rows = mode ? (long long)N * (H + 2 * dp) : (long long)N * H;
+    const int rpb = rows_per_block(rows, W * (C / V), kp_device_cus());
+    const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
+    const int pool = tail == KP_TAIL_MAXPOOL2;
+#define KP_BWD(POOLv, GPv, MODEv)                                                                                    \
+    bn_bwd_fast_k<POOLv, GPv, MODEv><<<grid, TPB, 0, st>>>((const bf16_t*)gsrc, argmax, (const bf16_t*)y, bn, slope,  \
+                                                           partials, sums, (bf16_t*)dy, dp, N, H, W, C, rows, rpb)
+    if (mode == 0) {
+        if (pool) { if (gp) KP_BWD(1, 1, 0); else KP_BWD(1, 0, 0); }
+        else { if (gp) KP_BWD(0, 1, 0); else KP_BWD(0, 0, 0); }
+    } else {
+        if (pool) { if (gp) KP_BWD(1, 1, 1); else KP_BWD(1, 0, 1); }
+        else { if (gp) KP_BWD(0, 1, 1); else KP_BWD(0, 0, 1); }
+    }
+#undef KP_BWD
+    return kp_check_launch("bn_bwd_fast");
+}
