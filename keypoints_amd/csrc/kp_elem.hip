@@ -234,6 +234,10 @@ __global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float
         else { using T = bf16_t; __VA_ARGS__; }        \
     } while (0)
 
+int kp_head_fwd_fast(const void*, const float*, const float*, float, float*, long long, int, int, int, hipStream_t);
+int kp_head_dx_fast(const float*, const float*, const float*, float, void*, long long, int, int, int, hipStream_t);
+int kp_head_dw_fast(const float*, const float*, const void*, float, float*, float*, long long, int, int, int, hipStream_t);
+
 extern "C" {
 
 int kp_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int pad, int dtype, void* stream) {
@@ -269,6 +273,10 @@ int kp_head_fwd(const void* x, const float* w, const float* bias, float slope, f
     KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "kp_head_fwd: bad dims");
     KP_REQUIRE(C <= 2048, "kp_head_fwd: C too large for the LDS tile");
     const long long M = (long long)N * H * W;
+    if (dtype == KP_BF16) {
+        int rc = kp_head_fwd_fast(x, w, bias, slope, out, M, H * W, C, K, (hipStream_t)stream);
+        if (rc != KP_E_UNSUPPORTED) return rc;
+    }
     const size_t smem = (size_t)HPB * (C + 1) * sizeof(float);
     DISPATCH_T(dtype, head_fwd_k<T><<<cdiv(M, HPB), TPB, smem, (hipStream_t)stream>>>((const T*)x, w, bias, slope, out, M, H * W, C, K));
     return kp_check_launch("head_fwd");
@@ -280,6 +288,16 @@ int kp_head_bwd(const float* gout, const float* out, const void* x, const float*
     KP_REQUIRE(K <= 256 && C <= 2048, "kp_head_bwd: K <= 256, C <= 2048 supported");
     const long long M = (long long)N * H * W;
     hipStream_t st = (hipStream_t)stream;
+    if (dx && dtype == KP_BF16) {
+        int rc = kp_head_dx_fast(gout, out, w, slope, dx, M, H * W, C, K, st);
+        if (rc == KP_OK) dx = nullptr;
+        else if (rc != KP_E_UNSUPPORTED) return rc;
+    }
+    if (dw && dtype == KP_BF16) {
+        int rc = kp_head_dw_fast(gout, out, x, slope, dw, db, M, H * W, C, K, st);
+        if (rc == KP_OK) dw = nullptr;
+        else if (rc != KP_E_UNSUPPORTED) return rc;
+    }
     if (dx) {
         const size_t smem = (size_t)HPB * (K + 1) * sizeof(float);
         DISPATCH_T(dtype, head_bwd_dx_k<T><<<cdiv(M, HPB), TPB, smem, st>>>(gout, out, w, slope, (T*)dx, M, H * W, C, K));

@@ -1,0 +1,199 @@
+// Fast bf16 paths of the 1x1 head (out_block = Conv2d(core_out, out, 1) + LeakyReLU, knn.py:123-125) for a
+// SMALL number of output channels (K <= 16: the decoder's image channels, the keypoint net's K maps).
+// At the decoder head (C = 64 -> K = 3 over N*128*128 pixels) the op is a pure stream over the [pixels][C] bf16
+// activation (268 MB at 128 pairs), so all three kernels read / write it as 16-byte lanes on consecutive addresses:
+// a thread owns one 8-channel vector of a pixel; the C/8 lanes of a pixel are adjacent and combine by shuffles.
+//   fwd : out[n][k][hw] = act(bias[k] + sum_c x[m][c] w[k][c])                 (fp32 NCHW output)
+//   dx  : dx[m][c]      = sum_k dz[m][k] w[k][c],  dz = gout * act'(out)       (bf16 NHWC output)
+//   dw  : dw[k][c]     += sum_m dz[m][k] x[m][c];  db[k] += sum_m dz[m][k]     (fp32, atomics per workgroup)
+// kp_elem.hip keeps the general kernels (any K, fp32 storage) and the entry points.
+#include "kp_common.h"
+
+namespace {
+
+constexpr int TPB = 256, V = 8;
+
+__device__ __forceinline__ void unpack8(const uint4 v, float (&o)[V]) {
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+// KB = compile-time bound on K (4 or 16); CV = C/8 is a power of two <= 64 (checked by the launcher)
+template <int KB>
+__global__ __launch_bounds__(TPB) void head_fwd_small_k(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float slope,
+                                                        float* __restrict__ out, long long M, int HW, int C, int K,
+                                                        int ppb) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [K][C]
+    for (int i = threadIdx.x; i < K * C; i += TPB) wl[i] = w[i];
+    __syncthreads();
+    const int CV = C / V, cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
+    const long long m0 = (long long)blockIdx.x * ppb;
+    for (int i = pl; i < ppb; i += npl) {
+        const long long m = m0 + i;
+        if (m >= M) break;   // uniform within a pixel's lane group
+        float xv[V];
+        unpack8(*reinterpret_cast<const uint4*>(x + m * C + cv * V), xv);
+        float acc[KB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            acc[k] = 0.f;
+            if (k < K) {
+                const float4 w0 = *reinterpret_cast<const float4*>(wl + k * C + cv * V);
+                const float4 w1 = *reinterpret_cast<const float4*>(wl + k * C + cv * V + 4);
+                acc[k] = xv[0] * w0.x + xv[1] * w0.y + xv[2] * w0.z + xv[3] * w0.w + xv[4] * w1.x + xv[5] * w1.y +
+                         xv[6] * w1.z + xv[7] * w1.w;
+            }
+        }
+        for (int o = 1; o < CV; o <<= 1)
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                if (k < K) acc[k] += __shfl_xor(acc[k], o, 64);
+        if (cv == 0) {
+            const long long n = m / HW, hw = m - n * HW;
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                if (k < K) out[(n * K + k) * HW + hw] = act_fwd(acc[k] + (bias ? bias[k] : 0.f), slope);
+        }
+    }
+}
+
+template <int KB>
+__global__ __launch_bounds__(TPB) void head_dx_small_k(const float* __restrict__ gout, const float* __restrict__ out,
+                                                       const float* __restrict__ w, float slope,
+                                                       bf16_t* __restrict__ dx, long long M, int HW, int C, int K,
+                                                       int ppb) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [K][C]
+    for (int i = threadIdx.x; i < K * C; i += TPB) wl[i] = w[i];
+    __syncthreads();
+    const int CV = C / V, cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
+    const long long m0 = (long long)blockIdx.x * ppb;
+    for (int i = pl; i < ppb; i += npl) {
+        const long long m = m0 + i;
+        if (m >= M) break;
+        const long long n = m / HW, hw = m - n * HW;
+        float r[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) r[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            if (k < K) {
+                const long long idx = (n * K + k) * HW + hw;
+                const float dz = gout[idx] * act_grad(out[idx], slope);
+                const float4 w0 = *reinterpret_cast<const float4*>(wl + k * C + cv * V);
+                const float4 w1 = *reinterpret_cast<const float4*>(wl + k * C + cv * V + 4);
+                r[0] = fmaf(dz, w0.x, r[0]); r[1] = fmaf(dz, w0.y, r[1]); r[2] = fmaf(dz, w0.z, r[2]);
+                r[3] = fmaf(dz, w0.w, r[3]); r[4] = fmaf(dz, w1.x, r[4]); r[5] = fmaf(dz, w1.y, r[5]);
+                r[6] = fmaf(dz, w1.z, r[6]); r[7] = fmaf(dz, w1.w, r[7]);
+            }
+        }
+        uint4 pk;
+        pk.x = pack_bf16x2(r[0], r[1]); pk.y = pack_bf16x2(r[2], r[3]);
+        pk.z = pack_bf16x2(r[4], r[5]); pk.w = pack_bf16x2(r[6], r[7]);
+        *reinterpret_cast<uint4*>(dx + m * C + cv * V) = pk;
+    }
+}
+
+template <int KB>
+__global__ __launch_bounds__(TPB) void head_dw_small_k(const float* __restrict__ gout, const float* __restrict__ out,
+                                                       const bf16_t* __restrict__ x, float slope,
+                                                       float* __restrict__ dw, float* __restrict__ db, long long M,
+                                                       int HW, int C, int K, int ppb) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [npl][K][C] (+ [npl][K] for db)
+    const int CV = C / V, cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
+    float acc[KB][V], dbs[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        dbs[k] = 0.f;
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[k][e] = 0.f;
+    }
+    const long long m0 = (long long)blockIdx.x * ppb;
+    for (int i = pl; i < ppb; i += npl) {
+        const long long m = m0 + i;
+        if (m >= M) break;
+        const long long n = m / HW, hw = m - n * HW;
+        float xv[V];
+        unpack8(*reinterpret_cast<const uint4*>(x + m * C + cv * V), xv);
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            if (k < K) {
+                const long long idx = (n * K + k) * HW + hw;
+                const float dz = gout[idx] * act_grad(out[idx], slope);
+                dbs[k] += dz;
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[k][e] = fmaf(dz, xv[e], acc[k][e]);
+            }
+        }
+    }
+    float* rdb = red + (size_t)npl * K * C;
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        if (k < K) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) red[((size_t)pl * K + k) * C + cv * V + e] = acc[k][e];
+            if (cv == 0) rdb[pl * K + k] = dbs[k];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * C; i += TPB) {
+        float s = 0.f;
+        for (int r2 = 0; r2 < npl; ++r2) s += red[(size_t)r2 * K * C + i];
+        unsafeAtomicAdd(dw + i, s);
+    }
+    if (db && threadIdx.x < K) {
+        float s = 0.f;
+        for (int r2 = 0; r2 < npl; ++r2) s += rdb[r2 * K + threadIdx.x];
+        unsafeAtomicAdd(db + threadIdx.x, s);
+    }
+}
+
+bool small_shape(int C, int K) {
+    const int CV = C / V;
+    return C % V == 0 && CV >= 1 && CV <= 64 && (CV & (CV - 1)) == 0 && K >= 1 && K <= 16;
+}
+
+}  // namespace
+
+#define KP_HEAD_KB(K, CALL)                          \
+    do {                                             \
+        if ((K) <= 4) { constexpr int KB = 4; CALL; } \
+        else { constexpr int KB = 16; CALL; }        \
+    } while (0)
+
+int kp_head_fwd_fast(const void* x, const float* w, const float* bias, float slope, float* out, long long M, int HW,
+                     int C, int K, hipStream_t st) {
+    if (!small_shape(C, K)) return KP_E_UNSUPPORTED;
+    const int npl = TPB / (C / V), ppb = npl * 8;
+    const unsigned grid = (unsigned)((M + ppb - 1) / ppb);
+    const size_t lds = (size_t)K * C * sizeof(float);
+    KP_HEAD_KB(K, (head_fwd_small_k<KB><<<grid, TPB, lds, st>>>((const bf16_t*)x, w, bias, slope, out, M, HW, C, K, ppb)));
+    return kp_check_launch("head_fwd_fast");
+}
+
+int kp_head_dx_fast(const float* gout, const float* out, const float* w, float slope, void* dx, long long M, int HW,
+                    int C, int K, hipStream_t st) {
+    if (!small_shape(C, K)) return KP_E_UNSUPPORTED;
+    const int npl = TPB / (C / V), ppb = npl * 8;
+    const unsigned grid = (unsigned)((M + ppb - 1) / ppb);
+    const size_t lds = (size_t)K * C * sizeof(float);
+    KP_HEAD_KB(K, (head_dx_small_k<KB><<<grid, TPB, lds, st>>>(gout, out, w, slope, (bf16_t*)dx, M, HW, C, K, ppb)));
+    return kp_check_launch("head_dx_fast");
+}
+
+int kp_head_dw_fast(const float* gout, const float* out, const void* x, float slope, float* dw, float* db, long long M,
+                    int HW, int C, int K, hipStream_t st) {
+    if (!small_shape(C, K)) return KP_E_UNSUPPORTED;
+    const int npl = TPB / (C / V);
+    const size_t lds = ((size_t)npl * K * C + (size_t)npl * K) * sizeof(float);
+    if (lds > 64 * 1024) return KP_E_UNSUPPORTED;
+    // ~2048 workgroups, each a contiguous run of pixels
+    long long ppb = (M + 2047) / 2048;
+    if (ppb < npl) ppb = npl;
+    ppb = (ppb + npl - 1) / npl * npl;
+    const unsigned grid = (unsigned)((M + ppb - 1) / ppb);
+    KP_HEAD_KB(K, (head_dw_small_k<KB><<<grid, TPB, lds, st>>>(gout, out, (const bf16_t*)x, slope, dw, db, M, HW, C, K, (int)ppb)));
+    return kp_check_launch("head_dw_fast");
+}

@@ -122,3 +122,30 @@ def test_head_against_golden(golden, precision, tol):
     call('kp_head_bwd', ptr(gout), ptr(out), ptr(a), ptr(wt), 0.01, ptr(dxn), ptr(dw), ptr(db), N, H, W, C, K, code, st)
     assert relerr(dxn.float().permute(0, 3, 1, 2), z['head.dx']) < tol
     assert relerr(dw.view(K, C, 1, 1), z['head.dweight']) < tol and relerr(db, z['head.dbias']) < tol
+
+
+@pytest.mark.parametrize('N,H,W,C,K', [(2, 16, 16, 64, 3), (1, 8, 8, 512, 10), (3, 5, 7, 16, 1), (2, 32, 32, 128, 16)])
+def test_head_small_k_bf16(N, H, W, C, K):
+    """kp_head_fast.hip (bf16, K <= 16) against a torch fp32 computation on the same bf16-rounded activation."""
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    g = torch.Generator().manual_seed(N + H * 3 + C + K)
+    a = torch.randn(N, H, W, C, generator=g).bfloat16()
+    wt = torch.randn(K, C, generator=g) * C ** -0.5
+    b = torch.randn(K, generator=g)
+    gout = torch.randn(N, K, H, W, generator=g)
+    af = a.float().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    ref = torch.nn.functional.leaky_relu(torch.einsum('nhwc,kc->nkhw', af, wr) + br[None, :, None, None], 0.01)
+    ref.backward(gout)
+    st = stream_ptr()
+    ad, wd, bd, gd = a.cuda(), wt.cuda(), b.cuda(), gout.cuda()
+    out = torch.full((N, K, H, W), float('nan'), device='cuda')
+    call('kp_head_fwd', ptr(ad), ptr(wd), ptr(bd), 0.01, ptr(out), N, H, W, C, K, _lib.KP_BF16, st)
+    assert (out.cpu() - ref.detach()).abs().max().item() < 1e-4 * ref.abs().max().item() + 1e-5
+    dx = torch.full((N, H, W, C), float('nan'), device='cuda', dtype=torch.bfloat16)
+    dw = torch.zeros(K, C, device='cuda'); db = torch.zeros(K, device='cuda')
+    call('kp_head_bwd', ptr(gd), ptr(out), ptr(ad), ptr(wd), 0.01, ptr(dx), ptr(dw), ptr(db), N, H, W, C, K, _lib.KP_BF16, st)
+    assert relerr(dx.float(), af.grad.numpy()) < 1e-2
+    assert relerr(dw, wr.grad.numpy()) < 1e-4 and relerr(db, br.grad.numpy()) < 1e-4
