@@ -431,8 +431,8 @@ static int reduce_rows(const float* partials, double* ws, long long rows, int C2
     return kp_check_launch("reduce_rows");
 }
 
-int kp_bn_act_fwd_fast(const void*, const float*, const float*, const float*, const float*, float, int, void*, int, int,
-                       int, int, int, hipStream_t);
+int kp_bn_act_fwd_fast(const void*, const float*, const float*, const float*, const float*, float, int, void*, int,
+                       unsigned char*, int, int, int, int, hipStream_t);
 int kp_bn_bwd_fast(int, const void*, int, int, const unsigned char*, const void*, const float*, const float*,
                    const float*, const float*, float, float*, const float*, void*, int, int, int, int, int, hipStream_t);
 extern int g_kp_bn_fast;
@@ -463,7 +463,7 @@ int kp_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
     const unsigned grid = (unsigned)((long long)N * (Ho + 2 * out_pad));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == KP_BF16 && g_kp_bn_fast) {
-        int rc = kp_bn_act_fwd_fast(y, mean, invstd, gamma, beta, slope, tail, out, out_pad, N, H, W, C, st);
+        int rc = kp_bn_act_fwd_fast(y, mean, invstd, gamma, beta, slope, tail, out, out_pad, argmax, N, H, W, C, st);
         if (rc != KP_E_UNSUPPORTED) return rc;
     }
     KP_BN_DISPATCH(dtype, C, (bn_act_fwd_k<T, V><<<grid, TPB, 0, st>>>((const T*)y, bn, slope, tail, (T*)out, out_pad, argmax, H, W, C)));

@@ -93,6 +93,106 @@ __global__ __launch_bounds__(TPB) void bn_act_fwd_none_fast_k(const bf16_t* __re
     }
 }
 
+// torch's upsample_bilinear2d(align_corners=True) source index / lambda for output index o
+__device__ __forceinline__ void bilin(int o, int in_size, int out_size, int& i0, int& ip, float& l0, float& l1) {
+    const float scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+    const float r = scale * (float)o;
+    i0 = (int)r;
+    ip = (i0 < in_size - 1) ? 1 : 0;
+    l1 = r - (float)i0;
+    l0 = 1.f - l1;
+}
+
+// ---- forward with a 2x2 max-pool (TAIL 1) or bilinear x2 (TAIL 2) tail: 4 source vectors per output vector ----
+template <int TAIL>
+__global__ __launch_bounds__(TPB) void bn_act_fwd_tail_fast_k(const bf16_t* __restrict__ y, BnP bn, float slope,
+                                                              bf16_t* __restrict__ out, int p,
+                                                              unsigned char* __restrict__ argmax, int H, int W, int C,
+                                                              long long total_rows, int rpb) {
+    constexpr int U2 = 2;   // output pixels in flight per thread (8 loads)
+    const int Ho = TAIL == 1 ? H / 2 : 2 * H, Wo = TAIL == 1 ? W / 2 : 2 * W;
+    const int CV = C / V, Hp = Ho + 2 * p, Wp = Wo + 2 * p;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
+    const int c = cv * V;
+    BnC k; k.load(bn, c);
+    const long long r0 = (long long)blockIdx.x * rpb;
+    for (int rr = 0; rr < rpb; ++rr) {
+        const long long row = r0 + rr;
+        if (row >= total_rows) break;
+        const long long n = row / Hp;
+        const int i = (int)(row - n * Hp);
+        const int oh = clampi(i - p, 0, Ho - 1);
+        const bf16_t* yn = y + n * H * W * (long long)C + c;
+        bf16_t* orow = out + row * Wp * (long long)C + c;
+        const bf16_t *y0, *y1;
+        float lh0 = 0.f, lh1 = 0.f;
+        if (TAIL == 1) {
+            y0 = yn + (long long)(2 * oh) * W * C;
+            y1 = y0 + (long long)W * C;
+        } else {
+            int h0, hp;
+            bilin(oh, H, Ho, h0, hp, lh0, lh1);
+            y0 = yn + (long long)h0 * W * C;
+            y1 = y0 + (long long)hp * W * C;
+        }
+        for (int j0 = pl; j0 < Wp; j0 += U2 * npl) {
+            uint4 raw[U2][4];
+            float lw0[U2], lw1[U2];
+#pragma unroll
+            for (int u = 0; u < U2; ++u) {
+                const int j = j0 + u * npl;
+                if (j < Wp) {
+                    const int ow = clampi(j - p, 0, Wo - 1);
+                    int wa, wb;
+                    if (TAIL == 1) { wa = 2 * ow; wb = 2 * ow + 1; lw0[u] = lw1[u] = 0.f; }
+                    else { int w0, wp; bilin(ow, W, Wo, w0, wp, lw0[u], lw1[u]); wa = w0; wb = w0 + wp; }
+                    raw[u][0] = ldv(y0 + (long long)wa * C);
+                    raw[u][1] = ldv(y0 + (long long)wb * C);
+                    raw[u][2] = ldv(y1 + (long long)wa * C);
+                    raw[u][3] = ldv(y1 + (long long)wb * C);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U2; ++u) {
+                const int j = j0 + u * npl;
+                if (j < Wp) {
+                    float a[4][V], res[V];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v[V];
+                        unpack8(raw[u][q], v);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) a[q][e] = act_fwd(k.z(v[e], e), slope);
+                    }
+                    if (TAIL == 1) {
+                        int best[V];
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float aq = bf2f(f2bf(a[q][e]));   // compare at storage precision
+                                if (q == 0 || aq > res[e] || aq != aq) { res[e] = aq; best[e] = q; }
+                            }
+                        }
+                        const int ow = clampi(j - p, 0, Wo - 1);
+                        if (argmax && i - p == oh && j - p == ow) {
+                            uint2 pk;
+                            pk.x = best[0] | (best[1] << 8) | (best[2] << 16) | (best[3] << 24);
+                            pk.y = best[4] | (best[5] << 8) | (best[6] << 16) | (best[7] << 24);
+                            *reinterpret_cast<uint2*>(argmax + ((n * Ho + oh) * Wo + ow) * (long long)C + c) = pk;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < V; ++e)
+                            res[e] = lh0 * (lw0[u] * a[0][e] + lw1[u] * a[1][e]) + lh1 * (lw0[u] * a[2][e] + lw1[u] * a[3][e]);
+                    }
+                    stv(orow + (long long)j * C, pack8(res));
+                }
+            }
+        }
+    }
+}
+
 // ---- backward ---------------------------------------------------------------------------------------------
 // Incoming gradient for pre-tail pixel (h, w): TAIL none -> source pixel (h, w); TAIL pool -> source pixel
 // (h/2, w/2) taken only where argmax == position.  GP = 1: the source is a padded-domain gradient
@@ -259,13 +359,23 @@ int rows_per_block(long long total_rows, int vec_per_row, int cus) {
 }  // namespace
 
 int kp_bn_act_fwd_fast(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                       float slope, int tail, void* out, int out_pad, int N, int H, int W, int C, hipStream_t st) {
-    if (tail != KP_TAIL_NONE || !fast_shape(C)) return KP_E_UNSUPPORTED;
+                       float slope, int tail, void* out, int out_pad, unsigned char* argmax, int N, int H, int W, int C,
+                       hipStream_t st) {
+    if (!fast_shape(C)) return KP_E_UNSUPPORTED;
+    if (tail == KP_TAIL_MAXPOOL2 && ((H | W) & 1)) return KP_E_UNSUPPORTED;
     BnP bn{mean, invstd, gamma, beta};
-    const long long rows = (long long)N * (H + 2 * out_pad);
-    const int rpb = rows_per_block(rows, (W + 2 * out_pad) * (C / V), kp_device_cus());
+    const int Ho = tail == KP_TAIL_MAXPOOL2 ? H / 2 : (tail == KP_TAIL_UPSAMPLE2 ? 2 * H : H);
+    const int Wo = tail == KP_TAIL_MAXPOOL2 ? W / 2 : (tail == KP_TAIL_UPSAMPLE2 ? 2 * W : W);
+    const long long rows = (long long)N * (Ho + 2 * out_pad);
+    const int work = tail == KP_TAIL_NONE ? 1 : 3;   // 4 source vectors per output vector
+    const int rpb = rows_per_block(rows, (Wo + 2 * out_pad) * (C / V) * work, kp_device_cus());
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
-    bn_act_fwd_none_fast_k<<<grid, TPB, 0, st>>>((const bf16_t*)y, bn, slope, (bf16_t*)out, out_pad, H, W, C, rows, rpb);
+    if (tail == KP_TAIL_NONE)
+        bn_act_fwd_none_fast_k<<<grid, TPB, 0, st>>>((const bf16_t*)y, bn, slope, (bf16_t*)out, out_pad, H, W, C, rows, rpb);
+    else if (tail == KP_TAIL_MAXPOOL2)
+        bn_act_fwd_tail_fast_k<1><<<grid, TPB, 0, st>>>((const bf16_t*)y, bn, slope, (bf16_t*)out, out_pad, argmax, H, W, C, rows, rpb);
+    else
+        bn_act_fwd_tail_fast_k<2><<<grid, TPB, 0, st>>>((const bf16_t*)y, bn, slope, (bf16_t*)out, out_pad, nullptr, H, W, C, rows, rpb);
     return kp_check_launch("bn_act_fwd_fast");
 }
 

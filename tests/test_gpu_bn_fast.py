@@ -18,6 +18,33 @@ def _params(C, g):
 
 @pytest.mark.parametrize('N,H,W,C', SHAPES)
 @pytest.mark.parametrize('pad', [0, 1])
+@pytest.mark.parametrize('tail', ['pool', 'up'])
+def test_bn_act_fwd_tail_fast(N, H, W, C, pad, tail):
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    g = torch.Generator().manual_seed(N * 100 + C + pad + 5 * (tail == 'up'))
+    y = torch.randn(N, H, W, C, generator=g).bfloat16().cuda()
+    mean, invstd, gamma, beta = _params(C, g)
+    tcode = _lib.TAIL_MAXPOOL2 if tail == 'pool' else _lib.TAIL_UPSAMPLE2
+    Ho, Wo = (H // 2, W // 2) if tail == 'pool' else (2 * H, 2 * W)
+    res = []
+    for fast in (0, 1):
+        call('kp_config', 4, fast)
+        out = torch.full((N, Ho + 2 * pad, Wo + 2 * pad, C), float('nan'), device='cuda', dtype=torch.bfloat16)
+        am = torch.full((N, Ho, Wo, C), 9, device='cuda', dtype=torch.uint8) if tail == 'pool' else None
+        call('kp_bn_act_fwd', ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), 0.01, tcode, ptr(out), pad,
+             ptr(am), N, H, W, C, _lib.KP_BF16, stream_ptr())
+        res.append((out.float().cpu(), am.cpu() if am is not None else None))
+    call('kp_config', 4, 1)
+    assert torch.isfinite(res[1][0]).all()
+    assert torch.equal(res[0][0], res[1][0])
+    if tail == 'pool':
+        assert torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize('N,H,W,C', SHAPES)
+@pytest.mark.parametrize('pad', [0, 1])
 def test_bn_act_fwd_fast(N, H, W, C, pad):
     from keypoints_amd import _lib
     from keypoints_amd._lib import call, ptr
