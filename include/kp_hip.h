@@ -42,6 +42,10 @@ extern "C" {
 
 int kp_version(void);
 const char* kp_last_error(void);
+/* Number of leading rows of the partial-sum buffer that the most recent kp_conv_fwd (stats != NULL) or
+ * kp_bn_act_bwd_reduce call of this thread wrote.  Only those rows are defined; pass the value on to
+ * kp_bn_finalize / kp_bn_bwd_finalize.  It never exceeds the documented buffer size (ceil(N*Ho*Wo/64) and N*H rows). */
+long long kp_last_rows(void);
 /* number of CUs of the current device (for grid sizing by host code) */
 int kp_device_cus(void);
 
@@ -91,9 +95,10 @@ int kp_wgrad_unpack(const float* scratch, float* dw, int K, int C, int R, void* 
  * Forward of nn.Conv2d(k=3) after ReplicationPad2d (vgg.py:30-33, knn.py:115);
  * with x = zero-padded dy and w = the flipped/transposed pack it is the
  * data-gradient of the same layer.  If stats != NULL it receives the BatchNorm batch statistics
- * (vgg.py:35) as deterministic partial sums: one row per 64 output pixels,
- *   stats[row][0][k] = sum_{m in row} y[m][k],  stats[row][1][k] = sum y^2   (fp32, no atomics),
- * rows = ceil(N*Ho*Wo / 64); kp_bn_finalize reduces the rows in fp64. */
+ * (vgg.py:35) as deterministic partial sums over disjoint groups of output pixels,
+ *   stats[row][0][k] = sum_{m in row} y[m][k],  stats[row][1][k] = sum y^2   (fp32, no atomics).
+ * The buffer must hold ceil(N*Ho*Wo / 64) rows; kp_last_rows() tells how many the kernel used (the persistent
+ * MFMA kernel keeps running sums per workgroup and writes 4 rows per workgroup); kp_bn_finalize reduces them in fp64. */
 int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, float* stats,
                 int N, int Hi, int Wi, int C, int K, int R, int dtype, void* stream);
 /* Weight gradient: scratch[k][r][s][c] += sum_{n,p,q} dy[n][p][q][k] * x[n][p+r][q+s][c]
@@ -105,10 +110,11 @@ int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, 
 /* ---- BatchNorm(train) + activation (+ pool / upsample) ----------------- */
 /* fp64 workspace size (in doubles) needed by kp_bn_finalize / kp_bn_bwd_finalize for C channels. */
 int kp_bn_ws_doubles(int C);
-/* stats rows (from kp_conv_fwd) -> batch mean / 1/sqrt(var+eps); updates running stats with momentum
- * (unbiased var) like nn.BatchNorm2d in train mode.  count = N*H*W; rows = ceil(count/64).
- * Two-stage deterministic fp64 reduction through `ws` (kp_bn_ws_doubles(C) doubles). */
-int kp_bn_finalize(const float* stats, double* ws, float* save_mean, float* save_invstd, float* running_mean,
+/* stats rows (from kp_conv_fwd; rows = kp_last_rows()) -> batch mean / 1/sqrt(var+eps); updates running stats
+ * with momentum (unbiased var) like nn.BatchNorm2d in train mode.  count = N*H*W.
+ * Deterministic fp64 reduction (one fused launch for rows <= 128, else two-stage through `ws`,
+ * kp_bn_ws_doubles(C) doubles). */
+int kp_bn_finalize(const float* stats, long long rows, double* ws, float* save_mean, float* save_invstd, float* running_mean,
                    float* running_var, long long* num_batches_tracked, float momentum, float eps, long long count,
                    int C, void* stream);
 /* out = tail(act((y - mean) * invstd * gamma + beta)); act = LeakyReLU(slope) (slope 0 = ReLU).
@@ -119,8 +125,8 @@ int kp_bn_finalize(const float* stats, double* ws, float* save_mean, float* save
 int kp_bn_act_fwd(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                   float slope, int tail, void* out, int out_pad, unsigned char* argmax,
                   int N, int H, int W, int C, int dtype, void* stream);
-/* Backward, pass 1: per image row r = (n,h): partials[r][0][c] = sum_w g*act'(z), partials[r][1][c] =
- * sum_w g*act'(z)*xhat  (fp32 [N*H][2][C], fully written, no atomics).
+/* Backward, pass 1: partial sums over disjoint groups of pixels: partials[r][0][c] = sum g*act'(z),
+ * partials[r][1][c] = sum g*act'(z)*xhat  (fp32, buffer of [N*H][2][C], no atomics; kp_last_rows() rows are used).
  * The incoming gradient g w.r.t. the activation output of this layer is read through `gsrc`:
  *   tail none    : gsrc = [N][H+2gp][W+2gp][C] T, gp in {0,1}; gp=1 folds the border (adjoint of replicate pad)
  *   tail maxpool2: gsrc = [N][H/2+2gp][W/2+2gp][C] T routed through argmax

@@ -25,7 +25,7 @@ SIGNATURES = {
     'kp_wgrad_unpack': [_p, _p, _i, _i, _i, _p],
     'kp_conv_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'kp_conv_wgrad': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
-    'kp_bn_finalize': [_p, _p, _p, _p, _p, _p, _p, _f, _f, _ll, _i, _p],
+    'kp_bn_finalize': [_p, _ll, _p, _p, _p, _p, _p, _p, _f, _f, _ll, _i, _p],
     'kp_bn_act_fwd': [_p, _p, _p, _p, _p, _f, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p],
     'kp_bn_act_bwd_reduce': [_p, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p],
     'kp_bn_bwd_finalize': [_p, _p, _ll, _i, _p, _p, _p, _p],
@@ -47,7 +47,7 @@ SIGNATURES = {
     'kp_config_ptr': [_i, _p],
     'kp_prof_collect': [_i, _p, _p, _p],
 }
-PLAIN = {'kp_bn_ws_doubles': ([_i], _i), 'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
+PLAIN = {'kp_last_rows': ([], _ll), 'kp_bn_ws_doubles': ([_i], _i), 'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
 
 _lib = None
 
@@ -78,6 +78,11 @@ def call(name: str, *args):
     rc = getattr(lib(), name)(*args)
     if rc != 0:
         raise KpError(f'{name} failed ({rc}): {lib().kp_last_error().decode()}')
+
+
+def last_rows() -> int:
+    """Rows of the partial-sum buffer written by the latest kp_conv_fwd(stats) / kp_bn_act_bwd_reduce call."""
+    return int(lib().kp_last_rows())
 
 
 def ptr(t):

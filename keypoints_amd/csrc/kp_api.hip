@@ -15,6 +15,8 @@ int kp_conv_first_fwd(const void*, const void*, const float*, void*, float*, int
 int kp_conv_first_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 
 static thread_local char g_err[512] = "";
+static thread_local long long g_last_rows = 0;
+void kp_set_last_rows(long long r) { g_last_rows = r; }
 long long* g_kp_trace = nullptr;   // kp_config_ptr(KP_CFG_TRACE, dev_ptr): s_memtime trace buffer (512 x i64) or NULL
 int g_kp_wgrad_patch = 1;   // kp_config(KP_CFG_WGRAD_PATCH, v)
 int g_kp_bn_fast = 1;       // kp_config(KP_CFG_BN_FAST, v)
@@ -77,7 +79,8 @@ extern int g_kp_conv_patch;
 
 extern "C" {
 
-int kp_version(void) { return 100; }
+int kp_version(void) { return 101; }
+long long kp_last_rows(void) { return g_last_rows; }
 const char* kp_last_error(void) { return g_err; }
 
 int kp_device_cus(void) {
@@ -131,6 +134,7 @@ int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, float*
     KP_REQUIRE(dtype == KP_F32 || dtype == KP_BF16, "kp_conv_fwd: bad dtype %d", dtype);
     const double flops = 2.0 * N * (double)(Hi - R + 1) * (Wi - R + 1) * C * K * R * R;
     ProfScope ps(KP_PROF_CONV_GENERIC, flops, (hipStream_t)stream);
+    if (stats) kp_set_last_rows(((long long)N * (Hi - R + 1) * (Wi - R + 1) + 63) / 64);
     if (dtype == KP_BF16 && use_mfma()) {
         int rc = kp_conv_fwd_mfma(x, w, bias, y, stats, N, Hi, Wi, C, K, R, (hipStream_t)stream);
         if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_MFMA); return rc; }

@@ -138,6 +138,49 @@ __global__ void bn_bwd_finalize_k(const double* __restrict__ ws, float* __restri
     if (dgamma) dgamma[c] += (float)q;
 }
 
+// Single-launch variant for a moderate number of rows: one workgroup per 32 channels reduces its 64 columns
+// (sum | sumsq of each channel) over all rows in fp64 (4 row lanes, fixed order -> deterministic) and finalizes.
+// MODE 0: BatchNorm forward statistics; MODE 1: backward sums (dbeta | dgamma).
+template <int MODE>
+__global__ __launch_bounds__(TPB) void bn_reduce_finalize_k(const float* __restrict__ partials, long long rows, int C,
+                                                            float* __restrict__ o0, float* __restrict__ o1,
+                                                            float* __restrict__ r0p, float* __restrict__ r1p,
+                                                            long long* __restrict__ nbt, float momentum, float eps,
+                                                            long long count) {
+    const int cl = threadIdx.x & 31, which = (threadIdx.x >> 5) & 1, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0;
+    if (c < C) {
+        const float* col = partials + (long long)which * C + c;
+        for (long long r = rl; r < rows; r += 4) s += (double)col[r * 2 * C];
+    }
+    __shared__ double red[4][64];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (threadIdx.x < 32 && c < C) {
+        const double sum = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        const double sq = red[0][32 + cl] + red[1][32 + cl] + red[2][32 + cl] + red[3][32 + cl];
+        if (MODE == 0) {
+            const double mu = sum / (double)count;
+            double var = sq / (double)count - mu * mu;
+            if (var < 0.0) var = 0.0;
+            o0[c] = (float)mu;
+            o1[c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (r0p) r0p[c] = (1.f - momentum) * r0p[c] + momentum * (float)mu;
+            if (r1p) {
+                const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+                r1p[c] = (1.f - momentum) * r1p[c] + momentum * (float)unbiased;
+            }
+        } else {
+            o0[c] = (float)sum;        // sums[c]
+            o0[C + c] = (float)sq;     // sums[C + c]
+            if (r0p) r0p[c] += (float)sum;   // dbeta
+            if (r1p) r1p[c] += (float)sq;    // dgamma
+        }
+    }
+    if (MODE == 0 && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
 // ---- forward ----------------------------------------------------------------------------------------
 template <typename T, int V>
 __global__ __launch_bounds__(TPB) void bn_act_fwd_k(const T* __restrict__ y, BnP bn, float slope, int tail,
@@ -441,12 +484,17 @@ extern "C" {
 
 int kp_bn_ws_doubles(int C) { return RED_R * 2 * C; }
 
-int kp_bn_finalize(const float* stats, double* ws, float* save_mean, float* save_invstd, float* running_mean,
-                   float* running_var, long long* num_batches_tracked, float momentum, float eps, long long count,
-                   int C, void* stream) {
-    KP_REQUIRE(C > 0 && count > 0 && stats && ws, "kp_bn_finalize: bad args");
+int kp_bn_finalize(const float* stats, long long rows, double* ws, float* save_mean, float* save_invstd,
+                   float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                   long long count, int C, void* stream) {
+    KP_REQUIRE(C > 0 && count > 0 && rows > 0 && stats && ws, "kp_bn_finalize: bad args");
     hipStream_t st = (hipStream_t)stream;
-    int rc = reduce_rows(stats, ws, (count + 63) / 64, 2 * C, st);
+    if (rows <= 128) {
+        bn_reduce_finalize_k<0><<<cdiv(C, 32), TPB, 0, st>>>(stats, rows, C, save_mean, save_invstd, running_mean,
+                                                             running_var, num_batches_tracked, momentum, eps, count);
+        return kp_check_launch("bn_reduce_finalize");
+    }
+    int rc = reduce_rows(stats, ws, rows, 2 * C, st);
     if (rc) return rc;
     bn_finalize_k<<<cdiv(C, 128), 128, 0, st>>>(ws, save_mean, save_invstd, running_mean, running_var,
                                                 num_batches_tracked, momentum, eps, count, C);
@@ -483,6 +531,7 @@ int kp_bn_act_bwd_reduce(const void* gsrc, int gp, int tail, const unsigned char
                                 0, N, H, W, C, st);
         if (rc != KP_E_UNSUPPORTED) return rc;
     }
+    kp_set_last_rows((long long)N * H);
     KP_BN_DISPATCH(dtype, C, (bn_bwd_reduce_k<T, V><<<grid, TPB, (size_t)TPB * 2 * V * sizeof(float), st>>>((const T*)gsrc, gp, tail, argmax, (const T*)y, bn, slope, partials, H, W, C)));
     return kp_check_launch("bn_bwd_reduce");
 }
@@ -491,6 +540,11 @@ int kp_bn_bwd_finalize(const float* partials, double* ws, long long rows, int C,
                        float* dbeta, void* stream) {
     KP_REQUIRE(partials && ws && sums && rows > 0 && C > 0, "kp_bn_bwd_finalize: bad args");
     hipStream_t st = (hipStream_t)stream;
+    if (rows <= 128) {
+        bn_reduce_finalize_k<1><<<cdiv(C, 32), TPB, 0, st>>>(partials, rows, C, sums, nullptr, dbeta, dgamma, nullptr, 0.f,
+                                                             0.f, 1);
+        return kp_check_launch("bn_bwd_reduce_finalize");
+    }
     int rc = reduce_rows(partials, ws, rows, 2 * C, st);
     if (rc) return rc;
     bn_bwd_finalize_k<<<cdiv(C, 128), 128, 0, st>>>(ws, sums, dgamma, dbeta, C);

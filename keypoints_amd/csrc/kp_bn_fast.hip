@@ -7,7 +7,7 @@
 //   * the pixel loop is unrolled by 4 with all loads issued before the first use (4-8 x 16 B in flight per lane);
 //   * tail / border-width are template parameters; the replicate-pad adjoint ("fold") of an incoming gradient
 //     is one unconditional centre load plus a rare edge path;
-//   * the backward reduction leaves ONE partial row per workgroup (the other rows of its range are zeroed),
+//   * the backward reduction leaves ONE partial row per workgroup (kp_last_rows() = number of workgroups),
 //     which also shortens the fp64 column reduction that follows.
 // Arithmetic is expression-for-expression the same as the general kernels (only the summation order of the
 // fold at image edges differs).
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_fast_k(const bf16_t* __restrict__ 
         }
     }
     if (MODE == 0) {
-        // workgroup reduction over the pixel lanes -> partial row r0; rows r0+1 .. r0+rpb-1 are zeroed
+        // workgroup reduction over the pixel lanes -> partial row blockIdx.x (kp_last_rows() = grid size)
         __shared__ float red[TPB * 2 * V];
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -336,12 +336,10 @@ __global__ __launch_bounds__(TPB) void bn_bwd_fast_k(const bf16_t* __restrict__ 
                     a += red[(r2 * CV + cv) * 2 * V + e];
                     b += red[(r2 * CV + cv) * 2 * V + V + e];
                 }
-                partials[(r0 * 2 + 0) * C + c + e] = a;
-                partials[(r0 * 2 + 1) * C + c + e] = b;
+                partials[((long long)blockIdx.x * 2 + 0) * C + c + e] = a;
+                partials[((long long)blockIdx.x * 2 + 1) * C + c + e] = b;
             }
         }
-        for (int rr = 1; rr < rpb && r0 + rr < total_rows; ++rr)
-            for (int i = threadIdx.x; i < 2 * C; i += TPB) partials[(r0 + rr) * 2 * C + i] = 0.f;
     }
 }
 
@@ -390,6 +388,7 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
     const int rpb = rows_per_block(rows, W * (C / V), kp_device_cus());
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
     const int pool = tail == KP_TAIL_MAXPOOL2;
+    if (mode == 0) kp_set_last_rows(grid);
 #define KP_BWD(POOLv, GPv, MODEv)                                                                                    \
     bn_bwd_fast_k<POOLv, GPv, MODEv><<<grid, TPB, 0, st>>>((const bf16_t*)gsrc, argmax, (const bf16_t*)y, bn, slope,  \
                                                            partials, sums, (bf16_t*)dy, dp, N, H, W, C, rows, rpb)

@@ -77,6 +77,7 @@ __device__ __forceinline__ float ruler_at(int i, int n) {
 // ---- host side -------------------------------------------------------------
 void kp_set_error(const char* fmt, ...);
 int kp_check_launch(const char* what);
+void kp_set_last_rows(long long rows);   // see kp_last_rows() in kp_hip.h
 
 #define KP_REQUIRE(cond, ...)                 \
     do {                                      \

@@ -96,6 +96,7 @@ struct PatchArgs {
     int Hob, Wob, ooff;   // output buffer rows / cols, offset of the tile domain in it
     int H, W;             // tile domain (multiples of 16)
     int C, K, ktiles, ntiles, dbg;
+    int compact;          // 1: BN partial sums are accumulated per workgroup (rows = 4 * grid); 0: 4 rows per pixel tile
     long long* trace;     // optional: s_memtime stamps of workgroup 0 / wave 0 (512 entries), measurement only
 };
 
@@ -129,6 +130,10 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     const int Q = (A.ntiles + 7) >> 3;
     const int tile_hi = (xcd + 1) * Q < A.ntiles ? (xcd + 1) * Q : A.ntiles;
     int tile = xcd * Q + jb;
+    if (A.partials && A.compact) {   // this workgroup's 4 rows: zero everywhere, its own k-tile columns are set at the end
+        float* rowp = A.partials + (long long)blockIdx.x * 4 * 2 * K;
+        for (int i = tid; i < 4 * 2 * K; i += TPB) rowp[i] = 0.f;
+    }
     if (tile >= tile_hi) return;
     const int tiles_x = A.W / TS, tiles_y = A.H / TS;
 
@@ -228,6 +233,9 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     // (64-byte for BN = 64) runs per pixel: 8x fewer cache lines per store instruction than storing straight
     // from the MFMA layout.
     constexpr int CPP = WN / 8;            // 16-byte chunks per pixel (this wave's channels)
+    float st_acc[TN][2];                   // running BN partial sums of this lane's channel (compact mode)
+#pragma unroll
+    for (int a = 0; a < TN; ++a) st_acc[a][0] = st_acc[a][1] = 0.f;
     auto epilogue = [&](const TileRef& t, int free_pb) {
         unsigned char* stg = smem + free_pb * PBYTES + wave * (32 * WN * 2);
         const long long prow = (long long)t.pt * 4 + wm;   // statistics row of this wave (64 pixels)
@@ -276,7 +284,10 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                 int r1, r2;
                 const float ts = reduce16_over32(sm[a], lane, r1);
                 const float tq = reduce16_over32(sq[a], lane, r2);
-                if ((lane & 1) == 0) {
+                if (A.compact) {
+                    st_acc[a][0] += ts;
+                    st_acc[a][1] += tq;
+                } else if ((lane & 1) == 0) {
                     const int k = kb + 8 * (r1 >> 2) + 4 * fh + (r1 & 3);
                     A.partials[(prow * 2 + 0) * K + k] = ts;
                     A.partials[(prow * 2 + 1) * K + k] = tq;
@@ -413,6 +424,17 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         zero_acc();
         tile = ntile_id; cur = nxt; xr = xrn; wr = wrn;
     }
+    if (A.partials && A.compact && !(A.dbg & 2) && (lane & 1) == 0) {
+        // lane -> channel mapping of reduce16_over32: reg = lane bits 4..1
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int rg = ((lane & 16) ? 8 : 0) | ((lane & 8) ? 4 : 0) | ((lane & 4) ? 2 : 0) | ((lane & 2) ? 1 : 0);
+            const int k = cur.k0 + wn * WN + a * 32 + 8 * (rg >> 2) + 4 * fh + (rg & 3);
+            const long long prow = (long long)blockIdx.x * 4 + wm;
+            A.partials[(prow * 2 + 0) * K + k] = st_acc[a][0];
+            A.partials[(prow * 2 + 1) * K + k] = st_acc[a][1];
+        }
+    }
     if (tracing && lane == 0)
         for (int i = 0; i < 512; ++i) A.trace[i] = i < tri ? reinterpret_cast<long long*>(smem + OFF_TRACE)[i] : 0;
 }
@@ -445,6 +467,8 @@ int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* 
     if (grid < 8) grid = 8;
     const int need = ((a.ntiles + 7) / 8) * 8;
     if (grid > need) grid = need;
+    a.compact = (stats && ptiles >= grid && ((grid / 8) % a.ktiles) == 0) ? 1 : 0;
+    if (stats) kp_set_last_rows(a.compact ? (long long)grid * 4 : ptiles * 4);
     if (bn == 128) conv3x3_patch_k<128><<<grid, TPB, 0, st>>>(a);
     else conv3x3_patch_k<64><<<grid, TPB, 0, st>>>(a);
     return kp_check_launch("conv3x3_patch");

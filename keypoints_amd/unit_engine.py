@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import call, ptr
+from ._lib import call, last_rows, ptr
 from .runtime import f32c, precision_dtype, require_device, stream_ptr
 
 TAILS = {None: _lib.TAIL_NONE, 'M': _lib.TAIL_MAXPOOL2, 'U': _lib.TAIL_UPSAMPLE2}
@@ -143,7 +143,7 @@ class UnitFunction(torch.autograd.Function):
                     mom = 0.1 if bn.momentum is None else float(bn.momentum)
                     track = bn.track_running_stats and bn.running_mean is not None
                     ws = torch.empty(128 * K, device=dev, dtype=torch.float64)
-                    call('kp_bn_finalize', ptr(stats), ptr(ws), ptr(mean), ptr(invstd),
+                    call('kp_bn_finalize', ptr(stats), last_rows(), ptr(ws), ptr(mean), ptr(invstd),
                          ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
                          ptr(bn.num_batches_tracked) if track else None, mom, float(bn.eps), N * H * W, K, st)
                 else:
@@ -219,7 +219,7 @@ class UnitFunction(torch.autograd.Function):
                 dgam, dbet = None, (ptr(gv[id(conv.bias)]) if conv.bias is not None else None)
             sums = torch.empty(2 * K, device=dev, dtype=torch.float32)
             ws = torch.empty(128 * K, device=dev, dtype=torch.float64)
-            call('kp_bn_bwd_finalize', ptr(partials), ptr(ws), N * H, K, ptr(sums), dgam, dbet, st)
+            call('kp_bn_bwd_finalize', ptr(partials), ptr(ws), last_rows(), K, ptr(sums), dgam, dbet, st)
             need_dx = idx > 0 or need_x
             dp = 2 if need_dx else 0
             dy = torch.empty(N, H + 2 * dp, W + 2 * dp, K, device=dev, dtype=tdt)

@@ -85,7 +85,7 @@ def test_bn_bwd_fast(N, H, W, C, tail, gp):
         partials = torch.full((N * H, 2, C), float('nan'), device='cuda')
         call('kp_bn_act_bwd_reduce', ptr(gsrc), gp, tcode, ptr(argmax), ptr(y), ptr(mean), ptr(invstd), ptr(gamma),
              ptr(beta), 0.01, ptr(partials), N, H, W, C, _lib.KP_BF16, st)
-        tot = partials.double().sum(0).cpu()
+        tot = partials[:_lib.last_rows()].double().sum(0).cpu()
         sums = tot.float().reshape(-1).cuda()
         outs = []
         for dp in (0, 2):

@@ -49,7 +49,7 @@ def test_conv_fwd_mfma(N, Ho, Wo, C, K, with_stats):
     close = (got - ref.bfloat16().float()).abs() <= 2 ** -7 * ref.abs() + 1e-3
     assert close.float().mean().item() > 0.999
     if with_stats:
-        s = stats.double().sum(0).cpu()
+        s = stats[:_lib.last_rows()].double().sum(0).cpu()
         assert torch.isfinite(s).all()
         flat = ref.double().reshape(-1, K)
         assert (s[0] - flat.sum(0)).abs().max().item() <= 1e-3 * flat.abs().sum(0).max().item()
@@ -127,7 +127,7 @@ def test_conv_first_layer(N, Ho, Wo, C, K):
     assert torch.isfinite(got).all()
     close = (got - ref.bfloat16().float()).abs() <= 2 ** -7 * ref.abs() + 1e-3
     assert close.float().mean().item() > 0.9995
-    s = stats.double().sum(0).cpu()
+    s = stats[:_lib.last_rows()].double().sum(0).cpu()
     flat = ref.double().reshape(-1, K)
     assert (s[0] - flat.sum(0)).abs().max().item() <= 1e-4 * flat.abs().sum(0).max().item()
     assert (s[1] - (flat ** 2).sum(0)).abs().max().item() <= 1e-4 * (flat ** 2).sum(0).max().item()

@@ -47,7 +47,8 @@ def test_block_against_golden(golden, tag, cin, cout, tail, slope, precision, to
     rm = torch.zeros(K, device=dev); rv = torch.ones(K, device=dev)
     nbt = torch.zeros((), device=dev, dtype=torch.long)
     ws = torch.empty(128 * K, device=dev, dtype=torch.float64)
-    call('kp_bn_finalize', ptr(stats), ptr(ws), ptr(mean), ptr(invstd), ptr(rm), ptr(rv), ptr(nbt), 0.1, 1e-5, N * H * W, K, st)
+    from keypoints_amd._lib import last_rows
+    call('kp_bn_finalize', ptr(stats), last_rows(), ptr(ws), ptr(mean), ptr(invstd), ptr(rm), ptr(rv), ptr(nbt), 0.1, 1e-5, N * H * W, K, st)
     tcode = {None: 0, 'M': 1, 'U': 2}[tail]
     Ho, Wo = (H // 2, W // 2) if tail == 'M' else ((2 * H, 2 * W) if tail == 'U' else (H, W))
     out = torch.empty(N, Ho, Wo, K, device=dev, dtype=tdt)
@@ -78,7 +79,7 @@ def test_block_against_golden(golden, tag, cin, cout, tail, slope, precision, to
          slope, ptr(partials), N, H, W, K, code, st)
     dgamma = torch.zeros(K, device=dev); dbeta = torch.zeros(K, device=dev)
     sums = torch.empty(2 * K, device=dev)
-    call('kp_bn_bwd_finalize', ptr(partials), ptr(ws), N * H, K, ptr(sums), ptr(dgamma), ptr(dbeta), st)
+    call('kp_bn_bwd_finalize', ptr(partials), ptr(ws), last_rows(), K, ptr(sums), ptr(dgamma), ptr(dbeta), st)
     dy = torch.empty(N, H + 4, W + 4, K, device=dev, dtype=tdt)
     call('kp_bn_act_bwd_apply', ptr(g), 0, tcode_b, ptr(argmax), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
          slope, ptr(sums), ptr(dy), 2, N, H, W, K, code, st)
