@@ -101,6 +101,13 @@ int kp_wgrad_unpack(const float* scratch, float* dw, int K, int C, int R, void* 
  * MFMA kernel keeps running sums per workgroup and writes 4 rows per workgroup); kp_bn_finalize reduces them in fp64. */
 int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, float* stats,
                 int N, int Hi, int Wi, int C, int K, int R, int dtype, void* stream);
+/* Data-gradient of the same layer (autograd of vgg.py:30-33): gx[N][H+2][W+2][C] (gradient over the replicate-padded
+ * input domain; the consumer folds the border ring onto the edge pixels) from dy[N][H+4][W+4][K], which MUST carry
+ * a zero border of 2 pixels (as written by kp_bn_act_bwd_apply with dp = 2), and w_dgrad = the flipped/transposed
+ * pack [C][3][3][K] of kp_pack_weights.  Same result as kp_conv_fwd(dy, w_dgrad, NULL, gx, NULL, N, H+4, W+4, K, C, 3);
+ * knowing the zero border lets the border ring be computed with 3 taps per pixel. */
+int kp_conv_dgrad(const void* dy, const void* w_dgrad, void* gx, int N, int H, int W, int K, int C, int dtype,
+                  void* stream);
 /* Weight gradient: scratch[k][r][s][c] += sum_{n,p,q} dy[n][p][q][k] * x[n][p+r][q+s][c]
  * x: [N][Ho+R-1][Wo+R-1][C] T; dy: interior of [N][Ho+2*dy_pad][Wo+2*dy_pad][K] T;
  * scratch fp32 [K][R][R][C], zeroed by the caller (atomically accumulated). */

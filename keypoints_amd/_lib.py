@@ -24,6 +24,7 @@ SIGNATURES = {
     'kp_pack_weights': [_p, _p, _p, _i, _i, _i, _i, _p],
     'kp_wgrad_unpack': [_p, _p, _i, _i, _i, _p],
     'kp_conv_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    'kp_conv_dgrad': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'kp_conv_wgrad': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'kp_bn_finalize': [_p, _ll, _p, _p, _p, _p, _p, _p, _f, _f, _ll, _i, _p],
     'kp_bn_act_fwd': [_p, _p, _p, _p, _p, _f, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p],

@@ -10,6 +10,7 @@ int kp_conv_wgrad_generic(const void*, const void*, float*, int, int, int, int, 
 int kp_conv_fwd_mfma(const void*, const void*, const float*, void*, float*, int, int, int, int, int, int,
                      hipStream_t);   // bf16 only; returns KP_E_UNSUPPORTED when the shape is not eligible
 int kp_conv_wgrad_mfma(const void*, const void*, float*, int, int, int, int, int, int, int, hipStream_t);
+int kp_conv_dgrad_mfma(const void*, const void*, void*, int, int, int, int, int, hipStream_t);
 int kp_conv_wgrad_patch(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 int kp_conv_first_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
 int kp_conv_first_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
@@ -57,6 +58,11 @@ struct ProfScope {
         if (!on) return;
         r.family = family; r.flops = flops; r.e0 = prof_event(); r.e1 = prof_event();
         hipEventRecord(r.e0, st);
+    }
+    void cancel() {   // nothing was launched under this scope: give the events back
+        if (!on) return;
+        g_event_pool.push_back(r.e0); g_event_pool.push_back(r.e1);
+        on = false;
     }
     void done(int family) {
         if (!on) return;
@@ -146,6 +152,21 @@ int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, float*
     int rc = kp_conv_fwd_generic(x, w, bias, y, stats, N, Hi, Wi, C, K, R, dtype, (hipStream_t)stream);
     ps.done(KP_PROF_CONV_GENERIC);
     return rc;
+}
+
+int kp_conv_dgrad(const void* dy, const void* w_dgrad, void* gx, int N, int H, int W, int K, int C, int dtype,
+                  void* stream) {
+    KP_REQUIRE(dy && w_dgrad && gx, "kp_conv_dgrad: null pointer");
+    KP_REQUIRE(N > 0 && C > 0 && K > 0 && H > 0 && W > 0, "kp_conv_dgrad: bad dims");
+    KP_REQUIRE(dtype == KP_F32 || dtype == KP_BF16, "kp_conv_dgrad: bad dtype %d", dtype);
+    if (dtype == KP_BF16 && use_mfma()) {
+        const double flops = 2.0 * N * (double)H * W * C * K * 9;
+        ProfScope ps(KP_PROF_CONV_MFMA, flops, (hipStream_t)stream);
+        int rc = kp_conv_dgrad_mfma(dy, w_dgrad, gx, N, H, W, K, C, (hipStream_t)stream);
+        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_MFMA); return rc; }
+        ps.cancel();
+    }
+    return kp_conv_fwd(dy, w_dgrad, nullptr, gx, nullptr, N, H + 4, W + 4, K, C, 3, dtype, stream);
 }
 
 int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R, int dy_pad,

@@ -63,27 +63,34 @@ __device__ __forceinline__ float reduce16_over32(float (&v)[16], int lane, int& 
     return d;
 }
 
-// Output pixel m -> (image n, row p, col q).  RING = false: all Ho x Wo pixels in row-major order.
-// RING = true: only the 1-pixel border ring of the output (2*Wo + 2*(Ho-2) pixels per image): used for the
-// data-gradient, whose interior is computed by the LDS-patch kernel (kp_conv_patch.hip) in exact 16x16 tiles.
-template <bool RING>
-__device__ __forceinline__ void pix_decode(long long m, int Ho, int Wo, long long& n, int& p, int& q) {
-    if (!RING) {
+// Output pixel m -> (image n, row p, col q).
+// MODE 0: all Ho x Wo pixels in row-major order.
+// MODE 1: only the 1-pixel border ring of the output (2*Wo + 2*(Ho-2) pixels per image), all 9 taps: used for
+//         outputs that are a 16x16 multiple plus a ring (interior: LDS-patch kernel, kp_conv_patch.hip).
+// MODE 2: the same ring for the data-gradient, whose input (dy) is known to carry a ZERO border of 2: ring pixels
+//         are grouped by edge (grp 0 top row, 1 bottom row, 2 left column, 3 right column; m indexes within the
+//         group) and only the 3 taps that can touch non-zero input are computed.
+template <int MODE>
+__device__ __forceinline__ void pix_decode(long long m, int Ho, int Wo, int grp, long long& n, int& p, int& q) {
+    if (MODE == 0) {
         q = (int)(m % Wo);
         const long long t = m / Wo;
         p = (int)(t % Ho);
         n = t / Ho;
-    } else {
+    } else if (MODE == 1) {
         const int RP = 2 * Wo + 2 * (Ho - 2);
         n = m / RP;
         const int r = (int)(m % RP);
         if (r < Wo) { p = 0; q = r; }
         else if (r < 2 * Wo) { p = Ho - 1; q = r - Wo; }
         else { const int r2 = r - 2 * Wo; p = 1 + (r2 >> 1); q = (r2 & 1) ? Wo - 1 : 0; }
+    } else {
+        if (grp < 2) { n = m / Wo; q = (int)(m % Wo); p = grp ? Ho - 1 : 0; }
+        else { n = m / (Ho - 2); p = 1 + (int)(m % (Ho - 2)); q = (grp == 3) ? Wo - 1 : 0; }
     }
 }
 
-template <int BN, bool RING>
+template <int BN, int MODE>
 __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                          const float* __restrict__ bias, bf16_t* __restrict__ y,
                                                          float* __restrict__ partials, int N, int Hi, int Wi, int C,
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restric
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
     const int Ho = Hi - 2, Wo = Wi - 2;
-    const long long M = RING ? (long long)N * (2 * Wo + 2 * (Ho - 2)) : (long long)N * Ho * Wo;
+    long long M = MODE == 1 ? (long long)N * (2 * Wo + 2 * (Ho - 2)) : (long long)N * Ho * Wo;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -107,7 +114,18 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restric
         const int b = blockIdx.x, q = nwg / 8, r = nwg % 8, xcd = b % 8, i = b / 8;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
     }
-    const int mt = tile / ktiles, kt = tile % ktiles;
+    int mt = tile / ktiles;
+    const int kt = tile % ktiles;
+    int grp = 0;
+    if (MODE == 2) {   // m-tiles are laid out group after group; every group is padded to whole tiles
+        const long long s01 = (long long)N * Wo, s23 = (long long)N * (Ho - 2);
+        const int t01 = (int)((s01 + BM - 1) / BM), t23 = (int)((s23 + BM - 1) / BM);
+        if (mt < t01) { grp = 0; }
+        else if (mt < 2 * t01) { grp = 1; mt -= t01; }
+        else if (mt < 2 * t01 + t23) { grp = 2; mt -= 2 * t01; }
+        else { grp = 3; mt -= 2 * t01 + t23; }
+        M = grp < 2 ? s01 : s23;
+    }
     const long long m0 = (long long)mt * BM;
     const int k0 = kt * BN;
 
@@ -120,7 +138,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restric
         long long m = m0 + row;
         if (m >= M) m = M - 1;   // tail rows: load something valid, masked at the store
         long long n; int p, q;
-        pix_decode<RING>(m, Ho, Wo, n, p, q);
+        pix_decode<MODE>(m, Ho, Wo, grp, n, p, q);
         xsrc[j] = (const unsigned char*)x + (((n * Hi + p) * Wi + q) * (long long)C + swz(row, lslot) * 8) * 2;
     }
     const unsigned char* wsrc[WI];
@@ -130,9 +148,11 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restric
         wsrc[j] = (const unsigned char*)w + (((long long)(k0 + row) * 9) * C + swz(row, lslot) * 8) * 2;
     }
 
-    auto stage = [&](int buf, int tap, int c0) {
+    auto stage = [&](int buf, int tapj, int c0) {
         unsigned char* sx = smem + buf * STAGE;
         unsigned char* sw = sx + XBYTES;
+        // MODE 2: j-th live tap of this edge group: top (2,j), bottom (0,j), left (j,2), right (j,0)
+        const int tap = MODE != 2 ? tapj : (grp == 0 ? 6 + tapj : (grp == 1 ? tapj : (grp == 2 ? 3 * tapj + 2 : 3 * tapj)));
         const long long xo = (((long long)(tap / 3) * Wi + (tap % 3)) * C + c0) * 2;
         const long long wo = ((long long)tap * C + c0) * 2;
 #pragma unroll
@@ -161,7 +181,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restric
 #pragma unroll
     for (int a = 0; a < TN; ++a) wsw[a] = ((wn * WN + a * 32 + fr) >> 1) & 7;
 
-    const int csteps = C / BK, T = 9 * csteps;
+    const int csteps = C / BK, T = (MODE == 2 ? 3 : 9) * csteps;
     stage(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -205,9 +225,9 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restric
             const long long m = m0 + wm * 64 + b * 32 + fr;
             const bool ok = m < M;
             long long opix = m;
-            if (RING && ok) {
+            if (MODE != 0 && ok) {
                 long long n; int p, q;
-                pix_decode<true>(m, Ho, Wo, n, p, q);
+                pix_decode<MODE>(m, Ho, Wo, grp, n, p, q);
                 opix = (n * Ho + p) * Wo + q;
             }
 #pragma unroll
@@ -245,23 +265,30 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restric
 int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hib,
                          int Wib, int ioff, int Hob, int Wob, int ooff, int H, int W, int C, int K, hipStream_t st);
 
-template <bool RING>
+template <int MODE>
 static int launch_linear(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi,
                          int C, int K, hipStream_t st) {
     const int Ho = Hi - 2, Wo = Wi - 2;
-    const long long M = RING ? (long long)N * (2 * Wo + 2 * (Ho - 2)) : (long long)N * Ho * Wo;
-    const long long mtiles = (M + BM - 1) / BM;
+    long long M, mtiles;
+    if (MODE == 2) {
+        const long long s01 = (long long)N * Wo, s23 = (long long)N * (Ho - 2);
+        M = 2 * s01 + 2 * s23;
+        mtiles = 2 * ((s01 + BM - 1) / BM) + 2 * ((s23 + BM - 1) / BM);
+    } else {
+        M = MODE == 1 ? (long long)N * (2 * Wo + 2 * (Ho - 2)) : (long long)N * Ho * Wo;
+        mtiles = (M + BM - 1) / BM;
+    }
     // statistics rows are per 64 pixels: a half-empty last tile would leave the odd row unwritten
-    if (stats && (RING || (M % 64) != 0)) return KP_E_UNSUPPORTED;
+    if (stats && (MODE != 0 || (M % 64) != 0)) return KP_E_UNSUPPORTED;
     const int bn = (K % 128 == 0) ? 128 : 64;
     const int ktiles = K / bn;
     if (mtiles * ktiles > 0x7fffffffLL) return KP_E_UNSUPPORTED;
     const unsigned grid = (unsigned)(mtiles * ktiles);
     if (bn == 128)
-        conv3x3_mfma_k<128, RING><<<grid, TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, stats, N, Hi,
+        conv3x3_mfma_k<128, MODE><<<grid, TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, stats, N, Hi,
                                                        Wi, C, K, (int)mtiles, ktiles);
     else
-        conv3x3_mfma_k<64, RING><<<grid, TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, stats, N, Hi,
+        conv3x3_mfma_k<64, MODE><<<grid, TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, stats, N, Hi,
                                                       Wi, C, K, (int)mtiles, ktiles);
     return kp_check_launch("conv3x3_mfma");
 }
@@ -288,9 +315,19 @@ int kp_conv_fwd_mfma(const void* x, const void* w, const float* bias, void* y, f
             if (rc != KP_E_UNSUPPORTED) return rc;
         } else if (!stats && Ho > 2 && Wo > 2 && (Ho - 2) % 16 == 0 && (Wo - 2) % 16 == 0) {
             int rc = kp_conv_patch_launch(x, w, bias, y, nullptr, N, Hi, Wi, 1, Ho, Wo, 1, Ho - 2, Wo - 2, C, K, st);
-            if (rc == KP_OK) return launch_linear<true>(x, w, bias, y, nullptr, N, Hi, Wi, C, K, st);
+            if (rc == KP_OK) return launch_linear<1>(x, w, bias, y, nullptr, N, Hi, Wi, C, K, st);
             if (rc != KP_E_UNSUPPORTED) return rc;
         }
     }
-    return launch_linear<false>(x, w, bias, y, stats, N, Hi, Wi, C, K, st);
+    return launch_linear<0>(x, w, bias, y, stats, N, Hi, Wi, C, K, st);
+}
+
+// Data-gradient of a 3x3 layer: gx[N][H+2][W+2][C] = valid correlation of dy[N][H+4][W+4][K] with the flipped pack,
+// where dy is KNOWN to carry a zero border of 2 pixels (written by kp_bn_act_bwd_apply).  Interior by the LDS-patch
+// kernel, border ring with 3 taps per pixel.  KP_E_UNSUPPORTED -> the caller falls back to kp_conv_fwd semantics.
+int kp_conv_dgrad_mfma(const void* dy, const void* w, void* gx, int N, int H, int W, int K, int C, hipStream_t st) {
+    if (K % BK != 0 || C % 64 != 0 || H % 16 != 0 || W % 16 != 0 || H < 16 || W < 16 || !patch_mode()) return KP_E_UNSUPPORTED;
+    int rc = kp_conv_patch_launch(dy, w, nullptr, gx, nullptr, N, H + 4, W + 4, 1, H + 2, W + 2, 1, H, W, K, C, st);
+    if (rc != KP_OK) return rc;
+    return launch_linear<2>(dy, w, nullptr, gx, nullptr, N, H + 4, W + 4, K, C, st);
 }

@@ -20,6 +20,7 @@
 // MFMA operands are swapped ("A" = weights, "B" = pixels): a lane's accumulator registers hold 4 consecutive
 // output channels of one pixel -> packed 8-byte bf16 stores into the NHWC output.
 // BatchNorm batch statistics (vgg.py:35) fall out of the epilogue as per-64-pixel partial rows (no atomics).
+#include <type_traits>
 #include "kp_common.h"
 
 namespace {
@@ -38,6 +39,13 @@ constexpr int PBYTES = PINSTR * 1024;
 constexpr int PSLICES = (PINSTR + NWAVE - 1) / NWAVE;   // patch DMA instructions per wave per chunk (6)
 constexpr int ROWB = 128;               // bytes per LDS row (64 bf16)
 constexpr int NWBUF = 3;
+
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_vm_n(int n) {   // n is wave-uniform
@@ -332,7 +340,6 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     load_frag(f0, smem, smem + OFF_W, 0, 0);
     load_frag(f1, smem, smem + OFF_W, 0, 1);
     zero_acc();
-    int pend = 0;      // DMA instructions issued after the previous barrier (still allowed in flight at the next)
     int pbi = 0;       // patch buffer of the current chunk
     bool after_epi = false;
 
@@ -348,9 +355,9 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
             const unsigned char* npb = smem + (pbi ^ 1) * PBYTES;
             const bool last_ch = ch + 1 == nchunks;
             const bool more_p = !last_ch || has_next;          // is there a "next chunk" to prefetch a patch for
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int r = tap / 3, s = tap % 3;
+            static_for<0, 9>([&](auto tapc) {
+                constexpr int tap = decltype(tapc)::value;
+                constexpr int r = tap / 3, s = tap % 3;
                 const unsigned char* xb = pb + (r * PW + s) * ROWB;
                 const unsigned char* wb = smem + OFF_W + (tap % NWBUF) * WBYTES;
                 constexpr int dummy_c = 0; (void)dummy_c;
@@ -358,7 +365,8 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                 const unsigned char* nxb = (tap == 8 ? npb : pb) + (nr * PW + ns) * ROWB;
                 const unsigned char* nwb = smem + OFF_W + ((tap + 1) % NWBUF) * WBYTES;
 
-                // -- first half: kk = 0,1 from registers; fetch kk = 2,3
+                // -- first half: kk = 0,1 from registers, interleaved with the fragment reads of kk = 2,3
+                //    (issuing all 8 reads ahead of the MFMAs measured 4 % slower: longer barrier skew)
                 mma(f0);
                 load_frag(f2, xb, wb, s, 2);
                 mma(f1);
@@ -367,44 +375,45 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                 stamp();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done reading ring slot tap%3
                 stamp();
-                // weights of step t+1 (+ older patch slices) landed; right after an epilogue everything older
-                // was already drained, and its stores must not be waited for here
-                if (!(tap == 0 && after_epi)) wait_vm_n(pend);
+                // Everything issued before the previous barrier has landed (weights of step t+1, older patch
+                // slices): the DMA count after a barrier is a compile-time constant per tap (dummy targets keep it
+                // so).  Right after an epilogue everything older was already drained and its stores must not be
+                // waited for here.
+                if (!(tap == 0 && after_epi)) wait_vm<NWI + (((tap + 8) % 9) < PSLICES ? 1 : 0)>();
                 stamp();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 stamp();
                 __builtin_amdgcn_sched_barrier(0);
 
-                // -- second half: kk = 2 first (keeps the matrix pipe fed while the DMA instructions issue)
+                // -- second half: kk = 2 MFMAs first (keeps the matrix pipe fed while the DMA instructions issue)
                 mma(f2);
                 __builtin_amdgcn_sched_barrier(0);
-                // -- issue: weight tile of step t+3 into the slot just released, one slice of the next patch.
-                //    The last step of a tile defers this until after the epilogue (see below).
-                pend = 0;
-                const bool defer = tap == 8 && last_ch;
-                if (!defer) {
+                // weight tile of step t+3 into the ring slot just released (the last step of a tile defers it until
+                // after the epilogue), one slice of the next patch in taps 0..5; no-op cases go to a dummy LDS target
+                if (!(tap == 8 && last_ch)) {
                     const int tap3 = (tap + 3) % 9;
                     const bool wrap = tap + 3 >= 9;
-                    if (!wrap || !last_ch) {
-                        issue_w(wr, tap % NWBUF, tap3, (wrap ? ch + 1 : ch) * 64);
-                        pend += NWI;
-                    } else if (has_next) {
-                        issue_w(wrn, tap % NWBUF, tap3, 0);
-                        pend += NWI;
-                    }
+                    const bool to_next = wrap && last_ch;
+                    const bool real = !to_next || has_next;
+                    unsigned char* dst = real ? smem + OFF_W + (tap % NWBUF) * WBYTES : smem + OFF_DUMMY;
+                    const int cw = to_next ? 0 : (wrap ? ch + 1 : ch) * 64;
+                    const int soff = (tap3 * C + cw) * 2;
+#pragma unroll
+                    for (int j = 0; j < NWI; ++j)
+                        dma16(to_next ? wrn : wr, real ? dst + (j * NWAVE + wave) * 1024 : dst, wvoff[j], soff);
                 }
-                if (tap < PSLICES && more_p) {
-                    if (!last_ch) issue_p(xr, pbi ^ 1, tap, (ch + 1) * 64);
-                    else issue_p(xrn, pbi ^ 1, tap, 0);
-                    pend += 1;
+                if (tap < PSLICES) {
+                    const int ii = tap * NWAVE + wave;
+                    unsigned char* dst = (more_p && ii < PINSTR) ? smem + (pbi ^ 1) * PBYTES + ii * 1024 : smem + OFF_DUMMY;
+                    dma16(last_ch ? xrn : xr, dst, pvoff[tap], last_ch ? 0 : (ch + 1) * 128);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 load_frag(f0, nxb, nwb, ns, 0);
                 mma(f3);
                 load_frag(f1, nxb, nwb, ns, 1);
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
             pbi ^= 1;
             after_epi = false;
         }
@@ -419,7 +428,6 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         if (!has_next) break;
         if (nxt.k0 != cur.k0) load_bias(nxt);   // read again only at the next epilogue (many barriers later)
         issue_w(wrn, 8 % NWBUF, 2, 0);
-        pend = NWI;
         after_epi = true;
         zero_acc();
         tile = ntile_id; cur = nxt; xr = xrn; wr = wrn;

@@ -231,7 +231,7 @@ class UnitFunction(torch.autograd.Function):
             call('kp_wgrad_unpack', ptr(scratch), ptr(gv[id(conv.weight)]), K, C, 3, st)
             if need_dx:
                 gx = torch.empty(N, H + 2, W + 2, C, device=dev, dtype=tdt)
-                call('kp_conv_fwd', ptr(dy), ptr(sv['wd']), None, ptr(gx), None, N, H + 4, W + 4, K, C, 3, code, st)
+                call('kp_conv_dgrad', ptr(dy), ptr(sv['wd']), ptr(gx), N, H, W, K, C, code, st)
                 g, gp = gx, 1
             else:
                 g = None

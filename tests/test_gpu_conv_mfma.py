@@ -150,3 +150,25 @@ def test_conv_first_layer(N, Ho, Wo, C, K):
         gotw = scratch.double().cpu()
         assert ((gotw - wref).norm() / wref.norm()).item() < 1e-5
     call('kp_prof_enable', 0)
+
+
+@pytest.mark.parametrize('N,H,W,K,C', [(2, 16, 16, 64, 64), (3, 16, 32, 128, 256), (1, 64, 64, 128, 64),
+                                       (2, 32, 32, 512, 128), (130, 16, 16, 64, 128), (1, 8, 8, 64, 64)])
+def test_conv_dgrad(N, H, W, K, C):
+    """kp_conv_dgrad (LDS-patch interior + 3-tap border ring) == valid correlation of the zero-bordered dy."""
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    g = torch.Generator().manual_seed(N * 13 + H + K + C)
+    dy = torch.zeros(N, H + 4, W + 4, K, dtype=torch.bfloat16)
+    dy[:, 2:2 + H, 2:2 + W] = torch.randn(N, H, W, K, generator=g).bfloat16()
+    wd = (torch.randn(C, 3, 3, K, generator=g) * (2.0 / (9 * K)) ** 0.5).bfloat16()
+    ref = F.conv2d(dy.float().permute(0, 3, 1, 2), wd.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+    dyd, wdd = dy.cuda(), wd.cuda()
+    gx = torch.full((N, H + 2, W + 2, C), float('nan'), device='cuda', dtype=torch.bfloat16)
+    call('kp_conv_dgrad', ptr(dyd), ptr(wdd), ptr(gx), N, H, W, K, C, _lib.KP_BF16, stream_ptr())
+    got = gx.float().cpu()
+    assert torch.isfinite(got).all()
+    close = (got - ref.bfloat16().float()).abs() <= 2 ** -7 * ref.abs() + 1e-3
+    assert close.float().mean().item() > 0.999
+    assert (got - ref).abs().max().item() <= 1e-2 * ref.abs().max().item() + 1e-3
