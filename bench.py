@@ -148,9 +148,12 @@ def main():
     for fid, name in FAMILIES.items():
         ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
         _lib.call('kp_prof_collect', fid, ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(n))
+        by = ctypes.c_double()
+        _lib.call('kp_prof_bytes', fid, ctypes.addressof(by))
         if n.value:
             fam[name] = dict(ms_total=ms.value, launches=n.value, avg_us=1e3 * ms.value / n.value,
-                             tflops=fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0)
+                             tflops=fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0,
+                             flop_per_launch=fl.value / n.value, algorithmic_bytes_per_launch=by.value / n.value)
     _lib.call('kp_prof_enable', 0)
 
     if rank == 0:
@@ -161,8 +164,21 @@ def main():
         value = B * world / (elapsed / args.steps)
         dom = max(fam.items(), key=lambda kv: kv[1]['ms_total']) if fam else (None, None)
         peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
+        # HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the
+        # gfx950 correction + WRITE_SIZE), condensed by tools/pmc_summary.py into profiles/ -- not measurable from
+        # inside the process, so it is the committed per-launch figure of the last profiled build (or null).
+        traffic, pmc = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))['conv_patch_bf16_bn128']
+            traffic = pmc['hbm_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = dict(bound='mfma', kernel=dom[0], achieved=dom[1]['tflops'] if dom[1] else None, peak=peak,
-                        unit='TFLOP/s', frac=(dom[1]['tflops'] / peak) if dom[1] else None, traffic=None,
+                        unit='TFLOP/s', frac=(dom[1]['tflops'] / peak) if dom[1] else None, traffic=traffic,
+                        traffic_unit='HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_summary.json)',
+                        algorithmic_bytes=dom[1]['algorithmic_bytes_per_launch'] if dom[1] else None,
+                        pmc_mfma_util=pmc['mfma_util'] if pmc else None,
+                        pmc_effective_clock_ghz=pmc['effective_clock_ghz'] if pmc else None,
                         avg_launch_us=dom[1]['avg_us'] if dom[1] else None,
                         launches=dom[1]['launches'] if dom[1] else None,
                         step_tflops=value / world * flop_pair / 1e12, step_frac=value / world * flop_pair / 1e12 / peak,

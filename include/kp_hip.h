@@ -70,6 +70,8 @@ int kp_prof_enable(int on);
 /* Synchronise the recorded events of one kernel family and return summed time (ms), algorithmic
  * FLOPs and launch count since kp_prof_enable(1).  Host-synchronising. */
 int kp_prof_collect(int family, double* ms, double* flops, long long* launches);
+/* Summed algorithmic HBM bytes (operands + result, each counted once) of the recorded launches of a family. */
+int kp_prof_bytes(int family, double* bytes);
 
 /* ---- layout ------------------------------------------------------------ */
 /* NCHW fp32 -> NHWC T with a replicated border of `pad` pixels.

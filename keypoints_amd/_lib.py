@@ -47,6 +47,7 @@ SIGNATURES = {
     'kp_config': [_i, _i],
     'kp_config_ptr': [_i, _p],
     'kp_prof_collect': [_i, _p, _p, _p],
+    'kp_prof_bytes': [_i, _p],
 }
 PLAIN = {'kp_last_rows': ([], _ll), 'kp_bn_ws_doubles': ([_i], _i), 'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
 

@@ -43,7 +43,7 @@ int kp_check_launch(const char* what) {
 // HIP events are recorded on the launch stream right around the convolution kernels; kp_prof_collect()
 // synchronises them after the timed region and sums time and algorithmic FLOPs per kernel family.
 #include <vector>
-struct ProfRec { int family; double flops; hipEvent_t e0, e1; };
+struct ProfRec { int family; double flops, bytes; hipEvent_t e0, e1; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_event_pool;
@@ -54,9 +54,9 @@ static hipEvent_t prof_event() {
 }
 struct ProfScope {
     bool on; ProfRec r; hipStream_t st;
-    ProfScope(int family, double flops, hipStream_t s) : on(g_prof_on), st(s) {
+    ProfScope(int family, double flops, hipStream_t s, double bytes = 0.0) : on(g_prof_on), st(s) {
         if (!on) return;
-        r.family = family; r.flops = flops; r.e0 = prof_event(); r.e1 = prof_event();
+        r.family = family; r.flops = flops; r.bytes = bytes; r.e0 = prof_event(); r.e1 = prof_event();
         hipEventRecord(r.e0, st);
     }
     void cancel() {   // nothing was launched under this scope: give the events back
@@ -133,13 +133,23 @@ int kp_prof_collect(int family, double* ms, double* flops, long long* launches) 
     return KP_OK;
 }
 
+int kp_prof_bytes(int family, double* bytes) {
+    double b = 0.0;
+    for (auto& r : g_prof)
+        if (r.family == family) b += r.bytes;
+    if (bytes) *bytes = b;
+    return KP_OK;
+}
+
 int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C,
                 int K, int R, int dtype, void* stream) {
     KP_REQUIRE(x && w && y, "kp_conv_fwd: null pointer");
     KP_REQUIRE(N > 0 && C > 0 && K > 0 && (R == 1 || R == 3) && Hi >= R && Wi >= R, "kp_conv_fwd: bad dims N=%d Hi=%d Wi=%d C=%d K=%d R=%d", N, Hi, Wi, C, K, R);
     KP_REQUIRE(dtype == KP_F32 || dtype == KP_BF16, "kp_conv_fwd: bad dtype %d", dtype);
     const double flops = 2.0 * N * (double)(Hi - R + 1) * (Wi - R + 1) * C * K * R * R;
-    ProfScope ps(KP_PROF_CONV_GENERIC, flops, (hipStream_t)stream);
+    const double esz = dtype == KP_BF16 ? 2.0 : 4.0;   // algorithmic HBM bytes: input + output + weights, each once
+    const double bytes = esz * ((double)N * Hi * Wi * C + (double)N * (Hi - R + 1) * (Wi - R + 1) * K + (double)R * R * C * K);
+    ProfScope ps(KP_PROF_CONV_GENERIC, flops, (hipStream_t)stream, bytes);
     if (stats) kp_set_last_rows(((long long)N * (Hi - R + 1) * (Wi - R + 1) + 63) / 64);
     if (dtype == KP_BF16 && use_mfma()) {
         int rc = kp_conv_fwd_mfma(x, w, bias, y, stats, N, Hi, Wi, C, K, R, (hipStream_t)stream);
@@ -161,7 +171,8 @@ int kp_conv_dgrad(const void* dy, const void* w_dgrad, void* gx, int N, int H, i
     KP_REQUIRE(dtype == KP_F32 || dtype == KP_BF16, "kp_conv_dgrad: bad dtype %d", dtype);
     if (dtype == KP_BF16 && use_mfma()) {
         const double flops = 2.0 * N * (double)H * W * C * K * 9;
-        ProfScope ps(KP_PROF_CONV_MFMA, flops, (hipStream_t)stream);
+        const double bytes = 2.0 * ((double)N * (H + 4) * (W + 4) * K + (double)N * (H + 2) * (W + 2) * C + 9.0 * C * K);
+        ProfScope ps(KP_PROF_CONV_MFMA, flops, (hipStream_t)stream, bytes);
         int rc = kp_conv_dgrad_mfma(dy, w_dgrad, gx, N, H, W, K, C, (hipStream_t)stream);
         if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_MFMA); return rc; }
         ps.cancel();
@@ -175,7 +186,9 @@ int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, 
     KP_REQUIRE(N > 0 && C > 0 && K > 0 && (R == 1 || R == 3) && Ho > 0 && Wo > 0 && dy_pad >= 0, "kp_conv_wgrad: bad dims");
     KP_REQUIRE(dtype == KP_F32 || dtype == KP_BF16, "kp_conv_wgrad: bad dtype %d", dtype);
     const double flops = 2.0 * N * (double)Ho * Wo * C * K * R * R;
-    ProfScope ps(KP_PROF_WGRAD_GENERIC, flops, (hipStream_t)stream);
+    const double wesz = dtype == KP_BF16 ? 2.0 : 4.0;
+    const double wbytes = wesz * ((double)N * (Ho + R - 1) * (Wo + R - 1) * C + (double)N * Ho * Wo * K) + 4.0 * R * R * C * K;
+    ProfScope ps(KP_PROF_WGRAD_GENERIC, flops, (hipStream_t)stream, wbytes);
     if (dtype == KP_BF16 && use_mfma()) {
         int rc = (R == 3 && g_kp_wgrad_patch) ? kp_conv_wgrad_patch(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream)
                                               : KP_E_UNSUPPORTED;

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 --pmc runs of bench.py (gpurun_out/pmc_<COUNTER>/...) into profiles/<tag>_pmc_summary.json.
+
+Passes (each its own run, as MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE do not fit one pass):
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_FETCH_SIZE -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE ...
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE ...
+Corrections applied (guide, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the
+bytes of wide coalesced reads -> doubled.  GRBM_GUI_ACTIVE comes back summed over the 8 XCDs -> divided by 8.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+KERNELS = {'conv3x3_patch_k<128>': 'conv_patch_bf16_bn128', 'wgrad3x3_patch_k<128, 64>': 'wgrad_patch_bf16_128x64'}
+
+
+def load(name):
+    f = glob.glob(f'gpurun_out/pmc_{name}/*/*counter_collection.csv')[0]
+    return list(csv.DictReader(open(f)))
+
+
+def main(tag):
+    out = {}
+    rows = {n: load(n) for n in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES')}
+    for key, label in KERNELS.items():
+        acc = collections.defaultdict(lambda: [0.0, 0])
+        dur = [0.0, 0]
+        for n, rs in rows.items():
+            for r in rs:
+                if key in r['Kernel_Name']:
+                    a = acc[r['Counter_Name']]
+                    a[0] += float(r['Counter_Value']); a[1] += 1
+                    if n == 'FETCH_SIZE':
+                        dur[0] += int(r['End_Timestamp']) - int(r['Start_Timestamp']); dur[1] += 1
+        per = {c: v / n for c, (v, n) in acc.items()}
+        fetch_b = 2.0 * per['FETCH_SIZE'] * 1024.0
+        write_b = per['WRITE_SIZE'] * 1024.0
+        gui = per['GRBM_GUI_ACTIVE'] / 8.0
+        out[label] = dict(
+            launches_sampled=acc['FETCH_SIZE'][1],
+            avg_launch_us=dur[0] / dur[1] / 1e3,
+            hbm_read_bytes_per_launch=fetch_b, hbm_write_bytes_per_launch=write_b,
+            hbm_bytes_per_launch=fetch_b + write_b,
+            mfma_busy_cycles_per_launch=per['SQ_VALU_MFMA_BUSY_CYCLES'],
+            gpu_active_cycles_per_launch=gui,
+            mfma_util=per['SQ_VALU_MFMA_BUSY_CYCLES'] / (gui * 1024.0),
+            effective_clock_ghz=gui / (dur[0] / dur[1]),
+            lds_bank_conflict_frac=per['SQ_LDS_BANK_CONFLICT'] / per['SQ_LDS_IDX_ACTIVE'])
+    json.dump(out, open(f'profiles/{tag}_pmc_summary.json', 'w'), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1] if len(sys.argv) > 1 else 'r01')
