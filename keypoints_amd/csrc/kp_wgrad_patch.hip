@@ -13,6 +13,7 @@
 // transpose read ds_read_b64_tr_b16; 64-byte blocks of every LDS row are XOR-swizzled by the row index so the 4
 // rows of a transpose read hit 4 different bank groups for every tap shift.
 // Split over pixel blocks across workgroups; partial tiles are combined with hardware fp32 atomics.
+#include <type_traits>
 #include "kp_common.h"
 
 namespace {
@@ -28,6 +29,13 @@ constexpr int BH = 8, BW = 16;                 // pixel block
 constexpr int PH = BH + 2, PWC = BW + 2;       // input patch
 constexpr int PROWS = PH * PWC;                // 180 patch pixels
 
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, int voff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_wave_base, 16, voff, 0, 0, 0);
 }
@@ -35,16 +43,23 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wav
 template <int P>   // row pitch in bytes (128 or 256): swizzle of the 64-B block index by the LDS row
 __device__ __forceinline__ int blk_swz(int row) { return P == 256 ? (row & 3) : ((row >> 1) & 1); }
 
-// 8 consecutive LDS rows (pixels) prow..prow+7 of this lane's channel, as two 4-row transpose reads.
-// `prow` already includes the lane's (t16>>2) row and 8*h.
+// Transpose-read addressing.  A fragment = 8 consecutive LDS rows (pixels) R..R+7 of this lane's channel, read as two
+// 4-row ds_read_b64_tr_b16.  The lane's row is R + lrow (+4 for the second read) with R a compile-time constant
+// after unrolling; the XOR swizzle of the 64-byte block depends on the row only through (R mod 4) and lrow, so the
+// per-lane part is precomputed once for the 4 residues (tr_base) and R*P + 4*P*u folds into the instruction's
+// immediate offset: no address arithmetic next to the MFMAs.
 template <int P>
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int prow, int colbyte) {
+__device__ __forceinline__ int tr_base(int v, int lrow, int colbyte) {
+    const int row = v + lrow;
+    return lrow * P + ((((colbyte >> 6) ^ blk_swz<P>(row)) << 6) | (colbyte & 63));
+}
+template <int P, int R>
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, const int (&base)[4]) {
     bf16x8 r;
+    const unsigned char* a = tile + base[R & 3];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int row = prow + 4 * u;
-        const int off = row * P + ((((colbyte >> 6) ^ blk_swz<P>(row)) << 6) | (colbyte & 63));
-        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(tile + off));
+        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(a + (R + 4 * u) * P));
         r[4 * u + 0] = v[0]; r[4 * u + 1] = v[1]; r[4 * u + 2] = v[2]; r[4 * u + 3] = v[3];
     }
     return r;
@@ -53,7 +68,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int prow, i
 struct WgArgs {
     const bf16_t* x; const bf16_t* dy; float* scratch;
     int Ho, Wo, C, K, dy_pad;
-    int ctiles, ktiles, stages_per_split, total_stages, bx, by;
+    int ctiles, ktiles, stages_per_split, total_stages, bx, by, dbg;
 };
 
 template <int TK, int TC>
@@ -135,6 +150,9 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_patch_k(const WgArgs A) {
     const int lrow = 8 * h + (t16 >> 2);
     const int kcol = (wk * 32 + 16 * g16 + (t16 & 3) * 4) * 2;
     const int ccol = (wc * 32 + 16 * g16 + (t16 & 3) * 4) * 2;
+    int kbase[4], cbase[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { kbase[v] = tr_base<PK>(v, lrow, kcol); cbase[v] = tr_base<PC>(v, lrow, ccol); }
 
     stage(0, s_beg);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -148,20 +166,21 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_patch_k(const WgArgs A) {
         const unsigned char* sx = sd + DYB;
         // walk the 10 patch rows; patch row p meets output rows p, p-1, p-2 through taps r = 0, 1, 2
         bf16x8 a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0, a2 = a0;   // dY fragments of output rows p, p-1, p-2 (rotating)
-#pragma unroll
-        for (int p = 0; p < PH; ++p) {
+        static_for<0, PH>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
             a2 = a1; a1 = a0;
-            if (p < BH) a0 = tr_frag<PK>(sd, p * BW + lrow, kcol);
+            if constexpr (p < BH) a0 = tr_frag<PK, p * BW>(sd, kbase);
             bf16x8 b[3];
-#pragma unroll
-            for (int s = 0; s < 3; ++s) b[s] = tr_frag<PC>(sx, p * PWC + s + lrow, ccol);
+            b[0] = tr_frag<PC, p * PWC + 0>(sx, cbase);
+            b[1] = tr_frag<PC, p * PWC + 1>(sx, cbase);
+            b[2] = tr_frag<PC, p * PWC + 2>(sx, cbase);
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
-                if (p < BH) acc[0 * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[s], acc[0 * 3 + s], 0, 0, 0);
-                if (p >= 1 && p - 1 < BH) acc[1 * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[s], acc[1 * 3 + s], 0, 0, 0);
-                if (p >= 2) acc[2 * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[s], acc[2 * 3 + s], 0, 0, 0);
+                if constexpr (p < BH) acc[0 * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[s], acc[0 * 3 + s], 0, 0, 0);
+                if constexpr (p >= 1 && p - 1 < BH) acc[1 * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[s], acc[1 * 3 + s], 0, 0, 0);
+                if constexpr (p >= 2) acc[2 * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[s], acc[2 * 3 + s], 0, 0, 0);
             }
-        }
+        });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -175,7 +194,8 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_patch_k(const WgArgs A) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int kk = kb + (i & 3) + 8 * (i >> 2);
-            unsafeAtomicAdd(A.scratch + ((long long)kk * 9 + t) * C + cc, acc[t][i]);
+            if (!(A.dbg & 4)) unsafeAtomicAdd(A.scratch + ((long long)kk * 9 + t) * C + cc, acc[t][i]);
+            else if (acc[t][i] == 12345.678f) A.scratch[0] = 1.f;   // keep the accumulators live
         }
 }
 
@@ -194,6 +214,7 @@ int kp_conv_wgrad_patch(const void* x, const void* dy, float* scratch, int N, in
     a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.scratch = scratch;
     a.Ho = Ho; a.Wo = Wo; a.C = C; a.K = K; a.dy_pad = dy_pad;
     a.bx = Wo / BW; a.by = Ho / BH;
+    { extern int g_kp_debug; a.dbg = g_kp_debug; }
     const long long total = (long long)N * a.bx * a.by;
     if (total >= (1LL << 31)) return KP_E_UNSUPPORTED;
     a.total_stages = (int)total;
