@@ -189,6 +189,15 @@ int kp_transport_max_bwd(const float* gphi, const float* phi_s, const float* phi
                          float* d_phi_s, float* d_phi_t, float* d_m_s, float* d_m_t,
                          int B, int C, int K, int H, int W, void* stream);
 
+/* ---- input-side augmentation (keypoints/tps.py, keypoints/data_augments.py) ----------------------- */
+/* out = F.grid_sample(x, tps_grid(theta, ctrl, x.shape), padding_mode='zeros')   tps.py:60-87,128-131.
+ * x/out fp32 NCHW; theta [N][T+3][2] (reduced != 0: [N][T+2][2], tps.py:48-50); ctrl [N][T][2] or, with
+ * ctrl_batched == 0, [T][2] shared by the batch.  The sampling grid is evaluated per pixel, never materialised. */
+int kp_warp_tps(const float* x, const float* theta, const float* ctrl, float* out, int N, int C, int H, int W, int T,
+                int reduced, int ctrl_batched, void* stream);
+/* out = F.grid_sample(x, F.affine_grid(mat, x.shape), padding_mode='zeros'); mat [N][2][3]   tps.py:154-166 */
+int kp_warp_affine(const float* x, const float* mat, float* out, int N, int C, int H, int W, void* stream);
+
 /* ---- loss and optimiser -------------------------------------------------- */
 /* l2_reconstruction_loss (transporter.py:56-60): loss_sum[0] += sum (x-t)^2*mask (fp64, zeroed by caller);
  * grad = 2*(x-t)*mask*scale  (scale = 1/numel).  mask may be NULL. */

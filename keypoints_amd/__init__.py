@@ -2,6 +2,7 @@
 `keypoints.models` surface of DuaneNielsen/keypoints.  See DESIGN.md / INTEGRATION.md."""
 from .runtime import default_precision, set_default_precision  # noqa: F401
 from . import models  # noqa: F401
+from . import data_augments, tps  # noqa: F401
 from .optim import FusedAdam, l2_reconstruction_loss  # noqa: F401
 
 
@@ -14,3 +15,6 @@ def install_as_keypoints():
     sys.modules['keypoints.models'] = models
     for name in ('functional', 'knn', 'vgg', 'transporter', 'keynet'):
         sys.modules[f'keypoints.models.{name}'] = getattr(models, name)
+    # the train scripts import these two as top-level modules (transporter.py:6,11 with keypoints/ on sys.path)
+    sys.modules.setdefault('data_augments', data_augments)
+    sys.modules.setdefault('tps', tps)

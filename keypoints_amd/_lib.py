@@ -41,6 +41,8 @@ SIGNATURES = {
     'kp_point_map_fwd': [_p, _p, _i, _i, _i, _p],
     'kp_transport_max_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'kp_transport_max_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    'kp_warp_tps': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    'kp_warp_affine': [_p, _p, _p, _i, _i, _i, _i, _p],
     'kp_l2_loss': [_p, _p, _p, _p, _p, _f, _z, _p],
     'kp_adam_step': [_p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _f, _p],
     'kp_prof_enable': [_i],

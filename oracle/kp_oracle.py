@@ -356,6 +356,67 @@ def keynet_train_step(plans, P: Params, buffers: Params, state: dict, x: Tensor,
     return loss.detach(), tuple(o.detach() if torch.is_tensor(o) else o for o in out), G
 
 
+# --------------------------------------------------------------------------
+# Thin-plate-spline + rotation augmentation (keypoints/tps.py, keypoints/data_augments.py): the input-side
+# step of the KeyNet config.  Random parameters are drawn by the caller exactly as
+# the reference draws them (tps.py:122-125, data_augments.py:6-10); everything below is deterministic in them.
+# grid_sample / affine_grid run with the defaults of the torch in this image (align_corners=False), which is
+# what the reference's calls resolve to here.
+# --------------------------------------------------------------------------
+def tps(theta: Tensor, ctrl: Tensor, grid: Tensor) -> Tensor:
+    """tps.py:10-57: z[n,i,j,:] = a0 + a1*x + a2*y + sum_t U(|(x,y) - ctrl_t|) w_t, U(D) = D^2 log(D + 1e-6)."""
+    N, H, W, _ = grid.shape
+    if ctrl.dim() == 2:
+        ctrl = ctrl.expand(N, *ctrl.shape)
+    T = ctrl.shape[1]
+    diff = grid[..., 1:].unsqueeze(-2) - ctrl.unsqueeze(1).unsqueeze(1)
+    D = torch.sqrt((diff ** 2).sum(-1))
+    U = (D ** 2) * torch.log(D + 1e-6)
+    w, a = theta[:, :-3, :], theta[:, -3:, :]
+    if T + 2 == theta.shape[1]:                                     # reduced form, tps.py:48-50
+        w = torch.cat((-w.sum(dim=1, keepdim=True), w), dim=1)
+    b = torch.bmm(U.reshape(N, -1, T), w).view(N, H, W, 2)
+    return torch.bmm(grid.reshape(N, -1, 3), a).view(N, H, W, 2) + b
+
+
+def tps_grid(theta: Tensor, ctrl: Tensor, size) -> Tensor:
+    """tps.py:60-87: sampling grid in [-1, 1] for an N x C x H x W output."""
+    N, _, H, W = size
+    grid = theta.new_empty(N, H, W, 3)
+    grid[..., 0] = 1.0
+    grid[..., 1] = torch.linspace(0, 1, W)
+    grid[..., 2] = torch.linspace(0, 1, H).unsqueeze(-1)
+    return (grid[..., 1:] + tps(theta, ctrl, grid)) * 2 - 1
+
+
+def tps_transform(x: Tensor, theta: Tensor, ctrl: Tensor) -> Tensor:
+    """tps.py:128-131."""
+    return F.grid_sample(x, tps_grid(theta, ctrl, x.shape).type_as(x), padding_mode='zeros')
+
+
+def rotate_affine_grid_multi(x: Tensor, angle: Tensor) -> Tensor:
+    """tps.py:154-166: per-sample rotation [[cos, sin, 0], [-sin, cos, 0]] through affine_grid + grid_sample."""
+    c, s_ = torch.cos(angle), torch.sin(angle)
+    tr = torch.zeros(x.size(0), 2, 3, dtype=x.dtype)
+    tr[:, 0, 0] = c; tr[:, 0, 1] = s_; tr[:, 1, 0] = -s_; tr[:, 1, 1] = c
+    return F.grid_sample(x, F.affine_grid(tr, x.shape), padding_mode='zeros')
+
+
+def peturb(x: Tensor, tps_theta: Tensor, ctrl: Tensor, angle: Tensor) -> Tensor:
+    """data_augments.py:13-16: TPS warp, then rotation."""
+    return rotate_affine_grid_multi(tps_transform(x, tps_theta, ctrl), angle)
+
+
+def tps_and_rotate(x: Tensor, params1, params2):
+    """data_augments.py:27-38 with the two parameter draws passed in: returns (x, x_, loss_mask)."""
+    mask = torch.ones_like(x)
+    x1 = peturb(x, *params1)
+    mask = peturb(mask, *params1)
+    x2 = peturb(x1, *params2)
+    mask = peturb(mask, *params2)
+    return x1, x2, mask
+
+
 def conv_flops_per_pair(plans, height: int, width: int, transporter: bool = True) -> float:
     """Conv MACs x2 for one train step on one image pair (SURVEY.md section 8d accounting)."""
     def unit_macs(plan, h, w):
