@@ -16,25 +16,32 @@ namespace {
 
 constexpr int TPB = 256;
 
-// 8 per-lane values -> each lane gets the sum over all 64 lanes of ONE of them (index returned in idx)
+// 8 per-lane values -> each lane gets the sum over all 64 lanes of ONE of them (index returned in idx).
+// Halving butterfly on VALU cross-lane ops only (v_permlane32_swap, v_permlane16_swap, DPP row_ror / half-mirror /
+// quad_perm): the ds_bpermute version cost ~100 dependent LDS round trips per wavefront, more than the FMAs.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float reduce8_over64(const float (&v)[8], int lane, int& idx) {
     const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
     float a[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float keep = b5 ? v[i + 4] : v[i], send = b5 ? v[i] : v[i + 4];
-        a[i] = keep + __shfl_xor(send, 32, 64);
+    for (int i = 0; i < 4; ++i) {   // halves of 32 lanes: upper half of v[i] <-> lower half of v[i+4]
+        float lo = v[i], hi = v[i + 4];
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+        a[i] = lo + hi;
     }
     float b[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float keep = b4 ? a[i + 2] : a[i], send = b4 ? a[i] : a[i + 2];
-        b[i] = keep + __shfl_xor(send, 16, 64);
+    for (int i = 0; i < 2; ++i) {   // rows of 16 lanes: odd rows of a[i] <-> even rows of a[i+2]
+        float lo = a[i], hi = a[i + 2];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+        b[i] = lo + hi;
     }
-    float d = (b3 ? b[1] : b[0]) + __shfl_xor(b3 ? b[0] : b[1], 8, 64);
-    d += __shfl_xor(d, 4, 64);
-    d += __shfl_xor(d, 2, 64);
-    d += __shfl_xor(d, 1, 64);
+    float d = (b3 ? b[1] : b[0]) + dpp_mov<0x128>(b3 ? b[0] : b[1]);   // partner = lane ^ 8 (row_ror:8)
+    d += dpp_mov<0x141>(d);    // + lane ^ 7 (row_half_mirror)
+    d += dpp_mov<0x4E>(d);     // + lane ^ 2
+    d += dpp_mov<0xB1>(d);     // + lane ^ 1
     idx = (b5 ? 4 : 0) | (b4 ? 2 : 0) | (b3 ? 1 : 0);
     return d;
 }
