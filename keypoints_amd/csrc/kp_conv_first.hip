@@ -147,24 +147,51 @@ __global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const bf16_t* __restr
         const long long n = row / Ho;
         // stage input rows p..p+2 as fp32, 4 floats per pixel (channels >= CIN are never read)
         const bf16_t* xr = x + ((n * Hi + p) * Wi) * CIN;
-        for (int i = lane; i < 3 * Wi * CIN; i += 64) {
-            const int r = i / (Wi * CIN), rem = i - r * (Wi * CIN);
-            const int px = rem / CIN, c = rem - px * CIN;
-            xw[r * rowf + px * 4 + c] = bf2f(xr[i]);
-        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            for (int i = lane; i < Wi * CIN; i += 64) {
+                const int px = i / CIN, c = i - px * CIN;
+                xw[r * rowf + px * 4 + c] = bf2f(xr[r * Wi * CIN + i]);
+            }
         const bf16_t* dr = dy + (((n * Hd + p + dy_pad) * Wd) + dy_pad) * (long long)K + k;
-#pragma unroll 4
-        for (int q = stream; q < Wo; q += KS) {
-            const float d = bf2f(dr[(long long)q * K]);
+        if (KS == 1 && (Wo & 7) == 0) {
+            // one stream per wave (K = 64): UQ pixels per iteration share their UQ+2 window columns (aligned 16-byte
+            // broadcast reads) and the UQ dy loads are issued together (the loop is bound by their latency)
+            constexpr int UQ = 8;
+            for (int q = 0; q < Wo; q += UQ) {
+                float d[UQ];
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+                for (int u = 0; u < UQ; ++u) d[u] = bf2f(dr[(long long)(q + u) * K]);
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const float4 v = *reinterpret_cast<const float4*>(xw + r * rowf + (q + s) * 4);
-                    const float vv[4] = {v.x, v.y, v.z, v.w};
+                for (int r = 0; r < 3; ++r) {
+                    float4 col[UQ + 2];
 #pragma unroll
-                    for (int c = 0; c < CIN; ++c) acc[(r * 3 + s) * CIN + c] = fmaf(d, vv[c], acc[(r * 3 + s) * CIN + c]);
+                    for (int e = 0; e < UQ + 2; ++e) col[e] = *reinterpret_cast<const float4*>(xw + r * rowf + (q + e) * 4);
+#pragma unroll
+                    for (int u = 0; u < UQ; ++u)
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) {
+                            const float vv[4] = {col[u + s].x, col[u + s].y, col[u + s].z, col[u + s].w};
+#pragma unroll
+                            for (int c = 0; c < CIN; ++c)
+                                acc[(r * 3 + s) * CIN + c] = fmaf(d[u], vv[c], acc[(r * 3 + s) * CIN + c]);
+                        }
                 }
+            }
+        } else {
+#pragma unroll 4
+            for (int q = stream; q < Wo; q += KS) {
+                const float d = bf2f(dr[(long long)q * K]);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        const float4 v = *reinterpret_cast<const float4*>(xw + r * rowf + (q + s) * 4);
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int c = 0; c < CIN; ++c) acc[(r * 3 + s) * CIN + c] = fmaf(d, vv[c], acc[(r * 3 + s) * CIN + c]);
+                    }
+            }
         }
     }
     // fold the pixel streams (lanes k, k+K, ...), then the 4 wavefronts, then one atomic per (k, j) per block
