@@ -87,8 +87,8 @@ int kp_nhwc_grad_to_nchw(const void* gsrc, float* dst, int N, int C, int H, int 
 /* fp32 [K][C][R][R] (nn.Conv2d.weight) -> T [K][R][R][C] (forward operand) and,
  * if w_dgrad != NULL, T [C][R][R][K] with the taps flipped (dgrad operand). */
 int kp_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int K, int C, int R, int dtype, void* stream);
-/* dw[K][C][R][R] += transpose(scratch[K][R][R][C])   (fp32 both) */
-int kp_wgrad_unpack(const float* scratch, float* dw, int K, int C, int R, void* stream);
+/* dw[K][C][R][R] += sum_p transpose(scratch[p][K][R][R][C])   (fp32; p < partials summed in a fixed order) */
+int kp_wgrad_unpack(const float* scratch, int partials, float* dw, int K, int C, int R, void* stream);
 
 /* ---- convolution ------------------------------------------------------- */
 /* "Valid" RxR correlation (R = 1 or 3) over an already padded image:
@@ -110,9 +110,13 @@ int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, float*
  * knowing the zero border lets the border ring be computed with 3 taps per pixel. */
 int kp_conv_dgrad(const void* dy, const void* w_dgrad, void* gx, int N, int H, int W, int K, int C, int dtype,
                   void* stream);
-/* Weight gradient: scratch[k][r][s][c] += sum_{n,p,q} dy[n][p][q][k] * x[n][p+r][q+s][c]
- * x: [N][Ho+R-1][Wo+R-1][C] T; dy: interior of [N][Ho+2*dy_pad][Wo+2*dy_pad][K] T;
- * scratch fp32 [K][R][R][C], zeroed by the caller (atomically accumulated). */
+/* Weight gradient: sum_p scratch[p][k][r][s][c] (+)= sum_{n,p,q} dy[n][p][q][k] * x[n][p+r][q+s][c]
+ * x: [N][Ho+R-1][Wo+R-1][C] T; dy: interior of [N][Ho+2*dy_pad][Wo+2*dy_pad][K] T.
+ * P = kp_conv_wgrad_partials(same shape arguments) tells the scratch protocol of this shape:
+ *   P == 1: scratch fp32 [K][R][R][C], ZEROED by the caller, accumulated with hardware fp32 atomics;
+ *   P  > 1: scratch fp32 [P][K][R][R][C], no zeroing needed: every partial is fully written by the workgroups of one
+ *           pixel split (plain stores) and kp_wgrad_unpack sums them in a fixed order (bitwise reproducible). */
+int kp_conv_wgrad_partials(int N, int Ho, int Wo, int C, int K, int R, int dy_pad, int dtype);
 int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R,
                   int dy_pad, int dtype, void* stream);
 

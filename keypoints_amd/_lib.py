@@ -22,7 +22,7 @@ SIGNATURES = {
     'kp_nchw_to_nhwc': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     'kp_nhwc_grad_to_nchw': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     'kp_pack_weights': [_p, _p, _p, _i, _i, _i, _i, _p],
-    'kp_wgrad_unpack': [_p, _p, _i, _i, _i, _p],
+    'kp_wgrad_unpack': [_p, _i, _p, _i, _i, _i, _p],
     'kp_conv_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'kp_conv_dgrad': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'kp_conv_wgrad': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
@@ -51,7 +51,7 @@ SIGNATURES = {
     'kp_prof_collect': [_i, _p, _p, _p],
     'kp_prof_bytes': [_i, _p],
 }
-PLAIN = {'kp_last_rows': ([], _ll), 'kp_bn_ws_doubles': ([_i], _i), 'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
+PLAIN = {'kp_conv_wgrad_partials': ([_i] * 8, _i), 'kp_last_rows': ([], _ll), 'kp_bn_ws_doubles': ([_i], _i), 'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
 
 _lib = None
 

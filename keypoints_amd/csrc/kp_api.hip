@@ -12,6 +12,7 @@ int kp_conv_fwd_mfma(const void*, const void*, const float*, void*, float*, int,
 int kp_conv_wgrad_mfma(const void*, const void*, float*, int, int, int, int, int, int, int, hipStream_t);
 int kp_conv_dgrad_mfma(const void*, const void*, void*, int, int, int, int, int, hipStream_t);
 int kp_conv_wgrad_patch(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
+long long kp_conv_wgrad_patch_partials(int, int, int, int, int, int);
 int kp_conv_first_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
 int kp_conv_first_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 
@@ -178,6 +179,14 @@ int kp_conv_dgrad(const void* dy, const void* w_dgrad, void* gx, int N, int H, i
         ps.cancel();
     }
     return kp_conv_fwd(dy, w_dgrad, nullptr, gx, nullptr, N, H + 4, W + 4, K, C, 3, dtype, stream);
+}
+
+int kp_conv_wgrad_partials(int N, int Ho, int Wo, int C, int K, int R, int dy_pad, int dtype) {
+    if (dtype == KP_BF16 && use_mfma() && R == 3 && g_kp_wgrad_patch) {
+        const long long p = kp_conv_wgrad_patch_partials(N, Ho, Wo, C, K, dy_pad);
+        if (p > 0 && p < 0x7fffffffLL) return (int)p;
+    }
+    return 1;
 }
 
 int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R, int dy_pad,

@@ -67,15 +67,46 @@ __global__ void pack_weights_k(const float* __restrict__ w, T* __restrict__ wf, 
     if (wd) st<T>(wd + (((long long)c * R + (R - 1 - r)) * R + (R - 1 - s)) * K + k, v);
 }
 
-__global__ void wgrad_unpack_k(const float* __restrict__ scratch, float* __restrict__ dw, int K, int C, int R) {
+// dw[k][c][r][s] += sum_p scratch[p][k][r][s][c].  A workgroup = 64 element groups (VEC consecutive c of one
+// (k, r, s) of the scratch layout: coalesced 16-byte lanes) x 4 partial lanes; lane q sums the partials p = q, q+4, ...
+// (4 loads in flight), the 4 lanes are combined through LDS in a fixed order -> deterministic.
+template <int VEC>
+__global__ __launch_bounds__(256) void wgrad_unpack_k(const float* __restrict__ scratch, int partials,
+                                                      float* __restrict__ dw, int K, int C, int R) {
     const long long total = (long long)K * C * R * R;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const int s = (int)(t % R);
-    const int r = (int)((t / R) % R);
-    const int c = (int)((t / ((long long)R * R)) % C);
-    const int k = (int)(t / ((long long)R * R * C));
-    dw[t] += scratch[(((long long)k * R + r) * R + s) * C + c];
+    const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long long t = ((long long)blockIdx.x * 64 + el) * VEC;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    if (t < total) {
+        int p = q;
+        if (VEC == 4) {
+            for (; p + 12 < partials; p += 16) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(scratch + (long long)(p + 4 * u) * total + t);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { acc[0] += v[u].x; acc[1] += v[u].y; acc[2] += v[u].z; acc[3] += v[u].w; }
+            }
+        }
+        for (; p < partials; p += 4)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] += scratch[(long long)p * total + t + e];
+    }
+    __shared__ float red[4][64][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[q][el][e] = acc[e];
+    __syncthreads();
+    if (q == 0 && t < total) {
+        const int c = (int)(t % C);
+        const int s = (int)((t / C) % R);
+        const int r = (int)((t / ((long long)C * R)) % R);
+        const int k = (int)(t / ((long long)C * R * R));
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            dw[(((long long)k * C + c + e) * R + r) * R + s] += ((red[0][el][e] + red[1][el][e]) + red[2][el][e]) + red[3][el][e];
+    }
 }
 
 // ---------------------------------------------------------------- 1x1 head
@@ -261,10 +292,13 @@ int kp_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int K, int C, in
     return kp_check_launch("pack_weights");
 }
 
-int kp_wgrad_unpack(const float* scratch, float* dw, int K, int C, int R, void* stream) {
-    KP_REQUIRE(K > 0 && C > 0 && (R == 1 || R == 3), "kp_wgrad_unpack: bad dims");
+int kp_wgrad_unpack(const float* scratch, int partials, float* dw, int K, int C, int R, void* stream) {
+    KP_REQUIRE(K > 0 && C > 0 && (R == 1 || R == 3) && partials >= 1, "kp_wgrad_unpack: bad dims");
     const long long total = (long long)K * C * R * R;
-    wgrad_unpack_k<<<cdiv(total, TPB), TPB, 0, (hipStream_t)stream>>>(scratch, dw, K, C, R);
+    if (C % 4 == 0)
+        wgrad_unpack_k<4><<<cdiv(total / 4, 64), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, R);
+    else
+        wgrad_unpack_k<1><<<cdiv(total, 64), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, R);
     return kp_check_launch("wgrad_unpack");
 }
 

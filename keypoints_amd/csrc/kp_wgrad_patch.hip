@@ -69,6 +69,7 @@ struct WgArgs {
     const bf16_t* x; const bf16_t* dy; float* scratch;
     int Ho, Wo, C, K, dy_pad;
     int ctiles, ktiles, stages_per_split, total_stages, bx, by, dbg;
+    long long partial_stride;   // floats between the partial gradients of consecutive pixel splits (0: one buffer, atomics)
 };
 
 template <int TK, int TC>
@@ -194,27 +195,26 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_patch_k(const WgArgs A) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int kk = kb + (i & 3) + 8 * (i >> 2);
-            if (!(A.dbg & 4)) unsafeAtomicAdd(A.scratch + ((long long)kk * 9 + t) * C + cc, acc[t][i]);
-            else if (acc[t][i] == 12345.678f) A.scratch[0] = 1.f;   // keep the accumulators live
+            float* dst = A.scratch + (long long)sp * A.partial_stride + ((long long)kk * 9 + t) * C + cc;
+            if (A.dbg & 4) { if (acc[t][i] == 12345.678f) A.scratch[0] = 1.f; }   // ablation: keep the accumulators live
+            else if (A.partial_stride) *dst = acc[t][i];     // this split's own buffer: plain coalesced store
+            else unsafeAtomicAdd(dst, acc[t][i]);
         }
 }
 
 }  // namespace
 
-// Returns KP_E_UNSUPPORTED when the shape is not eligible (then the per-tap kernel takes it).
-int kp_conv_wgrad_patch(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K,
-                        int dy_pad, hipStream_t st) {
+// Launch plan shared by the query (kp_conv_wgrad_partials) and the launch.  KP_E_UNSUPPORTED when the shape is not
+// eligible (then the per-tap kernel takes it).
+static int plan(int N, int Ho, int Wo, int C, int K, int dy_pad, WgArgs& a, unsigned& grid, long long& splits, bool& k128) {
     if (C % 64 != 0 || K % 64 != 0 || Ho % BH != 0 || Wo % BW != 0) return KP_E_UNSUPPORTED;
-    const bool k128 = (K % 128 == 0);
+    k128 = (K % 128 == 0);
     if (!k128 && C % 128 != 0) return KP_E_UNSUPPORTED;            // (64 x 64) blocks: per-tap kernel
     // 32-bit DMA offsets inside one pixel block
     if ((long long)(PH + 1) * (Wo + 2 * (dy_pad > 1 ? dy_pad : 1)) * (C > K ? C : K) * 2 >= 0x7fffffffLL)
         return KP_E_UNSUPPORTED;
-    WgArgs a;
-    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.scratch = scratch;
     a.Ho = Ho; a.Wo = Wo; a.C = C; a.K = K; a.dy_pad = dy_pad;
     a.bx = Wo / BW; a.by = Ho / BH;
-    { extern int g_kp_debug; a.dbg = g_kp_debug; }
     const long long total = (long long)N * a.bx * a.by;
     if (total >= (1LL << 31)) return KP_E_UNSUPPORTED;
     a.total_stages = (int)total;
@@ -224,12 +224,31 @@ int kp_conv_wgrad_patch(const void* x, const void* dy, float* scratch, int N, in
     static int cus = 0;
     if (!cus) { cus = kp_device_cus(); if (cus <= 0) cus = 256; }
     // one workgroup per CU (>= 112 KB of LDS each); split the pixel blocks so that the grid fills the chip
-    long long splits = (cus + tiles - 1) / tiles;
+    splits = (cus + tiles - 1) / tiles;
     if (splits > total / 4) splits = total / 4;
     if (splits < 1) splits = 1;
     a.stages_per_split = (int)((total + splits - 1) / splits);
     splits = (total + a.stages_per_split - 1) / a.stages_per_split;
-    const unsigned grid = (unsigned)(tiles * splits);
+    grid = (unsigned)(tiles * splits);
+    return KP_OK;
+}
+
+// Number of partial gradient buffers kp_conv_wgrad_patch writes for this shape (0: shape not eligible).
+long long kp_conv_wgrad_patch_partials(int N, int Ho, int Wo, int C, int K, int dy_pad) {
+    WgArgs a; unsigned grid; long long splits; bool k128;
+    return plan(N, Ho, Wo, C, K, dy_pad, a, grid, splits, k128) == KP_OK ? splits : 0;
+}
+
+// scratch: `splits` buffers of [K][9][C] fp32, each fully written by the workgroups of one pixel split (no zeroing,
+// no atomics: the sum over splits is taken in a fixed order by kp_wgrad_unpack -> bitwise reproducible gradients).
+int kp_conv_wgrad_patch(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K,
+                        int dy_pad, hipStream_t st) {
+    WgArgs a; unsigned grid; long long splits; bool k128;
+    int rc = plan(N, Ho, Wo, C, K, dy_pad, a, grid, splits, k128);
+    if (rc != KP_OK) return rc;
+    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.scratch = scratch;
+    a.partial_stride = (long long)K * 9 * C;
+    { extern int g_kp_debug; a.dbg = g_kp_debug; }
     if (k128) wgrad3x3_patch_k<128, 64><<<grid, TPB, 0, st>>>(a);
     else wgrad3x3_patch_k<64, 128><<<grid, TPB, 0, st>>>(a);
     return kp_check_launch("wgrad3x3_patch");

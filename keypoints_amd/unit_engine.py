@@ -226,9 +226,10 @@ class UnitFunction(torch.autograd.Function):
             call('kp_bn_act_bwd_apply', ptr(g), gp, tcode, ptr(sv['argmax']), ptr(sv['y']), *bn_args, stp['slope'],
                  ptr(sums), ptr(dy), dp, N, H, W, K, code, st)
             # (conv bias in front of train-mode BN: analytically zero gradient -> its arena slot stays 0)
-            scratch = torch.zeros(K, 3, 3, C, device=dev, dtype=torch.float32)
+            parts = _lib.lib().kp_conv_wgrad_partials(N, H, W, C, K, 3, dp, code)
+            scratch = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device=dev, dtype=torch.float32)
             call('kp_conv_wgrad', ptr(sv['a']), ptr(dy), ptr(scratch), N, H, W, C, K, 3, dp, code, st)
-            call('kp_wgrad_unpack', ptr(scratch), ptr(gv[id(conv.weight)]), K, C, 3, st)
+            call('kp_wgrad_unpack', ptr(scratch), parts, ptr(gv[id(conv.weight)]), K, C, 3, st)
             if need_dx:
                 gx = torch.empty(N, H + 2, W + 2, C, device=dev, dtype=tdt)
                 call('kp_conv_dgrad', ptr(dy), ptr(sv['wd']), ptr(gx), N, H, W, K, C, code, st)

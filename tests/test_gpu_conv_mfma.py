@@ -82,7 +82,9 @@ def test_conv_wgrad_mfma(N, Ho, Wo, C, K, dp):
     for r in range(3):
         for s in range(3):
             ref[:, r, s, :] = torch.einsum('npqk,npqc->kc', df, xf[:, r:r + Ho, s:s + Wo])
-    scratch = torch.zeros(K, 3, 3, C, device='cuda')
+    parts = _lib.lib().kp_conv_wgrad_partials(N, Ho, Wo, C, K, 3, dp, _lib.KP_BF16)
+    scratch = torch.zeros(K, 3, 3, C, device='cuda') if parts == 1 else \
+        torch.full((parts, K, 3, 3, C), float('nan'), device='cuda')   # partial buffers need no zeroing
     xd, dyd = x.cuda(), dy.cuda()   # keep alive: ptr() of a temporary would dangle
     call('kp_prof_enable', 1)
     call('kp_conv_wgrad', ptr(xd), ptr(dyd), ptr(scratch), N, Ho, Wo, C, K, 3, dp, _lib.KP_BF16, stream_ptr())
@@ -90,7 +92,8 @@ def test_conv_wgrad_mfma(N, Ho, Wo, C, K, dp):
     call('kp_prof_collect', 3, None, None, ctypes.addressof(n))
     call('kp_prof_enable', 0)
     assert n.value == 1, 'the MFMA wgrad kernel did not take this shape'
-    got = scratch.double().cpu()
+    got = scratch.double().cpu() if parts == 1 else scratch.double().sum(0).cpu()
+    assert torch.isfinite(got).all()
     err = (got - ref).abs().max().item()
     assert err <= 2e-5 * ref.abs().max().item() * (N * Ho * Wo) ** 0.5 + 1e-4, (err, ref.abs().max().item())
     assert ((got - ref).norm() / ref.norm()).item() < 1e-5
@@ -141,6 +144,7 @@ def test_conv_first_layer(N, Ho, Wo, C, K):
         for r in range(3):
             for s_ in range(3):
                 wref[:, r, s_, :] = torch.einsum('npqk,npqc->kc', df, xf[:, r:r + Ho, s_:s_ + Wo])
+        assert _lib.lib().kp_conv_wgrad_partials(N, Ho, Wo, C, K, 3, dp, _lib.KP_BF16) == 1
         scratch = torch.zeros(K, 3, 3, C, device='cuda')
         dyd = dy.cuda()
         call('kp_prof_enable', 1)

@@ -84,10 +84,11 @@ def test_block_against_golden(golden, tag, cin, cout, tail, slope, precision, to
     call('kp_bn_act_bwd_apply', ptr(g), 0, tcode_b, ptr(argmax), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
          slope, ptr(sums), ptr(dy), 2, N, H, W, K, code, st)
     assert float(dy.float()[:, :2].abs().max()) == 0 and float(dy.float()[:, :, -2:].abs().max()) == 0
-    scratch = torch.zeros(K, 3, 3, C, device=dev)
+    parts = _lib.lib().kp_conv_wgrad_partials(N, H, W, C, K, 3, 2, code)
+    scratch = torch.zeros(parts, K, 3, 3, C, device=dev)
     call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, W, C, K, 3, 2, code, st)
     dw = torch.zeros(K, C, 3, 3, device=dev)
-    call('kp_wgrad_unpack', ptr(scratch), ptr(dw), K, C, 3, st)
+    call('kp_wgrad_unpack', ptr(scratch), parts, ptr(dw), K, C, 3, st)
     gx = torch.empty(N, H + 2, W + 2, C, device=dev, dtype=tdt)
     call('kp_conv_fwd', ptr(dy), ptr(wd), None, ptr(gx), None, N, H + 4, W + 4, K, C, 3, code, st)
     dx = torch.empty(N, C, H, W, device=dev)

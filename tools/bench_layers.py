@@ -70,7 +70,7 @@ def main():
         dy = torch.zeros(N, H + 4, W + 4, K, device='cuda', dtype=bf)
         dy[:, 2:-2, 2:-2] = (torch.randn(N, H, W, K, device='cuda') * 0.5).to(bf)
         gx = torch.empty(N, H + 2, W + 2, C, device='cuda', dtype=bf)
-        scratch = torch.zeros(K, 3, 3, C, device='cuda')
+        scratch = torch.zeros(_lib.lib().kp_conv_wgrad_partials(N, H, W, C, K, 3, 2, _lib.KP_BF16), K, 3, 3, C, device='cuda')
         cols = []
         for mode in modes:
             call('kp_config', 0, mode)
