@@ -379,7 +379,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                 // slices): the DMA count after a barrier is a compile-time constant per tap (dummy targets keep it
                 // so).  Right after an epilogue everything older was already drained and its stores must not be
                 // waited for here.
-                if (!(tap == 0 && after_epi)) wait_vm<NWI + (((tap + 8) % 9) < PSLICES ? 1 : 0)>();
+                if (!(tap == 0 && after_epi) && !(A.dbg & 16)) wait_vm<NWI + (((tap + 8) % 9) < PSLICES ? 1 : 0)>();
                 stamp();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
