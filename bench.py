@@ -42,6 +42,9 @@ def parse():
     ap.add_argument('--model_z_channels', type=int, default=64)
     ap.add_argument('--model_keypoints', type=int, default=10)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--net', default='transporter', choices=['transporter', 'keynet'],
+                    help="'keynet' = BASELINE config 3 (KeyNet + TPS/rotation augmentation); not the headline metric")
+    ap.add_argument('--no-augment', action='store_true', help='keynet: skip the TPS/rotation augmentation')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=16)
     ap.add_argument('--cpu-steps', type=int, default=3)
@@ -102,7 +105,14 @@ def main():
     from oracle import kp_oracle as O   # flop accounting only (conv MACs x 2)
 
     torch.manual_seed(0)
-    net = transporter.make(args.model_type, args.model_in_channels, args.model_z_channels, args.model_keypoints)
+    if args.net == 'keynet':
+        from keypoints_amd.models import keynet
+        from keypoints_amd.data_augments import TpsAndRotate, nop
+        net = keynet.make(args)
+        # configs/keypoints_celeba.yaml:13-16: 4 control points, variance 0.05, max rotation 0.1
+        augment = nop if args.no_augment else TpsAndRotate(4, 0.05, 0.1)
+    else:
+        net = transporter.make(args.model_type, args.model_in_channels, args.model_z_channels, args.model_keypoints)
     net = net.to(dev).set_precision(args.precision)
     opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
     reducer = GradReducer(net) if world > 1 else None
@@ -114,8 +124,13 @@ def main():
 
     def step():
         opt.zero_grad()
-        out = net(xs, xt)
-        loss = ka.l2_reconstruction_loss(out[0], xt)
+        if args.net == 'keynet':     # keypoints.py:72-79: x, x_, loss_mask = augment(*data); net(x, x_); masked L2
+            x, x_, mask = augment(xs, xt)
+            out = net(x, x_)
+            loss = ka.l2_reconstruction_loss(out[0], x_, mask)
+        else:
+            out = net(xs, xt)
+            loss = ka.l2_reconstruction_loss(out[0], xt)
         loss.backward()
         if reducer is not None:
             reducer.finish()
@@ -157,9 +172,9 @@ def main():
     _lib.call('kp_prof_enable', 0)
 
     if rank == 0:
-        plans = O.transporter_plans(args.model_type, args.model_in_channels, args.model_z_channels,
-                                    args.model_keypoints)
-        flop_pair = O.conv_flops_per_pair(plans, args.size, args.size)
+        mk = O.keynet_plans if args.net == 'keynet' else O.transporter_plans
+        plans = mk(args.model_type, args.model_in_channels, args.model_z_channels, args.model_keypoints)
+        flop_pair = O.conv_flops_per_pair(plans, args.size, args.size, transporter=args.net != 'keynet')
         ms_step = 1e3 * elapsed / args.steps
         value = B * world / (elapsed / args.steps)
         dom = max(fam.items(), key=lambda kv: kv[1]['ms_total']) if fam else (None, None)
@@ -183,17 +198,19 @@ def main():
                         launches=dom[1]['launches'] if dom[1] else None,
                         step_tflops=value / world * flop_pair / 1e12, step_frac=value / world * flop_pair / 1e12 / peak,
                         kernels=fam)
-        line = dict(metric='image-pairs/sec (train step) Transporter 128x128 K=10', value=value,
+        what = 'Transporter' if args.net == 'transporter' else 'KeyNet+TPS' if not args.no_augment else 'KeyNet'
+        line = dict(metric=f'image-pairs/sec (train step) {what} {args.size}x{args.size} K={args.model_keypoints}', value=value,
                     unit='image-pairs/sec', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_step,
                     higher_is_better=True, scaling='weak', vs_baseline=None,
                     dtype=args.precision if args.precision == 'bf16' else 'f32', data='synthetic',
-                    config=dict(workload=f'Transporter {args.model_type} {args.size}x{args.size}x'
+                    config=dict(workload=f'{what} {args.model_type} {args.size}x{args.size}x'
                                          f'{args.model_in_channels} K={args.model_keypoints}, '
-                                         f'{B} pairs/GPU (BASELINE config 4 shape), fwd+loss+bwd+Adam',
+                                         f'{B} pairs/GPU (BASELINE config {4 if args.net == "transporter" else 3} shape), '
+                                         f'{"augment+" if args.net == "keynet" and not args.no_augment else ""}fwd+loss+bwd+Adam',
                                 global_batch=B * world, per_gpu_batch=B, parallelism=f'dp{world}',
                                 gflop_per_pair=flop_pair / 1e9, loss=float(loss.item())),
                     roofline=roofline)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.net == 'transporter':
             line['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -76,19 +76,23 @@ int kp_prof_bytes(int family, double* bytes);
 /* ---- layout ------------------------------------------------------------ */
 /* NCHW fp32 -> NHWC T with a replicated border of `pad` pixels.
  * Replaces nn.ReplicationPad2d(1) in front of the first conv of a Unit
- * (knn.py:115) plus the layout change into our internal format. */
-int kp_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int pad, int dtype, void* stream);
+ * (knn.py:115) plus the layout change into our internal format.
+ * Cp >= C is the channel count of dst: channels C..Cp-1 are written as zeros (Cp > C pads an odd width such as the
+ * KeyNet decoder's z+K = 74 input channels, keynet.py:55, up to a multiple of 64 so that the MFMA kernels take the
+ * layer; kp_pack_weights / kp_wgrad_unpack / kp_nhwc_grad_to_nchw take the same Cp). */
+int kp_nchw_to_nhwc(const float* src, void* dst, int N, int C, int Cp, int H, int W, int pad, int dtype, void* stream);
 /* Adjoint of the above: gsrc is the gradient w.r.t. the padded image
  * [N][H+2pad][W+2pad][C] (T); border contributions are folded back onto the
  * edge pixels and the result is written NCHW fp32. */
-int kp_nhwc_grad_to_nchw(const void* gsrc, float* dst, int N, int C, int H, int W, int pad, int dtype, void* stream);
+int kp_nhwc_grad_to_nchw(const void* gsrc, float* dst, int N, int C, int Cp, int H, int W, int pad, int dtype,
+                         void* stream);
 
 /* ---- weights ----------------------------------------------------------- */
-/* fp32 [K][C][R][R] (nn.Conv2d.weight) -> T [K][R][R][C] (forward operand) and,
- * if w_dgrad != NULL, T [C][R][R][K] with the taps flipped (dgrad operand). */
-int kp_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int K, int C, int R, int dtype, void* stream);
-/* dw[K][C][R][R] += sum_p transpose(scratch[p][K][R][R][C])   (fp32; p < partials summed in a fixed order) */
-int kp_wgrad_unpack(const float* scratch, int partials, float* dw, int K, int C, int R, void* stream);
+/* fp32 [K][C][R][R] (nn.Conv2d.weight) -> T [K][R][R][Cp] (forward operand) and,
+ * if w_dgrad != NULL, T [Cp][R][R][K] with the taps flipped (dgrad operand); channels C..Cp-1 are zero. */
+int kp_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int K, int C, int Cp, int R, int dtype, void* stream);
+/* dw[K][C][R][R] += sum_p transpose(scratch[p][K][R][R][Cp])[.., :C]   (fp32; p < partials summed in a fixed order) */
+int kp_wgrad_unpack(const float* scratch, int partials, float* dw, int K, int C, int Cp, int R, void* stream);
 
 /* ---- convolution ------------------------------------------------------- */
 /* "Valid" RxR correlation (R = 1 or 3) over an already padded image:

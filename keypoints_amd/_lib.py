@@ -19,10 +19,10 @@ _p, _i, _f, _z, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
 
 # name -> argument ctypes (all return int unless noted); mirrors include/kp_hip.h one to one
 SIGNATURES = {
-    'kp_nchw_to_nhwc': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
-    'kp_nhwc_grad_to_nchw': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
-    'kp_pack_weights': [_p, _p, _p, _i, _i, _i, _i, _p],
-    'kp_wgrad_unpack': [_p, _i, _p, _i, _i, _i, _p],
+    'kp_nchw_to_nhwc': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    'kp_nhwc_grad_to_nchw': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    'kp_pack_weights': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    'kp_wgrad_unpack': [_p, _i, _p, _i, _i, _i, _i, _p],
     'kp_conv_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'kp_conv_dgrad': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'kp_conv_wgrad': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -16,7 +16,8 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 // ---------------------------------------------------------------- layout
 template <typename T>
-__global__ void nchw_to_nhwc_k(const float* __restrict__ src, T* __restrict__ dst, int N, int C, int H, int W, int p) {
+__global__ void nchw_to_nhwc_k(const float* __restrict__ src, T* __restrict__ dst, int N, int C, int Cp, int H, int W,
+                               int p) {
     const int Hp = H + 2 * p, Wp = W + 2 * p;
     const long long total = (long long)N * Hp * Wp;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -26,13 +27,14 @@ __global__ void nchw_to_nhwc_k(const float* __restrict__ src, T* __restrict__ ds
     const int n = (int)(t / ((long long)Wp * Hp));
     const int h = clampi(i - p, 0, H - 1), w = clampi(j - p, 0, W - 1);
     const float* s = src + ((long long)n * C * H + h) * W + w;
-    T* d = dst + t * C;
+    T* d = dst + t * Cp;
     for (int c = 0; c < C; ++c) st<T>(d + c, s[(long long)c * H * W]);
+    for (int c = C; c < Cp; ++c) st<T>(d + c, 0.f);   // channel padding up to an MFMA-friendly width
 }
 
 template <typename T>
-__global__ void nhwc_grad_to_nchw_k(const T* __restrict__ g, float* __restrict__ dst, int N, int C, int H, int W,
-                                    int p) {
+__global__ void nhwc_grad_to_nchw_k(const T* __restrict__ g, float* __restrict__ dst, int N, int C, int Cp, int H,
+                                    int W, int p) {
     const int Wp = W + 2 * p, Hp = H + 2 * p;
     const long long total = (long long)N * H * W;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -46,7 +48,7 @@ __global__ void nhwc_grad_to_nchw_k(const T* __restrict__ g, float* __restrict__
     for (int c = 0; c < C; ++c) {
         float a = 0.f;
         for (int i = ilo; i <= ihi; ++i)
-            for (int j = jlo; j <= jhi; ++j) a += ld<T>(g + (((long long)n * Hp + i) * Wp + j) * C + c);
+            for (int j = jlo; j <= jhi; ++j) a += ld<T>(g + (((long long)n * Hp + i) * Wp + j) * Cp + c);
         dst[(((long long)n * C + c) * H + h) * W + w] = a;
     }
 }
@@ -54,15 +56,15 @@ __global__ void nhwc_grad_to_nchw_k(const T* __restrict__ g, float* __restrict__
 // ---------------------------------------------------------------- weights
 template <typename T>
 __global__ void pack_weights_k(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int K, int C,
-                               int R) {
-    const long long total = (long long)K * R * R * C;
+                               int Cp, int R) {
+    const long long total = (long long)K * R * R * Cp;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
-    const int c = (int)(t % C);
-    const int s = (int)((t / C) % R);
-    const int r = (int)((t / ((long long)C * R)) % R);
-    const int k = (int)(t / ((long long)C * R * R));
-    const float v = w[(((long long)k * C + c) * R + r) * R + s];
+    const int c = (int)(t % Cp);
+    const int s = (int)((t / Cp) % R);
+    const int r = (int)((t / ((long long)Cp * R)) % R);
+    const int k = (int)(t / ((long long)Cp * R * R));
+    const float v = c < C ? w[(((long long)k * C + c) * R + r) * R + s] : 0.f;   // zero weights for padded channels
     st<T>(wf + t, v);
     if (wd) st<T>(wd + (((long long)c * R + (R - 1 - r)) * R + (R - 1 - s)) * K + k, v);
 }
@@ -72,7 +74,8 @@ __global__ void pack_weights_k(const float* __restrict__ w, T* __restrict__ wf, 
 // (4 loads in flight), the 4 lanes are combined through LDS in a fixed order -> deterministic.
 template <int VEC>
 __global__ __launch_bounds__(256) void wgrad_unpack_k(const float* __restrict__ scratch, int partials,
-                                                      float* __restrict__ dw, int K, int C, int R) {
+                                                      float* __restrict__ dw, int K, int Cd, int C, int R) {
+    // C = channels of the scratch layout (possibly padded), Cd <= C = channels of dw
     const long long total = (long long)K * C * R * R;
     const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
     const long long t = ((long long)blockIdx.x * 64 + el) * VEC;
@@ -105,7 +108,8 @@ __global__ __launch_bounds__(256) void wgrad_unpack_k(const float* __restrict__ 
         const int k = (int)(t / ((long long)C * R * R));
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
-            dw[(((long long)k * C + c + e) * R + r) * R + s] += ((red[0][el][e] + red[1][el][e]) + red[2][el][e]) + red[3][el][e];
+            if (c + e < Cd)
+                dw[(((long long)k * Cd + c + e) * R + r) * R + s] += ((red[0][el][e] + red[1][el][e]) + red[2][el][e]) + red[3][el][e];
     }
 }
 
@@ -271,34 +275,35 @@ int kp_head_dw_fast(const float*, const float*, const void*, float, float*, floa
 
 extern "C" {
 
-int kp_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int pad, int dtype, void* stream) {
-    KP_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && pad >= 0, "kp_nchw_to_nhwc: bad dims");
+int kp_nchw_to_nhwc(const float* src, void* dst, int N, int C, int Cp, int H, int W, int pad, int dtype, void* stream) {
+    KP_REQUIRE(N > 0 && C > 0 && Cp >= C && H > 0 && W > 0 && pad >= 0, "kp_nchw_to_nhwc: bad dims");
     const long long total = (long long)N * (H + 2 * pad) * (W + 2 * pad);
-    DISPATCH_T(dtype, nchw_to_nhwc_k<T><<<cdiv(total, TPB), TPB, 0, (hipStream_t)stream>>>(src, (T*)dst, N, C, H, W, pad));
+    DISPATCH_T(dtype, nchw_to_nhwc_k<T><<<cdiv(total, TPB), TPB, 0, (hipStream_t)stream>>>(src, (T*)dst, N, C, Cp, H, W, pad));
     return kp_check_launch("nchw_to_nhwc");
 }
 
-int kp_nhwc_grad_to_nchw(const void* gsrc, float* dst, int N, int C, int H, int W, int pad, int dtype, void* stream) {
-    KP_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && pad >= 0, "kp_nhwc_grad_to_nchw: bad dims");
+int kp_nhwc_grad_to_nchw(const void* gsrc, float* dst, int N, int C, int Cp, int H, int W, int pad, int dtype,
+                         void* stream) {
+    KP_REQUIRE(N > 0 && C > 0 && Cp >= C && H > 0 && W > 0 && pad >= 0, "kp_nhwc_grad_to_nchw: bad dims");
     const long long total = (long long)N * H * W;
-    DISPATCH_T(dtype, nhwc_grad_to_nchw_k<T><<<cdiv(total, TPB), TPB, 0, (hipStream_t)stream>>>((const T*)gsrc, dst, N, C, H, W, pad));
+    DISPATCH_T(dtype, nhwc_grad_to_nchw_k<T><<<cdiv(total, TPB), TPB, 0, (hipStream_t)stream>>>((const T*)gsrc, dst, N, C, Cp, H, W, pad));
     return kp_check_launch("nhwc_grad_to_nchw");
 }
 
-int kp_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int K, int C, int R, int dtype, void* stream) {
-    KP_REQUIRE(K > 0 && C > 0 && (R == 1 || R == 3), "kp_pack_weights: bad dims");
-    const long long total = (long long)K * C * R * R;
-    DISPATCH_T(dtype, pack_weights_k<T><<<cdiv(total, TPB), TPB, 0, (hipStream_t)stream>>>(w, (T*)w_fwd, (T*)w_dgrad, K, C, R));
+int kp_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int K, int C, int Cp, int R, int dtype, void* stream) {
+    KP_REQUIRE(K > 0 && C > 0 && Cp >= C && (R == 1 || R == 3), "kp_pack_weights: bad dims");
+    const long long total = (long long)K * Cp * R * R;
+    DISPATCH_T(dtype, pack_weights_k<T><<<cdiv(total, TPB), TPB, 0, (hipStream_t)stream>>>(w, (T*)w_fwd, (T*)w_dgrad, K, C, Cp, R));
     return kp_check_launch("pack_weights");
 }
 
-int kp_wgrad_unpack(const float* scratch, int partials, float* dw, int K, int C, int R, void* stream) {
-    KP_REQUIRE(K > 0 && C > 0 && (R == 1 || R == 3) && partials >= 1, "kp_wgrad_unpack: bad dims");
-    const long long total = (long long)K * C * R * R;
-    if (C % 4 == 0)
-        wgrad_unpack_k<4><<<cdiv(total / 4, 64), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, R);
+int kp_wgrad_unpack(const float* scratch, int partials, float* dw, int K, int C, int Cp, int R, void* stream) {
+    KP_REQUIRE(K > 0 && C > 0 && Cp >= C && (R == 1 || R == 3) && partials >= 1, "kp_wgrad_unpack: bad dims");
+    const long long total = (long long)K * Cp * R * R;
+    if (Cp % 4 == 0)
+        wgrad_unpack_k<4><<<cdiv(total / 4, 64), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, Cp, R);
     else
-        wgrad_unpack_k<1><<<cdiv(total, 64), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, R);
+        wgrad_unpack_k<1><<<cdiv(total, 64), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, Cp, R);
     return kp_check_launch("wgrad_unpack");
 }
 

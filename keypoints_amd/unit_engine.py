@@ -119,8 +119,13 @@ class UnitFunction(torch.autograd.Function):
         N, Cin, H, W = x.shape
         first = plan[0]
         pad0 = 1 if first['kind'] == 'conv3' else 0
-        a = torch.empty(N, H + 2 * pad0, W + 2 * pad0, Cin, device=dev, dtype=tdt)
-        call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, Cin, H, W, pad0, code, st)
+        # An odd input width (KeyNet decoder: z + K = 74 channels, keynet.py:55) is zero-padded to a multiple of 64
+        # so that the bf16 MFMA kernels take the first layer; its weights are zero-padded to match.
+        Cp0 = Cin
+        if first['kind'] == 'conv3' and unit.precision == 'bf16' and Cin > 4 and Cin % 64 != 0:
+            Cp0 = (Cin + 63) // 64 * 64
+        a = torch.empty(N, H + 2 * pad0, W + 2 * pad0, Cp0, device=dev, dtype=tdt)
+        call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, Cin, Cp0, H, W, pad0, code, st)
         saved = []
         C = Cin
         for idx, stp in enumerate(plan[:-1]):
@@ -128,9 +133,11 @@ class UnitFunction(torch.autograd.Function):
             K = conv.out_channels
             if conv.in_channels != C:
                 raise RuntimeError(f'channel mismatch: conv expects {conv.in_channels}, got {C}')
+            Cl = C                       # logical input channels of this layer (the conv's)
+            C = Cp0 if idx == 0 else C   # physical channels of `a`
             wf = torch.empty(K, 3, 3, C, device=dev, dtype=tdt)
             wd = torch.empty(C, 3, 3, K, device=dev, dtype=tdt) if record else None
-            call('kp_pack_weights', ptr(conv.weight), ptr(wf), ptr(wd), K, C, 3, code, st)
+            call('kp_pack_weights', ptr(conv.weight), ptr(wf), ptr(wd), K, Cl, C, 3, code, st)
             y = torch.empty(N, H, W, K, device=dev, dtype=tdt)
             training = bn is not None and bn.training
             stats = torch.empty((N * H * W + 63) // 64, 2, K, device=dev, dtype=torch.float32) if training else None
@@ -161,7 +168,7 @@ class UnitFunction(torch.autograd.Function):
                  ptr(bn.bias) if bn is not None else None, stp['slope'], TAILS[tail], ptr(a_next), out_pad, ptr(argmax),
                  N, H, W, K, code, st)
             if record:
-                saved.append(dict(a=a, y=y, mean=mean, invstd=invstd, argmax=argmax, wd=wd, H=H, W=W, C=C, K=K))
+                saved.append(dict(a=a, y=y, mean=mean, invstd=invstd, argmax=argmax, wd=wd, H=H, W=W, C=C, Cl=Cl, K=K))
             a, C, H, W = a_next, K, Ho, Wo
         head = plan[-1]
         hconv = head['conv']
@@ -171,6 +178,7 @@ class UnitFunction(torch.autograd.Function):
         if record:
             ctx.unit, ctx.saved, ctx.head_in, ctx.out = unit, saved, a, out
             ctx.dims = (N, Cin, x.shape[2], x.shape[3], H, W, C, Kout, pad0)
+            ctx.cp0 = Cp0
         return out
 
     @staticmethod
@@ -229,7 +237,7 @@ class UnitFunction(torch.autograd.Function):
             parts = _lib.lib().kp_conv_wgrad_partials(N, H, W, C, K, 3, dp, code)
             scratch = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device=dev, dtype=torch.float32)
             call('kp_conv_wgrad', ptr(sv['a']), ptr(dy), ptr(scratch), N, H, W, C, K, 3, dp, code, st)
-            call('kp_wgrad_unpack', ptr(scratch), parts, ptr(gv[id(conv.weight)]), K, C, 3, st)
+            call('kp_wgrad_unpack', ptr(scratch), parts, ptr(gv[id(conv.weight)]), K, sv['Cl'], C, 3, st)
             if need_dx:
                 gx = torch.empty(N, H + 2, W + 2, C, device=dev, dtype=tdt)
                 call('kp_conv_dgrad', ptr(dy), ptr(sv['wd']), ptr(gx), N, H, W, K, C, code, st)
@@ -239,7 +247,7 @@ class UnitFunction(torch.autograd.Function):
         dx = None
         if need_x:
             dx = torch.empty(N, Cin, H0, W0, device=dev, dtype=torch.float32)
-            call('kp_nhwc_grad_to_nchw', ptr(g), ptr(dx), N, Cin, H0, W0, gp, code, st)
+            call('kp_nhwc_grad_to_nchw', ptr(g), ptr(dx), N, Cin, ctx.cp0, H0, W0, gp, code, st)
         ctx.saved = None
         unit._after_backward()
         return (dx, None, None) + (None,) * len(params)

@@ -247,13 +247,13 @@ def transporter_forward(plans, P: Params, xs: Tensor, xt: Tensor, buffers: Optio
 
 
 def keynet_forward(plans, P: Params, x: Tensor, x_t: Tensor, buffers: Optional[Params] = None,
-                   training: bool = True, sigma: float = 0.1):
-    """KeyNet.forward (keynet.py:21-31)."""
-    z = unit_forward(plans['encoder'], P, 'encoder', x, buffers, training)
-    heat = unit_forward(plans['keypoint'], P, 'keypoint', x_t, buffers, training)
+                   training: bool = True, sigma: float = 0.1, quant=None):
+    """KeyNet.forward (keynet.py:21-31).  `quant`: see unit_forward."""
+    z = unit_forward(plans['encoder'], P, 'encoder', x, buffers, training, quant=quant)
+    heat = unit_forward(plans['keypoint'], P, 'keypoint', x_t, buffers, training, quant=quant)
     k, p = spatial_logsoftmax(heat)
     m = gaussian_like(k, z.shape[2], z.shape[3], sigma)
-    out = unit_forward(plans['decoder'], P, 'decoder', torch.cat((z, m), dim=1), buffers, training)
+    out = unit_forward(plans['decoder'], P, 'decoder', torch.cat((z, m), dim=1), buffers, training, quant=quant)
     return out, z, k, m, p, heat
 
 
@@ -342,12 +342,12 @@ def transporter_train_step(plans, P: Params, buffers: Params, state: dict, xs: T
 
 
 def keynet_train_step(plans, P: Params, buffers: Params, state: dict, x: Tensor, x_t: Tensor,
-                      loss_mask: Optional[Tensor] = None, lr: float = 1e-4):
+                      loss_mask: Optional[Tensor] = None, lr: float = 1e-4, quant=None):
     """keypoints.py:74-84."""
     for p in P.values():
         p.requires_grad_(True)
         p.grad = None
-    out = keynet_forward(plans, P, x, x_t, buffers, True)
+    out = keynet_forward(plans, P, x, x_t, buffers, True, quant=quant)
     loss = l2_reconstruction_loss(out[0], x_t, loss_mask)
     loss.backward()
     G = {n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in P.items()}

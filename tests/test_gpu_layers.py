@@ -36,10 +36,10 @@ def test_block_against_golden(golden, tag, cin, cout, tail, slope, precision, to
     beta = torch.tensor(z[f'{tag}.beta'], device=dev)
     st = stream_ptr()
     a = torch.empty(N, H + 2, W + 2, C, device=dev, dtype=tdt)
-    call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, C, H, W, 1, code, st)
+    call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, C, C, H, W, 1, code, st)
     wf = torch.empty(K, 3, 3, C, device=dev, dtype=tdt)
     wd = torch.empty(C, 3, 3, K, device=dev, dtype=tdt)
-    call('kp_pack_weights', ptr(wt), ptr(wf), ptr(wd), K, C, 3, code, st)
+    call('kp_pack_weights', ptr(wt), ptr(wf), ptr(wd), K, C, C, 3, code, st)
     y = torch.empty(N, H, W, K, device=dev, dtype=tdt)
     stats = torch.empty((N * H * W + 63) // 64, 2, K, device=dev, dtype=torch.float32)
     call('kp_conv_fwd', ptr(a), ptr(wf), ptr(bias), ptr(y), ptr(stats), N, H + 2, W + 2, C, K, 3, code, st)
@@ -88,11 +88,11 @@ def test_block_against_golden(golden, tag, cin, cout, tail, slope, precision, to
     scratch = torch.zeros(parts, K, 3, 3, C, device=dev)
     call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, W, C, K, 3, 2, code, st)
     dw = torch.zeros(K, C, 3, 3, device=dev)
-    call('kp_wgrad_unpack', ptr(scratch), parts, ptr(dw), K, C, 3, st)
+    call('kp_wgrad_unpack', ptr(scratch), parts, ptr(dw), K, C, C, 3, st)
     gx = torch.empty(N, H + 2, W + 2, C, device=dev, dtype=tdt)
     call('kp_conv_fwd', ptr(dy), ptr(wd), None, ptr(gx), None, N, H + 4, W + 4, K, C, 3, code, st)
     dx = torch.empty(N, C, H, W, device=dev)
-    call('kp_nhwc_grad_to_nchw', ptr(gx), ptr(dx), N, C, H, W, 1, code, st)
+    call('kp_nhwc_grad_to_nchw', ptr(gx), ptr(dx), N, C, C, H, W, 1, code, st)
     gt = tol * 5
     assert relerr(dgamma, z[f'{tag}.dgamma']) < gt and relerr(dbeta, z[f'{tag}.dbeta']) < gt
     assert relerr(dw, z[f'{tag}.dweight']) < gt
@@ -113,7 +113,7 @@ def test_head_against_golden(golden, precision, tol):
     K = 5
     a = torch.empty(N, H, W, C, device=dev, dtype=tdt)
     st = stream_ptr()
-    call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, C, H, W, 0, code, st)
+    call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, C, C, H, W, 0, code, st)
     wt = torch.tensor(z['head.weight'], device=dev); b = torch.tensor(z['head.bias'], device=dev)
     out = torch.empty(N, K, H, W, device=dev)
     call('kp_head_fwd', ptr(a), ptr(wt), ptr(b), 0.01, ptr(out), N, H, W, C, K, code, st)

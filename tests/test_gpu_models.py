@@ -217,6 +217,48 @@ def test_keynet_F_128_golden(golden):
         assert e_s <= tol and e_n <= tol, (n, e_s, e_n, tol)
 
 
+def test_keynet_F_128_bf16_tracks_emulation(golden):
+    """KeyNet in bf16 (decoder input z + K = 74 channels, zero-padded to 128 for the MFMA kernels) must be no further
+    from the fp32 reference vectors than a torch emulation of bf16 storage of the reference (oracle quant), within
+    25 % -- the same criterion as the Transporter bf16 test."""
+    import types
+    import keypoints_amd as ka
+    from keypoints_amd.models import keynet
+    from oracle import kp_oracle as O
+    z = golden('keynet_F_128.npz')
+    plans = O.keynet_plans('F', 3, 64, 10)
+    P, Bf = O.init_params(plans, seed=int(z['seed_params']))
+    net = keynet.make(types.SimpleNamespace(model_type='F', model_in_channels=3, model_z_channels=64,
+                                            model_keypoints=10, load=None, transfer_load=None))
+    net.load_state_dict({**P, **Bf}, strict=True)
+    net = net.cuda().set_precision('bf16')
+    g = torch.Generator().manual_seed(int(z['seed_inputs']))
+    x = torch.rand(2, 3, 128, 128, generator=g)
+    x_ = torch.rand(2, 3, 128, 128, generator=g)
+    mask = (torch.rand(2, 3, 128, 128, generator=g) > 0.1).float()
+    x_t, zz, k, m, p, heat = net(x.cuda(), x_.cuda())
+    loss = ka.l2_reconstruction_loss(x_t, x_.cuda(), mask.cuda())
+    loss.backward()
+    oP = {kk: v.clone() for kk, v in P.items()}
+    oB = {kk: v.clone() for kk, v in Bf.items()}
+    eloss, eout, eG = O.keynet_train_step(plans, oP, oB, {}, x, x_, loss_mask=mask, quant=O.bf16_storage)
+    ref = z['x_t']
+    hip_e, emu_e = rel_l2(x_t, ref), rel_l2(eout[0], ref)
+    assert hip_e <= 1.25 * emu_e + 1e-3, (hip_e, emu_e)
+    assert maxerr(k, z['k']) <= 1.5 * maxerr(eout[2], z['k']) + 2e-3
+    assert abs(loss.item() - float(z['loss'])) <= 1.5 * abs(eloss.item() - float(z['loss'])) + 1e-2 * float(z['loss'])
+    # the padded first decoder layer: its weight gradient must have the right shape and be finite / non-trivial
+    gw = net.decoder.in_block[1].weight.grad
+    assert gw.shape == (512, 74, 3, 3) and torch.isfinite(gw).all() and gw.abs().max().item() > 0
+    noise = pre_bn_bias_names(net)
+    ratios = []
+    for n, (e_s, _) in _grad_errors(net, z, noise).items():
+        idx = torch.tensor(z['gidx.' + n])
+        emu = np.linalg.norm(t2n(eG[n].flatten()[idx]) - z['g64val.' + n]) / np.linalg.norm(z['g64val.' + n])
+        ratios.append(e_s / max(emu, 1e-3))
+    assert np.median(ratios) <= 1.25 and np.percentile(ratios, 90) <= 2.0, (np.median(ratios), max(ratios))
+
+
 def test_train_steps_vs_oracle_bf16_pong():
     """BASELINE config 2 shape (Pong-grey 84x84 K=4, bf16) on a small batch: 3 train steps track the
     fp32 oracle within mixed-precision error, and the loss decreases identically in sign."""
