@@ -343,6 +343,137 @@ __global__ __launch_bounds__(TPB) void bn_bwd_fast_k(const bf16_t* __restrict__ 
     }
 }
 
+// MaxPool2d(2,2) tail, walking POOLED pixels: one load of the pooled gradient and of the argmax codes serves the four
+// pre-pool positions (the per-pre-pool-pixel form above re-reads them four times: 12 loads per pooled pixel, here 6).
+// MODE 0 rows = N*(H/2) pooled rows; MODE 1 also rows = N*(H/2): a pooled row writes pre-pool rows 2sh, 2sh+1 of dy
+// (+ the zero border columns, and the zero border rows when it is the first / last pooled row of an image).
+template <int GP, int MODE>
+__global__ __launch_bounds__(TPB) void bn_bwd_pool_fast_k(const bf16_t* __restrict__ gsrc, const unsigned char* __restrict__ argmax,
+                                                          const bf16_t* __restrict__ y, BnP bn, float slope,
+                                                          float* __restrict__ partials, const float* __restrict__ sums,
+                                                          bf16_t* __restrict__ dy, int dp, int N, int H, int W, int C,
+                                                          long long total_rows, int rpb) {
+    constexpr int U2 = 2;
+    const int CV = C / V;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
+    const int c = cv * V;
+    const int Hs = H / 2, Ws = W / 2, Wp = W + 2 * dp, Hp = H + 2 * dp;
+    BnC k; k.load(bn, c);
+    float sb[V], sg[V], db[V], dg[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) sb[e] = sg[e] = db[e] = dg[e] = 0.f;
+    if (MODE == 1) {
+        const float invM = 1.0f / (float)((long long)N * H * W);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            db[e] = k.affine ? sums[c + e] * invM : 0.f;
+            dg[e] = k.affine ? sums[C + c + e] * invM : 0.f;
+        }
+    }
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    const long long r0 = (long long)blockIdx.x * rpb;
+    for (int rr = 0; rr < rpb; ++rr) {
+        const long long row = r0 + rr;
+        if (row >= total_rows) break;
+        const long long n = row / Hs;
+        const int sh = (int)(row - n * Hs);
+        const bool hedge = GP && (sh == 0 || sh == Hs - 1);
+        const bf16_t* y0 = y + ((n * H + 2 * sh) * W) * (long long)C + c;
+        const bf16_t* y1 = y0 + (long long)W * C;
+        bf16_t* d0 = nullptr;
+        if (MODE == 1) {
+            d0 = dy + ((n * Hp + 2 * sh + dp) * Wp) * (long long)C + c;   // pre-pool row 2sh (incl. left border)
+            for (int j = pl; j < dp; j += npl) {                             // zero border columns of both rows
+                stv(d0 + (long long)j * C, zero4); stv(d0 + (long long)(W + dp + j) * C, zero4);
+                stv(d0 + (long long)(Wp + j) * C, zero4); stv(d0 + (long long)(Wp + W + dp + j) * C, zero4);
+            }
+            if (sh == 0)
+                for (int r = 0; r < dp; ++r)
+                    for (int j = pl; j < Wp; j += npl) stv(dy + ((n * Hp + r) * Wp + j) * (long long)C + c, zero4);
+            if (sh == Hs - 1)
+                for (int r = 0; r < dp; ++r)
+                    for (int j = pl; j < Wp; j += npl) stv(dy + ((n * Hp + H + dp + r) * Wp + j) * (long long)C + c, zero4);
+        }
+        for (int w0 = pl; w0 < Ws; w0 += U2 * npl) {
+            uint4 graw[U2], yraw[U2][4];
+            uint2 amraw[U2];
+#pragma unroll
+            for (int u = 0; u < U2; ++u) {
+                const int sw = w0 + u * npl;
+                if (sw < Ws) {
+                    graw[u] = ldv(g_centre<GP>(gsrc, n, sh, sw, Hs, Ws, C) + c);
+                    amraw[u] = *reinterpret_cast<const uint2*>(argmax + ((n * Hs + sh) * Ws + sw) * (long long)C + c);
+                    yraw[u][0] = ldv(y0 + (long long)(2 * sw) * C);
+                    yraw[u][1] = ldv(y0 + (long long)(2 * sw + 1) * C);
+                    yraw[u][2] = ldv(y1 + (long long)(2 * sw) * C);
+                    yraw[u][3] = ldv(y1 + (long long)(2 * sw + 1) * C);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U2; ++u) {
+                const int sw = w0 + u * npl;
+                if (sw < Ws) {
+                    float g[V];
+                    unpack8(graw[u], g);
+                    if (GP && (hedge || sw == 0 || sw == Ws - 1)) g_edge_add(gsrc, n, sh, sw, Hs, Ws, C, c, g);
+                    unsigned code[V];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        code[e] = (amraw[u].x >> (8 * e)) & 0xffu;
+                        code[e + 4] = (amraw[u].y >> (8 * e)) & 0xffu;
+                    }
+                    if (MODE == 0) {
+                        // only the argmax position of a window carries gradient: pick its y per channel
+                        float y4[4][V], ys[V];
+#pragma unroll
+                        for (int pos = 0; pos < 4; ++pos) unpack8(yraw[u][pos], y4[pos]);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            ys[e] = code[e] == 0 ? y4[0][e] : (code[e] == 1 ? y4[1][e] : (code[e] == 2 ? y4[2][e] : y4[3][e]));
+                            const float gh = g[e] * act_grad(k.z(ys[e], e), slope);
+                            sb[e] += gh;
+                            sg[e] += gh * k.xhat(ys[e], e);
+                        }
+                    } else {
+#pragma unroll
+                        for (int pos = 0; pos < 4; ++pos) {
+                            float yv[V], res[V];
+                            unpack8(yraw[u][pos], yv);
+#pragma unroll
+                            for (int e = 0; e < V; ++e) {
+                                const float gh = (code[e] == (unsigned)pos ? g[e] : 0.f) * act_grad(k.z(yv[e], e), slope);
+                                res[e] = k.affine ? k.ga[e] * k.is[e] * (gh - db[e] - k.xhat(yv[e], e) * dg[e]) : gh;
+                            }
+                            stv(d0 + ((long long)(pos >> 1) * Wp + dp + 2 * sw + (pos & 1)) * C, pack8(res));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == 0) {
+        __shared__ float red[TPB * 2 * V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            red[(pl * CV + cv) * 2 * V + e] = sb[e];
+            red[(pl * CV + cv) * 2 * V + V + e] = sg[e];
+        }
+        __syncthreads();
+        if (pl == 0) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float a = 0.f, b = 0.f;
+                for (int r2 = 0; r2 < npl; ++r2) {
+                    a += red[(r2 * CV + cv) * 2 * V + e];
+                    b += red[(r2 * CV + cv) * 2 * V + V + e];
+                }
+                partials[((long long)blockIdx.x * 2 + 0) * C + c + e] = a;
+                partials[((long long)blockIdx.x * 2 + 1) * C + c + e] = b;
+            }
+        }
+    }
+}
+
 bool fast_shape(int C) { return C % V == 0 && (C / V) <= TPB && TPB % (C / V) == 0; }
 
 int rows_per_block(long long total_rows, int vec_per_row, int cus) {
@@ -384,10 +515,23 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
     if (!(tail == KP_TAIL_NONE || tail == KP_TAIL_MAXPOOL2) || gp < 0 || gp > 1 || !fast_shape(C)) return KP_E_UNSUPPORTED;
     if (tail == KP_TAIL_MAXPOOL2 && ((H | W) & 1)) return KP_E_UNSUPPORTED;
     BnP bn{mean, invstd, gamma, beta};
+    const int pool = tail == KP_TAIL_MAXPOOL2;
+    if (pool) {   // walk pooled rows
+        const long long prows = (long long)N * (H / 2);
+        const int prpb = rows_per_block(prows, (W / 2) * (C / V) * 4, kp_device_cus());
+        const unsigned pgrid = (unsigned)((prows + prpb - 1) / prpb);
+        if (mode == 0) kp_set_last_rows(pgrid);
+#define KP_BWDP(GPv, MODEv)                                                                                               \
+    bn_bwd_pool_fast_k<GPv, MODEv><<<pgrid, TPB, 0, st>>>((const bf16_t*)gsrc, argmax, (const bf16_t*)y, bn, slope, partials, \
+                                                         sums, (bf16_t*)dy, dp, N, H, W, C, prows, prpb)
+        if (mode == 0) { if (gp) KP_BWDP(1, 0); else KP_BWDP(0, 0); }
+        else { if (gp) KP_BWDP(1, 1); else KP_BWDP(0, 1); }
+#undef KP_BWDP
+        return kp_check_launch("bn_bwd_pool_fast");
+    }
     const long long rows = mode ? (long long)N * (H + 2 * dp) : (long long)N * H;
     const int rpb = rows_per_block(rows, W * (C / V), kp_device_cus());
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
-    const int pool = tail == KP_TAIL_MAXPOOL2;
     if (mode == 0) kp_set_last_rows(grid);
 #define KP_BWD(POOLv, GPv, MODEv)                                                                                    \
     bn_bwd_fast_k<POOLv, GPv, MODEv><<<grid, TPB, 0, st>>>((const bf16_t*)gsrc, argmax, (const bf16_t*)y, bn, slope,  \
