@@ -193,6 +193,99 @@ __global__ __launch_bounds__(TPB) void bn_act_fwd_tail_fast_k(const bf16_t* __re
     }
 }
 
+// ---- forward with the bilinear x2 tail, 2x2 blocks of the (padded) output ----------------------------------
+// With align_corners=True and a border of 1, the two output rows 2b, 2b+1 of the padded image interpolate between
+// the SAME two source rows (and likewise for columns), so a 2x2 output block needs 2x2 source vectors: 4 loads and
+// 4 BN+activation evaluations for 4 outputs instead of 16.  The interpolation indices / weights still come from
+// the exact per-output formula (bilin); an output whose taps fall outside the block's source pair (possible only
+// at odd paddings / image ends) takes the direct path.
+__global__ __launch_bounds__(TPB) void bn_act_fwd_up_fast_k(const bf16_t* __restrict__ y, BnP bn, float slope,
+                                                            bf16_t* __restrict__ out, int p, int H, int W, int C,
+                                                            long long total_rows, int rpb) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const int CV = C / V, Hp = Ho + 2 * p, Wp = Wo + 2 * p, HB = (Hp + 1) / 2, WB = (Wp + 1) / 2;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
+    const int c = cv * V;
+    BnC k; k.load(bn, c);
+    const long long r0 = (long long)blockIdx.x * rpb;
+    for (int rr = 0; rr < rpb; ++rr) {
+        const long long row = r0 + rr;              // block row: (n, bi)
+        if (row >= total_rows) break;
+        const long long n = row / HB;
+        const int bi = (int)(row - n * HB);
+        const bf16_t* yn = y + n * H * W * (long long)C + c;
+        int hh0[2], hhp[2]; float lh0[2], lh1[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) bilin(clampi(2 * bi + a - p, 0, Ho - 1), H, Ho, hh0[a], hhp[a], lh0[a], lh1[a]);
+        const int rA = hh0[0], rB = rA + 1 < H ? rA + 1 : H - 1;
+        const bf16_t* yA = yn + (long long)rA * W * C;
+        const bf16_t* yB = yn + (long long)rB * W * C;
+        for (int bj = pl; bj < WB; bj += npl) {
+            int ww0[2], wwp[2]; float lw0[2], lw1[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bilin(clampi(2 * bj + b - p, 0, Wo - 1), W, Wo, ww0[b], wwp[b], lw0[b], lw1[b]);
+            const int cA = ww0[0], cB = cA + 1 < W ? cA + 1 : W - 1;
+            float s[2][2][V];   // activated sources [row A/B][col A/B]
+            {
+                const uint4 rAA = ldv(yA + (long long)cA * C), rAB = ldv(yA + (long long)cB * C);
+                const uint4 rBA = ldv(yB + (long long)cA * C), rBB = ldv(yB + (long long)cB * C);
+                float v[V];
+                unpack8(rAA, v);
+#pragma unroll
+                for (int e = 0; e < V; ++e) s[0][0][e] = act_fwd(k.z(v[e], e), slope);
+                unpack8(rAB, v);
+#pragma unroll
+                for (int e = 0; e < V; ++e) s[0][1][e] = act_fwd(k.z(v[e], e), slope);
+                unpack8(rBA, v);
+#pragma unroll
+                for (int e = 0; e < V; ++e) s[1][0][e] = act_fwd(k.z(v[e], e), slope);
+                unpack8(rBB, v);
+#pragma unroll
+                for (int e = 0; e < V; ++e) s[1][1][e] = act_fwd(k.z(v[e], e), slope);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int i = 2 * bi + a;
+                if (i >= Hp) continue;
+                const int r0i = hh0[a], r1i = hh0[a] + hhp[a];
+                const bool rok = (r0i == rA || r0i == rB) && (r1i == rA || r1i == rB);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int j = 2 * bj + b;
+                    if (j >= Wp) continue;
+                    const int c0i = ww0[b], c1i = ww0[b] + wwp[b];
+                    const bool cok = (c0i == cA || c0i == cB) && (c1i == cA || c1i == cB);
+                    float res[V];
+                    if (rok && cok) {
+                        const int ra = r0i == rA ? 0 : 1, rb = r1i == rA ? 0 : 1, ca = c0i == cA ? 0 : 1, cb = c1i == cA ? 0 : 1;
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            const float a00 = ra ? (ca ? s[1][1][e] : s[1][0][e]) : (ca ? s[0][1][e] : s[0][0][e]);
+                            const float a01 = ra ? (cb ? s[1][1][e] : s[1][0][e]) : (cb ? s[0][1][e] : s[0][0][e]);
+                            const float a10 = rb ? (ca ? s[1][1][e] : s[1][0][e]) : (ca ? s[0][1][e] : s[0][0][e]);
+                            const float a11 = rb ? (cb ? s[1][1][e] : s[1][0][e]) : (cb ? s[0][1][e] : s[0][0][e]);
+                            res[e] = lh0[a] * (lw0[b] * a00 + lw1[b] * a01) + lh1[a] * (lw0[b] * a10 + lw1[b] * a11);
+                        }
+                    } else {   // direct path
+                        const bf16_t* q0 = yn + (long long)r0i * W * C;
+                        const bf16_t* q1 = yn + (long long)r1i * W * C;
+                        float v00[V], v01[V], v10[V], v11[V];
+                        unpack8(ldv(q0 + (long long)c0i * C), v00); unpack8(ldv(q0 + (long long)c1i * C), v01);
+                        unpack8(ldv(q1 + (long long)c0i * C), v10); unpack8(ldv(q1 + (long long)c1i * C), v11);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            const float a00 = act_fwd(k.z(v00[e], e), slope), a01 = act_fwd(k.z(v01[e], e), slope);
+                            const float a10 = act_fwd(k.z(v10[e], e), slope), a11 = act_fwd(k.z(v11[e], e), slope);
+                            res[e] = lh0[a] * (lw0[b] * a00 + lw1[b] * a01) + lh1[a] * (lw0[b] * a10 + lw1[b] * a11);
+                        }
+                    }
+                    stv(out + ((n * Hp + i) * Wp + j) * (long long)C + c, pack8(res));
+                }
+            }
+        }
+    }
+}
+
 // ---- backward ---------------------------------------------------------------------------------------------
 // Incoming gradient for pre-tail pixel (h, w): TAIL none -> source pixel (h, w); TAIL pool -> source pixel
 // (h/2, w/2) taken only where argmax == position.  GP = 1: the source is a padded-domain gradient
@@ -503,8 +596,13 @@ int kp_bn_act_fwd_fast(const void* y, const float* mean, const float* invstd, co
         bn_act_fwd_none_fast_k<<<grid, TPB, 0, st>>>((const bf16_t*)y, bn, slope, (bf16_t*)out, out_pad, H, W, C, rows, rpb);
     else if (tail == KP_TAIL_MAXPOOL2)
         bn_act_fwd_tail_fast_k<1><<<grid, TPB, 0, st>>>((const bf16_t*)y, bn, slope, (bf16_t*)out, out_pad, argmax, H, W, C, rows, rpb);
-    else
-        bn_act_fwd_tail_fast_k<2><<<grid, TPB, 0, st>>>((const bf16_t*)y, bn, slope, (bf16_t*)out, out_pad, nullptr, H, W, C, rows, rpb);
+    else {
+        const int HB = (Ho + 2 * out_pad + 1) / 2, WB = (Wo + 2 * out_pad + 1) / 2;
+        const long long brows = (long long)N * HB;
+        const int brpb = rows_per_block(brows, WB * (C / V) * 4, kp_device_cus());
+        bn_act_fwd_up_fast_k<<<(unsigned)((brows + brpb - 1) / brpb), TPB, 0, st>>>((const bf16_t*)y, bn, slope, (bf16_t*)out,
+                                                                                  out_pad, H, W, C, brows, brpb);
+    }
     return kp_check_launch("bn_act_fwd_fast");
 }
 
