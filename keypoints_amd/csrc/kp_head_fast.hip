@@ -20,6 +20,21 @@ __device__ __forceinline__ void unpack8(const uint4 v, float (&o)[V]) {
     o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
 }
 
+// Sum over the CV adjacent lanes of a pixel (CV a power of two <= 64): DPP for the steps inside a 16-lane row
+// (quad_perm xor 1 / xor 2, row_half_mirror, row_ror:8 -- no LDS round trip), ds_bpermute only across rows.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float group_sum(float v, int CV) {
+    if (CV >= 2) v += dpp_mov<0xB1>(v);    // lane ^ 1
+    if (CV >= 4) v += dpp_mov<0x4E>(v);    // lane ^ 2
+    if (CV >= 8) v += dpp_mov<0x141>(v);   // lane ^ 7: the other quad of the 8-lane group (quads are uniform by now)
+    if (CV >= 16) v += dpp_mov<0x128>(v);  // lane ^ 8
+    if (CV >= 32) v += __shfl_xor(v, 16, 64);
+    if (CV >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 // KB = compile-time bound on K (4 or 16); CV = C/8 is a power of two <= 64 (checked by the launcher)
 template <int KB>
 __global__ __launch_bounds__(TPB) void head_fwd_small_k(const bf16_t* __restrict__ x, const float* __restrict__ w,
@@ -47,10 +62,9 @@ __global__ __launch_bounds__(TPB) void head_fwd_small_k(const bf16_t* __restrict
                          xv[6] * w1.z + xv[7] * w1.w;
             }
         }
-        for (int o = 1; o < CV; o <<= 1)
 #pragma unroll
-            for (int k = 0; k < KB; ++k)
-                if (k < K) acc[k] += __shfl_xor(acc[k], o, 64);
+        for (int k = 0; k < KB; ++k)
+            if (k < K) acc[k] = group_sum(acc[k], CV);
         if (cv == 0) {
             const long long n = m / HW, hw = m - n * HW;
 #pragma unroll
