@@ -12,13 +12,14 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
 KERNELS = {'conv3x3_patch_k<128>': 'conv_patch_bf16_bn128', 'wgrad3x3_patch_k<128, 64>': 'wgrad_patch_bf16_128x64'}
 
 
 def load(name):
-    f = glob.glob(f'gpurun_out/pmc_{name}/*/*counter_collection.csv')[0]
+    f = max(glob.glob(f'gpurun_out/pmc_{name}/*/*counter_collection.csv'), key=os.path.getmtime)
     return list(csv.DictReader(open(f)))
 
 
