@@ -298,12 +298,41 @@ def test_full_size_batch_properties():
     net = transporter.make('F', 3, 64, 10).cuda().set_precision('bf16')
     net.eval()
     g = torch.Generator().manual_seed(5)
-    xs = torch.rand(32, 3, 128, 128, generator=g).cuda()
-    xt = torch.rand(32, 3, 128, 128, generator=g).cuda()
+    xs = torch.rand(128, 3, 128, 128, generator=g).cuda()     # 128 pairs = the bench's per-GPU batch
+    xt = torch.rand(128, 3, 128, 128, generator=g).cuda()
     with torch.no_grad():
         full = net(xs, xt)
         again = net(xs, xt)
-        part = net(xs[8:12], xt[8:12])
+        part = net(xs[72:76], xt[72:76])
     assert torch.equal(full[0], again[0]) and torch.equal(full[2], again[2])
-    assert torch.equal(full[0][8:12], part[0]) and torch.equal(full[2][8:12], part[2])
+    assert torch.equal(full[0][72:76], part[0]) and torch.equal(full[2][72:76], part[2])
     assert full[2].min() >= 0 and full[2].max() <= 1
+
+
+def test_inference_keypoint_extractor_matches_oracle():
+    """the inference-only consumer (atari_demo.py:35-36) runs `net.keypoint(x)` then
+    `spacial_logsoftmax` with BatchNorm in eval mode (running statistics): fp32 parity with the oracle."""
+    from keypoints_amd.models import functional as MF, transporter
+    from oracle import kp_oracle as O
+    torch.manual_seed(3)
+    net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 4)
+    g = torch.Generator().manual_seed(9)
+    for name, buf in net.named_buffers():       # non-trivial running statistics
+        if name.endswith('running_mean'):
+            buf.copy_(torch.randn(buf.shape, generator=g) * 0.1)
+        elif name.endswith('running_var'):
+            buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+    P = {k: v.detach().clone() for k, v in net.named_parameters()}
+    Bf = {k: v.detach().clone() for k, v in net.named_buffers()}
+    net = net.cuda().eval()
+    x = torch.rand(3, 1, 84, 84, generator=g) * 2 - 1
+    with torch.no_grad():
+        heat = net.keypoint(x.cuda())
+        k = MF.spacial_logsoftmax(heat)
+    plans = O.transporter_plans('VGG_PONG_LAYERNECK', 1, 16, 4)
+    oheat = O.unit_forward(plans['keypoint'], P, 'keypoint', x, Bf, training=False)
+    ok, _ = O.spatial_logsoftmax(oheat)
+    assert maxerr(heat, oheat) <= 1e-4 * float(oheat.abs().max()) + 1e-5
+    assert maxerr(k, ok) <= 2e-5
+    for name, buf in net.named_buffers():       # eval mode must not touch the running statistics
+        assert torch.equal(buf.cpu(), Bf[name]), name
