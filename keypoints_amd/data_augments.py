@@ -1,36 +1,50 @@
-"""`nop` / `TpsAndRotate` with the reference's surface (keypoints/data_augments.py:6-38): the augmentation that
-turns a batch x into (x, x_, loss_mask) for the KeyNet config (configs/keypoints_celeba.yaml:13-16)."""
+"""Input augmentation with the reference's surface (keypoints/data_augments.py:6-38): `nop` and `TpsAndRotate`
+turn a batch into the (x, x_, loss_mask) triple the train loop feeds to the model (keypoints.py:72-79,
+configs/keypoints_celeba.yaml:13-16).  Every warp is one HIP resampling pass (keypoints_amd.tps); the image and its
+all-ones validity mask go through the same two (TPS, rotation) stages, so the mask marks what survived both.
+"""
 import torch
 
-from .tps import rotate_affine_grid_multi, tps_sample_params, tps_transform
+from . import tps as _tps
 
 
 def rand_peturb_params(batch_items, tps_cntl_pts, tps_variance, max_rotate):
-    theta_tps, cntl_pts = tps_sample_params(batch_items, tps_cntl_pts, tps_variance)
-    theta_rotate = (torch.rand(batch_items) * 2 - 1) * max_rotate
-    return theta_tps, cntl_pts, theta_rotate
+    """One random (TPS weights, control points, rotation angle) draw per sample; same torch RNG calls, in the same
+    order, as data_augments.py:6-10, so a seed reproduces the reference's augmentation."""
+    weights, points = _tps.tps_sample_params(batch_items, tps_cntl_pts, tps_variance)
+    angles = max_rotate * (2 * torch.rand(batch_items) - 1)
+    return weights, points, angles
 
 
 def peturb(x, tps_theta, cntl_pts, theta_rotate):
-    return rotate_affine_grid_multi(tps_transform(x, tps_theta, cntl_pts), theta_rotate)
+    """TPS warp followed by a rotation (data_augments.py:13-16)."""
+    warped = _tps.tps_transform(x, tps_theta, cntl_pts)
+    return _tps.rotate_affine_grid_multi(warped, theta_rotate)
 
 
 def nop(*data):
+    """No augmentation: (x, x_) pass through, no loss mask."""
     return data[0], data[1], None
 
 
 class TpsAndRotate(object):
+    """x -> (peturb_1(x), peturb_2(peturb_1(x)), mask) with two independent random draws."""
+
     def __init__(self, data_aug_tps_cntl_pts, data_aug_tps_variance, data_aug_max_rotate):
-        self.tps_cntl_pts, self.tps_variance, self.max_rotate = \
-            data_aug_tps_cntl_pts, data_aug_tps_variance, data_aug_max_rotate
+        self.tps_cntl_pts = data_aug_tps_cntl_pts
+        self.tps_variance = data_aug_tps_variance
+        self.max_rotate = data_aug_max_rotate
+
+    def _draw(self, n):
+        return rand_peturb_params(n, self.tps_cntl_pts, self.tps_variance, self.max_rotate)
 
     def __call__(self, *data):
-        x = data[0]
-        loss_mask = torch.ones(x.shape, dtype=x.dtype, device=x.device)
-        p1 = rand_peturb_params(x.size(0), self.tps_cntl_pts, self.tps_variance, self.max_rotate)
-        x = peturb(x, *p1)
-        loss_mask = peturb(loss_mask, *p1)
-        p2 = rand_peturb_params(x.size(0), self.tps_cntl_pts, self.tps_variance, self.max_rotate)
-        x_ = peturb(x, *p2)
-        loss_mask = peturb(loss_mask, *p2)
-        return x, x_, loss_mask
+        image = data[0]
+        valid = torch.ones_like(image)
+        stages = []
+        for _ in range(2):                      # draw, warp the image, warp the mask -- in the reference's order
+            params = self._draw(image.size(0))
+            image = peturb(image, *params)
+            valid = peturb(valid, *params)
+            stages.append(image)
+        return stages[0], stages[1], valid
