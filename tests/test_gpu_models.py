@@ -309,6 +309,45 @@ def test_full_size_batch_properties():
     assert full[2].min() >= 0 and full[2].max() <= 1
 
 
+def test_transporter_F_256_K30_bf16_tracks_emulation():
+    """BASELINE config 5 shape (F, 256x256x3, K=30; the reference's fp16 role is played by bf16) on B=2: no golden
+    file (the oracle runs here in ~20 s), same criterion as the 128x128 bf16 test: the HIP result is no further from the
+    fp32 oracle than the oracle's own bf16-storage emulation, within 25 %."""
+    import keypoints_amd as ka
+    from keypoints_amd.models import transporter
+    from oracle import kp_oracle as O
+    plans = O.transporter_plans('F', 3, 64, 30)
+    P, Bf = O.init_params(plans, seed=11)
+    net = transporter.make('F', 3, 64, 30)
+    net.load_state_dict({**P, **Bf}, strict=True)
+    net = net.cuda().set_precision('bf16')
+    g = torch.Generator().manual_seed(12)
+    xs = torch.rand(2, 3, 256, 256, generator=g)
+    xt = torch.rand(2, 3, 256, 256, generator=g)
+    out = net(xs.cuda(), xt.cuda())
+    loss = ka.l2_reconstruction_loss(out[0], xt.cuda())
+    loss.backward()
+    torch.set_num_threads(max(1, min(16, (torch.get_num_threads() or 1))))
+    clone = lambda d: {k: v.clone() for k, v in d.items()}
+    rloss, rout, rG = O.transporter_train_step(plans, clone(P), clone(Bf), {}, xs, xt)
+    eloss, eout, eG = O.transporter_train_step(plans, clone(P), clone(Bf), {}, xs, xt, quant=O.bf16_storage)
+    assert out[0].shape == (2, 3, 256, 256) and out[2].shape == (2, 30, 2) and out[3].shape == (2, 30, 32, 32)
+    hip_e, emu_e = rel_l2(out[0], rout[0]), rel_l2(eout[0], rout[0])
+    assert hip_e <= 1.25 * emu_e + 1e-3, (hip_e, emu_e)
+    assert maxerr(out[2], rout[2]) <= 1.5 * maxerr(eout[2], rout[2]) + 2e-3
+    assert abs(loss.item() - rloss.item()) <= 1.5 * abs(eloss.item() - rloss.item()) + 1e-2 * rloss.item()
+    noise = pre_bn_bias_names(net)
+    ratios = []
+    for n, prm in net.named_parameters():
+        if n in noise:
+            continue
+        ref = rG[n].double()
+        hip = np.linalg.norm(t2n(prm.grad) - t2n(ref)) / max(1e-30, float(ref.norm()))
+        emu = float((eG[n].double() - ref).norm() / ref.norm())
+        ratios.append(hip / max(emu, 1e-3))
+    assert np.median(ratios) <= 1.25 and np.percentile(ratios, 90) <= 2.0, (np.median(ratios), max(ratios))
+
+
 def test_inference_keypoint_extractor_matches_oracle():
     """the inference-only consumer (atari_demo.py:35-36) runs `net.keypoint(x)` then
     `spacial_logsoftmax` with BatchNorm in eval mode (running statistics): fp32 parity with the oracle."""
