@@ -27,7 +27,7 @@ import torch.distributed as dist
 
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3     # fp32 vector / f32-MFMA peak
-FAMILIES = {0: 'conv_valid_generic', 1: 'conv_wgrad_generic', 2: 'conv_mfma_bf16', 3: 'wgrad_mfma_bf16', 4: 'conv_first_bf16'}
+FAMILIES = {0: 'conv_valid_generic', 1: 'conv_wgrad_generic', 2: 'conv_mfma_bf16', 3: 'wgrad_mfma_bf16', 4: 'conv_first_bf16', 5: 'conv_small_bf16'}
 
 
 def parse():

@@ -64,6 +64,7 @@ int kp_config_ptr(int key, void* value);
 #define KP_PROF_CONV_MFMA 2      /* bf16 MFMA implicit-GEMM conv (fwd + dgrad) */
 #define KP_PROF_WGRAD_MFMA 3
 #define KP_PROF_CONV_FIRST 4     /* Cin <= 4 first-layer VALU kernels (fwd + wgrad), HBM-bound */
+#define KP_PROF_CONV_SMALL 5     /* C, K in {16, 32} small-channel kernels (MFMA fwd/dgrad, VALU wgrad), HBM-bound */
 /* Start (on=1, resets) / stop (on=0) recording a HIP-event pair around every convolution launch,
  * on the launch stream. */
 int kp_prof_enable(int on);

@@ -13,6 +13,8 @@ int kp_conv_wgrad_mfma(const void*, const void*, float*, int, int, int, int, int
 int kp_conv_dgrad_mfma(const void*, const void*, void*, int, int, int, int, int, hipStream_t);
 int kp_conv_wgrad_patch(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 long long kp_conv_wgrad_patch_partials(int, int, int, int, int, int);
+int kp_conv_small_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
+int kp_conv_small_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 int kp_conv_first_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
 int kp_conv_first_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 
@@ -159,7 +161,12 @@ int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, float*
             rc = kp_conv_first_fwd(x, w, bias, y, stats, N, Hi, Wi, C, K, (hipStream_t)stream);
             if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_FIRST); return rc; }
         }
+        if (R == 3) {
+            rc = kp_conv_small_fwd(x, w, bias, y, stats, N, Hi, Wi, C, K, (hipStream_t)stream);
+            if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_SMALL); return rc; }
+        }
     }
+    if (getenv("KP_LOG_GENERIC")) fprintf(stderr, "generic conv: N=%d Hi=%d Wi=%d C=%d K=%d R=%d dtype=%d stats=%d\n", N, Hi, Wi, C, K, R, dtype, stats != nullptr);
     int rc = kp_conv_fwd_generic(x, w, bias, y, stats, N, Hi, Wi, C, K, R, dtype, (hipStream_t)stream);
     ps.done(KP_PROF_CONV_GENERIC);
     return rc;
@@ -208,7 +215,12 @@ int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, 
             rc = kp_conv_first_wgrad(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
             if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_FIRST); return rc; }
         }
+        if (R == 3) {
+            rc = kp_conv_small_wgrad(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
+            if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_SMALL); return rc; }
+        }
     }
+    if (getenv("KP_LOG_GENERIC")) fprintf(stderr, "generic wgrad: N=%d Ho=%d Wo=%d C=%d K=%d R=%d dp=%d dtype=%d\n", N, Ho, Wo, C, K, R, dy_pad, dtype);
     int rc = kp_conv_wgrad_generic(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, dtype, (hipStream_t)stream);
     ps.done(KP_PROF_WGRAD_GENERIC);
     return rc;
