@@ -8,9 +8,9 @@
 //   tap), the 9 (18 for C = 32) weight fragments stay in registers for the whole kernel.  D = [32 k][32 px]; K = 16
 //   uses half of it.  Epilogue: bias, running BN partial sums per lane (one partial row per wavefront at the end),
 //   v_permlane32_swap pairs the two half-waves' 8-byte pieces into 16-byte stores.
-// weight gradient (wgrad3x3_small_k): VALU, a thread owns (k, 8 input channels) and walks pixels: dy[px][k] scalar x
-//   the 9 x 16-byte input vectors of the window (shared by all k-lanes: one L1 transaction), 72 accumulators;
-//   block reduction over the pixel streams, fp32 atomics into the zeroed scratch.
+// weight gradient (wgrad3x3_small_k): also MFMA and LDS-free: one 32x32 [k][c] tile per tap (9 accumulators), the
+//   pixel-reduction fragments gathered with 2-byte loads at a channel stride (L1-resident 64-byte runs); the 4
+//   wavefronts of a workgroup are summed through LDS, then fp32 atomics into the zeroed scratch.
 #include "kp_common.h"
 
 namespace {
@@ -140,56 +140,78 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_k(const bf16_t* __restrict_
     }
 }
 
-// scratch[k][tap][c] += sum_pixels dy[pixel][k] * x[pixel + tap][c];  thread = (k, group of 8 input channels)
+// scratch[k][tap][c] += sum_pixels dy[pixel][k] * x[pixel + tap][c] on the matrix cores, no LDS staging:
+// D[k][c] (one 32x32 tile per tap, 9 accumulators) += A[k][16 px] B[16 px][c].  Both operands are pixel-major in HBM, so
+// a lane gathers its fragment (8 consecutive pixels of ONE channel) with 2-byte loads at a channel stride -- 64-byte
+// runs per pixel across the wave, L1-resident; the 10 loads of an input row serve its 3 column taps.
+// A wavefront walks whole image rows in 16-pixel segments; tail pixels get dy = 0 (and a clamped, finite x).
 template <int K, int C>
 __global__ __launch_bounds__(TPB) void wgrad3x3_small_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                        float* __restrict__ scratch, int Ho, int Wo, int dy_pad,
-                                                        long long total_rows, int rows_per_block) {
-    constexpr int TPP = K * C / 8;          // threads per pixel stream
-    constexpr int NS = TPB / TPP;           // pixel streams per block
-    const int sid = threadIdx.x / TPP, r = threadIdx.x % TPP;
-    const int k = r % K, cg = r / K;
+                                                           float* __restrict__ scratch, int Ho, int Wo, int dy_pad,
+                                                           long long total_rows, int rows_per_wave) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 31, h = lane >> 5;
     const int Hi = Ho + 2, Wi = Wo + 2, Hd = Ho + 2 * dy_pad, Wd = Wo + 2 * dy_pad;
-    float acc[9][8];
+    const int kk = fr < K ? fr : K - 1, cc = fr < C ? fr : C - 1;   // lanes beyond the channel count: clamped, zeroed below
+    f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
-    const long long row0 = (long long)blockIdx.x * rows_per_block;
-    for (int rr = sid; rr < rows_per_block; rr += NS) {
-        const long long row = row0 + rr;
-        if (row >= total_rows) break;
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    const long long gw = (long long)blockIdx.x * 4 + wave;
+    const long long r_beg = gw * rows_per_wave;
+    const long long r_end = r_beg + rows_per_wave < total_rows ? r_beg + rows_per_wave : total_rows;
+    for (long long row = r_beg; row < r_end; ++row) {
         const int p = (int)(row % Ho);
         const long long n = row / Ho;
-        const bf16_t* dr = dy + (((n * Hd + p + dy_pad) * Wd) + dy_pad) * (long long)K + k;
-        const bf16_t* xr = x + ((n * Hi + p) * Wi) * (long long)C + cg * 8;
-        for (int q = 0; q < Wo; ++q) {
-            const float d = bf2f(dr[(long long)q * K]);
+        const unsigned short* dr = dy + (((n * Hd + p + dy_pad) * Wd) + dy_pad) * (long long)K + kk;
+        const unsigned short* xr = x + ((n * Hi + p) * Wi) * (long long)C + cc;
+        for (int q0 = 0; q0 < Wo; q0 += 16) {
+            const int qb = q0 + 8 * h;
+            unsigned a16[8];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const uint4 raw = *reinterpret_cast<const uint4*>(xr + ((long long)(t / 3) * Wi + q + (t % 3)) * C);
-                const float xv[8] = {__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u),
-                                     __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xffff0000u),
-                                     __uint_as_float(raw.z << 16), __uint_as_float(raw.z & 0xffff0000u),
-                                     __uint_as_float(raw.w << 16), __uint_as_float(raw.w & 0xffff0000u)};
+            for (int j = 0; j < 8; ++j) {
+                const int q = qb + j;
+                const unsigned v = dr[(long long)(q < Wo ? q : Wo - 1) * K];
+                a16[j] = (q < Wo && fr < K) ? v : 0u;
+            }
+            bf16x8 af;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[t][e] = fmaf(d, xv[e], acc[t][e]);
+            for (int j = 0; j < 8; ++j) af[j] = (short)a16[j];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                unsigned b16[10];
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const int col = qb + j;
+                    const unsigned v = xr[((long long)r * Wi + (col < Wi ? col : Wi - 1)) * C];
+                    b16[j] = fr < C ? v : 0u;
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 3; ++s_) {
+                    bf16x8 bfv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bfv[j] = (short)b16[j + s_];
+                    acc[r * 3 + s_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfv, acc[r * 3 + s_], 0, 0, 0);
+                }
             }
         }
     }
-    // reduce the NS pixel streams through LDS, then one atomic per (k, tap, c) per block
-    __shared__ float red[TPB * 9];   // reused per channel e: [NS][TPP][9]
-    for (int e = 0; e < 8; ++e) {
+    // D[k][c]: lane col = c (fr), rows k = (i&3) + 8*(i>>2) + 4*h.  Sum the 4 wavefronts per tap through LDS, then atomics.
+    __shared__ float red[4][16][64];
+    for (int t = 0; t < 9; ++t) {
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 9; ++t) red[(sid * TPP + r) * 9 + t] = acc[t][e];
+        for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[t][i];
         __syncthreads();
-        if (sid == 0) {
+        if (wave == 0) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                float s = 0.f;
-                for (int s2 = 0; s2 < NS; ++s2) s += red[(s2 * TPP + r) * 9 + t];
-                unsafeAtomicAdd(scratch + ((long long)k * 9 + t) * C + cg * 8 + e, s);
+            for (int i = 0; i < 16; ++i) {
+                const int k = (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (k < K && fr < C) {
+                    const float s = ((red[0][i][lane] + red[1][i][lane]) + red[2][i][lane]) + red[3][i][lane];
+                    unsafeAtomicAdd(scratch + ((long long)k * 9 + t) * C + fr, s);
+                }
             }
         }
     }
@@ -223,12 +245,11 @@ int kp_conv_small_wgrad(const void* x, const void* dy, float* scratch, int N, in
                         hipStream_t st) {
     if (!small_ch(C) || !small_ch(K)) return KP_E_UNSUPPORTED;
     const long long rows = (long long)N * Ho;
-    const int ns = TPB / (K * C / 8);
-    int rpb = (int)((rows + 2047) / 2048);
-    if (rpb < ns) rpb = ns;
-    rpb = (rpb + ns - 1) / ns * ns;
-    const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
-#define KP_SWG(Kv, Cv) wgrad3x3_small_k<Kv, Cv><<<grid, TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, scratch, Ho, Wo, dy_pad, rows, rpb)
+    int rpw = (int)((rows + 2047) / 2048);      // ~2048 wavefronts (512 workgroups), each a contiguous run of rows
+    if (rpw < 1) rpw = 1;
+    const long long waves = (rows + rpw - 1) / rpw;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+#define KP_SWG(Kv, Cv) wgrad3x3_small_k<Kv, Cv><<<grid, TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, scratch, Ho, Wo, dy_pad, rows, rpw)
     if (K == 16 && C == 16) KP_SWG(16, 16);
     else if (K == 16) KP_SWG(16, 32);
     else if (C == 16) KP_SWG(32, 16);
