@@ -115,7 +115,7 @@ __global__ __launch_bounds__(TPB) void head_dw_small_k(const float* __restrict__
                                                        const bf16_t* __restrict__ x, float slope,
                                                        float* __restrict__ dw, float* __restrict__ db, long long M,
                                                        int HW, int C, int K, int ppb) {
-    extern __shared__ __attribute__((aligned(16))) float red[];   // [npl][K][C] (+ [npl][K] for db)
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [npl][KC][C] (+ [npl][KC] for db)
     const int CV = C / V, cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
     float acc[KB][V], dbs[KB];
 #pragma unroll
@@ -142,25 +142,31 @@ __global__ __launch_bounds__(TPB) void head_dw_small_k(const float* __restrict__
             }
         }
     }
-    float* rdb = red + (size_t)npl * K * C;
+    // block reduction over the pixel lanes, KC output channels at a time (LDS = npl * KC * C floats, <= 32 KB)
+    constexpr int KC = 4;
+    float* rdb = red + (size_t)npl * KC * C;
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < KB; ++k) {
-        if (k < K) {
+        for (int k = 0; k < KB; ++k) {
+            if (k >= k0 && k < k0 + KC && k < K) {
 #pragma unroll
-            for (int e = 0; e < V; ++e) red[((size_t)pl * K + k) * C + cv * V + e] = acc[k][e];
-            if (cv == 0) rdb[pl * K + k] = dbs[k];
+                for (int e = 0; e < V; ++e) red[((size_t)pl * KC + (k - k0)) * C + cv * V + e] = acc[k][e];
+                if (cv == 0) rdb[pl * KC + (k - k0)] = dbs[k];
+            }
         }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < K * C; i += TPB) {
-        float s = 0.f;
-        for (int r2 = 0; r2 < npl; ++r2) s += red[(size_t)r2 * K * C + i];
-        unsafeAtomicAdd(dw + i, s);
-    }
-    if (db && threadIdx.x < K) {
-        float s = 0.f;
-        for (int r2 = 0; r2 < npl; ++r2) s += rdb[r2 * K + threadIdx.x];
-        unsafeAtomicAdd(db + threadIdx.x, s);
+        __syncthreads();
+        const int kn = K - k0 < KC ? K - k0 : KC;
+        for (int i = threadIdx.x; i < kn * C; i += TPB) {
+            float s = 0.f;
+            for (int r2 = 0; r2 < npl; ++r2) s += red[(size_t)r2 * KC * C + i];
+            unsafeAtomicAdd(dw + (size_t)k0 * C + i, s);
+        }
+        if (db && threadIdx.x < kn) {
+            float s = 0.f;
+            for (int r2 = 0; r2 < npl; ++r2) s += rdb[r2 * KC + threadIdx.x];
+            unsafeAtomicAdd(db + k0 + threadIdx.x, s);
+        }
     }
 }
 
@@ -201,7 +207,7 @@ int kp_head_dw_fast(const float* gout, const float* out, const void* x, float sl
                     int HW, int C, int K, hipStream_t st) {
     if (!small_shape(C, K)) return KP_E_UNSUPPORTED;
     const int npl = TPB / (C / V);
-    const size_t lds = ((size_t)npl * K * C + (size_t)npl * K) * sizeof(float);
+    const size_t lds = ((size_t)npl * 4 * C + (size_t)npl * 4) * sizeof(float);   // KC = 4 channels per reduction pass
     if (lds > 64 * 1024) return KP_E_UNSUPPORTED;
     // ~2048 workgroups, each a contiguous run of pixels
     long long ppb = (M + 2047) / 2048;
