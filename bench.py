@@ -102,7 +102,7 @@ def main():
     from keypoints_amd import _lib
     from keypoints_amd.dist import GradReducer
     from keypoints_amd.models import transporter
-    from oracle import kp_oracle as O   # flop accounting only (conv MACs x 2)
+    from keypoints_amd.flops import conv_flops_per_pair
 
     torch.manual_seed(0)
     if args.net == 'keynet':
@@ -172,9 +172,7 @@ def main():
     _lib.call('kp_prof_enable', 0)
 
     if rank == 0:
-        mk = O.keynet_plans if args.net == 'keynet' else O.transporter_plans
-        plans = mk(args.model_type, args.model_in_channels, args.model_z_channels, args.model_keypoints)
-        flop_pair = O.conv_flops_per_pair(plans, args.size, args.size, transporter=args.net != 'keynet')
+        flop_pair = conv_flops_per_pair(net, args.size, args.size)
         ms_step = 1e3 * elapsed / args.steps
         value = B * world / (elapsed / args.steps)
         dom = max(fam.items(), key=lambda kv: kv[1]['ms_total']) if fam else (None, None)

@@ -148,3 +148,18 @@ def test_grad_arena_views_and_attach():
     params[1].grad = None
     arena.attach(params)                      # only the detached slot is re-zeroed
     assert float(params[0].grad.min()) == 2.0 and float(params[1].grad.abs().max()) == 0
+
+
+def test_flop_accounting_matches_survey():
+    """keypoints_amd.flops (what bench.py reports as FLOP/pair) reproduces SURVEY.md 8(d): 235.23 GFLOP per pair and
+    train step for Transporter F 128x128 K=10, 196.5 for KeyNet, and agrees with the oracle's independent accounting."""
+    import types
+    from keypoints_amd.flops import conv_flops_per_pair
+    from keypoints_amd.models import keynet, transporter
+    from oracle import kp_oracle as O
+    net = transporter.make('F', 3, 64, 10)
+    f = conv_flops_per_pair(net, 128, 128)
+    assert abs(f - 235.23e9) < 0.01e9
+    assert f == O.conv_flops_per_pair(O.transporter_plans('F', 3, 64, 10), 128, 128)
+    kn = keynet.make(types.SimpleNamespace(model_type='F', model_in_channels=3, model_z_channels=64, model_keypoints=10))
+    assert conv_flops_per_pair(kn, 128, 128) == O.conv_flops_per_pair(O.keynet_plans('F', 3, 64, 10), 128, 128, transporter=False)
