@@ -212,6 +212,9 @@ int kp_warp_affine(const float* x, const float* mat, float* out, int N, int C, i
  * grad = 2*(x-t)*mask*scale  (scale = 1/numel).  mask may be NULL. */
 int kp_l2_loss(const float* x, const float* t, const float* mask, double* loss_sum, float* grad, float scale,
                size_t n, void* stream);
+/* y[i] = x[i] * s[0] with s a DEVICE scalar: chains the loss gradient (autograd hands the upstream gradient of the
+ * scalar loss as a device tensor) without a host synchronisation.  x, y 16-byte aligned; y may alias x. */
+int kp_scale(const float* x, const float* s, float* y, size_t n, void* stream);
 /* torch.optim.Adam step (transporter.py:47,89) over a flat fp32 arena. bc1 = 1-b1^t, bc2 = 1-b2^t. */
 int kp_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
                  float eps, float bc1, float bc2, void* stream);

@@ -44,6 +44,7 @@ SIGNATURES = {
     'kp_warp_tps': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'kp_warp_affine': [_p, _p, _p, _i, _i, _i, _i, _p],
     'kp_l2_loss': [_p, _p, _p, _p, _p, _f, _z, _p],
+    'kp_scale': [_p, _p, _p, _z, _p],
     'kp_adam_step': [_p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _f, _p],
     'kp_prof_enable': [_i],
     'kp_config': [_i, _i],

@@ -261,6 +261,20 @@ __global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float
     p[i] -= (lr / bc1) * (mi / denom);
 }
 
+// y = x * s[0] (s on the device: the upstream gradient of the scalar loss, no host round trip)
+__global__ void scale_k(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ y, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float f = s[0];
+    if (i + 4 <= n) {
+        float4 v = *reinterpret_cast<const float4*>(x + i);
+        v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+        *reinterpret_cast<float4*>(y + i) = v;
+    } else {
+        for (size_t j = i; j < n; ++j) y[j] = x[j] * f;
+    }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, ...)                         \
@@ -361,6 +375,13 @@ int kp_l2_loss(const float* x, const float* t, const float* mask, double* loss_s
     if (grid > 2048) grid = 2048;
     l2_loss_k<<<grid, TPB, 0, (hipStream_t)stream>>>(x, t, mask, loss_sum, grad, scale, n);
     return kp_check_launch("l2_loss");
+}
+
+int kp_scale(const float* x, const float* s, float* y, size_t n, void* stream) {
+    KP_REQUIRE(x && s && y && n > 0, "kp_scale: bad args");
+    KP_REQUIRE((((size_t)x | (size_t)y) & 15) == 0, "kp_scale: pointers must be 16-byte aligned");
+    scale_k<<<cdiv((n + 3) / 4, TPB), TPB, 0, (hipStream_t)stream>>>(x, s, y, n);
+    return kp_check_launch("scale");
 }
 
 int kp_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,

@@ -30,7 +30,10 @@ class _L2Loss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return grad * g, None, None
+        gs = f32c(g).reshape(1)                       # upstream gradient of the scalar loss (device tensor)
+        out = torch.empty_like(grad)
+        call('kp_scale', ptr(grad), ptr(gs), ptr(out), grad.numel(), stream_ptr())
+        return out, None, None
 
 
 def l2_reconstruction_loss(x, x_, loss_mask=None):
