@@ -9,7 +9,7 @@
 //       the 18 x 18 x 64ch input patch is in LDS once (41 KB, double buffered, prefetched one chunk ahead)
 //       for each of the 9 taps:                                   (one "step": 16 or 8 MFMA 32x32x16 / wave)
 //           the pixel operand is read from the patch at the tap's (r,s) shift -- no new HBM/L2 traffic,
-//           the weight tile W[k0..k0+BN)[tap][c0..c0+64) streams through a 3-deep LDS ring (16 KB / step).
+//           the weight tile W[k0..k0+BN)[tap][c0..c0+64) streams through a 4-deep LDS ring (16 KB / step).
 //
 // L2->LDS traffic per step drops from 32 KB to ~21 KB for twice the MFMAs (256-pixel tile): ~200 FLOP/B.
 // All HBM->LDS movement is LDS-DMA (buffer_load_dwordx4 ... lds); loads stay in flight across the single
@@ -38,7 +38,7 @@ constexpr int PINSTR = (PPIX + 7) / 8;  // 41 DMA instructions of 8 pixels (1 Ki
 constexpr int PBYTES = PINSTR * 1024;
 constexpr int PSLICES = (PINSTR + NWAVE - 1) / NWAVE;   // patch DMA instructions per wave per chunk (6)
 constexpr int ROWB = 128;               // bytes per LDS row (64 bf16)
-constexpr int NWBUF = 3;
+constexpr int NWBUF = 4;               // weight ring slots (power of two: the slot of a step is a run-time counter)
 
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -112,11 +112,14 @@ struct PatchArgs {
 // pipeline, so the HBM latency of a tile's first patch / weights and the epilogue stores of the previous tile
 // overlap.  Step t (8 or 16 MFMA per wave, reduction slices kk = 0..3 of 16 channels):
 //     MFMA kk=0,1 (fragments already in registers)  ||  ds_read fragments kk=2,3 of step t
-//     s_waitcnt vmcnt(#DMA issued after the previous barrier); s_barrier      <- weights of step t+1 landed
-//     issue DMA: weight tile of step t+3 -> ring slot t%3 (its last reader was the first half of step t),
+//     s_waitcnt vmcnt(#DMA issued after the previous barrier); s_barrier   <- weights of step t+1 landed;
+//                                                                 no LDS wait in front of the barrier
+//     issue DMA: weight tile of step t+3 -> ring slot (t-1)%4 (its readers fed MFMAs issued before the barrier),
 //                one slice of the next chunk's patch
 //     MFMA kk=2,3                                    ||  ds_read fragments kk=0,1 of step t+1
-template <int BN>
+// STATS: the epilogue also accumulates the BatchNorm partial sums (forward); the data-gradient launches leave them out.
+// TRACE: s_memtime stamps for tools/probes/trace.py (measurement build of the same kernel).
+template <int BN, bool STATS, bool TRACE>
 __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     constexpr int WBYTES = BN * ROWB;
     constexpr int NWI = BN / 64;          // weight DMA instructions per wave per step
@@ -125,12 +128,13 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     constexpr int OFF_W = 2 * PBYTES, OFF_DUMMY = OFF_W + NWBUF * WBYTES;
     constexpr int OFF_BIAS = OFF_DUMMY + 1024;            // [8 waves][64] fp32: each wave's own output-channel biases
     constexpr int OFF_TRACE = OFF_BIAS + NWAVE * 64 * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_TRACE + 4096];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_TRACE + (TRACE ? 4096 : 16)];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int C = A.C, K = A.K;
+    const int dbg = TRACE ? A.dbg : 0;   // ablation switches exist in the measurement build only
 
     // ---- persistent tile list: XCD x owns tile ids [x*Q, (x+1)*Q) (k-tile fastest), its workgroups take them
     //      round-robin, so the workgroups of an XCD work on neighbouring tiles at the same time (L2 reuse)
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     const int Q = (A.ntiles + 7) >> 3;
     const int tile_hi = (xcd + 1) * Q < A.ntiles ? (xcd + 1) * Q : A.ntiles;
     int tile = xcd * Q + jb;
-    if (A.partials && A.compact) {   // this workgroup's 4 rows: zero everywhere, its own k-tile columns are set at the end
+    if (STATS && A.compact) {   // this workgroup's 4 rows: zero everywhere, its own k-tile columns are set at the end
         float* rowp = A.partials + (long long)blockIdx.x * 4 * 2 * K;
         for (int i = tid; i < 4 * 2 * K; i += TPB) rowp[i] = 0.f;
     }
@@ -219,13 +223,20 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     };
 
     f32x16 acc[TN][2];
-    auto zero_acc = [&]() {
+    // accumulators start at the bias of the lane's output channels (wave-private LDS copy, see load_bias): the
+    // epilogue then has no bias add, and no global load that would queue behind its own stores
+    auto init_acc = [&]() {
 #pragma unroll
         for (int a = 0; a < TN; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int g = 0; g < 4; ++g) {
+                const float4 bq = *reinterpret_cast<const float4*>(smem + OFF_BIAS + (wave * 64 + a * 32 + 8 * g + 4 * fh) * 4);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b][g * 4 + 0] = bq.x; acc[a][b][g * 4 + 1] = bq.y;
+                    acc[a][b][g * 4 + 2] = bq.z; acc[a][b][g * 4 + 3] = bq.w;
+                }
+            }
     };
     auto mma = [&](const Frag& f) {
 #pragma unroll
@@ -247,25 +258,27 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     auto epilogue = [&](const TileRef& t, int free_pb) {
         unsigned char* stg = smem + free_pb * PBYTES + wave * (32 * WN * 2);
         const long long prow = (long long)t.pt * 4 + wm;   // statistics row of this wave (64 pixels)
-        float sm[TN][16], sq[TN][16];
+        float sm[STATS ? TN : 1][16], sq[STATS ? TN : 1][16];
+        if constexpr (STATS) {
 #pragma unroll
-        for (int a = 0; a < TN; ++a)
+            for (int a = 0; a < TN; ++a)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sm[a][i] = sq[a][i] = 0.f;
+                for (int i = 0; i < 16; ++i) sm[a][i] = sq[a][i] = 0.f;
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
 #pragma unroll
             for (int a = 0; a < TN; ++a) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 bq = *reinterpret_cast<const float4*>(smem + OFF_BIAS + (wave * 64 + a * 32 + 8 * g + 4 * fh) * 4);
-                    const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[a][b][g * 4 + e] + bv[e];
-                        sm[a][g * 4 + e] += v[e];
-                        sq[a][g * 4 + e] += v[e] * v[e];
+                        v[e] = acc[a][b][g * 4 + e];
+                        if constexpr (STATS) {
+                            sm[a][g * 4 + e] += v[e];
+                            sq[a][g * 4 + e] += v[e] * v[e];
+                        }
                     }
                     uint2 pk;
                     pk.x = pack_bf16x2(v[0], v[1]);
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                     *reinterpret_cast<uint2*>(stg + fr * (WN * 2) + ((chunk ^ (fr & (CPP - 1))) << 4) + fh * 8) = pk;
                 }
             }
-            if (!(A.dbg & 1)) {
+            if (!(dbg & 1)) {
 #pragma unroll
                 for (int i = 0; i < 32 * CPP / 64; ++i) {
                     const int id = i * 64 + lane, px = id / CPP, c16 = id % CPP;
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                 }
             }
         }
-        if (A.partials && !(A.dbg & 2)) {
+        if constexpr (STATS) if (!(dbg & 2)) {
 #pragma unroll
             for (int a = 0; a < TN; ++a) {
                 const int kb = t.k0 + wn * WN + a * 32;
@@ -304,10 +317,10 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         }
     };
 
-    const bool tracing = A.trace != nullptr && blockIdx.x == 0 && wave == 0;
+    const bool tracing = TRACE && A.trace != nullptr && blockIdx.x == 0 && wave == 0;
     int tri = 0;
     auto stamp = [&]() {
-        if (tracing) {
+        if constexpr (TRACE) if (tracing) {
             const long long now = __builtin_amdgcn_s_memtime();
             if (lane == 0 && tri < 512) reinterpret_cast<long long*>(smem + OFF_TRACE)[tri] = now;
             ++tri;
@@ -339,8 +352,9 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     Frag f0, f1, f2, f3;
     load_frag(f0, smem, smem + OFF_W, 0, 0);
     load_frag(f1, smem, smem + OFF_W, 0, 1);
-    zero_acc();
+    init_acc();
     int pbi = 0;       // patch buffer of the current chunk
+    int wslot = 0;     // weight ring slot of the current step
     bool after_epi = false;
 
     while (true) {
@@ -359,11 +373,11 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                 constexpr int tap = decltype(tapc)::value;
                 constexpr int r = tap / 3, s = tap % 3;
                 const unsigned char* xb = pb + (r * PW + s) * ROWB;
-                const unsigned char* wb = smem + OFF_W + (tap % NWBUF) * WBYTES;
+                const unsigned char* wb = smem + OFF_W + wslot * WBYTES;
                 constexpr int dummy_c = 0; (void)dummy_c;
                 const int ntap = (tap + 1) % 9, nr = ntap / 3, ns = ntap % 3;
                 const unsigned char* nxb = (tap == 8 ? npb : pb) + (nr * PW + ns) * ROWB;
-                const unsigned char* nwb = smem + OFF_W + ((tap + 1) % NWBUF) * WBYTES;
+                const unsigned char* nwb = smem + OFF_W + ((wslot + 1) & (NWBUF - 1)) * WBYTES;
 
                 // -- first half: kk = 0,1 from registers, interleaved with the fragment reads of kk = 2,3
                 //    (issuing all 8 reads ahead of the MFMAs measured 4 % slower: longer barrier skew)
@@ -373,13 +387,16 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                 load_frag(f3, xb, wb, s, 3);
                 __builtin_amdgcn_sched_barrier(0);
                 stamp();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done reading ring slot tap%3
+                // No LDS wait here: the ring slot that is overwritten after this barrier is the one of step t-1,
+                // and every wave consumed its reads of it (MFMA operands) before it can arrive.  Only the last step
+                // of a tile waits, because the epilogue reuses the patch buffer that other waves may still be reading.
+                if (tap == 8 && last_ch) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 stamp();
                 // Everything issued before the previous barrier has landed (weights of step t+1, older patch
                 // slices): the DMA count after a barrier is a compile-time constant per tap (dummy targets keep it
                 // so).  Right after an epilogue everything older was already drained and its stores must not be
                 // waited for here.
-                if (!(tap == 0 && after_epi) && !(A.dbg & 16)) wait_vm<NWI + (((tap + 8) % 9) < PSLICES ? 1 : 0)>();
+                if (!(tap == 0 && after_epi) && !(dbg & 16)) wait_vm<NWI + (((tap + 8) % 9) < PSLICES ? 1 : 0)>();
                 stamp();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -389,21 +406,21 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                 // -- second half: kk = 2 MFMAs first (keeps the matrix pipe fed while the DMA instructions issue)
                 mma(f2);
                 __builtin_amdgcn_sched_barrier(0);
-                // weight tile of step t+3 into the ring slot just released (the last step of a tile defers it until
+                // weight tile of step t+3 into the ring slot of step t-1 (the last step of a tile defers it until
                 // after the epilogue), one slice of the next patch in taps 0..5; no-op cases go to a dummy LDS target
                 if (!(tap == 8 && last_ch)) {
-                    const int tap3 = (tap + 3) % 9;
-                    const bool wrap = tap + 3 >= 9;
+                    constexpr int tap3 = (tap + 3) % 9;
+                    constexpr bool wrap = tap + 3 >= 9;
                     const bool to_next = wrap && last_ch;
                     const bool real = !to_next || has_next;
-                    unsigned char* dst = real ? smem + OFF_W + (tap % NWBUF) * WBYTES : smem + OFF_DUMMY;
+                    unsigned char* dst = real ? smem + OFF_W + ((wslot + 3) & (NWBUF - 1)) * WBYTES : smem + OFF_DUMMY;
                     const int cw = to_next ? 0 : (wrap ? ch + 1 : ch) * 64;
                     const int soff = (tap3 * C + cw) * 2;
 #pragma unroll
                     for (int j = 0; j < NWI; ++j)
                         dma16(to_next ? wrn : wr, real ? dst + (j * NWAVE + wave) * 1024 : dst, wvoff[j], soff);
                 }
-                if (tap < PSLICES) {
+                if constexpr (tap < PSLICES) {
                     const int ii = tap * NWAVE + wave;
                     unsigned char* dst = (more_p && ii < PINSTR) ? smem + (pbi ^ 1) * PBYTES + ii * 1024 : smem + OFF_DUMMY;
                     dma16(last_ch ? xrn : xr, dst, pvoff[tap], last_ch ? 0 : (ch + 1) * 128);
@@ -413,6 +430,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                 mma(f3);
                 load_frag(f1, nxb, nwb, ns, 1);
                 __builtin_amdgcn_sched_barrier(0);
+                wslot = (wslot + 1) & (NWBUF - 1);
             });
             pbi ^= 1;
             after_epi = false;
@@ -427,12 +445,12 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         stamp();
         if (!has_next) break;
         if (nxt.k0 != cur.k0) load_bias(nxt);   // read again only at the next epilogue (many barriers later)
-        issue_w(wrn, 8 % NWBUF, 2, 0);
+        issue_w(wrn, (wslot + 2) & (NWBUF - 1), 2, 0);   // wslot = slot of the next tile's step 0
         after_epi = true;
-        zero_acc();
+        init_acc();
         tile = ntile_id; cur = nxt; xr = xrn; wr = wrn;
     }
-    if (A.partials && A.compact && !(A.dbg & 2) && (lane & 1) == 0) {
+    if (STATS && A.compact && !(dbg & 2) && (lane & 1) == 0) {
         // lane -> channel mapping of reduce16_over32: reg = lane bits 4..1
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
@@ -443,7 +461,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
             A.partials[(prow * 2 + 1) * K + k] = st_acc[a][1];
         }
     }
-    if (tracing && lane == 0)
+    if constexpr (TRACE) if (tracing && lane == 0)
         for (int i = 0; i < 512; ++i) A.trace[i] = i < tri ? reinterpret_cast<long long*>(smem + OFF_TRACE)[i] : 0;
 }
 
@@ -477,7 +495,10 @@ int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* 
     if (grid > need) grid = need;
     a.compact = (stats && ptiles >= grid && ((grid / 8) % a.ktiles) == 0) ? 1 : 0;
     if (stats) kp_set_last_rows(a.compact ? (long long)grid * 4 : ptiles * 4);
-    if (bn == 128) conv3x3_patch_k<128><<<grid, TPB, 0, st>>>(a);
-    else conv3x3_patch_k<64><<<grid, TPB, 0, st>>>(a);
+    if ((a.trace || a.dbg) && bn == 128 && stats) conv3x3_patch_k<128, true, true><<<grid, TPB, 0, st>>>(a);
+    else if (bn == 128 && stats) conv3x3_patch_k<128, true, false><<<grid, TPB, 0, st>>>(a);
+    else if (bn == 128) conv3x3_patch_k<128, false, false><<<grid, TPB, 0, st>>>(a);
+    else if (stats) conv3x3_patch_k<64, true, false><<<grid, TPB, 0, st>>>(a);
+    else conv3x3_patch_k<64, false, false><<<grid, TPB, 0, st>>>(a);
     return kp_check_launch("conv3x3_patch");
 }

@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int TPB = 256, TMAX = 16;
+constexpr int TPB = 256;
 
 // bilinear tap of grid_sample(padding_mode='zeros', align_corners=False) at normalised position (sx, sy)
 struct Taps {

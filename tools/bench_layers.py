@@ -49,7 +49,10 @@ def main():
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--ab', action='store_true')
     ap.add_argument('--only', default='')
+    ap.add_argument('--lib', default='', help='another build of libkp_hip.so to time (A/B between builds)')
     args = ap.parse_args()
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     N = args.batch
     st = torch.cuda.current_stream().cuda_stream
     bf = torch.bfloat16
