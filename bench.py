@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=16)
     ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--lib', default='', help='development: time another build of libkp_hip.so (A/B on one box)')
     return ap.parse_args()
 
 
@@ -100,6 +101,8 @@ def main():
 
     import keypoints_amd as ka
     from keypoints_amd import _lib
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     from keypoints_amd.dist import GradReducer
     from keypoints_amd.models import transporter
     from keypoints_amd.flops import conv_flops_per_pair

@@ -27,6 +27,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define LDS_AS __attribute__((address_space(3)))
 
@@ -69,8 +70,9 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wav
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float reduce16_over32(float (&v)[16], int lane, int& reg) {
-    float a[8];
+// First stage on its own (16 -> 8 values per lane, summed over the two 16-lane rows of each 32-lane half): what the
+// persistent workgroups accumulate per tile; the remaining stages then run once per workgroup.
+__device__ __forceinline__ void reduce16_stage1(const float (&v)[16], float (&a)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {   // rows of 16 lanes: odd rows of v[i] <-> even rows of v[i+8]
         // (inline asm: the builtin's second result comes back equal to the first with this hipcc; the s_nop covers
@@ -79,6 +81,8 @@ __device__ __forceinline__ float reduce16_over32(float (&v)[16], int lane, int& 
         asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
         a[i] = lo + hi;
     }
+}
+__device__ __forceinline__ float reduce8_rest(const float (&a)[8], int lane, int& reg) {
     const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
     float b[4];
 #pragma unroll
@@ -96,6 +100,11 @@ __device__ __forceinline__ float reduce16_over32(float (&v)[16], int lane, int& 
     d += dpp_mov<0xB1>(d);                                              // partner = lane ^ 1
     reg = (b4 ? 8 : 0) | (b3 ? 4 : 0) | (b2 ? 2 : 0) | (b1 ? 1 : 0);
     return d;
+}
+__device__ __forceinline__ float reduce16_over32(const float (&v)[16], int lane, int& reg) {
+    float a[8];
+    reduce16_stage1(v, a);
+    return reduce8_rest(a, lane, reg);
 }
 
 struct PatchArgs {
@@ -149,14 +158,28 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     if (tile >= tile_hi) return;
     const int tiles_x = A.W / TS, tiles_y = A.H / TS;
 
-    struct TileRef { int n, oy0, ox0, k0, pt; };
-    auto decode = [&](int id) {
+    struct TileRef { int n, oy0, ox0, k0, pt, kt, tx, ty; };
+    auto decode = [&](int id) {   // divisions: only for a workgroup's first tile
         TileRef t;
-        const int kt = id % A.ktiles;
+        t.kt = id % A.ktiles;
         t.pt = id / A.ktiles;
-        const int txi = t.pt % tiles_x, tyi = (t.pt / tiles_x) % tiles_y;
+        t.tx = t.pt % tiles_x; t.ty = (t.pt / tiles_x) % tiles_y;
         t.n = t.pt / (tiles_x * tiles_y);
-        t.oy0 = tyi * TS; t.ox0 = txi * TS; t.k0 = kt * BN;
+        t.oy0 = t.ty * TS; t.ox0 = t.tx * TS; t.k0 = t.kt * BN;
+        return t;
+    };
+    // a workgroup's next tile is per_xcd ids further: add the mixed-radix digits of that stride with carries
+    const int d_kt = per_xcd % A.ktiles, d_pt = per_xcd / A.ktiles;
+    const int d_tx = d_pt % tiles_x, d_ty = (d_pt / tiles_x) % tiles_y, d_n = d_pt / (tiles_x * tiles_y);
+    auto advance = [&](const TileRef& c) {
+        TileRef t;
+        int carry;
+        t.kt = c.kt + d_kt; carry = t.kt >= A.ktiles; t.kt -= carry ? A.ktiles : 0;
+        t.pt = c.pt + d_pt + carry;
+        t.tx = c.tx + d_tx + carry; carry = t.tx >= tiles_x; t.tx -= carry ? tiles_x : 0;
+        t.ty = c.ty + d_ty + carry; carry = t.ty >= tiles_y; t.ty -= carry ? tiles_y : 0;
+        t.n = c.n + d_n + carry;
+        t.oy0 = t.ty * TS; t.ox0 = t.tx * TS; t.k0 = t.kt * BN;
         return t;
     };
     auto x_rsrc = [&](const TileRef& t) {
@@ -216,6 +239,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
 
     struct Frag { bf16x8 x[2]; bf16x8 w[TN]; };
     auto load_frag = [&](Frag& f, const unsigned char* xb, const unsigned char* wb, int s, int kk) {
+        if (TRACE && (dbg & 64) && (kk & 1)) return;   // ablation: half the LDS fragment reads
 #pragma unroll
         for (int b = 0; b < 2; ++b) f.x[b] = *(const bf16x8*)(xb + xoff[b] + (xs16[s] ^ (kk << 5)));
 #pragma unroll
@@ -252,12 +276,24 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     // (64-byte for BN = 64) runs per pixel: 8x fewer cache lines per store instruction than storing straight
     // from the MFMA layout.
     constexpr int CPP = WN / 8;            // 16-byte chunks per pixel (this wave's channels)
-    float st_acc[TN][2];                   // running BN partial sums of this lane's channel (compact mode)
+    // running BN partial sums of the workgroup's tiles (compact mode), after the first reduction stage
+    float st8[STATS ? TN : 1][2][8];
+    if constexpr (STATS) {
 #pragma unroll
-    for (int a = 0; a < TN; ++a) st_acc[a][0] = st_acc[a][1] = 0.f;
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st8[a][0][i] = st8[a][1][i] = 0.f;
+    }
+    constexpr int PPI = 64 / CPP;          // pixels per store instruction
+    const int st_voff = ((lane / CPP) * K + (lane % CPP) * 8) * 2;   // lane part of the output address (bytes)
     auto epilogue = [&](const TileRef& t, int free_pb) {
         unsigned char* stg = smem + free_pb * PBYTES + wave * (32 * WN * 2);
         const long long prow = (long long)t.pt * 4 + wm;   // statistics row of this wave (64 pixels)
+        // this wave's 4 x 16 pixel x WN channel output window from one scalar base: stores carry a lane-constant
+        // VGPR offset and a scalar (row, column) offset -- no per-store vector address arithmetic
+        bf16_t* ybase = A.y + ((((long long)t.n * A.Hob + t.oy0 + wm * 4 + A.ooff) * A.Wob) + t.ox0 + A.ooff) * (long long)K +
+                        t.k0 + wn * WN;
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, 0x7ffffffe, 0x00020000);
         float sm[STATS ? TN : 1][16], sq[STATS ? TN : 1][16];
         if constexpr (STATS) {
 #pragma unroll
@@ -277,7 +313,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                         v[e] = acc[a][b][g * 4 + e];
                         if constexpr (STATS) {
                             sm[a][g * 4 + e] += v[e];
-                            sq[a][g * 4 + e] += v[e] * v[e];
+                            sq[a][g * 4 + e] = __builtin_fmaf(v[e], v[e], sq[a][g * 4 + e]);
                         }
                     }
                     uint2 pk;
@@ -291,10 +327,9 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
 #pragma unroll
                 for (int i = 0; i < 32 * CPP / 64; ++i) {
                     const int id = i * 64 + lane, px = id / CPP, c16 = id % CPP;
-                    const uint4 vv = *reinterpret_cast<const uint4*>(stg + px * (WN * 2) + ((c16 ^ (px & (CPP - 1))) << 4));
-                    const int oy = t.oy0 + wm * 4 + b * 2 + (px >> 4) + A.ooff, ox = t.ox0 + (px & 15) + A.ooff;
-                    bf16_t* yp = A.y + (((long long)t.n * A.Hob + oy) * A.Wob + ox) * K + t.k0 + wn * WN + c16 * 8;
-                    *reinterpret_cast<uint4*>(yp) = vv;
+                    const u32x4 vv = *reinterpret_cast<const u32x4*>(stg + px * (WN * 2) + ((c16 ^ (px & (CPP - 1))) << 4));
+                    const int soff = ((b * 2 + ((i * PPI) >> 4)) * A.Wob + ((i * PPI) & 15)) * K * 2;
+                    __builtin_amdgcn_raw_buffer_store_b128(vv, yr, st_voff, soff, 0);
                 }
             }
         }
@@ -302,16 +337,21 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
 #pragma unroll
             for (int a = 0; a < TN; ++a) {
                 const int kb = t.k0 + wn * WN + a * 32;
-                int r1, r2;
-                const float ts = reduce16_over32(sm[a], lane, r1);
-                const float tq = reduce16_over32(sq[a], lane, r2);
+                float h0[8], h1[8];
+                reduce16_stage1(sm[a], h0);
+                reduce16_stage1(sq[a], h1);
                 if (A.compact) {
-                    st_acc[a][0] += ts;
-                    st_acc[a][1] += tq;
-                } else if ((lane & 1) == 0) {
-                    const int k = kb + 8 * (r1 >> 2) + 4 * fh + (r1 & 3);
-                    A.partials[(prow * 2 + 0) * K + k] = ts;
-                    A.partials[(prow * 2 + 1) * K + k] = tq;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { st8[a][0][i] += h0[i]; st8[a][1][i] += h1[i]; }
+                } else {
+                    int r1, r2;
+                    const float ts = reduce8_rest(h0, lane, r1);
+                    const float tq = reduce8_rest(h1, lane, r2);
+                    if ((lane & 1) == 0) {
+                        const int k = kb + 8 * (r1 >> 2) + 4 * fh + (r1 & 3);
+                        A.partials[(prow * 2 + 0) * K + k] = ts;
+                        A.partials[(prow * 2 + 1) * K + k] = tq;
+                    }
                 }
             }
         }
@@ -319,8 +359,19 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
 
     const bool tracing = TRACE && A.trace != nullptr && blockIdx.x == 0 && wave == 0;
     int tri = 0;
+    // dbg & 32: one (s_memtime, s_memrealtime) pair per tile instead of the per-step stamps
+    auto stamp_tile = [&]() {
+        if constexpr (TRACE) if (tracing && (dbg & 32)) {
+            const long long now = __builtin_amdgcn_s_memtime(), real = __builtin_amdgcn_s_memrealtime();
+            if (lane == 0 && tri + 1 < 512) {
+                reinterpret_cast<long long*>(smem + OFF_TRACE)[tri] = now;
+                reinterpret_cast<long long*>(smem + OFF_TRACE)[tri + 1] = real;
+            }
+            tri += 2;
+        }
+    };
     auto stamp = [&]() {
-        if constexpr (TRACE) if (tracing) {
+        if constexpr (TRACE) if (tracing && !(dbg & 32)) {
             const long long now = __builtin_amdgcn_s_memtime();
             if (lane == 0 && tri < 512) reinterpret_cast<long long*>(smem + OFF_TRACE)[tri] = now;
             ++tri;
@@ -362,7 +413,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         const bool has_next = ntile_id < tile_hi;
         TileRef nxt = cur;
         __amdgpu_buffer_rsrc_t xrn = xr, wrn = wr;
-        if (has_next) { nxt = decode(ntile_id); xrn = x_rsrc(nxt); wrn = w_rsrc(nxt); }
+        if (has_next) { nxt = advance(cur); xrn = x_rsrc(nxt); wrn = w_rsrc(nxt); }
 
         for (int ch = 0; ch < nchunks; ++ch) {
             const unsigned char* pb = smem + pbi * PBYTES;
@@ -418,12 +469,13 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                     const int soff = (tap3 * C + cw) * 2;
 #pragma unroll
                     for (int j = 0; j < NWI; ++j)
-                        dma16(to_next ? wrn : wr, real ? dst + (j * NWAVE + wave) * 1024 : dst, wvoff[j], soff);
+                        if (!(TRACE && (dbg & 128)))   // ablation: no DMA in the main loop
+                            dma16(to_next ? wrn : wr, real ? dst + (j * NWAVE + wave) * 1024 : dst, wvoff[j], soff);
                 }
                 if constexpr (tap < PSLICES) {
                     const int ii = tap * NWAVE + wave;
                     unsigned char* dst = (more_p && ii < PINSTR) ? smem + (pbi ^ 1) * PBYTES + ii * 1024 : smem + OFF_DUMMY;
-                    dma16(last_ch ? xrn : xr, dst, pvoff[tap], last_ch ? 0 : (ch + 1) * 128);
+                    if (!(TRACE && (dbg & 128))) dma16(last_ch ? xrn : xr, dst, pvoff[tap], last_ch ? 0 : (ch + 1) * 128);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 load_frag(f0, nxb, nwb, ns, 0);
@@ -439,6 +491,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         // then issue the weight tile that the last step deferred.  The next barrier does not wait (after_epi);
         // the one after it retires these stores together with the DMA.
         stamp();
+        stamp_tile();
         wait_vm<0>();
         stamp();
         epilogue(cur, pbi ^ 1);   // pbi = buffer of the NEXT tile's first patch; the other one is free
@@ -450,15 +503,18 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         init_acc();
         tile = ntile_id; cur = nxt; xr = xrn; wr = wrn;
     }
-    if (STATS && A.compact && !(dbg & 2) && (lane & 1) == 0) {
-        // lane -> channel mapping of reduce16_over32: reg = lane bits 4..1
+    if constexpr (STATS) if (A.compact && !(dbg & 2)) {
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
-            const int rg = ((lane & 16) ? 8 : 0) | ((lane & 8) ? 4 : 0) | ((lane & 4) ? 2 : 0) | ((lane & 2) ? 1 : 0);
-            const int k = cur.k0 + wn * WN + a * 32 + 8 * (rg >> 2) + 4 * fh + (rg & 3);
-            const long long prow = (long long)blockIdx.x * 4 + wm;
-            A.partials[(prow * 2 + 0) * K + k] = st_acc[a][0];
-            A.partials[(prow * 2 + 1) * K + k] = st_acc[a][1];
+            int rg, r2;
+            const float ts = reduce8_rest(st8[a][0], lane, rg);
+            const float tq = reduce8_rest(st8[a][1], lane, r2);
+            if ((lane & 1) == 0) {
+                const int k = cur.k0 + wn * WN + a * 32 + 8 * (rg >> 2) + 4 * fh + (rg & 3);
+                const long long prow = (long long)blockIdx.x * 4 + wm;
+                A.partials[(prow * 2 + 0) * K + k] = ts;
+                A.partials[(prow * 2 + 1) * K + k] = tq;
+            }
         }
     }
     if constexpr (TRACE) if (tracing && lane == 0)

@@ -91,6 +91,7 @@ def test_full_size_properties():
     """BASELINE-size (B=128, K=10, 16x16 and K=30, 32x32) invariants: keypoints in [0,1], marginals sum
     to 1, a uniform map gives (0.5, 0.5), the rendered peak is exp(-sqrt(eps)/(2 sigma^2)) at a node."""
     from keypoints_amd.models import functional as MF
+    torch.manual_seed(7)
     for (B, K, H) in ((128, 10, 16), (64, 30, 32)):
         h = torch.randn(B, K, H, H, device='cuda') * 4
         k, (p, q) = MF.spacial_logsoftmax(h, probs=True)
@@ -104,4 +105,6 @@ def test_full_size_properties():
         from oracle import kp_oracle as O
         ok, _ = O.spatial_logsoftmax(h[:4].cpu())
         close(k[:4], ok.numpy())
-        close(m[:4], O.gaussian_like(ok, H, H).numpy(), atol=2e-6)
+        # the map is rendered from this implementation's keypoints: a 1-ulp (2.4e-7) difference of a coordinate
+        # against the oracle's moves exp(-50 d) by up to 50*sqrt(2)*ulp = 1.7e-5 relative
+        close(m[:4], O.gaussian_like(ok, H, H).numpy(), atol=2e-6, rtol=1e-4)
