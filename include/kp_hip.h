@@ -120,7 +120,8 @@ int kp_conv_dgrad(const void* dy, const void* w_dgrad, void* gx, int N, int H, i
  * P = kp_conv_wgrad_partials(same shape arguments) tells the scratch protocol of this shape:
  *   P == 1: scratch fp32 [K][R][R][C], ZEROED by the caller, accumulated with hardware fp32 atomics;
  *   P  > 1: scratch fp32 [P][K][R][R][C], no zeroing needed: every partial is fully written by the workgroups of one
- *           pixel split (plain stores) and kp_wgrad_unpack sums them in a fixed order (bitwise reproducible). */
+ *           pixel split (3x3 MFMA kernel) or by one workgroup (image-sized first layer) with plain stores, and
+ *           kp_wgrad_unpack sums them in a fixed order (bitwise reproducible). */
 int kp_conv_wgrad_partials(int N, int Ho, int Wo, int C, int K, int R, int dy_pad, int dtype);
 int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R,
                   int dy_pad, int dtype, void* stream);

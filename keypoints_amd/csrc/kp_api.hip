@@ -17,6 +17,7 @@ int kp_conv_small_fwd(const void*, const void*, const float*, void*, float*, int
 int kp_conv_small_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 int kp_conv_first_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
 int kp_conv_first_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
+long long kp_conv_first_wgrad_partials(int, int, int, int, int);
 
 static thread_local char g_err[512] = "";
 static thread_local long long g_last_rows = 0;
@@ -192,6 +193,10 @@ int kp_conv_wgrad_partials(int N, int Ho, int Wo, int C, int K, int R, int dy_pa
     if (dtype == KP_BF16 && use_mfma() && R == 3 && g_kp_wgrad_patch) {
         const long long p = kp_conv_wgrad_patch_partials(N, Ho, Wo, C, K, dy_pad);
         if (p > 0 && p < 0x7fffffffLL) return (int)p;
+    }
+    if (dtype == KP_BF16 && use_mfma() && R == 3 && C <= 4) {
+        const long long p = kp_conv_first_wgrad_partials(N, Ho, Wo, C, K);
+        if (p > 0) return (int)p;
     }
     return 1;
 }

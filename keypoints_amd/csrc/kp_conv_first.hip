@@ -10,7 +10,7 @@
 // wgrad   : one lane per output channel k; a wavefront walks the pixels of an image row, reading dy[pixel][k]
 //           coalesced and the 3x3xCin input window (fp32 in LDS, 16-byte aligned pixels) at uniform addresses;
 //           27 accumulators per lane, block reduction in LDS, fp32 atomics into the zeroed scratch.
-#include "kp_common.h"
+#include "kp_mfma_util.h"
 
 namespace {
 
@@ -19,9 +19,6 @@ constexpr int TPB = 256;
 // 8 per-lane values -> each lane gets the sum over all 64 lanes of ONE of them (index returned in idx).
 // Halving butterfly on VALU cross-lane ops only (v_permlane32_swap, v_permlane16_swap, DPP row_ror / half-mirror /
 // quad_perm): the ds_bpermute version cost ~100 dependent LDS round trips per wavefront, more than the FMAs.
-template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
 __device__ __forceinline__ float reduce8_over64(const float (&v)[8], int lane, int& idx) {
     const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
     float a[4];
@@ -210,6 +207,259 @@ __global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const bf16_t* __restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// MFMA versions for the image-sized first layer (K = 64, Cin <= 3, Wo % 32 == 0).  The VALU kernels above spend
+// ~4000 issue cycles per 32 pixels on the 27 x 64 FMAs; as a (64 x 32) x (32 x 32px) MFMA product the arithmetic is
+// 4 instructions and both kernels become what they should be: streaming the [N][H][W][64] bf16 tensor once.
+// A wavefront works alone on groups of 32 consecutive pixels of an image row (no workgroup barriers in the loops):
+// it copies the 3 x 34 pixel input window into its own LDS strip as it lies in memory (dword copies) and builds the
+// reduction-major fragment (8 consecutive (tap, channel) indices of one pixel) with 2-byte LDS reads.
+constexpr int FG = 32;            // pixels per group
+constexpr int F_RS = 256;         // bytes per staged input row: (32 + 2) pixels * Cin * 2 B <= 204
+constexpr int F_XSZ = 1024;       // 3 rows + a zero slot (offset 3 * F_RS) for the padded reduction indices
+
+struct GroupPos { long long n; int p, q; };
+__device__ __forceinline__ GroupPos group_pos(long long g, int Ho, int Wo) {
+    const long long m0 = g * FG;
+    GroupPos r;
+    r.q = (int)(m0 % Wo);
+    const long long t = m0 / Wo;
+    r.p = (int)(t % Ho);
+    r.n = t / Ho;
+    return r;
+}
+__device__ __forceinline__ void group_next(GroupPos& c, int Ho, int Wo) {   // the following group, without divisions
+    c.q += FG;
+    if (c.q >= Wo) { c.q = 0; if (++c.p >= Ho) { c.p = 0; ++c.n; } }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3_first_fwd_mfma_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                              const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                              float* __restrict__ partials, int Hi, int Wi,
+                                                              long long groups, int gpw) {
+    constexpr int J = 9 * CIN, NS = (J + 15) / 16, K = 64, KT = 2;
+    constexpr int ND = (FG + 2) * CIN * 2 / 4;            // dwords per staged row
+    constexpr int WSZ = F_XSZ + FG * K * 2;               // per wave: input strip + 32 px x 64 ch output staging
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * WSZ];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* xs = smem + wave * WSZ;
+    unsigned char* stg = xs + F_XSZ;
+    const int px = lane & 31, h = lane >> 5;
+    const int Ho = Hi - 2, Wo = Wi - 2;
+    if (lane < 4) *reinterpret_cast<uint32_t*>(xs + 3 * F_RS + lane * 4) = 0u;
+
+    // weights [K][J] -> A fragments (row = output channel, 8 consecutive reduction indices per lane), once per wave
+    bf16x8 wa[KT][NS];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = s * 16 + h * 8 + i;
+                wa[kt][s][i] = j < J ? (short)w[(kt * 32 + px) * J + j] : (short)0;
+            }
+    // accumulator layout: lane = pixel, register i = channel 8*(i>>2) + 4*h + (i&3) (+32 kt); start from the bias
+    float bs[KT][16];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bs[kt][i] = bias ? bias[kt * 32 + 8 * (i >> 2) + 4 * h + (i & 3)] : 0.f;
+    // LDS byte offsets of this lane's 8 * NS reduction elements (lane constants)
+    int xo[NS][8];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = s * 16 + h * 8 + i;
+            xo[s][i] = j < J ? (j / (3 * CIN)) * F_RS + (px * CIN + j % (3 * CIN)) * 2 : 3 * F_RS;
+        }
+    float sm[KT][16], sq[KT][16];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sm[kt][i] = sq[kt][i] = 0.f;
+
+    const long long wid = (long long)blockIdx.x * 4 + wave;
+    const long long g0 = wid * gpw, g1 = g0 + gpw < groups ? g0 + gpw : groups;
+    uint32_t xr[3] = {0u, 0u, 0u};
+    GroupPos c = group_pos(g0 < groups ? g0 : 0, Ho, Wo);   // fetch cursor
+    auto fetch = [&]() {
+        if (lane < ND) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                xr[r] = reinterpret_cast<const uint32_t*>(x + ((c.n * Hi + c.p + r) * Wi + c.q) * CIN)[lane];
+        }
+        group_next(c, Ho, Wo);
+    };
+    if (g0 < g1) fetch();
+    for (long long g = g0; g < g1; ++g) {
+        if (lane < ND) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) *reinterpret_cast<uint32_t*>(xs + r * F_RS + lane * 4) = xr[r];
+        }
+        bf16x8 xb[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xb[s][i] = *reinterpret_cast<const short*>(xs + xo[s][i]);
+        if (g + 1 < g1) fetch();
+        f32x16 acc[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[kt][i] = bs[kt][i];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[kt][s], xb[s], acc[kt], 0, 0, 0);
+        }
+        // statistics (fp32 values before rounding), bf16 pack, transpose through the wave's LDS tile, 1-KiB stores
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[kt][g4 * 4 + e];
+                    sm[kt][g4 * 4 + e] += v[e];
+                    sq[kt][g4 * 4 + e] = __builtin_fmaf(v[e], v[e], sq[kt][g4 * 4 + e]);
+                }
+                uint2 pk;
+                pk.x = pack_bf16x2(v[0], v[1]);
+                pk.y = pack_bf16x2(v[2], v[3]);
+                const int chunk = kt * 4 + g4;
+                *reinterpret_cast<uint2*>(stg + px * (K * 2) + ((chunk ^ (px & 7)) << 4) + h * 8) = pk;
+            }
+        bf16_t* yb = y + g * FG * K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = i * 64 + lane, pp = id >> 3, c16 = id & 7;
+            const uint4 vv = *reinterpret_cast<const uint4*>(stg + pp * (K * 2) + ((c16 ^ (pp & 7)) << 4));
+            *reinterpret_cast<uint4*>(yb + (size_t)id * 8) = vv;
+        }
+    }
+    if (partials) {   // one row per wavefront (zeros when it had no group)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            int r1, r2;
+            const float ts = reduce16_over32(sm[kt], lane, r1);
+            const float tq = reduce16_over32(sq[kt], lane, r2);
+            if ((lane & 1) == 0) {
+                const int k = kt * 32 + 8 * (r1 >> 2) + 4 * h + (r1 & 3);
+                partials[(wid * 2 + 0) * K + k] = ts;
+                partials[(wid * 2 + 1) * K + k] = tq;
+            }
+        }
+    }
+}
+
+// partial[b][k][tap][c] = sum over the pixels of workgroup b of dy[pixel][k] * x[pixel + tap][c]; the partial buffers
+// are summed in a fixed order by kp_wgrad_unpack (no atomics: bitwise reproducible).  dy tiles (32 px x 128 B) go to
+// LDS by DMA as they lie and are read with the transpose read (channel-major fragments), the input window as above.
+template <int CIN>
+__global__ __launch_bounds__(1024) void conv3_first_wgrad_mfma_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                 float* __restrict__ partial, int Ho, int Wo, int dy_pad,
+                                                                 long long groups, int gpw) {
+    constexpr int J = 9 * CIN, K = 64, KT = 2, PK = K * 2, NW = 16;
+    constexpr int ND = (FG + 2) * CIN * 2 / 4;
+    constexpr int DYB = FG * PK;                           // 4 KiB dy tile
+    constexpr int WSZ = 2 * DYB + F_XSZ;                   // per wave: double-buffered dy tile + input strip
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NW * WSZ];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* dyb = smem + wave * WSZ;
+    unsigned char* xs = dyb + 2 * DYB;
+    const int Hi = Ho + 2, Wi = Wo + 2, Hd = Ho + 2 * dy_pad, Wd = Wo + 2 * dy_pad;
+
+    // dy DMA: instruction u covers tile rows (pixels) 8u..8u+7; 64-byte blocks swizzled by the row (kp_mfma_util.h)
+    int dvoff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int row = u * 8 + (lane >> 3), slot = lane & 7;
+        dvoff[u] = row * PK + (((slot >> 2) ^ blk_swz<PK>(row)) << 6) + (slot & 3) * 16;
+    }
+    // transpose-read lane roles (see wgrad3x3_patch_k)
+    const int t16 = lane & 15, g16 = (lane >> 4) & 1, h = lane >> 5;
+    const int lrow = 8 * h + (t16 >> 2);
+    int kbase[KT][4];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) kbase[kt][v] = tr_base<PK>(v, lrow, (kt * 32 + 16 * g16 + (t16 & 3) * 4) * 2);
+    // input fragment: column j = (tap, channel) of this lane, 8 consecutive pixels (stride Cin elements)
+    const int jj = (lane & 31) < J ? (lane & 31) : J - 1;   // columns >= J are discarded: any valid address
+    const int xoff = (jj / (3 * CIN)) * F_RS + (jj % (3 * CIN)) * 2 + 8 * h * CIN * 2;
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[kt][i] = 0.f;
+
+    const long long wid = (long long)blockIdx.x * NW + wave;
+    const long long g0 = wid * gpw, g1 = g0 + gpw < groups ? g0 + gpw : groups;
+    uint32_t xr[3] = {0u, 0u, 0u};
+    GroupPos c = group_pos(g0 < groups ? g0 : 0, Ho, Wo);   // fetch cursor
+    auto fetch = [&](int buf) {
+        const bf16_t* db = dy + (((c.n * Hd + c.p + dy_pad) * Wd) + c.q + dy_pad) * K;
+        const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)db, 0, 0x7ffffffe, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dma16(dr, dyb + buf * DYB + u * 1024, dvoff[u]);
+        if (lane < ND) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                xr[r] = reinterpret_cast<const uint32_t*>(x + ((c.n * Hi + c.p + r) * Wi + c.q) * CIN)[lane];
+        }
+        group_next(c, Ho, Wo);
+    };
+    if (g0 < g1) fetch(0);
+    for (long long g = g0; g < g1; ++g) {
+        const int buf = (int)(g - g0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this group's dy tile and input rows have arrived
+        if (lane < ND) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) *reinterpret_cast<uint32_t*>(xs + r * F_RS + lane * 4) = xr[r];
+        }
+        if (g + 1 < g1) fetch(buf ^ 1);                       // in flight during this group's reads and MFMAs
+        bf16x8 xb[2];
+#pragma unroll
+        for (int R = 0; R < 2; ++R)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xb[R][i] = *reinterpret_cast<const short*>(xs + xoff + (R * 16 + i) * CIN * 2);
+        const unsigned char* tile = dyb + buf * DYB;
+        bf16x8 a[KT][2];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            a[kt][0] = tr_frag<PK, 0>(tile, kbase[kt]);
+            a[kt][1] = tr_frag<PK, 16>(tile, kbase[kt]);
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int R = 0; R < 2; ++R) acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kt][R], xb[R], acc[kt], 0, 0, 0);
+    }
+    // fold the 16 wavefronts in a fixed order; D[k][j]: lane column = j, rows k = 8*(i>>2) + 4*h + (i&3) (+32 kt)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);              // [16 waves][KT*16][64 lanes]
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[(wave * KT * 16 + kt * 16 + i) * 64 + lane] = acc[kt][i];
+    __syncthreads();
+    for (int e = tid; e < KT * 16 * 64; e += 1024) {
+        float s = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) s += red[wv * KT * 16 * 64 + e];
+        const int l = e & 63, i = (e >> 6) & 15, kt = e >> 10;
+        const int k = kt * 32 + 8 * (i >> 2) + 4 * (l >> 5) + (i & 3), j = l & 31;
+        if (j < J) partial[((long long)blockIdx.x * K + k) * J + j] = s;
+    }
+}
+
 }  // namespace
 
 int kp_conv_first_fwd(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi,
@@ -217,6 +467,23 @@ int kp_conv_first_fwd(const void* x, const void* w, const float* bias, void* y, 
     const long long M = (long long)N * (Hi - 2) * (Wi - 2);
     const int CP = K / 8;
     if (C < 1 || C > 4 || K % 8 != 0 || K > 128 || (CP & (CP - 1)) != 0 || M % 64 != 0) return KP_E_UNSUPPORTED;
+    if (K == 64 && C <= 3 && (Wi - 2) % FG == 0 && M >= 4096) {
+        // MFMA path: 8 groups of 32 pixels per wavefront, one statistics row per wavefront (<= M / 64 rows)
+        const long long groups = M / FG;
+        const int gpw = 8;
+        const unsigned grid = (unsigned)((groups + 4 * gpw - 1) / (4 * gpw));
+        if (stats) kp_set_last_rows((long long)grid * 4);
+#define KP_FIRST_FWD_M(CINv)                                                                                       \
+    conv3_first_fwd_mfma_k<CINv><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, stats, \
+                                                       Hi, Wi, groups, gpw)
+        switch (C) {
+            case 1: KP_FIRST_FWD_M(1); break;
+            case 2: KP_FIRST_FWD_M(2); break;
+            default: KP_FIRST_FWD_M(3); break;
+        }
+#undef KP_FIRST_FWD_M
+        return kp_check_launch("conv3_first_fwd_mfma");
+    }
     const size_t lds = (size_t)9 * C * K * sizeof(float) + (size_t)4 * 64 * K * 2;
     const unsigned grid = (unsigned)((M + TPB - 1) / TPB);
 #define KP_FIRST_FWD(CINv)                                                                                          \
@@ -232,9 +499,43 @@ int kp_conv_first_fwd(const void* x, const void* w, const float* bias, void* y, 
     return kp_check_launch("conv3_first_fwd");
 }
 
+// MFMA weight-gradient plan: workgroups of 16 wavefronts, one partial gradient buffer per workgroup.
+static bool first_wgrad_plan(int N, int Ho, int Wo, int C, int K, long long& groups, int& gpw, unsigned& grid) {
+    const long long M = (long long)N * Ho * Wo;
+    if (!(K == 64 && C >= 1 && C <= 3 && Wo % FG == 0 && M >= 65536)) return false;
+    groups = M / FG;
+    static int cus = 0;
+    if (!cus) { cus = kp_device_cus(); if (cus <= 0) cus = 256; }
+    long long per_wg = (groups + cus - 1) / cus;            // one workgroup (160 KB of LDS) per CU
+    gpw = (int)((per_wg + 15) / 16);
+    if (gpw < 1) gpw = 1;
+    grid = (unsigned)((groups + 16LL * gpw - 1) / (16LL * gpw));
+    return true;
+}
+
+long long kp_conv_first_wgrad_partials(int N, int Ho, int Wo, int C, int K) {
+    long long groups; int gpw; unsigned grid;
+    return first_wgrad_plan(N, Ho, Wo, C, K, groups, gpw, grid) ? (long long)grid : 0;
+}
+
 int kp_conv_first_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K,
                         int dy_pad, hipStream_t st) {
     if (C < 1 || C > 4 || !(K == 16 || K == 32 || K == 64)) return KP_E_UNSUPPORTED;
+    {
+        long long groups; int gpw; unsigned grid;
+        if (first_wgrad_plan(N, Ho, Wo, C, K, groups, gpw, grid)) {
+#define KP_FIRST_WG_M(CINv)                                                                                          \
+    conv3_first_wgrad_mfma_k<CINv><<<grid, 1024, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, scratch, Ho, Wo, dy_pad, \
+                                                          groups, gpw)
+            switch (C) {
+                case 1: KP_FIRST_WG_M(1); break;
+                case 2: KP_FIRST_WG_M(2); break;
+                default: KP_FIRST_WG_M(3); break;
+            }
+#undef KP_FIRST_WG_M
+            return kp_check_launch("conv3_first_wgrad_mfma");
+        }
+    }
     const long long rows = (long long)N * Ho;
     int rpb = (int)((rows + 1023) / 1024);
     if (rpb < 4) rpb = 4;

@@ -20,16 +20,9 @@
 // MFMA operands are swapped ("A" = weights, "B" = pixels): a lane's accumulator registers hold 4 consecutive
 // output channels of one pixel -> packed 8-byte bf16 stores into the NHWC output.
 // BatchNorm batch statistics (vgg.py:35) fall out of the epilogue as per-64-pixel partial rows (no atomics).
-#include <type_traits>
-#include "kp_common.h"
+#include "kp_mfma_util.h"
 
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-#define LDS_AS __attribute__((address_space(3)))
 
 constexpr int TPB = 512, NWAVE = 8;
 constexpr int TS = 16;                  // tile side (pixels)
@@ -41,14 +34,6 @@ constexpr int PSLICES = (PINSTR + NWAVE - 1) / NWAVE;   // patch DMA instruction
 constexpr int ROWB = 128;               // bytes per LDS row (64 bf16)
 constexpr int NWBUF = 4;               // weight ring slots (power of two: the slot of a step is a run-time counter)
 
-template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_vm_n(int n) {   // n is wave-uniform
     switch (n) {
         case 0: wait_vm<0>(); break;
@@ -57,54 +42,6 @@ __device__ __forceinline__ void wait_vm_n(int n) {   // n is wave-uniform
         case 3: wait_vm<3>(); break;
         default: wait_vm<4>(); break;
     }
-}
-
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, int voff, int soff) {
-    // 16 B per lane; LDS destination = wave-uniform base + lane*16
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_wave_base, 16, voff, soff, 0, 0);
-}
-
-// Halving butterfly: 16 per-lane values -> each lane ends with the sum over its 32-lane half of ONE value
-// (index returned in `reg`).  All exchanges are VALU cross-lane ops (v_permlane16_swap, DPP row_ror / half-mirror /
-// quad_perm) -- no ds_bpermute round trips through the LDS, whose latency used to dominate the epilogue.
-template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-// First stage on its own (16 -> 8 values per lane, summed over the two 16-lane rows of each 32-lane half): what the
-// persistent workgroups accumulate per tile; the remaining stages then run once per workgroup.
-__device__ __forceinline__ void reduce16_stage1(const float (&v)[16], float (&a)[8]) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {   // rows of 16 lanes: odd rows of v[i] <-> even rows of v[i+8]
-        // (inline asm: the builtin's second result comes back equal to the first with this hipcc; the s_nop covers
-        //  the VALU-write -> permlane-read hazard that the compiler does not pad inside asm)
-        float lo = v[i], hi = v[i + 8];
-        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-        a[i] = lo + hi;
-    }
-}
-__device__ __forceinline__ float reduce8_rest(const float (&a)[8], int lane, int& reg) {
-    const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
-    float b[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {   // partner = lane ^ 8 (row_ror:8)
-        const float keep = b3 ? a[i + 4] : a[i], send = b3 ? a[i] : a[i + 4];
-        b[i] = keep + dpp_mov<0x128>(send);
-    }
-    float c[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {   // partner = lane ^ 7 (row_half_mirror): opposite bit 2
-        const float keep = b2 ? b[i + 2] : b[i], send = b2 ? b[i] : b[i + 2];
-        c[i] = keep + dpp_mov<0x141>(send);
-    }
-    float d = (b1 ? c[1] : c[0]) + dpp_mov<0x4E>(b1 ? c[0] : c[1]);   // partner = lane ^ 2
-    d += dpp_mov<0xB1>(d);                                              // partner = lane ^ 1
-    reg = (b4 ? 8 : 0) | (b3 ? 4 : 0) | (b2 ? 2 : 0) | (b1 ? 1 : 0);
-    return d;
-}
-__device__ __forceinline__ float reduce16_over32(const float (&v)[16], int lane, int& reg) {
-    float a[8];
-    reduce16_stage1(v, a);
-    return reduce8_rest(a, lane, reg);
 }
 
 struct PatchArgs {

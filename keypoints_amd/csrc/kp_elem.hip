@@ -93,6 +93,15 @@ __global__ __launch_bounds__(256) void wgrad_unpack_k(const float* __restrict__ 
                 for (int u = 0; u < 4; ++u) { acc[0] += v[u].x; acc[1] += v[u].y; acc[2] += v[u].z; acc[3] += v[u].w; }
             }
         }
+        if (VEC == 1) {   // many small partials (first layer: one per workgroup): 8 loads in flight per lane
+            for (; p + 28 < partials; p += 32) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = scratch[(long long)(p + 4 * u) * total + t];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[0] += v[u];
+            }
+        }
         for (; p < partials; p += 4)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[e] += scratch[(long long)p * total + t + e];

@@ -13,57 +13,14 @@
 // transpose read ds_read_b64_tr_b16; 64-byte blocks of every LDS row are XOR-swizzled by the row index so the 4
 // rows of a transpose read hit 4 different bank groups for every tap shift.
 // Split over pixel blocks across workgroups; partial tiles are combined with hardware fp32 atomics.
-#include <type_traits>
-#include "kp_common.h"
+#include "kp_mfma_util.h"
 
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(4))) short bf16x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-#define LDS_AS __attribute__((address_space(3)))
 
 constexpr int TPB = 512, NWAVE = 8;
 constexpr int BH = 8, BW = 16;                 // pixel block
 constexpr int PH = BH + 2, PWC = BW + 2;       // input patch
 constexpr int PROWS = PH * PWC;                // 180 patch pixels
-
-template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, int voff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_wave_base, 16, voff, 0, 0, 0);
-}
-
-template <int P>   // row pitch in bytes (128 or 256): swizzle of the 64-B block index by the LDS row
-__device__ __forceinline__ int blk_swz(int row) { return P == 256 ? (row & 3) : ((row >> 1) & 1); }
-
-// Transpose-read addressing.  A fragment = 8 consecutive LDS rows (pixels) R..R+7 of this lane's channel, read as two
-// 4-row ds_read_b64_tr_b16.  The lane's row is R + lrow (+4 for the second read) with R a compile-time constant
-// after unrolling; the XOR swizzle of the 64-byte block depends on the row only through (R mod 4) and lrow, so the
-// per-lane part is precomputed once for the 4 residues (tr_base) and R*P + 4*P*u folds into the instruction's
-// immediate offset: no address arithmetic next to the MFMAs.
-template <int P>
-__device__ __forceinline__ int tr_base(int v, int lrow, int colbyte) {
-    const int row = v + lrow;
-    return lrow * P + ((((colbyte >> 6) ^ blk_swz<P>(row)) << 6) | (colbyte & 63));
-}
-template <int P, int R>
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, const int (&base)[4]) {
-    bf16x8 r;
-    const unsigned char* a = tile + base[R & 3];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(a + (R + 4 * u) * P));
-        r[4 * u + 0] = v[0]; r[4 * u + 1] = v[1]; r[4 * u + 2] = v[2]; r[4 * u + 3] = v[3];
-    }
-    return r;
-}
 
 struct WgArgs {
     const bf16_t* x; const bf16_t* dy; float* scratch;

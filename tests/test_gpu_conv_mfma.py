@@ -101,6 +101,9 @@ def test_conv_wgrad_mfma(N, Ho, Wo, C, K, dp):
 
 FIRST_SHAPES = [  # N, Ho, Wo, C, K
     (2, 32, 32, 3, 64), (1, 16, 16, 1, 16), (2, 128, 128, 3, 64), (3, 16, 48, 3, 32), (1, 8, 8, 4, 64),
+    # MFMA first-layer kernels (K = 64, Cin <= 3, Wo % 32 == 0): forward from 4096 pixels, weight gradient from 65536;
+    # partially filled and empty wavefronts (150 groups over 20 wavefronts), Cin = 1 and 2
+    (16, 64, 64, 3, 64), (1, 50, 96, 3, 64), (7, 96, 160, 3, 64), (8, 128, 128, 1, 64), (6, 128, 96, 2, 64),
 ]
 
 
@@ -144,14 +147,17 @@ def test_conv_first_layer(N, Ho, Wo, C, K):
         for r in range(3):
             for s_ in range(3):
                 wref[:, r, s_, :] = torch.einsum('npqk,npqc->kc', df, xf[:, r:r + Ho, s_:s_ + Wo])
-        assert _lib.lib().kp_conv_wgrad_partials(N, Ho, Wo, C, K, 3, dp, _lib.KP_BF16) == 1
-        scratch = torch.zeros(K, 3, 3, C, device='cuda')
+        parts = _lib.lib().kp_conv_wgrad_partials(N, Ho, Wo, C, K, 3, dp, _lib.KP_BF16)
+        assert (parts > 1) == (K == 64 and C <= 3 and Wo % 32 == 0 and N * Ho * Wo >= 65536)
+        scratch = torch.zeros(K, 3, 3, C, device='cuda') if parts == 1 else \
+            torch.full((parts, K, 3, 3, C), float('nan'), device='cuda')
         dyd = dy.cuda()
         call('kp_prof_enable', 1)
         call('kp_conv_wgrad', ptr(xd), ptr(dyd), ptr(scratch), N, Ho, Wo, C, K, 3, dp, _lib.KP_BF16, st)
         call('kp_prof_collect', 4, None, None, ctypes.addressof(n))
         assert n.value == 1, 'the first-layer wgrad kernel did not take this shape'
-        gotw = scratch.double().cpu()
+        gotw = scratch.double().cpu() if parts == 1 else scratch.double().sum(0).cpu()
+        assert torch.isfinite(gotw).all()
         assert ((gotw - wref).norm() / wref.norm()).item() < 1e-5
     call('kp_prof_enable', 0)
 
@@ -226,8 +232,10 @@ def test_conv_small_channels(N, Ho, Wo, C, K):
         for r in range(3):
             for s_ in range(3):
                 wref[:, r, s_, :] = torch.einsum('npqk,npqc->kc', df, xf[:, r:r + Ho, s_:s_ + Wo])
-        assert _lib.lib().kp_conv_wgrad_partials(N, Ho, Wo, C, K, 3, dp, _lib.KP_BF16) == 1
-        scratch = torch.zeros(K, 3, 3, C, device='cuda')
+        parts = _lib.lib().kp_conv_wgrad_partials(N, Ho, Wo, C, K, 3, dp, _lib.KP_BF16)
+        assert (parts > 1) == (K == 64 and C <= 3 and Wo % 32 == 0 and N * Ho * Wo >= 65536)
+        scratch = torch.zeros(K, 3, 3, C, device='cuda') if parts == 1 else \
+            torch.full((parts, K, 3, 3, C), float('nan'), device='cuda')
         dyd = dy.cuda()
         call('kp_prof_enable', 1)
         call('kp_conv_wgrad', ptr(xd), ptr(dyd), ptr(scratch), N, Ho, Wo, C, K, 3, dp, _lib.KP_BF16, st)

@@ -107,7 +107,7 @@ def main():
         y = torch.empty(N, H, H, K, device='cuda', dtype=bf)
         stats = torch.empty(N * H * H // 64, 2, K, device='cuda')
         dy = (torch.randn(N, H, H, K, device='cuda') * 0.5).to(bf)
-        scratch = torch.zeros(K, 3, 3, C, device='cuda')
+        scratch = torch.zeros(_lib.lib().kp_conv_wgrad_partials(N, H, H, C, K, 3, 0, _lib.KP_BF16), K, 3, 3, C, device='cuda')
         tf = timed(lambda: call('kp_conv_fwd', ptr(a), ptr(wf), ptr(bias), ptr(y), ptr(stats), N, H + 2, H + 2, C, K, 3,
                                 _lib.KP_BF16, st), args.reps)
         tw = timed(lambda: call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, H, C, K, 3, 0, _lib.KP_BF16, st),
