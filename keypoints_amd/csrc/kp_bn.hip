@@ -12,6 +12,7 @@ namespace {
 
 constexpr int TPB = 256;
 constexpr int RED_R = 64;   // row groups of the two-stage column reduction
+constexpr long long WIDE_ROWS = 8192;   // up to here the one-launch wide reduction is used
 
 __device__ __forceinline__ void fold_range(int h, int H, int p, int& lo, int& hi) {
     lo = (h == 0) ? 0 : h + p;
@@ -174,6 +175,59 @@ __global__ __launch_bounds__(TPB) void bn_reduce_finalize_k(const float* __restr
         } else {
             o0[c] = (float)sum;        // sums[c]
             o0[C + c] = (float)sq;     // sums[C + c]
+            if (r0p) r0p[c] += (float)sum;   // dbeta
+            if (r1p) r1p[c] += (float)sq;    // dgamma
+        }
+    }
+    if (MODE == 0 && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+// Single launch for up to a few thousand rows (the persistent conv kernels write 4 rows per workgroup = 1024): one
+// 1024-thread workgroup per 16 channels, 32 row lanes x (16 sum | 16 sumsq) columns, 8 independent loads in flight
+// per lane; the 32 lanes are folded through LDS in index order (deterministic).  (A "last workgroup finalizes"
+// two-stage kernel was measured 5x slower: device-scope fences between XCDs cost more than the second launch.)
+template <int MODE>
+__global__ __launch_bounds__(1024) void bn_reduce_finalize_wide_k(const float* __restrict__ partials, long long rows, int C,
+                                                                  float* __restrict__ o0, float* __restrict__ o1,
+                                                                  float* __restrict__ r0p, float* __restrict__ r1p,
+                                                                  long long* __restrict__ nbt, float momentum, float eps,
+                                                                  long long count) {
+    const int cl = threadIdx.x & 15, which = (threadIdx.x >> 4) & 1, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 16 + cl;
+    double s = 0.0;
+    if (c < C) {
+        const float* col = partials + (long long)which * C + c;
+        const long long stride = 2LL * C;
+        long long r = rl;
+        for (; r + 7 * 32 < rows; r += 8 * 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(r + 32 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; r < rows; r += 32) s += (double)col[r * stride];
+    }
+    __shared__ double red[32][32];
+    red[rl][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && c < C) {
+        double sum = 0.0, sq = 0.0;
+        for (int r = 0; r < 32; ++r) { sum += red[r][cl]; sq += red[r][16 + cl]; }
+        if (MODE == 0) {
+            const double mu = sum / (double)count;
+            double var = sq / (double)count - mu * mu;
+            if (var < 0.0) var = 0.0;
+            o0[c] = (float)mu;
+            o1[c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (r0p) r0p[c] = (1.f - momentum) * r0p[c] + momentum * (float)mu;
+            if (r1p) {
+                const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+                r1p[c] = (1.f - momentum) * r1p[c] + momentum * (float)unbiased;
+            }
+        } else {
+            o0[c] = (float)sum;
+            o0[C + c] = (float)sq;
             if (r0p) r0p[c] += (float)sum;   // dbeta
             if (r1p) r1p[c] += (float)sq;    // dgamma
         }
@@ -494,6 +548,11 @@ int kp_bn_finalize(const float* stats, long long rows, double* ws, float* save_m
                                                              running_var, num_batches_tracked, momentum, eps, count);
         return kp_check_launch("bn_reduce_finalize");
     }
+    if (rows <= WIDE_ROWS) {
+        bn_reduce_finalize_wide_k<0><<<cdiv(C, 16), 1024, 0, st>>>(stats, rows, C, save_mean, save_invstd, running_mean,
+                                                                   running_var, num_batches_tracked, momentum, eps, count);
+        return kp_check_launch("bn_reduce_finalize_wide");
+    }
     int rc = reduce_rows(stats, ws, rows, 2 * C, st);
     if (rc) return rc;
     bn_finalize_k<<<cdiv(C, 128), 128, 0, st>>>(ws, save_mean, save_invstd, running_mean, running_var,
@@ -544,6 +603,11 @@ int kp_bn_bwd_finalize(const float* partials, double* ws, long long rows, int C,
         bn_reduce_finalize_k<1><<<cdiv(C, 32), TPB, 0, st>>>(partials, rows, C, sums, nullptr, dbeta, dgamma, nullptr, 0.f,
                                                              0.f, 1);
         return kp_check_launch("bn_bwd_reduce_finalize");
+    }
+    if (rows <= WIDE_ROWS) {
+        bn_reduce_finalize_wide_k<1><<<cdiv(C, 16), 1024, 0, st>>>(partials, rows, C, sums, nullptr, dbeta, dgamma, nullptr,
+                                                                   0.f, 0.f, 1);
+        return kp_check_launch("bn_bwd_reduce_finalize_wide");
     }
     int rc = reduce_rows(partials, ws, rows, 2 * C, st);
     if (rc) return rc;
