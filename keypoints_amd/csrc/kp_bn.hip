@@ -532,6 +532,7 @@ int kp_bn_act_fwd_fast(const void*, const float*, const float*, const float*, co
                        unsigned char*, int, int, int, int, hipStream_t);
 int kp_bn_bwd_fast(int, const void*, int, int, const unsigned char*, const void*, const float*, const float*,
                    const float*, const float*, float, float*, const float*, void*, int, int, int, int, int, hipStream_t);
+int kp_upsample2_bwd_fast(const void*, int, void*, int, int, int, int, hipStream_t);
 extern int g_kp_bn_fast;
 
 extern "C" {
@@ -636,6 +637,10 @@ int kp_upsample2_bwd(const void* gsrc, int gp, void* g, int N, int H, int W, int
     KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && gp >= 0, "kp_upsample2_bwd: bad dims");
     const unsigned grid = (unsigned)((long long)N * H);
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == KP_BF16 && g_kp_bn_fast) {
+        int rc = kp_upsample2_bwd_fast(gsrc, gp, g, N, H, W, C, st);
+        if (rc != KP_E_UNSUPPORTED) return rc;
+    }
     KP_BN_DISPATCH(dtype, C, (upsample2_bwd_k<T, V><<<grid, TPB, 0, st>>>((const T*)gsrc, gp, (T*)g, H, W, C)));
     return kp_check_launch("upsample2_bwd");
 }

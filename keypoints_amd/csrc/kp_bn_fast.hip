@@ -578,6 +578,66 @@ int rows_per_block(long long total_rows, int vec_per_row, int cus) {
     return rpb;
 }
 
+
+// ---- adjoint of the bilinear x2 tail (align_corners=True) with the replicate-pad border folded in ---------------
+// Separable: workgroup = (image, coarse row h, 64-channel chunk).  Phase 1 folds the <= 5 fine rows that touch h
+// (weights Ah) and the padded border into T[fine column][64 ch] (fp32, LDS), every fine pixel read as a coalesced
+// 16-byte vector; phase 2 applies the column weights Aw from LDS.  The general kernel gathers up to 25 fine pixels
+// per output vector straight from memory with the index logic in the inner loop.
+__global__ __launch_bounds__(256) void upsample2_bwd_fast_k(const bf16_t* __restrict__ gsrc, int gp, bf16_t* __restrict__ g,
+                                                            int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) float T[];   // [Wo][64]
+    const int Ho = 2 * H, Wo = 2 * W, Hp = Ho + 2 * gp, Wp = Wo + 2 * gp, chunks = C / 64;
+    int b = blockIdx.x;
+    const int ch = b % chunks; b /= chunks;
+    const int h = b % H;
+    const long long n = b / H;
+    const int cv = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int c = ch * 64 + cv * 8;
+    const int i_lo = 2 * h - 2 < 0 ? 0 : 2 * h - 2, i_hi = 2 * h + 2 > Ho - 1 ? Ho - 1 : 2 * h + 2;
+    for (int j = pl; j < Wo; j += 32) {
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        const int jlo = (j == 0) ? 0 : j + gp, jhi = (j == Wo - 1) ? Wo + 2 * gp - 1 : j + gp;
+        for (int i = i_lo; i <= i_hi; ++i) {
+            int h0, hp; float lh0, lh1;
+            bilin(i, H, Ho, h0, hp, lh0, lh1);
+            const float wh = (h0 == h ? lh0 : 0.f) + (h0 + hp == h ? lh1 : 0.f);
+            if (wh == 0.f) continue;
+            const int ilo = (i == 0) ? 0 : i + gp, ihi = (i == Ho - 1) ? Ho + 2 * gp - 1 : i + gp;
+            for (int a = ilo; a <= ihi; ++a)
+                for (int bb = jlo; bb <= jhi; ++bb) {
+                    float v[V];
+                    unpack8(ldv(gsrc + ((n * Hp + a) * Wp + bb) * C + c), v);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[e] = fmaf(wh, v[e], acc[e]);
+                }
+        }
+        float4* t = reinterpret_cast<float4*>(T + j * 64 + cv * 8);
+        t[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        t[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+    __syncthreads();
+    for (int w = pl; w < W; w += 32) {
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        const int j_lo = 2 * w - 2 < 0 ? 0 : 2 * w - 2, j_hi = 2 * w + 2 > Wo - 1 ? Wo - 1 : 2 * w + 2;
+        for (int j = j_lo; j <= j_hi; ++j) {
+            int w0, wp; float lw0, lw1;
+            bilin(j, W, Wo, w0, wp, lw0, lw1);
+            const float ww = (w0 == w ? lw0 : 0.f) + (w0 + wp == w ? lw1 : 0.f);
+            if (ww == 0.f) continue;
+            const float4* t = reinterpret_cast<const float4*>(T + j * 64 + cv * 8);
+            const float4 t0 = t[0], t1 = t[1];
+            acc[0] = fmaf(ww, t0.x, acc[0]); acc[1] = fmaf(ww, t0.y, acc[1]); acc[2] = fmaf(ww, t0.z, acc[2]); acc[3] = fmaf(ww, t0.w, acc[3]);
+            acc[4] = fmaf(ww, t1.x, acc[4]); acc[5] = fmaf(ww, t1.y, acc[5]); acc[6] = fmaf(ww, t1.z, acc[6]); acc[7] = fmaf(ww, t1.w, acc[7]);
+        }
+        stv(g + ((n * H + h) * W + w) * C + c, pack8(acc));
+    }
+}
+
 }  // namespace
 
 int kp_bn_act_fwd_fast(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
@@ -643,4 +703,11 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
     }
 #undef KP_BWD
     return kp_check_launch("bn_bwd_fast");
+}
+
+int kp_upsample2_bwd_fast(const void* gsrc, int gp, void* g, int N, int H, int W, int C, hipStream_t st) {
+    const long long blocks = (long long)N * H * (C / 64);
+    if (C % 64 != 0 || W > 128 || blocks > 0x7fffffffLL) return KP_E_UNSUPPORTED;
+    upsample2_bwd_fast_k<<<(unsigned)blocks, 256, (size_t)2 * W * 64 * sizeof(float), st>>>((const bf16_t*)gsrc, gp, (bf16_t*)g, H, W, C);
+    return kp_check_launch("upsample2_bwd_fast");
 }

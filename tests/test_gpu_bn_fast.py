@@ -104,3 +104,34 @@ def test_bn_bwd_fast(N, H, W, C, tail, gp):
         # sums differ by summation-order noise -> a few results may round to the neighbouring bf16
         close = (a - b).abs() <= 2 ** -7 * a.abs() + 1e-3
         assert close.float().mean().item() > 0.9999
+
+
+@pytest.mark.parametrize('N,H,W,C', SHAPES + [(2, 64, 64, 128), (1, 7, 128, 64)])
+@pytest.mark.parametrize('gp', [0, 1])
+def test_upsample2_bwd_fast(N, H, W, C, gp):
+    """Separable adjoint of the bilinear x2 tail (with the replicate-pad border folded in) vs the general gather
+    kernel and vs torch autograd of F.interpolate(align_corners=True) + F.pad(replicate) in fp32."""
+    import torch.nn.functional as F
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    g = torch.Generator().manual_seed(N * 100 + C + gp)
+    gsrc = torch.randn(N, 2 * H + 2 * gp, 2 * W + 2 * gp, C, generator=g).bfloat16().cuda()
+    outs = []
+    for fast in (0, 1):
+        call('kp_config', 4, fast)
+        out = torch.full((N, H, W, C), float('nan'), device='cuda', dtype=torch.bfloat16)
+        call('kp_upsample2_bwd', ptr(gsrc), gp, ptr(out), N, H, W, C, _lib.KP_BF16, stream_ptr())
+        outs.append(out.float().cpu())
+    call('kp_config', 4, 1)
+    a, b = outs
+    assert torch.isfinite(b).all()
+    x = torch.zeros(N, C, H, W, requires_grad=True)
+    up = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
+    if gp:
+        up = F.pad(up, (gp,) * 4, mode='replicate')
+    up.backward(gsrc.float().cpu().permute(0, 3, 1, 2))
+    ref = x.grad.permute(0, 2, 3, 1)
+    for got in (a, b):   # one bf16 rounding of the result
+        assert ((got - ref).abs() <= 2 ** -7 * ref.abs() + 1e-3).float().mean().item() > 0.9999
+    assert ((a - b).abs() <= 2 ** -7 * a.abs() + 1e-3).float().mean().item() > 0.9999
