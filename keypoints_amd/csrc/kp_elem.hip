@@ -293,6 +293,9 @@ __global__ void scale_k(const float* __restrict__ x, const float* __restrict__ s
     } while (0)
 
 int kp_head_fwd_fast(const void*, const float*, const float*, float, float*, long long, int, int, int, hipStream_t);
+int kp_head_fwd_mfma(const void*, const float*, const float*, float, float*, long long, int, int, int, hipStream_t);
+int kp_head_dx_mfma(const float*, const float*, const float*, float, void*, long long, int, int, int, hipStream_t);
+int kp_head_dw_mfma(const float*, const float*, const void*, float, float*, float*, long long, int, int, int, hipStream_t);
 int kp_head_dx_fast(const float*, const float*, const float*, float, void*, long long, int, int, int, hipStream_t);
 int kp_head_dw_fast(const float*, const float*, const void*, float, float*, float*, long long, int, int, int, hipStream_t);
 
@@ -336,7 +339,9 @@ int kp_head_fwd(const void* x, const float* w, const float* bias, float slope, f
     KP_REQUIRE(C <= 2048, "kp_head_fwd: C too large for the LDS tile");
     const long long M = (long long)N * H * W;
     if (dtype == KP_BF16) {
-        int rc = kp_head_fwd_fast(x, w, bias, slope, out, M, H * W, C, K, (hipStream_t)stream);
+        int rc = kp_head_fwd_mfma(x, w, bias, slope, out, M, H * W, C, K, (hipStream_t)stream);
+        if (rc != KP_E_UNSUPPORTED) return rc;
+        rc = kp_head_fwd_fast(x, w, bias, slope, out, M, H * W, C, K, (hipStream_t)stream);
         if (rc != KP_E_UNSUPPORTED) return rc;
     }
     const size_t smem = (size_t)HPB * (C + 1) * sizeof(float);
@@ -351,12 +356,14 @@ int kp_head_bwd(const float* gout, const float* out, const void* x, const float*
     const long long M = (long long)N * H * W;
     hipStream_t st = (hipStream_t)stream;
     if (dx && dtype == KP_BF16) {
-        int rc = kp_head_dx_fast(gout, out, w, slope, dx, M, H * W, C, K, st);
+        int rc = kp_head_dx_mfma(gout, out, w, slope, dx, M, H * W, C, K, st);
+        if (rc == KP_E_UNSUPPORTED) rc = kp_head_dx_fast(gout, out, w, slope, dx, M, H * W, C, K, st);
         if (rc == KP_OK) dx = nullptr;
         else if (rc != KP_E_UNSUPPORTED) return rc;
     }
     if (dw && dtype == KP_BF16) {
-        int rc = kp_head_dw_fast(gout, out, x, slope, dw, db, M, H * W, C, K, st);
+        int rc = kp_head_dw_mfma(gout, out, x, slope, dw, db, M, H * W, C, K, st);
+        if (rc == KP_E_UNSUPPORTED) rc = kp_head_dw_fast(gout, out, x, slope, dw, db, M, H * W, C, K, st);
         if (rc == KP_OK) dw = nullptr;
         else if (rc != KP_E_UNSUPPORTED) return rc;
     }
