@@ -588,13 +588,53 @@ __global__ __launch_bounds__(256) void upsample2_bwd_fast_k(const bf16_t* __rest
                                                             int H, int W, int C) {
     extern __shared__ __attribute__((aligned(16))) float T[];   // [Wo][64]
     const int Ho = 2 * H, Wo = 2 * W, Hp = Ho + 2 * gp, Wp = Wo + 2 * gp, chunks = C / 64;
-    int b = blockIdx.x;
+    // XCD x (workgroups with blockIdx % 8 == x) walks a contiguous range of (image, row, chunk) items, so that the
+    // workgroups of neighbouring coarse rows, which share 3 of their 5 fine rows, meet in one L2
+    int b;
+    {
+        const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = blockIdx.x % 8, i = blockIdx.x / 8;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
     const int ch = b % chunks; b /= chunks;
     const int h = b % H;
     const long long n = b / H;
     const int cv = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int c = ch * 64 + cv * 8;
     const int i_lo = 2 * h - 2 < 0 ? 0 : 2 * h - 2, i_hi = 2 * h + 2 > Ho - 1 ? Ho - 1 : 2 * h + 2;
+    // rows away from the top / bottom border: exactly the 5 fine rows 2h-2 .. 2h+2, no vertical fold -> their loads
+    // are issued together (the general loop below waits for every load before it decides on the next one)
+    const bool vint = i_lo > 0 && i_hi < Ho - 1 && i_hi - i_lo == 4;
+    float rw[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        int h0, hp; float lh0, lh1;
+        bilin(i_lo + r, H, Ho, h0, hp, lh0, lh1);
+        rw[r] = (h0 == h ? lh0 : 0.f) + (h0 + hp == h ? lh1 : 0.f);
+    }
+    if (vint) {
+        const bf16_t* rowp = gsrc + ((n * Hp + i_lo + gp) * Wp) * C + c;
+        for (int j = pl; j < Wo; j += 32) {
+            float acc[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] = 0.f;
+            const int jlo = (j == 0) ? 0 : j + gp, jhi = (j == Wo - 1) ? Wo + 2 * gp - 1 : j + gp;
+            for (int bb = jlo; bb <= jhi; ++bb) {
+                uint4 raw[5];
+#pragma unroll
+                for (int r = 0; r < 5; ++r) raw[r] = ldv(rowp + ((long long)r * Wp + bb) * C);
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    float v[V];
+                    unpack8(raw[r], v);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[e] = fmaf(rw[r], v[e], acc[e]);
+                }
+            }
+            float4* t = reinterpret_cast<float4*>(T + j * 64 + cv * 8);
+            t[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            t[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+    } else
     for (int j = pl; j < Wo; j += 32) {
         float acc[V];
 #pragma unroll
