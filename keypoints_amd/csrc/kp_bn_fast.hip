@@ -446,7 +446,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_pool_fast_k(const bf16_t* __restri
                                                           float* __restrict__ partials, const float* __restrict__ sums,
                                                           bf16_t* __restrict__ dy, int dp, int N, int H, int W, int C,
                                                           long long total_rows, int rpb) {
-    constexpr int U2 = 2;
+    constexpr int U2 = MODE == 0 ? 1 : 2;   // reduce: occupancy beats loads in flight (measured 212 -> 192 us), apply: the reverse
     const int CV = C / V;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
     const int c = cv * V;
