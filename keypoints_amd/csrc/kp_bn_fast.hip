@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int TPB = 256, V = 8, UNR = 4;
+constexpr int UNB = 4;   // pixels in flight per thread in the backward kernels (2 and 1 measured slower)
 
 struct BnP {
     const float *mean, *invstd, *gamma, *beta;
@@ -359,11 +360,11 @@ __global__ __launch_bounds__(TPB) void bn_bwd_fast_k(const bf16_t* __restrict__ 
         const int sh = POOL ? (h >> 1) : h;
         const bool hedge = GP && (sh == 0 || sh == Hs - 1);
         const bf16_t* yr = y + ((n * H + h) * W) * (long long)C + c;
-        for (int w0 = pl; w0 < W; w0 += UNR * npl) {
-            uint4 graw[UNR], yraw[UNR];
-            uint2 amraw[UNR];
+        for (int w0 = pl; w0 < W; w0 += UNB * npl) {
+            uint4 graw[UNB], yraw[UNB];
+            uint2 amraw[UNB];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
+            for (int u = 0; u < UNB; ++u) {
                 const int w = w0 + u * npl;
                 if (w < W) {
                     const int sw = POOL ? (w >> 1) : w;
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_fast_k(const bf16_t* __restrict__ 
                 }
             }
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
+            for (int u = 0; u < UNB; ++u) {
                 const int w = w0 + u * npl;
                 if (w < W) {
                     const int sw = POOL ? (w >> 1) : w;
