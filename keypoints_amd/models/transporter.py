@@ -4,6 +4,7 @@ import torch.nn as nn
 
 from . import functional as MF
 from . import knn, vgg
+from ..unit_engine import shared_packs
 
 
 class TransporterNet(knn.Container):
@@ -26,9 +27,10 @@ class TransporterNet(knn.Container):
         return phi, heatmap, k, p, m
 
     def forward(self, xs, xt):
-        with torch.no_grad():   # source branch carries no gradient (transporter.py:36-37)
-            phi_xs, _, _, _, m_xs = self.extract(xs)
-        phi_xt, heatmap_xt, k_xt, p_xt, m_xt = self.extract(xt)
+        with shared_packs():   # both branches run on the same weights: pack them once
+            with torch.no_grad():   # source branch carries no gradient (transporter.py:36-37)
+                phi_xs, _, _, _, m_xs = self.extract(xs)
+            phi_xt, heatmap_xt, k_xt, p_xt, m_xt = self.extract(xt)
 
         mode = self.combine_method
         if mode == 'max':

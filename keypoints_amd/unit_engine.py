@@ -28,6 +28,28 @@ from .runtime import f32c, precision_dtype, require_device, stream_ptr
 TAILS = {None: _lib.TAIL_NONE, 'M': _lib.TAIL_MAXPOOL2, 'U': _lib.TAIL_UPSAMPLE2}
 
 
+# Packed (bf16, tap-major) copies of the conv weights shared between the Unit calls of ONE network forward: the
+# Transporter runs every encoder twice (source / target, transporter.py:36-39) on the same weights, which cannot
+# change inside a forward.  None outside of `shared_packs()`.
+_PACKS = None
+
+
+class shared_packs:
+    """Context manager: Unit forwards inside it pack each conv weight once (forward and data-gradient layouts)."""
+
+    def __enter__(self):
+        global _PACKS
+        self._outer = _PACKS
+        if _PACKS is None:
+            _PACKS = {}
+        return self
+
+    def __exit__(self, *exc):
+        global _PACKS
+        _PACKS = self._outer
+        return False
+
+
 def _slope_of(act: nn.Module) -> float:
     if isinstance(act, nn.LeakyReLU):
         return float(act.negative_slope)
@@ -136,9 +158,16 @@ class UnitFunction(torch.autograd.Function):
                 raise RuntimeError(f'channel mismatch: conv expects {conv.in_channels}, got {C}')
             Cl = C                       # logical input channels of this layer (the conv's)
             C = Cp0 if idx == 0 else C   # physical channels of `a`
-            wf = torch.empty(K, 3, 3, C, device=dev, dtype=tdt)
-            wd = torch.empty(C, 3, 3, K, device=dev, dtype=tdt) if record else None
-            call('kp_pack_weights', ptr(conv.weight), ptr(wf), ptr(wd), K, Cl, C, 3, code, st)
+            pkey = (id(conv.weight), C, code)
+            ent = _PACKS.get(pkey) if _PACKS is not None else None
+            if ent is None or (record and ent[1] is None):
+                wf = torch.empty(K, 3, 3, C, device=dev, dtype=tdt)
+                wd = torch.empty(C, 3, 3, K, device=dev, dtype=tdt) if (record or _PACKS is not None) else None
+                call('kp_pack_weights', ptr(conv.weight), ptr(wf), ptr(wd), K, Cl, C, 3, code, st)
+                if _PACKS is not None:
+                    _PACKS[pkey] = (wf, wd)
+            else:
+                wf, wd = ent
             y = torch.empty(N, H, W, K, device=dev, dtype=tdt)
             training = bn is not None and bn.training
             stats = torch.empty((N * H * W + 63) // 64, 2, K, device=dev, dtype=torch.float32) if training else None
