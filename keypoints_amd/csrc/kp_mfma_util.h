@@ -27,6 +27,26 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wav
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
+// The same instruction as inline asm, for kernels that interleave DMA issues with ds_read_b64_tr_b16: hipcc orders
+// every transpose read after any builtin LDS-DMA that might alias it (s_waitcnt vmcnt(0) after each DMA), which
+// serialises the DMA latencies; the asm form is invisible to that analysis, the kernel keeps its own vmcnt wait + barrier
+// before it reads a DMA'd buffer.  A kernel that uses this must not use the builtin form (M0 is written behind the
+// compiler's back).
+struct RsrcWords { unsigned w0, w1, w2, w3; };
+__device__ __forceinline__ u32x4 rsrc_words(const void* base) {
+    const unsigned long long b = (unsigned long long)base;
+    u32x4 d;
+    d.x = __builtin_amdgcn_readfirstlane((unsigned)b);
+    d.y = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);
+    d.z = 0x7ffffffeu;
+    d.w = 0x00020000u;
+    return d;
+}
+__device__ __forceinline__ void dma16_asm(u32x4 rsrc, const void* lds_wave_base, int voff) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(LDS_AS const unsigned char*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc));
+}
+
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }

@@ -27,20 +27,25 @@ struct WgArgs {
     int Ho, Wo, C, K, dy_pad;
     int ctiles, ktiles, stages_per_split, total_stages, bx, by, dbg;
     long long partial_stride;   // floats between the partial gradients of consecutive pixel splits (0: one buffer, atomics)
+    long long* trace;           // measurement build: s_memtime stamps of workgroup 0 / wave 0 (512 entries)
 };
 
-template <int TK, int TC>
+template <int TK, int TC, bool TRACE>
 __global__ __launch_bounds__(TPB, 2) void wgrad3x3_patch_k(const WgArgs A) {
     constexpr int PK = TK * 2, PC = TC * 2;                       // LDS row pitches (bytes)
     constexpr int RPI_K = 1024 / PK, RPI_C = 1024 / PC;           // LDS rows per DMA instruction
     constexpr int NI_DY = BH * BW / RPI_K;                        // DMA instructions for the dY tile
     constexpr int NI_X = (PROWS + RPI_C - 1) / RPI_C;             // ... for the input patch (last one partial)
-    constexpr int NW_DY = NI_DY / NWAVE, NW_X = (NI_X + NWAVE - 1) / NWAVE;   // per wave
+    constexpr int NW_X = (NI_X + NWAVE - 1) / NWAVE;   // input patch instructions rounded to 8 (LDS layout)
+    // Only wavefronts 0..3 issue DMA: a SIMD holds waves w and w+4 and gives the older one (w) priority; with the loads on
+    // all eight, wave w+4 finished every stage ~2000 cycles after wave w, running alone at half rate meanwhile.  With
+    // the whole non-MFMA work on the priority wave, the other one has nothing but MFMAs to fill its gaps with.
+    constexpr int LW = 4, ND2 = NI_DY / LW, NX2 = (NI_X + LW - 1) / LW, NT = ND2 + NX2;   // per loading wave
     constexpr int DYB = NI_DY * 1024, XB = NW_X * NWAVE * 1024, STAGE = DYB + XB;
     constexpr int LPR_K = PK / 16, LPR_C = PC / 16;               // lanes per LDS row
     constexpr int WK = TK / 32, WC = TC / 32;                     // wave grid (WK * WC == 8)
     static_assert(WK * WC == NWAVE, "one 32x32 gradient tile per wavefront");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 1024];   // + dummy DMA target
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,37 +69,55 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_patch_k(const WgArgs A) {
     if (s_beg >= s_end) return;
 
     // ---- per-lane DMA offsets (relative to the pixel block's origin) -----------------------------------------
-    int dvoff[NW_DY], xvoff[NW_X];
+    const int lw = wave & (LW - 1);
+    const bool loader = wave < LW;
+    int dvoff[ND2], xvoff[NX2];
 #pragma unroll
-    for (int j = 0; j < NW_DY; ++j) {
-        const int row = (j * NWAVE + wave) * RPI_K + lane / LPR_K;   // pixel of the 8x16 block, row-major
+    for (int j = 0; j < ND2; ++j) {
+        const int row = (j * LW + lw) * RPI_K + lane / LPR_K;   // pixel of the 8x16 block, row-major
         const int slot = lane % LPR_K;
         const int lblk = (slot >> 2) ^ blk_swz<PK>(row);
         dvoff[j] = ((row / BW) * Wd + (row % BW)) * K * 2 + lblk * 64 + (slot & 3) * 16;
     }
 #pragma unroll
-    for (int j = 0; j < NW_X; ++j) {
-        int row = (j * NWAVE + wave) * RPI_C + lane / LPR_C;         // patch pixel, row-major over 10 x 18
+    for (int j = 0; j < NX2; ++j) {
+        int row = (j * LW + lw) * RPI_C + lane / LPR_C;              // patch pixel, row-major over 10 x 18
         const int slot = lane % LPR_C;
         const int lblk = (slot >> 2) ^ blk_swz<PC>(row);
         if (row > PROWS - 1) row = PROWS - 1;                         // tail lanes: harmless duplicate
         xvoff[j] = ((row / PWC) * Wi + (row % PWC)) * C * 2 + lblk * 64 + (slot & 3) * 16;
     }
 
-    auto stage = [&](int buf, int sg) {
-        const int bxi = sg % A.bx, byi = (sg / A.bx) % A.by, n = sg / (A.bx * A.by);
+    // A stage's DMA = NT instructions per loading wave.  The first stage issues them in one go; afterwards the
+    // instructions of stage s+1 are spread over the patch rows of stage s (one or two after each row's MFMAs), so the
+    // ~100-cycle DMA issues hide behind queued MFMAs instead of stopping the waves at the top of a stage.
+    u32x4 dr, xr;   // buffer descriptors of the stage being fetched (asm DMA: see dma16_asm)
+    // fetch cursor: pixel block (bxi, byi) of image cn -- divisions only once per workgroup, then carries
+    int cbx = s_beg % A.bx, cby = (s_beg / A.bx) % A.by, cn = s_beg / (A.bx * A.by);
+    u32x4 dr2, xr2;   // ... and of the stage after it, computed late in a stage behind its MFMAs
+    auto stage_addr = [&]() {   // descriptors of the cursor's block -> (dr2, xr2), then advance the cursor
+        const int bxi = cbx, byi = cby, n = cn;
+        if (++cbx == A.bx) { cbx = 0; if (++cby == A.by) { cby = 0; ++cn; } }
         const int y0 = byi * BH, x0 = bxi * BW;
         const unsigned char* db = (const unsigned char*)A.dy + ((((long long)n * Hd + y0 + dp) * Wd + x0 + dp) * K + k0) * 2;
         const unsigned char* xb = (const unsigned char*)A.x + ((((long long)n * Hi + y0) * Wi + x0) * C + c0) * 2;
-        const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)db, 0, 0x7ffffffe, 0x00020000);
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, 0x7ffffffe, 0x00020000);
-        unsigned char* sd = smem + buf * STAGE;
-        unsigned char* sx = sd + DYB;
-#pragma unroll
-        for (int j = 0; j < NW_DY; ++j) dma16(dr, sd + (j * NWAVE + wave) * 1024, dvoff[j]);
-#pragma unroll
-        for (int j = 0; j < NW_X; ++j) dma16(xr, sx + (j * NWAVE + wave) * 1024, xvoff[j]);
+        dr2 = rsrc_words(db);
+        xr2 = rsrc_words(xb);
     };
+    // (`real` = false sends the instruction to a dummy LDS target: the row loop stays branch-free, which the
+    //  compiler needs to keep its software pipeline of transpose reads across rows)
+    auto stage_issue = [&](int buf, auto jc, bool real) {   // instruction jc of the stage whose addresses are set
+        constexpr int j = decltype(jc)::value;
+        unsigned char* sd = smem + buf * STAGE;
+        if constexpr (j < ND2) dma16_asm(dr, real ? sd + (j * LW + lw) * 1024 : smem + 2 * STAGE, dvoff[j]);
+        else if constexpr (j < NT) {
+            constexpr int jx = j - ND2;
+            // (instructions past the patch's last one exist only for some lw: they land in the buffer's padding)
+            dma16_asm(xr, real ? sd + DYB + (jx * LW + lw) * 1024 : smem + 2 * STAGE, xvoff[jx]);
+        }
+    };
+    static_assert(NT <= 2 * PH, "at most two DMA instructions per patch row");
+    static_assert(NX2 * LW * 1024 <= XB, "input patch instructions fit the staged buffer");
 
     f32x16 acc[9];
 #pragma unroll
@@ -112,37 +135,71 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_patch_k(const WgArgs A) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) { kbase[v] = tr_base<PK>(v, lrow, kcol); cbase[v] = tr_base<PC>(v, lrow, ccol); }
 
-    stage(0, s_beg);
+    int tri = 0;
+    const bool tracing = TRACE && A.trace != nullptr && blockIdx.x == 0 && wave == 0;
+    auto stamp = [&]() {
+        if constexpr (TRACE) if (tracing) {
+            const long long now = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && tri < 512) A.trace[tri] = now;
+            ++tri;
+        }
+    };
+    stamp();
+    stage_addr();
+    dr = dr2; xr = xr2;
+    if (loader) static_for<0, NT>([&](auto jc) { stage_issue(0, jc, true); });
+    stage_addr();   // block s_beg + 1 (fetched during the first stage)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
     for (int sg = s_beg; sg < s_end; ++sg) {
         const int buf = (sg - s_beg) & 1;
-        if (sg + 1 < s_end) stage(buf ^ 1, sg + 1);
+        stamp();
+        const bool more = sg + 1 < s_end;
+        if (more) { dr = dr2; xr = xr2; }   // block sg + 1; the last stage re-reads its own block into the dummy target
+                                            // (dr2 may then describe a block past the end of the tensors: never used)
+        stamp();
         const unsigned char* sd = smem + buf * STAGE;
         const unsigned char* sx = sd + DYB;
         // walk the 10 patch rows; patch row p meets output rows p, p-1, p-2 through taps r = 0, 1, 2
         bf16x8 a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0, a2 = a0;   // dY fragments of output rows p, p-1, p-2 (rotating)
+        // fragments are read one patch row ahead of their MFMAs, so a wave keeps the matrix pipe fed on its own
+        // (the second wave of a SIMD finishes a stage ~2000 cycles after the first and runs alone meanwhile)
+        bf16x8 an = tr_frag<PK, 0>(sd, kbase), bn[3];
+        bn[0] = tr_frag<PC, 0>(sx, cbase);
+        bn[1] = tr_frag<PC, 1>(sx, cbase);
+        bn[2] = tr_frag<PC, 2>(sx, cbase);
         static_for<0, PH>([&](auto pc) {
             constexpr int p = decltype(pc)::value;
             a2 = a1; a1 = a0;
-            if constexpr (p < BH) a0 = tr_frag<PK, p * BW>(sd, kbase);
-            bf16x8 b[3];
-            b[0] = tr_frag<PC, p * PWC + 0>(sx, cbase);
-            b[1] = tr_frag<PC, p * PWC + 1>(sx, cbase);
-            b[2] = tr_frag<PC, p * PWC + 2>(sx, cbase);
+            if constexpr (p < BH) a0 = an;
+            bf16x8 b[3] = {bn[0], bn[1], bn[2]};
+            if constexpr (p + 1 < PH) {
+                if constexpr (p + 1 < BH) an = tr_frag<PK, (p + 1) * BW>(sd, kbase);
+                bn[0] = tr_frag<PC, (p + 1) * PWC + 0>(sx, cbase);
+                bn[1] = tr_frag<PC, (p + 1) * PWC + 1>(sx, cbase);
+                bn[2] = tr_frag<PC, (p + 1) * PWC + 2>(sx, cbase);
+            }
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
                 if constexpr (p < BH) acc[0 * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[s], acc[0 * 3 + s], 0, 0, 0);
                 if constexpr (p >= 1 && p - 1 < BH) acc[1 * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[s], acc[1 * 3 + s], 0, 0, 0);
                 if constexpr (p >= 2) acc[2 * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[s], acc[2 * 3 + s], 0, 0, 0);
             }
+            if (loader) {   // two instructions per row from the top: the last one is issued ~3 rows before the stage ends
+                stage_issue(buf ^ 1, std::integral_constant<int, 2 * p>{}, more);
+                stage_issue(buf ^ 1, std::integral_constant<int, 2 * p + 1>{}, more);
+                if constexpr (p == PH - 2) stage_addr();   // block sg + 2, behind this row's MFMAs
+            }
         });
+        stamp();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+    stamp();
 
     // D[k][c]: lane col = c (lane&31), rows k = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int cc = c0 + wc * 32 + (lane & 31);
@@ -205,8 +262,9 @@ int kp_conv_wgrad_patch(const void* x, const void* dy, float* scratch, int N, in
     if (rc != KP_OK) return rc;
     a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.scratch = scratch;
     a.partial_stride = (long long)K * 9 * C;
-    { extern int g_kp_debug; a.dbg = g_kp_debug; }
-    if (k128) wgrad3x3_patch_k<128, 64><<<grid, TPB, 0, st>>>(a);
-    else wgrad3x3_patch_k<64, 128><<<grid, TPB, 0, st>>>(a);
+    { extern int g_kp_debug; extern long long* g_kp_trace; a.dbg = g_kp_debug; a.trace = g_kp_trace; }
+    if (k128 && a.trace) wgrad3x3_patch_k<128, 64, true><<<grid, TPB, 0, st>>>(a);
+    else if (k128) wgrad3x3_patch_k<128, 64, false><<<grid, TPB, 0, st>>>(a);
+    else wgrad3x3_patch_k<64, 128, false><<<grid, TPB, 0, st>>>(a);
     return kp_check_launch("wgrad3x3_patch");
 }
