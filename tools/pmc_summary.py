@@ -17,7 +17,7 @@ import sys
 
 # 'conv_patch_bf16_bn128' = both instantiations of the 128-channel-tile kernel (forward with statistics, data gradient)
 KERNELS = {'conv3x3_patch_k<128': 'conv_patch_bf16_bn128', 'conv3x3_patch_k<128, true': 'conv_patch_bf16_bn128_fwd',
-           'conv3x3_patch_k<128, false': 'conv_patch_bf16_bn128_dgrad', 'wgrad3x3_patch_k<128, 64>': 'wgrad_patch_bf16_128x64'}
+           'conv3x3_patch_k<128, false': 'conv_patch_bf16_bn128_dgrad', 'wgrad3x3_patch_k<128, 64': 'wgrad_patch_bf16_128x64'}
 
 
 def load(name):
