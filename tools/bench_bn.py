@@ -16,9 +16,12 @@ SHAPES = [(64, 128, 'none'), (128, 128, 'pool'), (256, 64, 'none'), (256, 64, 'p
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument('--batch', type=int, default=128)
+    ap.add_argument('--cfg', default='', help='kp_config switches key=value[,key=value]')
     ap.add_argument('--lib', default='', help='another build of libkp_hip.so (A/B between builds)'); args = ap.parse_args()
     if args.lib:
         _lib.LIB_PATH = os.path.abspath(args.lib)
+    for kv in filter(None, args.cfg.split(',')):   # e.g. --cfg 5=0: kp_config(KP_CFG_BN_FLAT, 0)
+        call('kp_config', *[int(v) for v in kv.split('=')])
     N = args.batch; st = torch.cuda.current_stream().cuda_stream; bf = torch.bfloat16
     print(f'{"C":>4} {"H":>4} {"tail":>5} | {"fwd us":>8} {"GB/s":>6} | {"reduce us":>9} {"GB/s":>6} | {"apply us":>8} {"GB/s":>6}')
     for C, H, tail in SHAPES:
