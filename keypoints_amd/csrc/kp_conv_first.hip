@@ -405,9 +405,9 @@ __global__ __launch_bounds__(1024) void conv3_first_wgrad_mfma_k(const bf16_t* _
     GroupPos c = group_pos(g0 < groups ? g0 : 0, Ho, Wo);   // fetch cursor
     auto fetch = [&](int buf) {
         const bf16_t* db = dy + (((c.n * Hd + c.p + dy_pad) * Wd) + c.q + dy_pad) * K;
-        const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)db, 0, 0x7ffffffe, 0x00020000);
+        const u32x4 dr = rsrc_words(db);   // asm DMA: the builtin would make every transpose read wait for it (kp_mfma_util.h)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) dma16(dr, dyb + buf * DYB + u * 1024, dvoff[u]);
+        for (int u = 0; u < 4; ++u) dma16_asm(dr, dyb + buf * DYB + u * 1024, dvoff[u]);
         if (lane < ND) {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
