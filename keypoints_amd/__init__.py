@@ -4,6 +4,7 @@ from .runtime import default_precision, set_default_precision  # noqa: F401
 from . import models  # noqa: F401
 from . import data_augments, tps  # noqa: F401
 from .optim import FusedAdam, l2_reconstruction_loss  # noqa: F401
+from . import inference  # noqa: F401
 
 
 def install_as_keypoints():

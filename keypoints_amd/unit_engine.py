@@ -35,12 +35,18 @@ _PACKS = None
 
 
 class shared_packs:
-    """Context manager: Unit forwards inside it pack each conv weight once (forward and data-gradient layouts)."""
+    """Context manager: Unit forwards inside it pack each conv weight once (forward and data-gradient layouts).
+    `store`: a dict that outlives the context (frozen weights: the inference extractor keeps its packs across frames)."""
+
+    def __init__(self, store=None):
+        self._store = store
 
     def __enter__(self):
         global _PACKS
         self._outer = _PACKS
-        if _PACKS is None:
+        if self._store is not None:
+            _PACKS = self._store
+        elif _PACKS is None:
             _PACKS = {}
         return self
 

@@ -375,3 +375,38 @@ def test_inference_keypoint_extractor_matches_oracle():
     assert maxerr(k, ok) <= 2e-5
     for name, buf in net.named_buffers():       # eval mode must not touch the running statistics
         assert torch.equal(buf.cpu(), Bf[name]), name
+
+
+@pytest.mark.parametrize('cfg', [('VGG_PONG_LAYERNECK', 1, 16, 4, 84, 1), ('VGG_PONG_LAYERNECK', 1, 16, 4, 84, 3),
+                                 ('F', 3, 64, 10, 128, 1)])
+def test_keypoint_extractor_graph_replay(cfg):
+    """keypoints_amd.inference.KeypointExtractor: the HIP-graph replay returns bit-for-bit what the eager chain returns,
+    for several frames through one captured graph, and leaves the running statistics alone."""
+    from keypoints_amd.inference import KeypointExtractor
+    from keypoints_amd.models import functional as MF, transporter
+    typ, cin, z, K, S, B = cfg
+    torch.manual_seed(5)
+    net = transporter.make(typ, cin, z, K).cuda()
+    if typ == 'F':
+        net = net.set_precision('bf16')
+    g = torch.Generator().manual_seed(11)
+    for name, buf in net.named_buffers():
+        if name.endswith('running_mean'):
+            buf.copy_((torch.randn(buf.shape, generator=g) * 0.1).cuda())
+        elif name.endswith('running_var'):
+            buf.copy_((torch.rand(buf.shape, generator=g) + 0.5).cuda())
+    bufs = {n: b.clone() for n, b in net.named_buffers()}
+    ex = KeypointExtractor(net, graph=True)
+    eager = KeypointExtractor(net, graph=False)
+    for frame in range(4):
+        x = (torch.rand(B, cin, S, S, generator=g) * 2 - 1).cuda()
+        k = ex(x).clone()
+        ke = eager(x)
+        assert k.shape == (B, K, 2) and torch.isfinite(k).all()
+        assert torch.equal(k, ke), frame
+        assert torch.equal(ex.heatmap, eager.heatmap)
+        with torch.no_grad():
+            assert torch.equal(ke, MF.spacial_logsoftmax(net.keypoint(x)))
+    assert len(ex._captured) == 1
+    for n, b in net.named_buffers():
+        assert torch.equal(b, bufs[n]), n
