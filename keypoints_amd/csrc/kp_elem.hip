@@ -122,6 +122,43 @@ __global__ __launch_bounds__(256) void wgrad_unpack_k(const float* __restrict__ 
     }
 }
 
+// The same sum for the MFMA kernels' layouts (C % 64 == 0), with both sides coalesced: a workgroup owns output channel k and
+// a 128-channel chunk; for fixed k both layouts are one contiguous run of R*R*C floats, so the (tap, c) -> (c, tap)
+// transposition happens in LDS.  Partials are summed per element in the same order as above: 4 interleaved running
+// sums p = q, q+4, ... combined as ((s0 + s1) + s2) + s3 -- bitwise the same gradients.
+__global__ __launch_bounds__(256) void wgrad_unpack_tile_k(const float* __restrict__ scratch, int partials,
+                                                           float* __restrict__ dw, int K, int Cd, int C, int R) {
+    constexpr int CH = 128;
+    __shared__ float tile[9 * CH];
+    const int RR = R * R;
+    const int k = blockIdx.x, c0 = blockIdx.y * CH;
+    const int cw = C - c0 < CH ? C - c0 : CH;             // channels of this chunk
+    const long long pstride = (long long)K * RR * C;
+    const float* base = scratch + ((long long)k * RR) * C + c0;
+    for (int e = threadIdx.x; e < RR * cw; e += 256) {
+        const int rs = e / cw, cl = e - rs * cw;
+        const float* src = base + (long long)rs * C + cl;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        int p = 0;
+        for (; p + 8 <= partials; p += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(long long)(p + u) * pstride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u & 3] += v[u];
+        }
+        for (; p < partials; ++p) s[p & 3] += src[(long long)p * pstride];
+        tile[rs * CH + cl] = ((s[0] + s[1]) + s[2]) + s[3];
+    }
+    __syncthreads();
+    const int cd = Cd - c0 < cw ? Cd - c0 : cw;           // channels that exist in dw (the scratch may be padded)
+    float* dst = dw + ((long long)k * Cd + c0) * RR;
+    for (int o = threadIdx.x; o < cd * RR; o += 256) {
+        const int cl = o / RR, rs = o - cl * RR;
+        dst[o] += tile[rs * CH + cl];
+    }
+}
+
 // ---------------------------------------------------------------- 1x1 head
 constexpr int HPB = 16;   // pixels per head block
 
@@ -326,6 +363,10 @@ int kp_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int K, int C, in
 int kp_wgrad_unpack(const float* scratch, int partials, float* dw, int K, int C, int Cp, int R, void* stream) {
     KP_REQUIRE(K > 0 && C > 0 && Cp >= C && (R == 1 || R == 3) && partials >= 1, "kp_wgrad_unpack: bad dims");
     const long long total = (long long)K * Cp * R * R;
+    if (Cp % 64 == 0 && K <= 65535) {
+        wgrad_unpack_tile_k<<<dim3(K, cdiv(Cp, 128)), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, Cp, R);
+        return kp_check_launch("wgrad_unpack_tile");
+    }
     if (Cp % 4 == 0)
         wgrad_unpack_k<4><<<cdiv(total / 4, 64), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, Cp, R);
     else

@@ -158,3 +158,20 @@ def test_head_small_k_bf16(N, H, W, C, K):
     call('kp_head_bwd', ptr(gd), ptr(out), ptr(ad), ptr(wd), 0.01, ptr(dx), ptr(dw), ptr(db), N, H, W, C, K, _lib.KP_BF16, st)
     assert relerr(dx.float(), af.grad.numpy()) < 1e-2
     assert relerr(dw, wr.grad.numpy()) < 1e-4 and relerr(db, br.grad.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize('P,K,Cd,Cp,R', [(1, 64, 64, 64, 3), (8, 128, 256, 256, 3), (37, 64, 128, 128, 3), (5, 32, 48, 64, 3),
+                                          (3, 16, 3, 3, 3), (256, 64, 3, 3, 3), (4, 64, 192, 192, 1), (6, 8, 20, 20, 3)])
+def test_wgrad_unpack(P, K, Cd, Cp, R):
+    """kp_wgrad_unpack: dw[k][c][r][s] += sum_p scratch[p][k][r][s][c] (LDS-transposing kernel for 64-multiples of
+    the physical channel count, vector / scalar kernels otherwise; padded channels are dropped)."""
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    g = torch.Generator().manual_seed(P * 7 + K + Cd)
+    scratch = torch.randn(P, K, R, R, Cp, generator=g)
+    dw0 = torch.randn(K, Cd, R, R, generator=g)
+    ref = dw0.double() + scratch.double().sum(0)[..., :Cd].permute(0, 3, 1, 2)
+    sd, dw = scratch.cuda(), dw0.cuda()
+    call('kp_wgrad_unpack', ptr(sd), P, ptr(dw), K, Cd, Cp, R, stream_ptr())
+    err = (dw.double().cpu() - ref).abs().max().item()
+    assert err <= 1e-5 * ref.abs().max().item() + 1e-6, err
