@@ -34,16 +34,6 @@ constexpr int PSLICES = (PINSTR + NWAVE - 1) / NWAVE;   // patch DMA instruction
 constexpr int ROWB = 128;               // bytes per LDS row (64 bf16)
 constexpr int NWBUF = 4;               // weight ring slots (power of two: the slot of a step is a run-time counter)
 
-__device__ __forceinline__ void wait_vm_n(int n) {   // n is wave-uniform
-    switch (n) {
-        case 0: wait_vm<0>(); break;
-        case 1: wait_vm<1>(); break;
-        case 2: wait_vm<2>(); break;
-        case 3: wait_vm<3>(); break;
-        default: wait_vm<4>(); break;
-    }
-}
-
 struct PatchArgs {
     const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y; float* partials;
     int Hib, Wib, ioff;   // input buffer rows / cols, offset of the tile domain's patch origin in it

@@ -32,7 +32,6 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wav
 // serialises the DMA latencies; the asm form is invisible to that analysis, the kernel keeps its own vmcnt wait + barrier
 // before it reads a DMA'd buffer.  A kernel that uses this must not use the builtin form (M0 is written behind the
 // compiler's back).
-struct RsrcWords { unsigned w0, w1, w2, w3; };
 __device__ __forceinline__ u32x4 rsrc_words(const void* base) {
     const unsigned long long b = (unsigned long long)base;
     u32x4 d;
