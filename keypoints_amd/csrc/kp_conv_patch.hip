@@ -203,13 +203,14 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     // (64-byte for BN = 64) runs per pixel: 8x fewer cache lines per store instruction than storing straight
     // from the MFMA layout.
     constexpr int CPP = WN / 8;            // 16-byte chunks per pixel (this wave's channels)
-    // running BN partial sums of the workgroup's tiles (compact mode), after the first reduction stage
-    float st8[STATS ? TN : 1][2][8];
+    // BN partial sums per lane (pixel) and accumulator register (channel).  A persistent workgroup (compact mode) keeps
+    // them across its tiles and runs the cross-lane reduction once at its end: no cross-lane work in the epilogue.
+    float sm[STATS ? TN : 1][16], sq[STATS ? TN : 1][16];
     if constexpr (STATS) {
 #pragma unroll
         for (int a = 0; a < TN; ++a)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) st8[a][0][i] = st8[a][1][i] = 0.f;
+            for (int i = 0; i < 16; ++i) sm[a][i] = sq[a][i] = 0.f;
     }
     constexpr int PPI = 64 / CPP;          // pixels per store instruction
     const int st_voff = ((lane / CPP) * K + (lane % CPP) * 8) * 2;   // lane part of the output address (bytes)
@@ -221,8 +222,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         bf16_t* ybase = A.y + ((((long long)t.n * A.Hob + t.oy0 + wm * 4 + A.ooff) * A.Wob) + t.ox0 + A.ooff) * (long long)K +
                         t.k0 + wn * WN;
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, 0x7ffffffe, 0x00020000);
-        float sm[STATS ? TN : 1][16], sq[STATS ? TN : 1][16];
-        if constexpr (STATS) {
+        if constexpr (STATS) if (!A.compact) {   // per-tile rows: start from zero
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -260,25 +260,17 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                 }
             }
         }
-        if constexpr (STATS) if (!(dbg & 2)) {
+        if constexpr (STATS) if (!A.compact && !(dbg & 2)) {
 #pragma unroll
             for (int a = 0; a < TN; ++a) {
                 const int kb = t.k0 + wn * WN + a * 32;
-                float h0[8], h1[8];
-                reduce16_stage1(sm[a], h0);
-                reduce16_stage1(sq[a], h1);
-                if (A.compact) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { st8[a][0][i] += h0[i]; st8[a][1][i] += h1[i]; }
-                } else {
-                    int r1, r2;
-                    const float ts = reduce8_rest(h0, lane, r1);
-                    const float tq = reduce8_rest(h1, lane, r2);
-                    if ((lane & 1) == 0) {
-                        const int k = kb + 8 * (r1 >> 2) + 4 * fh + (r1 & 3);
-                        A.partials[(prow * 2 + 0) * K + k] = ts;
-                        A.partials[(prow * 2 + 1) * K + k] = tq;
-                    }
+                int r1, r2;
+                const float ts = reduce16_over32(sm[a], lane, r1);
+                const float tq = reduce16_over32(sq[a], lane, r2);
+                if ((lane & 1) == 0) {
+                    const int k = kb + 8 * (r1 >> 2) + 4 * fh + (r1 & 3);
+                    A.partials[(prow * 2 + 0) * K + k] = ts;
+                    A.partials[(prow * 2 + 1) * K + k] = tq;
                 }
             }
         }
@@ -434,8 +426,8 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
             int rg, r2;
-            const float ts = reduce8_rest(st8[a][0], lane, rg);
-            const float tq = reduce8_rest(st8[a][1], lane, r2);
+            const float ts = reduce16_over32(sm[a], lane, rg);
+            const float tq = reduce16_over32(sq[a], lane, r2);
             if ((lane & 1) == 0) {
                 const int k = cur.k0 + wn * WN + a * 32 + 8 * (rg >> 2) + 4 * fh + (rg & 3);
                 const long long prow = (long long)blockIdx.x * 4 + wm;
