@@ -243,3 +243,51 @@ def test_conv_small_channels(N, Ho, Wo, C, K):
         assert n.value == 1, 'the small-channel wgrad kernel did not take this shape'
         assert ((scratch.double().cpu() - wref).norm() / wref.norm()).item() < 1e-5
     call('kp_prof_enable', 0)
+
+
+@pytest.mark.parametrize('C,K,H', [(256, 128, 128), (512, 512, 32)])
+def test_conv_full_size_against_gpu_fp32(C, K, H):
+    """BASELINE-size layers (128 images): forward (+ BN sums), data-gradient and weight-gradient kernels against an fp32
+    convolution of the same bf16-rounded operands computed on the GPU by torch (the CPU oracle takes minutes here)."""
+    import ctypes
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    N = 128
+    g = torch.Generator(device='cuda').manual_seed(C + K + H)
+    x = torch.randn(N, H + 2, H + 2, C, device='cuda', generator=g).bfloat16()
+    w = (torch.randn(K, 3, 3, C, device='cuda', generator=g) * (2.0 / (9 * C)) ** 0.5).bfloat16()
+    bias = torch.randn(K, device='cuda', generator=g)
+    st = stream_ptr()
+    y = torch.empty(N, H, H, K, device='cuda', dtype=torch.bfloat16)
+    stats = torch.empty(N * H * H // 64, 2, K, device='cuda')
+    call('kp_conv_fwd', ptr(x), ptr(w), ptr(bias), ptr(y), ptr(stats), N, H + 2, H + 2, C, K, 3, _lib.KP_BF16, st)
+    rows = _lib.last_rows()
+    xf, wf = x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2)
+    ref = F.conv2d(xf, wf, bias).permute(0, 2, 3, 1)
+    got = y.float()
+    assert torch.isfinite(got).all()
+    assert ((got - ref).abs() <= 2 ** -7 * ref.abs() + 2e-3).float().mean().item() > 0.9995
+    s = stats[:rows].double().sum(0)
+    flat = ref.double().reshape(-1, K)
+    assert (s[0] - flat.sum(0)).abs().max().item() <= 1e-3 * flat.abs().sum(0).max().item()
+    assert (s[1] - (flat ** 2).sum(0)).abs().max().item() <= 1e-3 * (flat ** 2).sum(0).max().item()
+    del ref, got, flat
+    # backward: dy with a zero border of 2
+    dyi = torch.randn(N, H, H, K, device='cuda', generator=g).bfloat16()
+    dy = torch.zeros(N, H + 4, H + 4, K, device='cuda', dtype=torch.bfloat16)
+    dy[:, 2:-2, 2:-2] = dyi
+    wd = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()            # [C][3][3][K], rotated by 180 degrees
+    gx = torch.empty(N, H + 2, H + 2, C, device='cuda', dtype=torch.bfloat16)
+    call('kp_conv_dgrad', ptr(dy), ptr(wd), ptr(gx), N, H, H, K, C, _lib.KP_BF16, st)
+    gref = torch.nn.grad.conv2d_input(xf.shape, wf, dyi.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    gg = gx.float()
+    assert ((gg - gref).abs() <= 2 ** -7 * gref.abs() + 2e-3).float().mean().item() > 0.9995
+    del gref, gg
+    parts = _lib.lib().kp_conv_wgrad_partials(N, H, H, C, K, 3, 2, _lib.KP_BF16)
+    scratch = torch.zeros(parts, K, 3, 3, C, device='cuda') if parts == 1 else torch.empty(parts, K, 3, 3, C, device='cuda')
+    call('kp_conv_wgrad', ptr(x), ptr(dy), ptr(scratch), N, H, H, C, K, 3, 2, _lib.KP_BF16, st)
+    dw = torch.zeros(K, C, 3, 3, device='cuda')
+    call('kp_wgrad_unpack', ptr(scratch), parts, ptr(dw), K, C, C, 3, st)
+    wref = torch.nn.grad.conv2d_weight(xf, wf.shape, dyi.float().permute(0, 3, 1, 2))
+    assert ((dw - wref).norm() / wref.norm()).item() < 2e-4
