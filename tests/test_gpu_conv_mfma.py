@@ -291,3 +291,42 @@ def test_conv_full_size_against_gpu_fp32(C, K, H):
     call('kp_wgrad_unpack', ptr(scratch), parts, ptr(dw), K, C, C, 3, st)
     wref = torch.nn.grad.conv2d_weight(xf, wf.shape, dyi.float().permute(0, 3, 1, 2))
     assert ((dw - wref).norm() / wref.norm()).item() < 2e-4
+
+
+def test_first_layer_full_size_against_gpu_fp32():
+    """The image-sized first layer (3 -> 64 at 128x128, 128 images) on its MFMA kernels against torch's fp32 GPU convolution."""
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    N, H, C, K = 128, 128, 3, 64
+    g = torch.Generator(device='cuda').manual_seed(77)
+    x = torch.randn(N, H + 2, H + 2, C, device='cuda', generator=g).bfloat16()
+    w = (torch.randn(K, 3, 3, C, device='cuda', generator=g) * (2.0 / 27) ** 0.5).bfloat16()
+    bias = torch.randn(K, device='cuda', generator=g)
+    st = stream_ptr()
+    y = torch.empty(N, H, H, K, device='cuda', dtype=torch.bfloat16)
+    stats = torch.empty(N * H * H // 64, 2, K, device='cuda')
+    call('kp_conv_fwd', ptr(x), ptr(w), ptr(bias), ptr(y), ptr(stats), N, H + 2, H + 2, C, K, 3, _lib.KP_BF16, st)
+    rows = _lib.last_rows()
+    xf, wf = x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2)
+    ref = F.conv2d(xf, wf, bias).permute(0, 2, 3, 1)
+    assert ((y.float() - ref).abs() <= 2 ** -7 * ref.abs() + 1e-3).float().mean().item() > 0.9995
+    s = stats[:rows].double().sum(0)
+    flat = ref.double().reshape(-1, K)
+    assert (s[0] - flat.sum(0)).abs().max().item() <= 1e-4 * flat.abs().sum(0).max().item()
+    assert (s[1] - (flat ** 2).sum(0)).abs().max().item() <= 1e-4 * (flat ** 2).sum(0).max().item()
+    dyi = torch.randn(N, H, H, K, device='cuda', generator=g).bfloat16()
+    dy = torch.zeros(N, H + 4, H + 4, K, device='cuda', dtype=torch.bfloat16)
+    dy[:, 2:-2, 2:-2] = dyi
+    parts = _lib.lib().kp_conv_wgrad_partials(N, H, H, C, K, 3, 2, _lib.KP_BF16)
+    assert parts > 1
+    scratch = torch.full((parts, K, 3, 3, C), float('nan'), device='cuda')
+    call('kp_conv_wgrad', ptr(x), ptr(dy), ptr(scratch), N, H, H, C, K, 3, 2, _lib.KP_BF16, st)
+    dw = torch.zeros(K, C, 3, 3, device='cuda')
+    call('kp_wgrad_unpack', ptr(scratch), parts, ptr(dw), K, C, C, 3, st)
+    wref = torch.nn.grad.conv2d_weight(xf, wf.shape, dyi.float().permute(0, 3, 1, 2))
+    assert ((dw - wref).norm() / wref.norm()).item() < 1e-4
+    # bitwise reproducible: a second run gives the same partials
+    scratch2 = torch.full((parts, K, 3, 3, C), float('nan'), device='cuda')
+    call('kp_conv_wgrad', ptr(x), ptr(dy), ptr(scratch2), N, H, H, C, K, 3, 2, _lib.KP_BF16, st)
+    assert torch.equal(scratch, scratch2)
