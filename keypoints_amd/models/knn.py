@@ -85,6 +85,7 @@ class Unit(nn.Module):
         self._plan = None
         self._arena = None
         self.after_backward = None   # optional hook(unit): data-parallel gradient reduction hangs here
+        self.layer_done = None       # optional hook(unit, idx): the gradients of plan steps >= idx are final
 
     # -- HIP execution -------------------------------------------------------------------------
     def plan(self):
@@ -101,6 +102,10 @@ class Unit(nn.Module):
     def _after_backward(self):
         if self.after_backward is not None:
             self.after_backward(self)
+
+    def _layer_done(self, idx):
+        if self.layer_done is not None:
+            self.layer_done(self, idx)
 
     def forward(self, x):
         require_device(x)

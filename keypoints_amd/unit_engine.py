@@ -274,6 +274,7 @@ class UnitFunction(torch.autograd.Function):
             scratch = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device=dev, dtype=torch.float32)
             call('kp_conv_wgrad', ptr(sv['a']), ptr(dy), ptr(scratch), N, H, W, C, K, 3, dp, code, st)
             call('kp_wgrad_unpack', ptr(scratch), parts, ptr(gv[id(conv.weight)]), K, sv['Cl'], C, 3, st)
+            unit._layer_done(idx)   # the arena slots of plan steps >= idx (and of the head) are final from here on
             if need_dx:
                 gx = torch.empty(N, H + 2, W + 2, C, device=dev, dtype=tdt)
                 call('kp_conv_dgrad', ptr(dy), ptr(sv['wd']), ptr(gx), N, H, W, K, C, code, st)

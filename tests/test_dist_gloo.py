@@ -28,13 +28,23 @@ def _worker(rank, world, port, q):
         same_init = all(torch.equal(ref[0], r) for r in ref)
         # emulate the end of each Unit's backward: arenas hold rank-dependent gradients
         units = [net.decoder, net.keypoint, net.feature]    # backward order
+        pieces = 0
         for i, u in enumerate(units):
             arena = u.grad_arena()
             arena.attach(list(u.parameters()))
             arena.flat.copy_(torch.arange(arena.flat.numel(), dtype=torch.float32) * (rank + 1) + i)
-            u._after_backward()                             # fires the async all-reduce of this bucket
+            for idx in range(len(u.plan()) - 2, -1, -1):    # the 3x3 layers report in, deepest first ...
+                u._layer_done(idx)                          # ... the reducer sends the arena's tail at its split
+            u._after_backward()                             # and the rest at the end of the Unit's backward
+            pieces += 2 if red._split[id(u)] is not None else 1
+        split_ok = len(red._pending) == pieces and any(red._split[id(u)] is not None for u in units)
+        for u in units:                                     # the tail piece covers >= 60 % of the arena
+            sp = red._split[id(u)]
+            if sp is not None:
+                n = u.grad_arena().flat.numel()
+                split_ok = split_ok and 0 < sp[1] <= 0.4 * n
         red.finish()
-        ok = True
+        ok = split_ok
         for i, u in enumerate(units):
             n = u.grad_arena().flat.numel()
             expect = torch.arange(n, dtype=torch.float32) * (sum(range(1, world + 1)) / world) + i

@@ -410,3 +410,32 @@ def test_keypoint_extractor_graph_replay(cfg):
     assert len(ex._captured) == 1
     for n, b in net.named_buffers():
         assert torch.equal(b, bufs[n]), n
+
+
+def test_layer_done_hook_sees_final_gradients():
+    """The data-parallel reducer sends the tail of a Unit's gradient arena from the `layer_done` hook in the middle of the
+    backward (keypoints_amd/dist.py): at that moment the arena from that layer's offset on must already be final."""
+    from keypoints_amd.models import transporter
+    torch.manual_seed(2)
+    net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 3).cuda()
+    unit = net.decoder
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(4, 16, 32, 32, generator=g).cuda().requires_grad_(True)
+    seen, snaps = [], {}
+
+    def hook(u, idx):
+        arena = u.grad_arena()
+        off = arena.views[id(u.plan()[idx]['conv'].weight)].storage_offset()
+        seen.append(idx)
+        snaps[idx] = (off, arena.flat[off:].clone())
+
+    unit.layer_done = hook
+    out = unit(x)
+    out.square().sum().backward()
+    unit.layer_done = None
+    n_layers = len(unit.plan()) - 1
+    assert seen == list(range(n_layers - 1, -1, -1))
+    final = unit.grad_arena().flat
+    assert final.abs().sum().item() > 0
+    for idx, (off, snap) in snaps.items():
+        assert torch.equal(snap, final[off:]), idx
