@@ -2,7 +2,8 @@
 all-reduce of each Unit's flat gradient arena per step (RCCL over xGMI; `backend="nccl"` is RCCL on ROCm).
 
 The reference has no distributed code; semantics follow the usual DDP reading:
-per-rank BatchNorm statistics, gradients averaged over ranks, identical parameters on every rank.
+per-rank BatchNorm statistics, gradients averaged over ranks, identical parameters on every rank, BatchNorm buffers
+of rank 0 are the ones a checkpoint holds.
 
 Each `knn.Unit` owns one contiguous fp32 gradient buffer (unit_engine.GradArena): the decoder's
 (23.9 MB for model F) is complete first and is reduced on RCCL's stream while the keypoint / feature
@@ -12,9 +13,15 @@ Inside a Unit the backward runs from the deep layers to the first one, and the d
 the parameters but little of the time: the arena is therefore reduced in two pieces -- the tail (every layer from the
 split on, plus the 1x1 head) as soon as those layers are done, overlapping the long high-resolution layers, and the
 small head of the arena at the end of the Unit's backward.  Only that last piece of the last Unit is exposed.
+
+Contract: between two `finish()` calls every Unit is reduced ONCE.  A second backward through a Unit whose pieces are
+already in flight (gradient accumulation over micro-batches, two losses) would add into memory an all-reduce is
+reading, so it raises; run the earlier backwards under `no_sync()` (they only accumulate into the arena) and the last
+one outside of it.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import List
 
 import torch
@@ -22,18 +29,28 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, root: torch.nn.Module, group=None, broadcast_init: bool = True, tail_fraction: float = 0.6):
+    def __init__(self, root: torch.nn.Module, group=None, broadcast_init: bool = True, tail_fraction: float = 0.6,
+                 transport: str = 'fp32'):
+        """transport: 'fp32' (exact mean of the fp32 gradients) or 'bf16' (each piece is rounded to bf16 for the wire
+        and the reduction: half the xGMI bytes, gradient error 2^-9 relative per element -- SURVEY.md 8e option)."""
         from .models.knn import Unit
+        if transport not in ('fp32', 'bf16'):
+            raise ValueError("transport must be 'fp32' or 'bf16'")
+        self.root = root
         self.group = group
         self.world = dist.get_world_size(group)
+        self.transport = transport
         self.units: List[Unit] = [m for m in root.modules() if isinstance(m, Unit)]
-        self._pending = []
+        self._pending = []   # (work, fp32 arena slice, wire tensor or None)
         self._avg = dist.get_backend(group) == 'nccl'   # RCCL has ncclAvg; gloo sums then scales
+        self._sync = True
+        self.pieces_issued = 0   # since the last finish() (tests / diagnostics)
         if broadcast_init:
             for t in list(root.parameters()) + list(root.buffers()):
                 dist.broadcast(t.data, src=0, group=group)
-        self._split = {}     # id(unit) -> (plan step index, arena offset): the tail from there on is reduced early
-        self._early = set()  # units whose tail piece is already in flight this step
+        self._split = {}      # id(unit) -> (plan step index, arena offset): the tail from there on is reduced early
+        self._early = set()   # units whose tail piece is already in flight this step
+        self._done = set()    # units whose whole arena is in flight this step
         for u in self.units:
             u.after_backward = self._on_unit_backward
             u.layer_done = self._on_layer_done
@@ -54,34 +71,82 @@ class GradReducer:
                 best = (idx, off)
         return best
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Backwards inside only accumulate into the gradient arenas (micro-batch accumulation); nothing is sent."""
+        prev, self._sync = self._sync, False
+        try:
+            yield self
+        finally:
+            self._sync = prev
+
     def _reduce(self, t) -> None:
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        work = dist.all_reduce(t, op=op, group=self.group, async_op=True)
-        self._pending.append((work, t))
+        wire = t.to(torch.bfloat16) if self.transport == 'bf16' else None
+        work = dist.all_reduce(wire if wire is not None else t, op=op, group=self.group, async_op=True)
+        self._pending.append((work, t, wire))
+        self.pieces_issued += 1
+
+    def _check_not_in_flight(self, unit) -> None:
+        if id(unit) in self._done or id(unit) in self._early:
+            raise RuntimeError(
+                'GradReducer: a second backward reached a Unit whose gradient arena is already being all-reduced '
+                '(no finish() in between).  Run all but the last backward of a step under reducer.no_sync().')
 
     def _on_layer_done(self, unit, idx) -> None:
         """Fires after each 3x3 layer of a Unit's backward (deepest first): at the split, reduce the arena's tail."""
+        if not self._sync:
+            return
+        if id(unit) in self._done:
+            self._check_not_in_flight(unit)
         sp = self._split.get(id(unit))
-        if sp is not None and idx == sp[0] and id(unit) not in self._early:
+        if sp is not None and idx == sp[0]:
+            self._check_not_in_flight(unit)
             self._early.add(id(unit))
             self._reduce(unit.grad_arena().flat[sp[1]:])
 
     def _on_unit_backward(self, unit) -> None:
         """Fires at the end of a Unit's backward: its arena is final -> reduce what is not in flight yet."""
+        if not self._sync:
+            return
+        if id(unit) in self._done:
+            self._check_not_in_flight(unit)
         flat = unit.grad_arena().flat
         if id(unit) in self._early:
             self._early.discard(id(unit))
             self._reduce(flat[:self._split[id(unit)][1]])
         else:
             self._reduce(flat)
+        self._done.add(id(unit))
 
     def finish(self) -> None:
-        """Join every outstanding gradient all-reduce (call between backward() and optimiser.step())."""
-        for work, flat in self._pending:
+        """Join every outstanding gradient all-reduce (call between backward() and optimiser.step()).  Every piece is
+        a disjoint arena slice, reduced and scaled exactly once."""
+        if self._early:
+            raise RuntimeError('GradReducer.finish(): a Unit sent its arena tail but never finished its backward')
+        for work, flat, wire in self._pending:
             work.wait()
+            if wire is not None:
+                flat.copy_(wire)
             if not self._avg:
                 flat.div_(self.world)
         self._pending.clear()
+        self._done.clear()
+        self.pieces_issued = 0
+
+    def broadcast_buffers(self, src: int = 0) -> None:
+        """BatchNorm running statistics are per-rank (each rank normalises its own shard); before a checkpoint every
+        rank takes rank `src`'s buffers, so that what is saved -- and what every rank continues from -- is one state."""
+        for b in self.root.buffers():
+            dist.broadcast(b.data, src=src, group=self.group)
+
+    def save(self, directory: str) -> None:
+        """Checkpoint under DP: buffers from rank 0 to everyone, then rank 0 writes `root.save(directory)`
+        (the reference's file layout, transporter.py:66-70 / keynet.py:33-37)."""
+        self.broadcast_buffers(0)
+        if dist.get_rank(self.group) == 0:
+            self.root.save(directory)
+        dist.barrier(group=self.group)
 
     def detach(self) -> None:
         for u in self.units:

@@ -101,6 +101,10 @@ class FusedAdam:
             self._loose = list(self.params)
         self.step_count += 1
         t = self.step_count
+        # hyper-parameters are read from param_groups[0] every step, like torch.optim.Adam: LR schedulers and manual
+        # edits of `opt.param_groups[0]['lr']` take effect (one group: the arenas are per Unit, not per group)
+        grp = self.param_groups[0]
+        self.lr, self.betas, self.eps = grp['lr'], grp['betas'], grp['eps']
         b1, b2 = self.betas
         bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
         st = stream_ptr()

@@ -87,6 +87,12 @@ def build_plan(blocks: List[nn.Sequential]) -> List[dict]:
                     raise NotImplementedError('only MaxPool2d(2, 2) has a HIP kernel')
                 tail = 'M'; i += 1
             elif i < len(mods) and isinstance(mods[i], (nn.UpsamplingBilinear2d, nn.Upsample)):
+                up = mods[i]
+                sf = up.scale_factor
+                sf = tuple(float(v) for v in sf) if isinstance(sf, (tuple, list)) else (float(sf),) * 2 if sf else None
+                if up.mode != 'bilinear' or not up.align_corners or sf != (2.0, 2.0) or up.size is not None:
+                    raise NotImplementedError('only bilinear x2 upsampling with align_corners=True '
+                                              '(nn.UpsamplingBilinear2d(scale_factor=2), vgg.py:26) has a HIP kernel')
                 tail = 'U'; i += 1
             steps.append(dict(kind='conv3', conv=conv, bn=bn, slope=slope, tail=tail))
         elif isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1) and i + 2 == len(mods):
@@ -183,8 +189,14 @@ class UnitFunction(torch.autograd.Function):
                 if training:
                     mean = torch.empty(K, device=dev, dtype=torch.float32)
                     invstd = torch.empty(K, device=dev, dtype=torch.float32)
-                    mom = 0.1 if bn.momentum is None else float(bn.momentum)
                     track = bn.track_running_stats and bn.running_mean is not None
+                    if bn.momentum is None:
+                        # torch: cumulative moving average, factor 1 / num_batches_tracked (after this batch's increment).
+                        # The counter lives on the device; reading it here is a host sync, taken only in this
+                        # non-default mode (the reference never sets momentum=None).
+                        mom = 1.0 / (int(bn.num_batches_tracked.item()) + 1) if track else 0.0
+                    else:
+                        mom = float(bn.momentum)
                     ws = torch.empty(128 * K, device=dev, dtype=torch.float64)
                     call('kp_bn_finalize', ptr(stats), last_rows(), ptr(ws), ptr(mean), ptr(invstd),
                          ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
@@ -212,14 +224,19 @@ class UnitFunction(torch.autograd.Function):
         out = torch.empty(N, Kout, H, W, device=dev, dtype=torch.float32)
         call('kp_head_fwd', ptr(a), ptr(hconv.weight), ptr(hconv.bias), head['slope'], ptr(out), N, H, W, C, Kout, code, st)
         if record:
-            ctx.unit, ctx.saved, ctx.head_in, ctx.out = unit, saved, a, out
+            ctx.unit, ctx.saved, ctx.head_in = unit, saved, a
+            ctx.save_for_backward(out)   # an OUTPUT kept as a plain ctx attribute would be a reference cycle
             ctx.dims = (N, Cin, x.shape[2], x.shape[3], H, W, C, Kout, pad0)
             ctx.cp0 = Cp0
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        unit, saved, a_last, out = ctx.unit, ctx.saved, ctx.head_in, ctx.out
+        if getattr(ctx, 'saved', None) is None:
+            raise RuntimeError('keypoints_amd Unit: backward was already run for this forward; the saved activations are '
+                               'released after the first backward (retain_graph=True is not supported)')
+        unit, saved, a_last = ctx.unit, ctx.saved, ctx.head_in
+        (out,) = ctx.saved_tensors
         N, Cin, H0, W0, Hh, Wh, Ch, Kout, pad0 = ctx.dims
         plan = unit.plan()
         tdt, code = precision_dtype(unit.precision)
@@ -285,6 +302,7 @@ class UnitFunction(torch.autograd.Function):
         if need_x:
             dx = torch.empty(N, Cin, H0, W0, device=dev, dtype=torch.float32)
             call('kp_nhwc_grad_to_nchw', ptr(g), ptr(dx), N, Cin, ctx.cp0, H0, W0, gp, code, st)
-        ctx.saved = None
+        # release the saved activations now (not when the graph dies): hundreds of MB per Unit
+        ctx.saved = ctx.head_in = ctx.unit = None
         unit._after_backward()
         return (dx, None, None) + (None,) * len(params)

@@ -101,7 +101,7 @@ def unit_forward(plan: List[dict], P: Params, prefix: str, x: Tensor,
     the conv epilogue) and the activation after the pool / upsample tail.  quant=None is the reference."""
     q = quant if quant is not None else (lambda t: t)
     h = q(x)
-    for st in plan:
+    for pos, st in enumerate(plan):
         if st['op'] == 'conv3':
             h = F.pad(h, (1, 1, 1, 1), mode='replicate')                      # vgg.py:30
             h = F.conv2d(h, q(P[f"{prefix}.{st['key']}.weight"]), P[f"{prefix}.{st['key']}.bias"])
@@ -124,7 +124,7 @@ def unit_forward(plan: List[dict], P: Params, prefix: str, x: Tensor,
             if buffers is not None and training and bn + '.num_batches_tracked' in buffers:
                 buffers[bn + '.num_batches_tracked'] += 1
             h = F.leaky_relu(h, st['slope']) if st['slope'] > 0 else F.relu(h)
-            nxt = plan[plan.index(st) + 1]['op']
+            nxt = plan[pos + 1]['op'] if pos + 1 < len(plan) else None
             if nxt not in ('pool', 'up'):
                 h = q(h)
         elif st['op'] == 'pool':

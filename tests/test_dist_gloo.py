@@ -50,7 +50,62 @@ def _worker(rank, world, port, q):
             expect = torch.arange(n, dtype=torch.float32) * (sum(range(1, world + 1)) / world) + i
             ok = ok and torch.allclose(u.grad_arena().flat, expect, rtol=1e-6, atol=1e-6)
             ok = ok and all(p.grad is u.grad_arena().views[id(p)] for p in u.parameters())
-        q.put((rank, same_init, ok, len(red._pending)))
+        pending_after = len(red._pending)
+
+        # (2) a second backward into a Unit whose arena is in flight must raise, not corrupt the gradients
+        u = units[0]
+        for idx in range(len(u.plan()) - 2, -1, -1):
+            u._layer_done(idx)
+        u._after_backward()
+        raised = False
+        try:
+            for idx in range(len(u.plan()) - 2, -1, -1):
+                u._layer_done(idx)
+            u._after_backward()
+        except RuntimeError as e:
+            raised = 'no_sync' in str(e)
+        red.finish()
+
+        # (3) micro-batch accumulation: backwards under no_sync() send nothing; the last one reduces the sum ONCE
+        acc_ok = True
+        arena = u.grad_arena()
+        arena.flat.fill_(float(rank + 1))
+        with red.no_sync():
+            for idx in range(len(u.plan()) - 2, -1, -1):
+                u._layer_done(idx)
+            u._after_backward()
+            acc_ok = acc_ok and red.pieces_issued == 0
+        arena.flat.add_(float(rank + 1))                    # the second micro-batch accumulates
+        for idx in range(len(u.plan()) - 2, -1, -1):
+            u._layer_done(idx)
+        u._after_backward()
+        red.finish()
+        mean2 = 2.0 * sum(range(1, world + 1)) / world
+        acc_ok = acc_ok and torch.allclose(arena.flat, torch.full_like(arena.flat, mean2))
+
+        # (4) bf16 transport: same mean within bf16 rounding of each rank's contribution
+        red16 = GradReducer(net, broadcast_init=False, transport='bf16')
+        g0 = torch.linspace(-1, 1, arena.flat.numel()) * (rank + 1)
+        arena.flat.copy_(g0)
+        for idx in range(len(u.plan()) - 2, -1, -1):
+            u._layer_done(idx)
+        u._after_backward()
+        red16.finish()
+        expect16 = torch.linspace(-1, 1, arena.flat.numel()) * (sum(range(1, world + 1)) / world)
+        bf_ok = float((arena.flat - expect16).abs().max()) <= 2 ** -7 and arena.flat.dtype == torch.float32
+
+        # (5) checkpoint: per-rank BatchNorm buffers -> rank 0's on every rank, rank 0 writes the reference's layout
+        import tempfile
+        for b in net.buffers():
+            if b.dtype.is_floating_point:
+                b.fill_(float(rank + 3))
+        d = tempfile.mkdtemp(prefix=f'kp_dp_{rank}_')
+        red16.save(d)
+        buf_ok = all(float(b.float().mean()) == 3.0 for b in net.buffers() if b.dtype.is_floating_point)
+        wrote = os.path.exists(os.path.join(d, 'encoder', 'core.mdl'))
+        buf_ok = buf_ok and (wrote == (rank == 0))
+        q.put((rank, same_init, ok and raised and acc_ok and bf_ok and buf_ok, pending_after,
+               dict(base=ok, raised=raised, acc=acc_ok, bf16=bf_ok, save=buf_ok)))
     finally:
         dist.destroy_process_group()
 
@@ -66,7 +121,7 @@ def test_grad_reducer_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, same_init, ok, pending in res:
+    for rank, same_init, ok, pending, detail in res:
         assert same_init, f'rank {rank}: parameters not broadcast from rank 0'
-        assert ok, f'rank {rank}: averaged gradient arena mismatch'
+        assert ok, f'rank {rank}: {detail}'
         assert pending == 0

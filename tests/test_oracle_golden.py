@@ -1,5 +1,7 @@
 """CPU: the oracle (oracle/kp_oracle.py) against the golden vectors that tools/make_golden.py captured
 from the reference itself.  This is what pins the oracle; the GPU tests then compare HIP vs oracle/golden."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -62,13 +64,12 @@ def test_layer_block(golden, tag, cin, cout, tail, slope):
         plan.append(dict(op='pool'))
     if tail == 'U':
         plan.append(dict(op='up'))
-    plan.append(dict(op='stop'))
     P = {'n.b.1.weight': torch.tensor(z[f'{tag}.weight'], requires_grad=True), 'n.b.1.bias': torch.tensor(z[f'{tag}.bias']),
          'n.b.2.weight': torch.tensor(z[f'{tag}.gamma'], requires_grad=True),
          'n.b.2.bias': torch.tensor(z[f'{tag}.beta'], requires_grad=True)}
     Bf = {'n.b.2.running_mean': torch.zeros(cout), 'n.b.2.running_var': torch.ones(cout)}
     x = torch.tensor(z[f'{tag}.x'], requires_grad=True)
-    h = _run(plan, P, x, Bf)
+    h = O.unit_forward(plan, P, 'n', x, Bf)
     close(h, z[f'{tag}.y'])
     (h * torch.tensor(z[f'{tag}.w'])).sum().backward()
     close(x.grad, z[f'{tag}.dx'], 1e-5)
@@ -77,20 +78,27 @@ def test_layer_block(golden, tag, cin, cout, tail, slope):
     close(Bf['n.b.2.running_var'], z[f'{tag}.running_var'])
 
 
-def _run(plan, P, x, Bf):
-    """unit_forward wants a trailing step after each conv3 (it peeks at the next op)."""
-    steps = [s for s in plan if s['op'] != 'stop'] + [dict(op='stop')]
-    h = x
-    import torch.nn.functional as F
-    st = steps[0]
-    h = F.pad(h, (1, 1, 1, 1), mode='replicate')
-    h = F.conv2d(h, P['n.b.1.weight'], P['n.b.1.bias'])
-    h = F.batch_norm(h, Bf['n.b.2.running_mean'], Bf['n.b.2.running_var'], P['n.b.2.weight'], P['n.b.2.bias'],
-                     training=True, momentum=O.BN_MOMENTUM, eps=O.BN_EPS)
-    h = F.leaky_relu(h, st['slope']) if st['slope'] > 0 else F.relu(h)
-    for s in steps[1:-1]:
-        h = O.unit_forward([s], P, 'n', h, Bf)
-    return h
+def test_unit_forward_accepts_a_plan_without_a_head():
+    """A plan that ends in a conv3 / pool / up step (no 1x1 head behind it) runs: tools/make_golden.py feeds single
+    blocks (the round-1 oracle peeked past the end of such a plan and the committed generator crashed)."""
+    plan = [dict(op='conv3', key='b.1', bn='b.2', cin=3, cout=4, slope=0.01)]
+    P = {'n.b.1.weight': torch.randn(4, 3, 3, 3), 'n.b.1.bias': torch.zeros(4), 'n.b.2.weight': torch.ones(4),
+         'n.b.2.bias': torch.zeros(4)}
+    assert O.unit_forward(plan, P, 'n', torch.randn(2, 3, 6, 6)).shape == (2, 4, 6, 6)
+    assert O.unit_forward(plan + [dict(op='pool')], P, 'n', torch.randn(2, 3, 6, 6)).shape == (2, 4, 3, 3)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/keypoints'), reason='the reference exists in the build container only')
+def test_fixture_generator_check_mode_small():
+    """tools/make_golden.py --check regenerates the fixtures from the imported reference into a temp dir and demands
+    bit-equality with tests/golden/ (small fixtures here; the full run's log is tests/golden/CHECK.log)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'make_golden.py'), '--check', 'bottleneck', 'transport',
+                        'layers', 'adam', 'pong32', 'tps'], capture_output=True, text=True, timeout=600,
+                       env={**os.environ, 'PYTHONDONTWRITEBYTECODE': '1'})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_adam(golden):
