@@ -27,7 +27,10 @@ import torch.distributed as dist
 
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3     # fp32 vector / f32-MFMA peak
-FAMILIES = {0: 'conv_valid_generic', 1: 'conv_wgrad_generic', 2: 'conv_mfma_bf16', 3: 'wgrad_mfma_bf16', 4: 'conv_first_bf16', 5: 'conv_small_bf16'}
+PEAK_HBM_GBS = 8000.0       # HBM3E spec (MI355X_MICROARCH.md; 6.3 TB/s is what a plain copy reaches)
+FAMILIES = {0: 'conv_valid_generic', 1: 'conv_wgrad_generic', 2: 'conv_mfma_16bit', 3: 'wgrad_mfma_16bit', 4: 'conv_first_16bit',
+            5: 'conv_small_16bit', 6: 'keypoint_bottleneck'}
+HBM_BOUND = {'conv_first_16bit', 'conv_small_16bit', 'keypoint_bottleneck'}
 
 
 def parse():
@@ -41,7 +44,12 @@ def parse():
     ap.add_argument('--model_in_channels', type=int, default=3)
     ap.add_argument('--model_z_channels', type=int, default=64)
     ap.add_argument('--model_keypoints', type=int, default=10)
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'],
+                    help="storage type of activations / packed weights; 'fp16' trains with dynamic loss scaling (keypoints_amd.amp)")
+    ap.add_argument('--profile-steps', type=int, default=3,
+                    help='extra steps AFTER the timed region with a HIP-event pair around every convolution / bottleneck '
+                         'launch (the roofline leg); 0 = skip')
+    ap.add_argument('--out', default='', help='also write the JSON line to this file')
     ap.add_argument('--net', default='transporter', choices=['transporter', 'keynet'],
                     help="'keynet' = BASELINE config 3 (KeyNet + TPS/rotation augmentation); not the headline metric")
     ap.add_argument('--no-augment', action='store_true', help='keynet: skip the TPS/rotation augmentation')
@@ -118,6 +126,8 @@ def main():
         net = transporter.make(args.model_type, args.model_in_channels, args.model_z_channels, args.model_keypoints)
     net = net.to(dev).set_precision(args.precision)
     opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
+    if args.precision == 'fp16':   # the reference's O2 recipe: fp16 storage + dynamic loss scaling (transporter.py:51,84-86)
+        opt.scaler = ka.amp.LossScaler(dev)
     reducer = GradReducer(net) if world > 1 else None
 
     g = torch.Generator().manual_seed(1234 + rank)
@@ -134,7 +144,8 @@ def main():
         else:
             out = net(xs, xt)
             loss = ka.l2_reconstruction_loss(out[0], xt)
-        loss.backward()
+        with ka.amp.scale_loss(loss, opt) as scaled_loss:
+            scaled_loss.backward()
         if reducer is not None:
             reducer.finish()
         opt.step()
@@ -149,61 +160,94 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- the timed region: EXACTLY --steps steps between two barrier + synchronize pairs; nothing else is recorded
+    # inside it except one HIP event per step boundary on the launch stream (torch's current stream is the stream every
+    # kp_* call is enqueued on), from which the per-step median comes
     barrier()
-    _lib.call('kp_prof_enable', 1)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
 
-    # per-kernel-family timing from the HIP events recorded inside the timed region
+    # ---- the roofline leg, OUTSIDE the timed region: a few more steps with an event pair around every convolution /
+    # bottleneck launch on its launch stream
     fam = {}
-    for fid, name in FAMILIES.items():
-        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
-        _lib.call('kp_prof_collect', fid, ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(n))
-        by = ctypes.c_double()
-        _lib.call('kp_prof_bytes', fid, ctypes.addressof(by))
-        if n.value:
-            fam[name] = dict(ms_total=ms.value, launches=n.value, avg_us=1e3 * ms.value / n.value,
-                             tflops=fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0,
-                             flop_per_launch=fl.value / n.value, algorithmic_bytes_per_launch=by.value / n.value)
-    _lib.call('kp_prof_enable', 0)
+    if args.profile_steps > 0:
+        barrier()
+        _lib.call('kp_prof_enable', 1)
+        for _ in range(args.profile_steps):
+            step()
+        barrier()
+        for fid, name in FAMILIES.items():
+            ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+            _lib.call('kp_prof_collect', fid, ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(n))
+            by = ctypes.c_double()
+            _lib.call('kp_prof_bytes', fid, ctypes.addressof(by))
+            if n.value:
+                fam[name] = dict(ms_per_step=ms.value / args.profile_steps, launches_per_step=n.value / args.profile_steps,
+                                 avg_us=1e3 * ms.value / n.value,
+                                 tflops=fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0,
+                                 flop_per_launch=fl.value / n.value, algorithmic_bytes_per_launch=by.value / n.value,
+                                 algorithmic_gbs=by.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0)
+        _lib.call('kp_prof_enable', 0)
 
     if rank == 0:
         flop_pair = conv_flops_per_pair(net, args.size, args.size)
         ms_step = 1e3 * elapsed / args.steps
         value = B * world / (elapsed / args.steps)
-        dom = max(fam.items(), key=lambda kv: kv[1]['ms_total']) if fam else (None, None)
-        peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
+        dom = max(fam.items(), key=lambda kv: kv[1]['ms_per_step']) if fam else (None, None)
+        peak = PEAK_BF16_TFLOPS if args.precision != 'fp32' else PEAK_F32_TFLOPS
         # HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the
         # gfx950 correction + WRITE_SIZE), condensed by tools/pmc_summary.py into profiles/ -- not measurable from
         # inside the process, so it is the committed per-launch figure of the last profiled build (or null).
-        traffic, pmc = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))['conv_patch_bf16_bn128']
-            traffic = pmc['hbm_bytes_per_launch']
-        except (OSError, KeyError, ValueError):
-            pass
-        roofline = dict(bound='mfma', kernel=dom[0], achieved=dom[1]['tflops'] if dom[1] else None, peak=peak,
-                        unit='TFLOP/s', frac=(dom[1]['tflops'] / peak) if dom[1] else None, traffic=traffic,
-                        traffic_unit='HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_summary.json)',
-                        algorithmic_bytes=dom[1]['algorithmic_bytes_per_launch'] if dom[1] else None,
-                        pmc_mfma_util=pmc['mfma_util'] if pmc else None,
-                        pmc_effective_clock_ghz=pmc['effective_clock_ghz'] if pmc else None,
-                        avg_launch_us=dom[1]['avg_us'] if dom[1] else None,
-                        launches=dom[1]['launches'] if dom[1] else None,
-                        step_tflops=value / world * flop_pair / 1e12, step_frac=value / world * flop_pair / 1e12 / peak,
-                        kernels=fam)
+        traffic, pmc, pmc_file = None, None, None
+        for cand in ('r02_pmc_summary.json', 'r01_pmc_summary.json'):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', cand)))['conv_patch_bf16_bn128']
+                traffic, pmc_file = pmc['hbm_bytes_per_launch'], cand
+                break
+            except (OSError, KeyError, ValueError):
+                pmc = None
+        hbm = dom[0] in HBM_BOUND
+        if dom[1] is None:
+            roofline = None
+        elif hbm:     # small-channel nets (Pong): the dominant kernels stream activations, the roofline is HBM
+            roofline = dict(bound='hbm', kernel=dom[0], achieved=dom[1]['algorithmic_gbs'], peak=PEAK_HBM_GBS, unit='GB/s',
+                            frac=dom[1]['algorithmic_gbs'] / PEAK_HBM_GBS, traffic=None,
+                            algorithmic_bytes=dom[1]['algorithmic_bytes_per_launch'], avg_launch_us=dom[1]['avg_us'],
+                            launches_per_step=dom[1]['launches_per_step'])
+        else:
+            roofline = dict(bound='mfma', kernel=dom[0], achieved=dom[1]['tflops'], peak=peak, unit='TFLOP/s',
+                            frac=dom[1]['tflops'] / peak, traffic=traffic if dom[0] == 'conv_mfma_16bit' else None,
+                            traffic_unit=f'HBM bytes per launch (rocprofv3 PMC, profiles/{pmc_file})' if pmc_file else None,
+                            algorithmic_bytes=dom[1]['algorithmic_bytes_per_launch'],
+                            pmc_mfma_util=pmc['mfma_util'] if pmc else None,
+                            pmc_effective_clock_ghz=pmc['effective_clock_ghz'] if pmc else None,
+                            avg_launch_us=dom[1]['avg_us'], launches_per_step=dom[1]['launches_per_step'])
+        if roofline is not None:
+            roofline.update(step_tflops=value / world * flop_pair / 1e12, step_frac=value / world * flop_pair / 1e12 / peak,
+                            measured='HIP events around each launch on the launch stream, '
+                                     f'{args.profile_steps} steps after the timed region', kernels=fam)
+            if 'keypoint_bottleneck' in fam:   # the bottleneck is HBM / latency class: report its GB/s
+                bk = fam['keypoint_bottleneck']
+                roofline['bottleneck'] = dict(bytes=bk['algorithmic_bytes_per_launch'], us=bk['avg_us'],
+                                              GBps=bk['algorithmic_gbs'], frac_of_hbm_peak=bk['algorithmic_gbs'] / PEAK_HBM_GBS)
         what = 'Transporter' if args.net == 'transporter' else 'KeyNet+TPS' if not args.no_augment else 'KeyNet'
         line = dict(metric=f'image-pairs/sec (train step) {what} {args.size}x{args.size} K={args.model_keypoints}', value=value,
                     unit='image-pairs/sec', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_step,
+                    ms_per_step_median_hipevent=median_ms, ms_per_step_min_hipevent=step_ms[0],
                     higher_is_better=True, scaling='weak', vs_baseline=None,
-                    dtype=args.precision if args.precision == 'bf16' else 'f32', data='synthetic',
+                    dtype={'bf16': 'bf16', 'fp16': 'fp16', 'fp32': 'f32'}[args.precision], data='synthetic',
                     config=dict(workload=f'{what} {args.model_type} {args.size}x{args.size}x'
                                          f'{args.model_in_channels} K={args.model_keypoints}, '
                                          f'{B} pairs/GPU (BASELINE config {4 if args.net == "transporter" else 3} shape), '
@@ -214,6 +258,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.net == 'transporter':
             line['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
+        if args.out:
+            with open(args.out, 'w') as f:
+                f.write(json.dumps(line, indent=1) + '\n')
     if world > 1:
         dist.destroy_process_group()
 

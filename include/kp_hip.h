@@ -13,8 +13,8 @@
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and
  *     the call never synchronises;
  *   - return value: 0 = ok, <0 = error (KP_E_*); kp_last_error() gives text;
- *   - dtype: KP_F32 (0) or KP_BF16 (1) = storage type of activations / packed
- *     weights ("T" below).  Accumulation is always fp32, statistics fp64;
+ *   - dtype: KP_F32 (0), KP_BF16 (1) or KP_F16 (2) = storage type of activations /
+ *     packed weights ("T" below).  Accumulation is always fp32, statistics fp64;
  *   - activation images are NHWC with an optional physical border:
  *     img[N][H+2*pad][W+2*pad][C]; (H, W) always name the interior size.
  */
@@ -29,6 +29,8 @@ extern "C" {
 
 #define KP_F32 0
 #define KP_BF16 1
+#define KP_F16 2   /* IEEE half storage (the reference's apex-O2 type, transporter.py:51): same kernels, same MFMA rate,
+                    * 3 more mantissa bits than bf16, 5-bit exponent -> train with loss scaling (kp_amp_*) */
 
 #define KP_OK 0
 #define KP_E_ARG (-1)         /* bad argument / unsupported shape */
@@ -65,6 +67,7 @@ int kp_config_ptr(int key, void* value);
 #define KP_PROF_WGRAD_MFMA 3
 #define KP_PROF_CONV_FIRST 4     /* Cin <= 4 first-layer VALU kernels (fwd + wgrad), HBM-bound */
 #define KP_PROF_CONV_SMALL 5     /* C, K in {16, 32} small-channel kernels (MFMA fwd/dgrad, VALU wgrad), HBM-bound */
+#define KP_PROF_BOTTLENECK 6     /* fused keypoint bottleneck (kp_keypoint_bottleneck_fwd / _bwd), HBM-bound; flops = 0 */
 /* Start (on=1, resets) / stop (on=0) recording a HIP-event pair around every convolution launch,
  * on the launch stream. */
 int kp_prof_enable(int on);
@@ -199,6 +202,43 @@ int kp_transport_max_bwd(const float* gphi, const float* phi_s, const float* phi
                          float* d_phi_s, float* d_phi_t, float* d_m_s, float* d_m_t,
                          int B, int C, int K, int H, int W, void* stream);
 
+/* The other combine modes of TransporterNet.forward (transporter.py:41-55), forward and adjoint, all fp32 NCHW:
+ *   KP_COMBINE_SUM_AND_CLAMP  mask = clamp(sum_k m, 0, 1)                                   transporter.py:47-50
+ *   KP_COMBINE_PRETRAINED     mask = m (K == 1: the MaskMaker output, transporter.py:83-92)  transporter.py:52-55
+ *   KP_COMBINE_LOOP           phi <- phi (1 - m_s,i)(1 - m_t,i) + phi_t m_t,i, i = 0..K-1     transporter.py:41-45
+ * then (modes 1, 2) phi = phi_s (1 - mask_s)(1 - mask_t) + phi_t mask_t.  mask_s / mask_t [B][H][W] are what forward()
+ * returns as mask_xs / mask_xt (the LAST per-keypoint slices in 'loop' mode, as in the reference).
+ * Backward: any d_* may be NULL; d_m_* are [B][K][H][W] (clamp passes the gradient where 0 <= sum <= 1, like torch). */
+#define KP_COMBINE_SUM_AND_CLAMP 1
+#define KP_COMBINE_PRETRAINED 2
+#define KP_COMBINE_LOOP 3
+int kp_transport_fwd(int mode, const float* phi_s, const float* phi_t, const float* m_s, const float* m_t, float* phi,
+                     float* mask_s, float* mask_t, int B, int C, int K, int H, int W, void* stream);
+int kp_transport_bwd(int mode, const float* gphi, const float* phi_s, const float* phi_t, const float* m_s,
+                     const float* m_t, float* d_phi_s, float* d_phi_t, float* d_m_s, float* d_m_t, int B, int C, int K,
+                     int H, int W, void* stream);
+
+/* The whole bottleneck of TransporterNet.forward for combine_method='max' in ONE launch (SURVEY.md 8b
+ * keypoint_bottleneck_fwd): spacial_logsoftmax of both branches' heat-maps (functional.py:37-44), gaussian_like_function
+ * of both keypoint sets (functional.py:56-63; key2map, transporter.py:31), max over K and the blend
+ * (transporter.py:57-60).  All fp32 NCHW.  heat_s/heat_t [B][K][H][W], phi_s/phi_t [B][C][H][W]; outputs: k_t [B][K][2]
+ * (y,x), p_t [B][K][H], q_t [B][K][W], m_t [B][K][H][W], phi [B][C][H][W], mask_s/mask_t [B][H][W], arg_t u8 [B][H][W]
+ * (argmax_k m_t, first index wins).  The source branch's maps are consumed inside the kernel and never written
+ * (TransporterNet.forward does not return them).  Same results as the piecewise entry points above, bit for bit.
+ * H, W <= 256. */
+int kp_keypoint_bottleneck_fwd(const float* heat_s, const float* heat_t, const float* phi_s, const float* phi_t,
+                               float* k_t, float* p_t, float* q_t, float* m_t, float* phi, float* mask_s, float* mask_t,
+                               unsigned char* arg_t, int B, int C, int K, int H, int W, float sigma, float eps,
+                               void* stream);
+/* Its adjoint w.r.t. the target branch (the source branch runs under no_grad, transporter.py:36-37):
+ * gphi = dL/dphi [B][C][H][W]; optional g_k = dL/dk_t [B][K][2] and g_m = dL/dm_t [B][K][H][W] (NULL = none) are
+ * added where they enter the chain.  Outputs d_phi_t [B][C][H][W] and d_heat_t [B][K][H][W] (fully written).
+ * Needs G*H*W <= 16384 with G = min(C, max(1, 1024 / (H*W/4))) (every BASELINE shape: 16x16, 32x32, 84x84). */
+int kp_keypoint_bottleneck_bwd(const float* gphi, const float* g_k, const float* g_m, const float* phi_s,
+                               const float* phi_t, const float* mask_s, const float* mask_t, const unsigned char* arg_t,
+                               const float* k_t, const float* p_t, const float* q_t, float* d_phi_t, float* d_heat_t,
+                               int B, int C, int K, int H, int W, float sigma, float eps, void* stream);
+
 /* ---- input-side augmentation (keypoints/tps.py, keypoints/data_augments.py) ----------------------- */
 /* out = F.grid_sample(x, tps_grid(theta, ctrl, x.shape), padding_mode='zeros')   tps.py:60-87,128-131.
  * x/out fp32 NCHW; theta [N][T+3][2] (reduced != 0: [N][T+2][2], tps.py:48-50); ctrl [N][T][2] or, with
@@ -219,6 +259,22 @@ int kp_scale(const float* x, const float* s, float* y, size_t n, void* stream);
 /* torch.optim.Adam step (transporter.py:47,89) over a flat fp32 arena. bc1 = 1-b1^t, bc2 = 1-b2^t. */
 int kp_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
                  float eps, float bc1, float bc2, void* stream);
+
+/* ---- dynamic loss scaling for dtype KP_F16 ----------------------------------------------------------------------
+ * The role of apex `amp.scale_loss(loss, optim)` + the O2 optimizer wrapper (transporter.py:51,84-89): the loss gradient
+ * is multiplied by state[0]; kp_amp_check flags inf / nan in the (all-reduced) gradient arenas; kp_amp_prepare
+ * advances Adam's step count and bias corrections unless the step overflowed; kp_adam_step_scaled un-scales and
+ * updates (a no-op on overflow); kp_amp_update halves the scale after an overflow or multiplies it by growth_factor
+ * after growth_interval clean steps, and clears the flag.  `state` is 8 DEVICE doubles:
+ * {scale, clean steps, found_inf, Adam step t, 1-b1^t, sqrt(1-b2^t), steps skipped, 1/scale}; nothing here synchronises
+ * with the host except kp_amp_init. */
+int kp_amp_init(double* state, double init_scale, void* stream);
+int kp_amp_check(const float* g, size_t n, double* state, void* stream);
+int kp_amp_prepare(double* state, float b1, float b2, void* stream);
+int kp_adam_step_scaled(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                        const double* state, void* stream);
+int kp_amp_update(double* state, float growth_factor, float backoff_factor, int growth_interval, float max_scale,
+                  void* stream);
 
 #ifdef __cplusplus
 }

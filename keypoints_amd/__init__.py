@@ -5,6 +5,7 @@ from . import models  # noqa: F401
 from . import data_augments, tps  # noqa: F401
 from .optim import FusedAdam, l2_reconstruction_loss  # noqa: F401
 from . import inference  # noqa: F401
+from . import amp  # noqa: F401
 
 
 def install_as_keypoints():
@@ -14,7 +15,7 @@ def install_as_keypoints():
     pkg = sys.modules.setdefault('keypoints', types.ModuleType('keypoints'))
     pkg.models = models
     sys.modules['keypoints.models'] = models
-    for name in ('functional', 'knn', 'vgg', 'transporter', 'keynet'):
+    for name in ('functional', 'knn', 'vgg', 'transporter', 'keynet', 'autoencoder'):
         sys.modules[f'keypoints.models.{name}'] = getattr(models, name)
     # the train scripts import these two as top-level modules (transporter.py:6,11 with keypoints/ on sys.path)
     sys.modules.setdefault('data_augments', data_augments)

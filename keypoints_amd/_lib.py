@@ -12,8 +12,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libkp_hip.so')
 
-KP_F32, KP_BF16 = 0, 1
+KP_F32, KP_BF16, KP_F16 = 0, 1, 2
 TAIL_NONE, TAIL_MAXPOOL2, TAIL_UPSAMPLE2 = 0, 1, 2
+COMBINE = {'sum_and_clamp': 1, 'pretrained_network': 2, 'loop': 3}
 
 _p, _i, _f, _z, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
 
@@ -41,11 +42,20 @@ SIGNATURES = {
     'kp_point_map_fwd': [_p, _p, _i, _i, _i, _p],
     'kp_transport_max_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'kp_transport_max_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    'kp_transport_fwd': [_i] + [_p] * 7 + [_i] * 5 + [_p],
+    'kp_transport_bwd': [_i] + [_p] * 9 + [_i] * 5 + [_p],
+    'kp_keypoint_bottleneck_fwd': [_p] * 12 + [_i] * 5 + [_f, _f, _p],
+    'kp_keypoint_bottleneck_bwd': [_p] * 13 + [_i] * 5 + [_f, _f, _p],
     'kp_warp_tps': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'kp_warp_affine': [_p, _p, _p, _i, _i, _i, _i, _p],
     'kp_l2_loss': [_p, _p, _p, _p, _p, _f, _z, _p],
     'kp_scale': [_p, _p, _p, _z, _p],
     'kp_adam_step': [_p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _f, _p],
+    'kp_amp_init': [_p, C.c_double, _p],
+    'kp_amp_check': [_p, _z, _p, _p],
+    'kp_amp_prepare': [_p, _f, _f, _p],
+    'kp_adam_step_scaled': [_p, _p, _p, _p, _z, _f, _f, _f, _f, _p, _p],
+    'kp_amp_update': [_p, _f, _f, _i, _f, _p],
     'kp_prof_enable': [_i],
     'kp_config': [_i, _i],
     'kp_config_ptr': [_i, _p],

@@ -1,0 +1,97 @@
+"""Loss scaling for the fp16 storage mode: what `apex.amp` does for the reference's train step
+(transporter.py:51 `amp.initialize(net, optim, opt_level=...)`, :84-86 `with amp.scale_loss(loss, optim) as scaled_loss:
+scaled_loss.backward()`), with the scale, the overflow flag, Adam's step count and its bias corrections in a small
+device-resident state block (include/kp_hip.h, kp_amp_*): no host synchronisation per step.
+
+    net, optim = amp.initialize(net, optim, opt_level='O2')          # 'O0' fp32, 'O1'/'O2' fp16 + dynamic loss scale
+    with amp.scale_loss(loss, optim) as scaled_loss:
+        scaled_loss.backward()
+    optim.step()                                                     # checks, un-scales, updates or skips, adapts
+
+bf16 storage (`set_precision('bf16')`) has fp32's exponent range and needs none of this.
+"""
+from __future__ import annotations
+
+import contextlib
+
+import torch
+
+from ._lib import call, ptr
+from .runtime import f32c, require_device, stream_ptr
+
+
+class LossScaler:
+    """Device-resident dynamic loss scale (defaults = apex's dynamic scaler: 2^16, x2 every 2000 clean steps, /2 on overflow)."""
+
+    def __init__(self, device, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,
+                 max_scale=2.0 ** 24):
+        self.state = torch.zeros(8, device=device, dtype=torch.float64)
+        self.growth_factor, self.backoff_factor = float(growth_factor), float(backoff_factor)
+        self.growth_interval, self.max_scale = int(growth_interval), float(max_scale)
+        call('kp_amp_init', ptr(self.state), float(init_scale), stream_ptr())
+
+    # host-side views for logging / tests (each is a device read: not for the train loop)
+    @property
+    def scale(self) -> float:
+        return float(self.state[0].item())
+
+    @property
+    def steps_skipped(self) -> int:
+        return int(self.state[6].item())
+
+    @property
+    def adam_steps(self) -> int:
+        return int(self.state[3].item())
+
+    def scale_tensor(self) -> torch.Tensor:
+        """fp32 0-dim device tensor holding the current scale (a kernel argument, never read on the host)."""
+        return self.state[0:1].to(torch.float32)
+
+
+class _ScaleLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loss, scale):
+        require_device(loss, scale)
+        x = f32c(loss).reshape(1)
+        buf = torch.empty(4, device=x.device, dtype=torch.float32)   # 16-byte aligned scratch for the 1-element kernel
+        src = torch.zeros(4, device=x.device, dtype=torch.float32)
+        src[:1] = x
+        call('kp_scale', ptr(src), ptr(scale), ptr(buf), 1, stream_ptr())
+        ctx.save_for_backward(scale)
+        return buf[0].reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        src = torch.zeros(4, device=g.device, dtype=torch.float32)
+        src[:1] = f32c(g).reshape(1)
+        out = torch.empty(4, device=g.device, dtype=torch.float32)
+        call('kp_scale', ptr(src), ptr(scale), ptr(out), 1, stream_ptr())
+        return out[0].reshape(()), None
+
+
+def initialize(net, optimizer, opt_level='O2', loss_scale='dynamic', **scaler_kwargs):
+    """apex.amp.initialize's role: 'O0' -> strict fp32 Units; 'O1' / 'O2' / 'O3' -> fp16 Units with fp32 master
+    weights and (loss_scale='dynamic') a device-resident dynamic loss scaler attached to `optimizer`."""
+    if opt_level == 'O0':
+        net.set_precision('fp32')
+        return net, optimizer
+    net.set_precision('fp16')
+    dev = next(net.parameters()).device
+    if loss_scale == 'dynamic':
+        optimizer.scaler = LossScaler(dev, **scaler_kwargs)
+    else:
+        optimizer.scaler = LossScaler(dev, init_scale=float(loss_scale), growth_factor=1.0, backoff_factor=1.0,
+                                      growth_interval=1 << 30)
+    return net, optimizer
+
+
+@contextlib.contextmanager
+def scale_loss(loss, optimizer):
+    """`with amp.scale_loss(loss, optim) as scaled_loss: scaled_loss.backward()` (transporter.py:84-86).  Without a
+    scaler on the optimizer (fp32 / bf16 modes) the loss passes through unchanged."""
+    scaler = getattr(optimizer, 'scaler', None)
+    if scaler is None:
+        yield loss
+    else:
+        yield _ScaleLoss.apply(loss, scaler.scale_tensor())

@@ -4,20 +4,11 @@
 #include <string.h>
 #include "kp_common.h"
 
-int kp_conv_fwd_generic(const void*, const void*, const float*, void*, float*, int, int, int, int, int, int, int,
-                        hipStream_t);
-int kp_conv_wgrad_generic(const void*, const void*, float*, int, int, int, int, int, int, int, int, hipStream_t);
-int kp_conv_fwd_mfma(const void*, const void*, const float*, void*, float*, int, int, int, int, int, int,
-                     hipStream_t);   // bf16 only; returns KP_E_UNSUPPORTED when the shape is not eligible
-int kp_conv_wgrad_mfma(const void*, const void*, float*, int, int, int, int, int, int, int, hipStream_t);
-int kp_conv_dgrad_mfma(const void*, const void*, void*, int, int, int, int, int, hipStream_t);
-int kp_conv_wgrad_patch(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
-long long kp_conv_wgrad_patch_partials(int, int, int, int, int, int);
-int kp_conv_small_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
-int kp_conv_small_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
-int kp_conv_first_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
-int kp_conv_first_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
-long long kp_conv_first_wgrad_partials(int, int, int, int, int);
+int kp_bottleneck_fused_fwd(const float*, const float*, const float*, const float*, float*, float*, float*, float*, float*,
+                            float*, float*, unsigned char*, int, int, int, int, int, float, float, hipStream_t);
+int kp_bottleneck_fused_bwd(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                            const unsigned char*, const float*, const float*, const float*, float*, float*, int, int, int,
+                            int, int, float, float, hipStream_t);
 
 static thread_local char g_err[512] = "";
 static thread_local long long g_last_rows = 0;
@@ -43,49 +34,18 @@ int kp_check_launch(const char* what) {
     return KP_OK;
 }
 
-// ---- in-library kernel timing (bench.py's roofline leg) -------------------------------------------
-// HIP events are recorded on the launch stream right around the convolution kernels; kp_prof_collect()
-// synchronises them after the timed region and sums time and algorithmic FLOPs per kernel family.
-#include <vector>
-struct ProfRec { int family; double flops, bytes; hipEvent_t e0, e1; };
-static bool g_prof_on = false;
-static std::vector<ProfRec> g_prof;
+// ---- in-library kernel timing: storage (kp_prof.h holds the scope object the launch sites use) -----------------
+#include "kp_prof.h"
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_event_pool;
-
-static hipEvent_t prof_event() {
+hipEvent_t kp_prof_event() {
     if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
-    hipEvent_t e; hipEventCreate(&e); return e;
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
-struct ProfScope {
-    bool on; ProfRec r; hipStream_t st;
-    ProfScope(int family, double flops, hipStream_t s, double bytes = 0.0) : on(g_prof_on), st(s) {
-        if (!on) return;
-        r.family = family; r.flops = flops; r.bytes = bytes; r.e0 = prof_event(); r.e1 = prof_event();
-        hipEventRecord(r.e0, st);
-    }
-    void cancel() {   // nothing was launched under this scope: give the events back
-        if (!on) return;
-        g_event_pool.push_back(r.e0); g_event_pool.push_back(r.e1);
-        on = false;
-    }
-    void done(int family) {
-        if (!on) return;
-        r.family = family;
-        hipEventRecord(r.e1, st);
-        g_prof.push_back(r);
-    }
-};
+void kp_prof_event_release(hipEvent_t e) { g_event_pool.push_back(e); }
 
-static int use_mfma() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("KP_DISABLE_MFMA");
-        v = (e && e[0] == '1') ? 0 : 1;
-    }
-    return v;
-}
-
-extern int g_kp_conv_patch;
+int g_kp_conv_patch = -1;   // kp_config(KP_CFG_CONV_PATCH, v); -1 = kp_conv_mfma reads KP_CONV_PATCH from the environment once
 
 extern "C" {
 
@@ -128,7 +88,7 @@ int kp_prof_collect(int family, double* ms, double* flops, long long* launches) 
         if (r.family != family) continue;
         if (hipEventSynchronize(r.e1) != hipSuccess) { kp_set_error("kp_prof_collect: event sync failed"); return KP_E_LAUNCH; }
         float dt = 0.f;
-        hipEventElapsedTime(&dt, r.e0, r.e1);
+        (void)hipEventElapsedTime(&dt, r.e0, r.e1);
         t += dt; f += r.flops; ++n;
     }
     if (ms) *ms = t;
@@ -145,90 +105,73 @@ int kp_prof_bytes(int family, double* bytes) {
     return KP_OK;
 }
 
-int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C,
-                int K, int R, int dtype, void* stream) {
-    KP_REQUIRE(x && w && y, "kp_conv_fwd: null pointer");
-    KP_REQUIRE(N > 0 && C > 0 && K > 0 && (R == 1 || R == 3) && Hi >= R && Wi >= R, "kp_conv_fwd: bad dims N=%d Hi=%d Wi=%d C=%d K=%d R=%d", N, Hi, Wi, C, K, R);
-    KP_REQUIRE(dtype == KP_F32 || dtype == KP_BF16, "kp_conv_fwd: bad dtype %d", dtype);
-    const double flops = 2.0 * N * (double)(Hi - R + 1) * (Wi - R + 1) * C * K * R * R;
-    const double esz = dtype == KP_BF16 ? 2.0 : 4.0;   // algorithmic HBM bytes: input + output + weights, each once
-    const double bytes = esz * ((double)N * Hi * Wi * C + (double)N * (Hi - R + 1) * (Wi - R + 1) * K + (double)R * R * C * K);
-    ProfScope ps(KP_PROF_CONV_GENERIC, flops, (hipStream_t)stream, bytes);
-    if (stats) kp_set_last_rows(((long long)N * (Hi - R + 1) * (Wi - R + 1) + 63) / 64);
-    if (dtype == KP_BF16 && use_mfma()) {
-        int rc = kp_conv_fwd_mfma(x, w, bias, y, stats, N, Hi, Wi, C, K, R, (hipStream_t)stream);
-        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_MFMA); return rc; }
-        if (R == 3 && C <= 4) {
-            rc = kp_conv_first_fwd(x, w, bias, y, stats, N, Hi, Wi, C, K, (hipStream_t)stream);
-            if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_FIRST); return rc; }
-        }
-        if (R == 3) {
-            rc = kp_conv_small_fwd(x, w, bias, y, stats, N, Hi, Wi, C, K, (hipStream_t)stream);
-            if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_SMALL); return rc; }
-        }
-    }
-    if (getenv("KP_LOG_GENERIC")) fprintf(stderr, "generic conv: N=%d Hi=%d Wi=%d C=%d K=%d R=%d dtype=%d stats=%d\n", N, Hi, Wi, C, K, R, dtype, stats != nullptr);
-    int rc = kp_conv_fwd_generic(x, w, bias, y, stats, N, Hi, Wi, C, K, R, dtype, (hipStream_t)stream);
-    ps.done(KP_PROF_CONV_GENERIC);
+int kp_keypoint_bottleneck_fwd(const float* heat_s, const float* heat_t, const float* phi_s, const float* phi_t,
+                               float* k_t, float* p_t, float* q_t, float* m_t, float* phi, float* mask_s, float* mask_t,
+                               unsigned char* arg_t, int B, int C, int K, int H, int W, float sigma, float eps,
+                               void* stream) {
+    // algorithmic HBM bytes: 2 heat stacks + 2 feature stacks in; blended features, target maps, 2 masks, argmax,
+    // keypoints and marginals out -- each once
+    const double hw = (double)H * W;
+    const double bytes = (double)B * (4.0 * (2.0 * K * hw + 2.0 * C * hw + C * hw + K * hw + 2.0 * hw) + hw + 4.0 * K * (2 + H + W));
+    ProfScope ps(KP_PROF_BOTTLENECK, 0.0, (hipStream_t)stream, bytes);
+    const int rc = kp_bottleneck_fused_fwd(heat_s, heat_t, phi_s, phi_t, k_t, p_t, q_t, m_t, phi, mask_s, mask_t, arg_t, B, C,
+                                           K, H, W, sigma, eps, (hipStream_t)stream);
+    ps.done(KP_PROF_BOTTLENECK);
     return rc;
 }
 
-int kp_conv_dgrad(const void* dy, const void* w_dgrad, void* gx, int N, int H, int W, int K, int C, int dtype,
-                  void* stream) {
-    KP_REQUIRE(dy && w_dgrad && gx, "kp_conv_dgrad: null pointer");
-    KP_REQUIRE(N > 0 && C > 0 && K > 0 && H > 0 && W > 0, "kp_conv_dgrad: bad dims");
-    KP_REQUIRE(dtype == KP_F32 || dtype == KP_BF16, "kp_conv_dgrad: bad dtype %d", dtype);
-    if (dtype == KP_BF16 && use_mfma()) {
-        const double flops = 2.0 * N * (double)H * W * C * K * 9;
-        const double bytes = 2.0 * ((double)N * (H + 4) * (W + 4) * K + (double)N * (H + 2) * (W + 2) * C + 9.0 * C * K);
-        ProfScope ps(KP_PROF_CONV_MFMA, flops, (hipStream_t)stream, bytes);
-        int rc = kp_conv_dgrad_mfma(dy, w_dgrad, gx, N, H, W, K, C, (hipStream_t)stream);
-        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_MFMA); return rc; }
-        ps.cancel();
-    }
-    return kp_conv_fwd(dy, w_dgrad, nullptr, gx, nullptr, N, H + 4, W + 4, K, C, 3, dtype, stream);
-}
-
-int kp_conv_wgrad_partials(int N, int Ho, int Wo, int C, int K, int R, int dy_pad, int dtype) {
-    if (dtype == KP_BF16 && use_mfma() && R == 3 && g_kp_wgrad_patch) {
-        const long long p = kp_conv_wgrad_patch_partials(N, Ho, Wo, C, K, dy_pad);
-        if (p > 0 && p < 0x7fffffffLL) return (int)p;
-    }
-    if (dtype == KP_BF16 && use_mfma() && R == 3 && C <= 4) {
-        const long long p = kp_conv_first_wgrad_partials(N, Ho, Wo, C, K);
-        if (p > 0) return (int)p;
-    }
-    return 1;
-}
-
-int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R, int dy_pad,
-                  int dtype, void* stream) {
-    KP_REQUIRE(x && dy && scratch, "kp_conv_wgrad: null pointer");
-    KP_REQUIRE(N > 0 && C > 0 && K > 0 && (R == 1 || R == 3) && Ho > 0 && Wo > 0 && dy_pad >= 0, "kp_conv_wgrad: bad dims");
-    KP_REQUIRE(dtype == KP_F32 || dtype == KP_BF16, "kp_conv_wgrad: bad dtype %d", dtype);
-    const double flops = 2.0 * N * (double)Ho * Wo * C * K * R * R;
-    const double wesz = dtype == KP_BF16 ? 2.0 : 4.0;
-    const double wbytes = wesz * ((double)N * (Ho + R - 1) * (Wo + R - 1) * C + (double)N * Ho * Wo * K) + 4.0 * R * R * C * K;
-    ProfScope ps(KP_PROF_WGRAD_GENERIC, flops, (hipStream_t)stream, wbytes);
-    if (dtype == KP_BF16 && use_mfma()) {
-        int rc = (R == 3 && g_kp_wgrad_patch) ? kp_conv_wgrad_patch(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream)
-                                              : KP_E_UNSUPPORTED;
-        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_WGRAD_MFMA); return rc; }
-        rc = kp_conv_wgrad_mfma(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, (hipStream_t)stream);
-        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_WGRAD_MFMA); return rc; }
-        if (R == 3 && C <= 4) {
-            rc = kp_conv_first_wgrad(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
-            if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_FIRST); return rc; }
-        }
-        if (R == 3) {
-            rc = kp_conv_small_wgrad(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
-            if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_SMALL); return rc; }
-        }
-    }
-    if (getenv("KP_LOG_GENERIC")) fprintf(stderr, "generic wgrad: N=%d Ho=%d Wo=%d C=%d K=%d R=%d dp=%d dtype=%d\n", N, Ho, Wo, C, K, R, dy_pad, dtype);
-    int rc = kp_conv_wgrad_generic(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, dtype, (hipStream_t)stream);
-    ps.done(KP_PROF_WGRAD_GENERIC);
+int kp_keypoint_bottleneck_bwd(const float* gphi, const float* g_k, const float* g_m, const float* phi_s,
+                               const float* phi_t, const float* mask_s, const float* mask_t, const unsigned char* arg_t,
+                               const float* k_t, const float* p_t, const float* q_t, float* d_phi_t, float* d_heat_t,
+                               int B, int C, int K, int H, int W, float sigma, float eps, void* stream) {
+    // in: gphi, phi_s, phi_t, masks, argmax, keypoints, marginals; out: d_phi_t, d_heat_t
+    const double hw = (double)H * W;
+    const double bytes = (double)B * (4.0 * (3.0 * C * hw + 2.0 * hw + C * hw + K * hw) + hw + 4.0 * K * (2 + H + W));
+    ProfScope ps(KP_PROF_BOTTLENECK, 0.0, (hipStream_t)stream, bytes);
+    const int rc = kp_bottleneck_fused_bwd(gphi, g_k, g_m, phi_s, phi_t, mask_s, mask_t, arg_t, k_t, p_t, q_t, d_phi_t,
+                                           d_heat_t, B, C, K, H, W, sigma, eps, (hipStream_t)stream);
+    ps.done(KP_PROF_BOTTLENECK);
     return rc;
 }
+
+// ---- dtype dispatch of the entry points whose kernels exist once per 16-bit storage type ---------------------------
+// name__bf16 (also serves KP_F32) and name__f16 come from the two builds of the same source (kp_h16_names.h).
+#define KP_DISPATCH(name, DECL, CALL)                                                        \
+    int name##__bf16 DECL;                                                                   \
+    int name##__f16 DECL;                                                                    \
+    int name DECL {                                                                          \
+        if (dtype != KP_F32 && dtype != KP_BF16 && dtype != KP_F16) {                        \
+            kp_set_error(#name ": bad dtype %d", dtype);                                     \
+            return KP_E_ARG;                                                                 \
+        }                                                                                    \
+        return dtype == KP_F16 ? name##__f16 CALL : name##__bf16 CALL;                       \
+    }
+
+KP_DISPATCH(kp_nchw_to_nhwc, (const float* src, void* dst, int N, int C, int Cp, int H, int W, int pad, int dtype, void* stream),
+            (src, dst, N, C, Cp, H, W, pad, dtype, stream))
+KP_DISPATCH(kp_nhwc_grad_to_nchw, (const void* gsrc, float* dst, int N, int C, int Cp, int H, int W, int pad, int dtype, void* stream),
+            (gsrc, dst, N, C, Cp, H, W, pad, dtype, stream))
+KP_DISPATCH(kp_pack_weights, (const float* w, void* w_fwd, void* w_dgrad, int K, int C, int Cp, int R, int dtype, void* stream),
+            (w, w_fwd, w_dgrad, K, C, Cp, R, dtype, stream))
+KP_DISPATCH(kp_conv_fwd, (const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C, int K, int R, int dtype, void* stream),
+            (x, w, bias, y, stats, N, Hi, Wi, C, K, R, dtype, stream))
+KP_DISPATCH(kp_conv_dgrad, (const void* dy, const void* w_dgrad, void* gx, int N, int H, int W, int K, int C, int dtype, void* stream),
+            (dy, w_dgrad, gx, N, H, W, K, C, dtype, stream))
+KP_DISPATCH(kp_conv_wgrad_partials, (int N, int Ho, int Wo, int C, int K, int R, int dy_pad, int dtype),
+            (N, Ho, Wo, C, K, R, dy_pad, dtype))
+KP_DISPATCH(kp_conv_wgrad, (const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R, int dy_pad, int dtype, void* stream),
+            (x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, dtype, stream))
+KP_DISPATCH(kp_bn_act_fwd, (const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, int tail, void* out, int out_pad, unsigned char* argmax, int N, int H, int W, int C, int dtype, void* stream),
+            (y, mean, invstd, gamma, beta, slope, tail, out, out_pad, argmax, N, H, W, C, dtype, stream))
+KP_DISPATCH(kp_bn_act_bwd_reduce, (const void* gsrc, int gp, int tail, const unsigned char* argmax, const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, float* partials, int N, int H, int W, int C, int dtype, void* stream),
+            (gsrc, gp, tail, argmax, y, mean, invstd, gamma, beta, slope, partials, N, H, W, C, dtype, stream))
+KP_DISPATCH(kp_bn_act_bwd_apply, (const void* gsrc, int gp, int tail, const unsigned char* argmax, const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, const float* sums, void* dy, int dp, int N, int H, int W, int C, int dtype, void* stream),
+            (gsrc, gp, tail, argmax, y, mean, invstd, gamma, beta, slope, sums, dy, dp, N, H, W, C, dtype, stream))
+KP_DISPATCH(kp_upsample2_bwd, (const void* gsrc, int gp, void* g, int N, int H, int W, int C, int dtype, void* stream),
+            (gsrc, gp, g, N, H, W, C, dtype, stream))
+KP_DISPATCH(kp_head_fwd, (const void* x, const float* w, const float* bias, float slope, float* out, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (x, w, bias, slope, out, N, H, W, C, K, dtype, stream))
+KP_DISPATCH(kp_head_bwd, (const float* gout, const float* out, const void* x, const float* w, float slope, void* dx, float* dw, float* db, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (gout, out, x, w, slope, dx, dw, db, N, H, W, C, K, dtype, stream))
 
 }  // extern "C"

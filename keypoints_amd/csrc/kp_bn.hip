@@ -26,20 +26,20 @@ template <> struct Vec<float, 4> {
     static __device__ __forceinline__ void ld(const float* p, float (&o)[4]) { ld4<float>(p, o); }
     static __device__ __forceinline__ void st(float* p, const float (&o)[4]) { st4<float>(p, o); }
 };
-template <> struct Vec<bf16_t, 8> {
-    static __device__ __forceinline__ void ld(const bf16_t* p, float (&o)[8]) {
+template <> struct Vec<h16_t, 8> {
+    static __device__ __forceinline__ void ld(const h16_t* p, float (&o)[8]) {
         const uint4 v = *reinterpret_cast<const uint4*>(p);
-        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
-        o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
-        o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+        unpack_h16x2(v.x, o[0], o[1]);
+        unpack_h16x2(v.y, o[2], o[3]);
+        unpack_h16x2(v.z, o[4], o[5]);
+        unpack_h16x2(v.w, o[6], o[7]);
     }
-    static __device__ __forceinline__ void st(bf16_t* p, const float (&o)[8]) {
+    static __device__ __forceinline__ void st(h16_t* p, const float (&o)[8]) {
         uint4 v;
-        v.x = pack_bf16x2(o[0], o[1]);
-        v.y = pack_bf16x2(o[2], o[3]);
-        v.z = pack_bf16x2(o[4], o[5]);
-        v.w = pack_bf16x2(o[6], o[7]);
+        v.x = pack_h16x2(o[0], o[1]);
+        v.y = pack_h16x2(o[2], o[3]);
+        v.z = pack_h16x2(o[4], o[5]);
+        v.w = pack_h16x2(o[6], o[7]);
         *reinterpret_cast<uint4*>(p) = v;
     }
 };
@@ -276,7 +276,9 @@ __global__ __launch_bounds__(TPB) void bn_act_fwd_k(const T* __restrict__ y, BnP
 #pragma unroll
                     for (int e = 0; e < V; ++e) {
                         float a = act_fwd(k.z(v[e], e), slope);
-                        if constexpr (sizeof(T) == 2) a = bf2f(f2bf(a));   // compare at storage precision
+                        // compared in fp32, before the storage rounding: two window values that round to the same
+                        // 16-bit number still resolve to the fp32 maximum, which is where the fp32 reference
+                        // (torch max_pool2d) routes the gradient; the stored maximum is the same either way
                         if (q == 0 || a > res[e] || a != a) { res[e] = a; best[e] = q; }
                     }
                 }
@@ -518,7 +520,7 @@ template <typename T> constexpr int vec_for(int C) { return (C % (16 / (int)size
             using T = float;                                                      \
             if ((C) % 4 == 0) { constexpr int V = 4; CALL; } else { constexpr int V = 1; CALL; } \
         } else {                                                                  \
-            using T = bf16_t;                                                     \
+            using T = h16_t;                                                     \
             if ((C) % 8 == 0) { constexpr int V = 8; CALL; } else { constexpr int V = 1; CALL; } \
         }                                                                         \
     } while (0)
@@ -537,6 +539,7 @@ extern int g_kp_bn_fast;
 
 extern "C" {
 
+#ifndef KP_F16_BUILD   // no dtype: defined once, by the bf16 build of this source
 int kp_bn_ws_doubles(int C) { return RED_R * 2 * C; }
 
 int kp_bn_finalize(const float* stats, long long rows, double* ws, float* save_mean, float* save_invstd,
@@ -561,6 +564,8 @@ int kp_bn_finalize(const float* stats, long long rows, double* ws, float* save_m
     return kp_check_launch("bn_finalize");
 }
 
+#endif
+
 int kp_bn_act_fwd(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                   float slope, int tail, void* out, int out_pad, unsigned char* argmax, int N, int H, int W, int C,
                   int dtype, void* stream) {
@@ -570,7 +575,7 @@ int kp_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
     BnP bn{mean, invstd, gamma, beta};
     const unsigned grid = (unsigned)((long long)N * (Ho + 2 * out_pad));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == KP_BF16 && g_kp_bn_fast) {
+    if (dtype == KP_H16 && g_kp_bn_fast) {
         int rc = kp_bn_act_fwd_fast(y, mean, invstd, gamma, beta, slope, tail, out, out_pad, argmax, N, H, W, C, st);
         if (rc != KP_E_UNSUPPORTED) return rc;
     }
@@ -586,7 +591,7 @@ int kp_bn_act_bwd_reduce(const void* gsrc, int gp, int tail, const unsigned char
     BnP bn{mean, invstd, gamma, beta};
     const unsigned grid = (unsigned)((long long)N * H);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == KP_BF16 && g_kp_bn_fast) {
+    if (dtype == KP_H16 && g_kp_bn_fast) {
         int rc = kp_bn_bwd_fast(0, gsrc, gp, tail, argmax, y, mean, invstd, gamma, beta, slope, partials, nullptr, nullptr,
                                 0, N, H, W, C, st);
         if (rc != KP_E_UNSUPPORTED) return rc;
@@ -596,6 +601,7 @@ int kp_bn_act_bwd_reduce(const void* gsrc, int gp, int tail, const unsigned char
     return kp_check_launch("bn_bwd_reduce");
 }
 
+#ifndef KP_F16_BUILD
 int kp_bn_bwd_finalize(const float* partials, double* ws, long long rows, int C, float* sums, float* dgamma,
                        float* dbeta, void* stream) {
     KP_REQUIRE(partials && ws && sums && rows > 0 && C > 0, "kp_bn_bwd_finalize: bad args");
@@ -616,6 +622,8 @@ int kp_bn_bwd_finalize(const float* partials, double* ws, long long rows, int C,
     return kp_check_launch("bn_bwd_finalize");
 }
 
+#endif
+
 int kp_bn_act_bwd_apply(const void* gsrc, int gp, int tail, const unsigned char* argmax, const void* y,
                         const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
                         const float* sums, void* dy, int dp, int N, int H, int W, int C, int dtype, void* stream) {
@@ -624,7 +632,7 @@ int kp_bn_act_bwd_apply(const void* gsrc, int gp, int tail, const unsigned char*
     BnP bn{mean, invstd, gamma, beta};
     const unsigned grid = (unsigned)((long long)N * (H + 2 * dp));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == KP_BF16 && g_kp_bn_fast) {
+    if (dtype == KP_H16 && g_kp_bn_fast) {
         int rc = kp_bn_bwd_fast(1, gsrc, gp, tail, argmax, y, mean, invstd, gamma, beta, slope, nullptr, sums, dy, dp, N,
                                 H, W, C, st);
         if (rc != KP_E_UNSUPPORTED) return rc;
@@ -637,7 +645,7 @@ int kp_upsample2_bwd(const void* gsrc, int gp, void* g, int N, int H, int W, int
     KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && gp >= 0, "kp_upsample2_bwd: bad dims");
     const unsigned grid = (unsigned)((long long)N * H);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == KP_BF16 && g_kp_bn_fast) {
+    if (dtype == KP_H16 && g_kp_bn_fast) {
         int rc = kp_upsample2_bwd_fast(gsrc, gp, g, N, H, W, C, st);
         if (rc != KP_E_UNSUPPORTED) return rc;
     }

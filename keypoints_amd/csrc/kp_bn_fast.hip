@@ -40,24 +40,24 @@ struct BnC {
 };
 
 __device__ __forceinline__ void unpack8(const uint4 v, float (&o)[V]) {
-    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
-    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
-    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+    unpack_h16x2(v.x, o[0], o[1]);
+    unpack_h16x2(v.y, o[2], o[3]);
+    unpack_h16x2(v.z, o[4], o[5]);
+    unpack_h16x2(v.w, o[6], o[7]);
 }
 __device__ __forceinline__ uint4 pack8(const float (&o)[V]) {
     uint4 v;
-    v.x = pack_bf16x2(o[0], o[1]); v.y = pack_bf16x2(o[2], o[3]);
-    v.z = pack_bf16x2(o[4], o[5]); v.w = pack_bf16x2(o[6], o[7]);
+    v.x = pack_h16x2(o[0], o[1]); v.y = pack_h16x2(o[2], o[3]);
+    v.z = pack_h16x2(o[4], o[5]); v.w = pack_h16x2(o[6], o[7]);
     return v;
 }
-__device__ __forceinline__ uint4 ldv(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
-__device__ __forceinline__ void stv(bf16_t* p, const uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+__device__ __forceinline__ uint4 ldv(const h16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void stv(h16_t* p, const uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ---- forward, tail none: out[n][i][j] = act(bn(y[n][clamp(i-p)][clamp(j-p)])) ------------------------------
-__global__ __launch_bounds__(TPB) void bn_act_fwd_none_fast_k(const bf16_t* __restrict__ y, BnP bn, float slope,
-                                                              bf16_t* __restrict__ out, int p, int H, int W, int C,
+__global__ __launch_bounds__(TPB) void bn_act_fwd_none_fast_k(const h16_t* __restrict__ y, BnP bn, float slope,
+                                                              h16_t* __restrict__ out, int p, int H, int W, int C,
                                                               long long total_rows, int rpb) {
     const int CV = C / V, Hp = H + 2 * p, Wp = W + 2 * p;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(TPB) void bn_act_fwd_none_fast_k(const bf16_t* __re
         const long long n = row / Hp;
         const int i = (int)(row - n * Hp);
         const int oh = clampi(i - p, 0, H - 1);
-        const bf16_t* yr = y + ((n * H + oh) * W) * (long long)C + c;
-        bf16_t* orow = out + row * Wp * (long long)C + c;
+        const h16_t* yr = y + ((n * H + oh) * W) * (long long)C + c;
+        h16_t* orow = out + row * Wp * (long long)C + c;
         for (int j0 = pl; j0 < Wp; j0 += UNR * npl) {
             uint4 raw[UNR];
 #pragma unroll
@@ -106,8 +106,8 @@ __device__ __forceinline__ void bilin(int o, int in_size, int out_size, int& i0,
 
 // ---- forward with a 2x2 max-pool (TAIL 1) or bilinear x2 (TAIL 2) tail: 4 source vectors per output vector ----
 template <int TAIL>
-__global__ __launch_bounds__(TPB) void bn_act_fwd_tail_fast_k(const bf16_t* __restrict__ y, BnP bn, float slope,
-                                                              bf16_t* __restrict__ out, int p,
+__global__ __launch_bounds__(TPB) void bn_act_fwd_tail_fast_k(const h16_t* __restrict__ y, BnP bn, float slope,
+                                                              h16_t* __restrict__ out, int p,
                                                               unsigned char* __restrict__ argmax, int H, int W, int C,
                                                               long long total_rows, int rpb) {
     constexpr int U2 = 2;   // output pixels in flight per thread (8 loads)
@@ -123,9 +123,9 @@ __global__ __launch_bounds__(TPB) void bn_act_fwd_tail_fast_k(const bf16_t* __re
         const long long n = row / Hp;
         const int i = (int)(row - n * Hp);
         const int oh = clampi(i - p, 0, Ho - 1);
-        const bf16_t* yn = y + n * H * W * (long long)C + c;
-        bf16_t* orow = out + row * Wp * (long long)C + c;
-        const bf16_t *y0, *y1;
+        const h16_t* yn = y + n * H * W * (long long)C + c;
+        h16_t* orow = out + row * Wp * (long long)C + c;
+        const h16_t *y0, *y1;
         float lh0 = 0.f, lh1 = 0.f;
         if (TAIL == 1) {
             y0 = yn + (long long)(2 * oh) * W * C;
@@ -171,7 +171,8 @@ __global__ __launch_bounds__(TPB) void bn_act_fwd_tail_fast_k(const bf16_t* __re
                         for (int e = 0; e < V; ++e) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const float aq = bf2f(f2bf(a[q][e]));   // compare at storage precision
+                                const float aq = a[q][e];   // compared in fp32 (see kp_bn.hip): ties of the 16-bit
+                                                            // values resolve to the fp32 maximum, like the reference
                                 if (q == 0 || aq > res[e] || aq != aq) { res[e] = aq; best[e] = q; }
                             }
                         }
@@ -200,8 +201,8 @@ __global__ __launch_bounds__(TPB) void bn_act_fwd_tail_fast_k(const bf16_t* __re
 // 4 BN+activation evaluations for 4 outputs instead of 16.  The interpolation indices / weights still come from
 // the exact per-output formula (bilin); an output whose taps fall outside the block's source pair (possible only
 // at odd paddings / image ends) takes the direct path.
-__global__ __launch_bounds__(TPB) void bn_act_fwd_up_fast_k(const bf16_t* __restrict__ y, BnP bn, float slope,
-                                                            bf16_t* __restrict__ out, int p, int H, int W, int C,
+__global__ __launch_bounds__(TPB) void bn_act_fwd_up_fast_k(const h16_t* __restrict__ y, BnP bn, float slope,
+                                                            h16_t* __restrict__ out, int p, int H, int W, int C,
                                                             long long total_rows, int rpb) {
     const int Ho = 2 * H, Wo = 2 * W;
     const int CV = C / V, Hp = Ho + 2 * p, Wp = Wo + 2 * p, HB = (Hp + 1) / 2, WB = (Wp + 1) / 2;
@@ -214,13 +215,13 @@ __global__ __launch_bounds__(TPB) void bn_act_fwd_up_fast_k(const bf16_t* __rest
         if (row >= total_rows) break;
         const long long n = row / HB;
         const int bi = (int)(row - n * HB);
-        const bf16_t* yn = y + n * H * W * (long long)C + c;
+        const h16_t* yn = y + n * H * W * (long long)C + c;
         int hh0[2], hhp[2]; float lh0[2], lh1[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) bilin(clampi(2 * bi + a - p, 0, Ho - 1), H, Ho, hh0[a], hhp[a], lh0[a], lh1[a]);
         const int rA = hh0[0], rB = rA + 1 < H ? rA + 1 : H - 1;
-        const bf16_t* yA = yn + (long long)rA * W * C;
-        const bf16_t* yB = yn + (long long)rB * W * C;
+        const h16_t* yA = yn + (long long)rA * W * C;
+        const h16_t* yB = yn + (long long)rB * W * C;
         for (int bj = pl; bj < WB; bj += npl) {
             int ww0[2], wwp[2]; float lw0[2], lw1[2];
 #pragma unroll
@@ -268,8 +269,8 @@ __global__ __launch_bounds__(TPB) void bn_act_fwd_up_fast_k(const bf16_t* __rest
                             res[e] = lh0[a] * (lw0[b] * a00 + lw1[b] * a01) + lh1[a] * (lw0[b] * a10 + lw1[b] * a11);
                         }
                     } else {   // direct path
-                        const bf16_t* q0 = yn + (long long)r0i * W * C;
-                        const bf16_t* q1 = yn + (long long)r1i * W * C;
+                        const h16_t* q0 = yn + (long long)r0i * W * C;
+                        const h16_t* q1 = yn + (long long)r1i * W * C;
                         float v00[V], v01[V], v10[V], v11[V];
                         unpack8(ldv(q0 + (long long)c0i * C), v00); unpack8(ldv(q0 + (long long)c1i * C), v01);
                         unpack8(ldv(q1 + (long long)c0i * C), v10); unpack8(ldv(q1 + (long long)c1i * C), v11);
@@ -292,11 +293,11 @@ __global__ __launch_bounds__(TPB) void bn_act_fwd_up_fast_k(const bf16_t* __rest
 // (h/2, w/2) taken only where argmax == position.  GP = 1: the source is a padded-domain gradient
 // [Hs+2][Ws+2] whose border ring folds onto the edge pixels.
 template <int GP>
-__device__ __forceinline__ const bf16_t* g_centre(const bf16_t* gsrc, long long n, int sh, int sw, int Hs, int Ws, int C) {
+__device__ __forceinline__ const h16_t* g_centre(const h16_t* gsrc, long long n, int sh, int sw, int Hs, int Ws, int C) {
     return gsrc + ((n * (Hs + 2 * GP) + sh + GP) * (Ws + 2 * GP) + sw + GP) * (long long)C;
 }
 // adds the ring neighbours of an edge pixel (everything in the fold range except the centre)
-__device__ __forceinline__ void g_edge_add(const bf16_t* gsrc, long long n, int sh, int sw, int Hs, int Ws, int C, int c,
+__device__ __forceinline__ void g_edge_add(const h16_t* gsrc, long long n, int sh, int sw, int Hs, int Ws, int C, int c,
                                            float (&g)[V]) {
     const int ilo = (sh == 0) ? 0 : sh + 1, ihi = (sh == Hs - 1) ? Hs + 1 : sh + 1;
     const int jlo = (sw == 0) ? 0 : sw + 1, jhi = (sw == Ws - 1) ? Ws + 1 : sw + 1;
@@ -312,10 +313,10 @@ __device__ __forceinline__ void g_edge_add(const bf16_t* gsrc, long long n, int 
 // MODE 0: per-workgroup partial sums of (ghat, ghat*xhat).  MODE 1: dy = gamma*invstd*(ghat - db - xhat*dg).
 // Rows: MODE 0 iterates the N*H pre-tail rows; MODE 1 iterates the N*(H+2dp) output rows (border rows zeroed).
 template <int POOL, int GP, int MODE>
-__global__ __launch_bounds__(TPB) void bn_bwd_fast_k(const bf16_t* __restrict__ gsrc, const unsigned char* __restrict__ argmax,
-                                                     const bf16_t* __restrict__ y, BnP bn, float slope,
+__global__ __launch_bounds__(TPB) void bn_bwd_fast_k(const h16_t* __restrict__ gsrc, const unsigned char* __restrict__ argmax,
+                                                     const h16_t* __restrict__ y, BnP bn, float slope,
                                                      float* __restrict__ partials, const float* __restrict__ sums,
-                                                     bf16_t* __restrict__ dy, int dp, int N, int H, int W, int C,
+                                                     h16_t* __restrict__ dy, int dp, int N, int H, int W, int C,
                                                      long long total_rows, int rpb) {
     const int CV = C / V;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_fast_k(const bf16_t* __restrict__ 
         const long long row = r0 + rr;
         if (row >= total_rows) break;
         long long n; int h;
-        bf16_t* drow = nullptr;
+        h16_t* drow = nullptr;
         if (MODE == 1) {
             n = row / Hp;
             h = (int)(row - n * Hp) - dp;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_fast_k(const bf16_t* __restrict__ 
         }
         const int sh = POOL ? (h >> 1) : h;
         const bool hedge = GP && (sh == 0 || sh == Hs - 1);
-        const bf16_t* yr = y + ((n * H + h) * W) * (long long)C + c;
+        const h16_t* yr = y + ((n * H + h) * W) * (long long)C + c;
         for (int w0 = pl; w0 < W; w0 += UNB * npl) {
             uint4 graw[UNB], yraw[UNB];
             uint2 amraw[UNB];
@@ -442,10 +443,10 @@ __global__ __launch_bounds__(TPB) void bn_bwd_fast_k(const bf16_t* __restrict__ 
 // MODE 0 rows = N*(H/2) pooled rows; MODE 1 also rows = N*(H/2): a pooled row writes pre-pool rows 2sh, 2sh+1 of dy
 // (+ the zero border columns, and the zero border rows when it is the first / last pooled row of an image).
 template <int GP, int MODE>
-__global__ __launch_bounds__(TPB) void bn_bwd_pool_fast_k(const bf16_t* __restrict__ gsrc, const unsigned char* __restrict__ argmax,
-                                                          const bf16_t* __restrict__ y, BnP bn, float slope,
+__global__ __launch_bounds__(TPB) void bn_bwd_pool_fast_k(const h16_t* __restrict__ gsrc, const unsigned char* __restrict__ argmax,
+                                                          const h16_t* __restrict__ y, BnP bn, float slope,
                                                           float* __restrict__ partials, const float* __restrict__ sums,
-                                                          bf16_t* __restrict__ dy, int dp, int N, int H, int W, int C,
+                                                          h16_t* __restrict__ dy, int dp, int N, int H, int W, int C,
                                                           long long total_rows, int rpb) {
     constexpr int U2 = MODE == 0 ? 1 : 2;   // reduce: occupancy beats loads in flight (measured 212 -> 192 us), apply: the reverse
     const int CV = C / V;
@@ -472,9 +473,9 @@ __global__ __launch_bounds__(TPB) void bn_bwd_pool_fast_k(const bf16_t* __restri
         const long long n = row / Hs;
         const int sh = (int)(row - n * Hs);
         const bool hedge = GP && (sh == 0 || sh == Hs - 1);
-        const bf16_t* y0 = y + ((n * H + 2 * sh) * W) * (long long)C + c;
-        const bf16_t* y1 = y0 + (long long)W * C;
-        bf16_t* d0 = nullptr;
+        const h16_t* y0 = y + ((n * H + 2 * sh) * W) * (long long)C + c;
+        const h16_t* y1 = y0 + (long long)W * C;
+        h16_t* d0 = nullptr;
         if (MODE == 1) {
             d0 = dy + ((n * Hp + 2 * sh + dp) * Wp) * (long long)C + c;   // pre-pool row 2sh (incl. left border)
             for (int j = pl; j < dp; j += npl) {                             // zero border columns of both rows
@@ -585,7 +586,7 @@ int rows_per_block(long long total_rows, int vec_per_row, int cus) {
 // (weights Ah) and the padded border into T[fine column][64 ch] (fp32, LDS), every fine pixel read as a coalesced
 // 16-byte vector; phase 2 applies the column weights Aw from LDS.  The general kernel gathers up to 25 fine pixels
 // per output vector straight from memory with the index logic in the inner loop.
-__global__ __launch_bounds__(256) void upsample2_bwd_fast_k(const bf16_t* __restrict__ gsrc, int gp, bf16_t* __restrict__ g,
+__global__ __launch_bounds__(256) void upsample2_bwd_fast_k(const h16_t* __restrict__ gsrc, int gp, h16_t* __restrict__ g,
                                                             int H, int W, int C) {
     extern __shared__ __attribute__((aligned(16))) float T[];   // [Wo][64]
     const int Ho = 2 * H, Wo = 2 * W, Hp = Ho + 2 * gp, Wp = Wo + 2 * gp, chunks = C / 64;
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(256) void upsample2_bwd_fast_k(const bf16_t* __rest
         rw[r] = (h0 == h ? lh0 : 0.f) + (h0 + hp == h ? lh1 : 0.f);
     }
     if (vint) {
-        const bf16_t* rowp = gsrc + ((n * Hp + i_lo + gp) * Wp) * C + c;
+        const h16_t* rowp = gsrc + ((n * Hp + i_lo + gp) * Wp) * C + c;
         for (int j = pl; j < Wo; j += 32) {
             float acc[V];
 #pragma unroll
@@ -694,14 +695,14 @@ int kp_bn_act_fwd_fast(const void* y, const float* mean, const float* invstd, co
     const int rpb = rows_per_block(rows, (Wo + 2 * out_pad) * (C / V) * work, kp_device_cus());
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
     if (tail == KP_TAIL_NONE)
-        bn_act_fwd_none_fast_k<<<grid, TPB, 0, st>>>((const bf16_t*)y, bn, slope, (bf16_t*)out, out_pad, H, W, C, rows, rpb);
+        bn_act_fwd_none_fast_k<<<grid, TPB, 0, st>>>((const h16_t*)y, bn, slope, (h16_t*)out, out_pad, H, W, C, rows, rpb);
     else if (tail == KP_TAIL_MAXPOOL2)
-        bn_act_fwd_tail_fast_k<1><<<grid, TPB, 0, st>>>((const bf16_t*)y, bn, slope, (bf16_t*)out, out_pad, argmax, H, W, C, rows, rpb);
+        bn_act_fwd_tail_fast_k<1><<<grid, TPB, 0, st>>>((const h16_t*)y, bn, slope, (h16_t*)out, out_pad, argmax, H, W, C, rows, rpb);
     else {
         const int HB = (Ho + 2 * out_pad + 1) / 2, WB = (Wo + 2 * out_pad + 1) / 2;
         const long long brows = (long long)N * HB;
         const int brpb = rows_per_block(brows, WB * (C / V) * 4, kp_device_cus());
-        bn_act_fwd_up_fast_k<<<(unsigned)((brows + brpb - 1) / brpb), TPB, 0, st>>>((const bf16_t*)y, bn, slope, (bf16_t*)out,
+        bn_act_fwd_up_fast_k<<<(unsigned)((brows + brpb - 1) / brpb), TPB, 0, st>>>((const h16_t*)y, bn, slope, (h16_t*)out,
                                                                                   out_pad, H, W, C, brows, brpb);
     }
     return kp_check_launch("bn_act_fwd_fast");
@@ -721,8 +722,8 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
         const unsigned pgrid = (unsigned)((prows + prpb - 1) / prpb);
         if (mode == 0) kp_set_last_rows(pgrid);
 #define KP_BWDP(GPv, MODEv)                                                                                               \
-    bn_bwd_pool_fast_k<GPv, MODEv><<<pgrid, TPB, 0, st>>>((const bf16_t*)gsrc, argmax, (const bf16_t*)y, bn, slope, partials, \
-                                                         sums, (bf16_t*)dy, dp, N, H, W, C, prows, prpb)
+    bn_bwd_pool_fast_k<GPv, MODEv><<<pgrid, TPB, 0, st>>>((const h16_t*)gsrc, argmax, (const h16_t*)y, bn, slope, partials, \
+                                                         sums, (h16_t*)dy, dp, N, H, W, C, prows, prpb)
         if (mode == 0) { if (gp) KP_BWDP(1, 0); else KP_BWDP(0, 0); }
         else { if (gp) KP_BWDP(1, 1); else KP_BWDP(0, 1); }
 #undef KP_BWDP
@@ -733,8 +734,8 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
     if (mode == 0) kp_set_last_rows(grid);
 #define KP_BWD(POOLv, GPv, MODEv)                                                                                    \
-    bn_bwd_fast_k<POOLv, GPv, MODEv><<<grid, TPB, 0, st>>>((const bf16_t*)gsrc, argmax, (const bf16_t*)y, bn, slope,  \
-                                                           partials, sums, (bf16_t*)dy, dp, N, H, W, C, rows, rpb)
+    bn_bwd_fast_k<POOLv, GPv, MODEv><<<grid, TPB, 0, st>>>((const h16_t*)gsrc, argmax, (const h16_t*)y, bn, slope,  \
+                                                           partials, sums, (h16_t*)dy, dp, N, H, W, C, rows, rpb)
     if (mode == 0) {
         if (pool) { if (gp) KP_BWD(1, 1, 0); else KP_BWD(1, 0, 0); }
         else { if (gp) KP_BWD(0, 1, 0); else KP_BWD(0, 0, 0); }
@@ -749,6 +750,6 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
 int kp_upsample2_bwd_fast(const void* gsrc, int gp, void* g, int N, int H, int W, int C, hipStream_t st) {
     const long long blocks = (long long)N * H * (C / 64);
     if (C % 64 != 0 || W > 128 || blocks > 0x7fffffffLL) return KP_E_UNSUPPORTED;
-    upsample2_bwd_fast_k<<<(unsigned)blocks, 256, (size_t)2 * W * 64 * sizeof(float), st>>>((const bf16_t*)gsrc, gp, (bf16_t*)g, H, W, C);
+    upsample2_bwd_fast_k<<<(unsigned)blocks, 256, (size_t)2 * W * 64 * sizeof(float), st>>>((const h16_t*)gsrc, gp, (h16_t*)g, H, W, C);
     return kp_check_launch("upsample2_bwd_fast");
 }

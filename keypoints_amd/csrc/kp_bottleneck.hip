@@ -187,6 +187,125 @@ __global__ void transport_max_bwd_k(const float* __restrict__ g, const float* __
     }
 }
 
+// ---- the other three combine modes of TransporterNet.forward (transporter.py:41-55) ---------------------------------
+// One thread per (image, pixel); channels / keypoints are walked in registers.  MODE 1 'sum_and_clamp':
+// mask = clamp(sum_k m, 0, 1); MODE 2 'pretrained_network': mask = m (one channel, from MaskMaker); MODE 3 'loop':
+// phi_0 = phi_s, phi_{i+1} = phi_i (1 - m_s,i)(1 - m_t,i) + phi_t m_t,i  for i < K (the masks returned are the last slices).
+constexpr int LOOP_MAXK = 64;
+
+template <int MODE>
+__global__ void transport_mode_fwd_k(const float* __restrict__ phi_s, const float* __restrict__ phi_t,
+                                     const float* __restrict__ m_s, const float* __restrict__ m_t,
+                                     float* __restrict__ phi, float* __restrict__ mask_s, float* __restrict__ mask_t,
+                                     int B, int C, int K, int HW) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)B * HW) return;
+    const long long b = t / HW;
+    const int pix = (int)(t % HW);
+    if (MODE == 3) {
+        for (int c = 0; c < C; ++c) {
+            const long long o = (b * C + c) * HW + pix;
+            float p = phi_s[o];
+            const float pt = phi_t[o];
+            for (int k = 0; k < K; ++k) {
+                const float vs = m_s[(b * K + k) * HW + pix], vt = m_t[(b * K + k) * HW + pix];
+                p = p * (1.f - vs) * (1.f - vt) + pt * vt;
+            }
+            phi[o] = p;
+        }
+        mask_s[t] = m_s[(b * K + K - 1) * HW + pix];
+        mask_t[t] = m_t[(b * K + K - 1) * HW + pix];
+        return;
+    }
+    float ms, mt;
+    if (MODE == 1) {
+        float ss = 0.f, st = 0.f;
+        for (int k = 0; k < K; ++k) { ss += m_s[(b * K + k) * HW + pix]; st += m_t[(b * K + k) * HW + pix]; }
+        ms = fminf(fmaxf(ss, 0.f), 1.f);
+        mt = fminf(fmaxf(st, 0.f), 1.f);
+    } else {
+        ms = m_s[b * HW + pix];
+        mt = m_t[b * HW + pix];
+    }
+    mask_s[t] = ms;
+    mask_t[t] = mt;
+    for (int c = 0; c < C; ++c) {
+        const long long o = (b * C + c) * HW + pix;
+        phi[o] = phi_s[o] * (1.f - ms) * (1.f - mt) + phi_t[o] * mt;
+    }
+}
+
+template <int MODE>
+__global__ void transport_mode_bwd_k(const float* __restrict__ g, const float* __restrict__ phi_s,
+                                     const float* __restrict__ phi_t, const float* __restrict__ m_s,
+                                     const float* __restrict__ m_t, float* __restrict__ d_phi_s,
+                                     float* __restrict__ d_phi_t, float* __restrict__ d_m_s, float* __restrict__ d_m_t,
+                                     int B, int C, int K, int HW) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)B * HW) return;
+    const long long b = t / HW;
+    const int pix = (int)(t % HW);
+    if (MODE == 3) {
+        float vs[LOOP_MAXK], vt[LOOP_MAXK], gs[LOOP_MAXK], gt[LOOP_MAXK], pi[LOOP_MAXK];
+        for (int k = 0; k < K; ++k) {
+            vs[k] = m_s[(b * K + k) * HW + pix];
+            vt[k] = m_t[(b * K + k) * HW + pix];
+            gs[k] = gt[k] = 0.f;
+        }
+        for (int c = 0; c < C; ++c) {
+            const long long o = (b * C + c) * HW + pix;
+            const float pt = phi_t[o];
+            float p = phi_s[o];
+            for (int k = 0; k < K; ++k) {   // forward again, keeping every phi_i
+                pi[k] = p;
+                p = p * (1.f - vs[k]) * (1.f - vt[k]) + pt * vt[k];
+            }
+            float gp = g[o], gpt = 0.f;
+            for (int k = K - 1; k >= 0; --k) {
+                gpt += gp * vt[k];
+                gt[k] += gp * (pt - pi[k] * (1.f - vs[k]));
+                gs[k] -= gp * pi[k] * (1.f - vt[k]);
+                gp = gp * (1.f - vs[k]) * (1.f - vt[k]);
+            }
+            if (d_phi_s) d_phi_s[o] = gp;
+            if (d_phi_t) d_phi_t[o] = gpt;
+        }
+        for (int k = 0; k < K; ++k) {
+            if (d_m_s) d_m_s[(b * K + k) * HW + pix] = gs[k];
+            if (d_m_t) d_m_t[(b * K + k) * HW + pix] = gt[k];
+        }
+        return;
+    }
+    float ms, mt, ss = 0.f, st = 0.f;
+    if (MODE == 1) {
+        for (int k = 0; k < K; ++k) { ss += m_s[(b * K + k) * HW + pix]; st += m_t[(b * K + k) * HW + pix]; }
+        ms = fminf(fmaxf(ss, 0.f), 1.f);
+        mt = fminf(fmaxf(st, 0.f), 1.f);
+    } else {
+        ms = m_s[b * HW + pix];
+        mt = m_t[b * HW + pix];
+    }
+    float gms = 0.f, gmt = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const long long o = (b * C + c) * HW + pix;
+        const float gv = g[o], ps = phi_s[o], pt = phi_t[o];
+        gmt += gv * (pt - ps * (1.f - ms));
+        gms -= gv * ps * (1.f - mt);
+        if (d_phi_t) d_phi_t[o] = gv * mt;
+        if (d_phi_s) d_phi_s[o] = gv * (1.f - ms) * (1.f - mt);
+    }
+    if (MODE == 1) {   // torch.clamp passes the gradient where min <= x <= max
+        const float ps_ = (ss >= 0.f && ss <= 1.f) ? gms : 0.f, pt_ = (st >= 0.f && st <= 1.f) ? gmt : 0.f;
+        for (int k = 0; k < K; ++k) {
+            if (d_m_s) d_m_s[(b * K + k) * HW + pix] = ps_;
+            if (d_m_t) d_m_t[(b * K + k) * HW + pix] = pt_;
+        }
+    } else {
+        if (d_m_s) d_m_s[b * HW + pix] = gms;
+        if (d_m_t) d_m_t[b * HW + pix] = gmt;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -246,6 +365,36 @@ int kp_transport_max_bwd(const float* gphi, const float* phi_s, const float* phi
     KP_REQUIRE(B > 0 && C > 0 && K > 0 && K <= 255 && H > 0 && W > 0, "kp_transport_max_bwd: bad dims");
     transport_max_bwd_k<<<cdiv((long long)B * H * W, TPB), TPB, 0, (hipStream_t)stream>>>(gphi, phi_s, phi_t, mask_s, mask_t, arg_s, arg_t, d_phi_s, d_phi_t, d_m_s, d_m_t, B, C, K, H * W);
     return kp_check_launch("transport_max_bwd");
+}
+
+int kp_transport_fwd(int mode, const float* phi_s, const float* phi_t, const float* m_s, const float* m_t, float* phi,
+                     float* mask_s, float* mask_t, int B, int C, int K, int H, int W, void* stream) {
+    KP_REQUIRE(phi_s && phi_t && m_s && m_t && phi && mask_s && mask_t, "kp_transport_fwd: null pointer");
+    KP_REQUIRE(B > 0 && C > 0 && K > 0 && H > 0 && W > 0, "kp_transport_fwd: bad dims");
+    KP_REQUIRE(mode != KP_COMBINE_PRETRAINED || K == 1, "kp_transport_fwd: 'pretrained_network' takes one-channel masks");
+    const unsigned grid = cdiv((long long)B * H * W, TPB);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == KP_COMBINE_SUM_AND_CLAMP) transport_mode_fwd_k<1><<<grid, TPB, 0, st>>>(phi_s, phi_t, m_s, m_t, phi, mask_s, mask_t, B, C, K, H * W);
+    else if (mode == KP_COMBINE_PRETRAINED) transport_mode_fwd_k<2><<<grid, TPB, 0, st>>>(phi_s, phi_t, m_s, m_t, phi, mask_s, mask_t, B, C, K, H * W);
+    else if (mode == KP_COMBINE_LOOP) transport_mode_fwd_k<3><<<grid, TPB, 0, st>>>(phi_s, phi_t, m_s, m_t, phi, mask_s, mask_t, B, C, K, H * W);
+    else { kp_set_error("kp_transport_fwd: unknown mode %d (use kp_transport_max_fwd for 'max')", mode); return KP_E_ARG; }
+    return kp_check_launch("transport_fwd");
+}
+
+int kp_transport_bwd(int mode, const float* gphi, const float* phi_s, const float* phi_t, const float* m_s,
+                     const float* m_t, float* d_phi_s, float* d_phi_t, float* d_m_s, float* d_m_t, int B, int C, int K,
+                     int H, int W, void* stream) {
+    KP_REQUIRE(gphi && phi_s && phi_t && m_s && m_t, "kp_transport_bwd: null pointer");
+    KP_REQUIRE(B > 0 && C > 0 && K > 0 && H > 0 && W > 0, "kp_transport_bwd: bad dims");
+    KP_REQUIRE(mode != KP_COMBINE_PRETRAINED || K == 1, "kp_transport_bwd: 'pretrained_network' takes one-channel masks");
+    KP_REQUIRE(mode != KP_COMBINE_LOOP || K <= LOOP_MAXK, "kp_transport_bwd: 'loop' supports up to %d keypoints", LOOP_MAXK);
+    const unsigned grid = cdiv((long long)B * H * W, TPB);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == KP_COMBINE_SUM_AND_CLAMP) transport_mode_bwd_k<1><<<grid, TPB, 0, st>>>(gphi, phi_s, phi_t, m_s, m_t, d_phi_s, d_phi_t, d_m_s, d_m_t, B, C, K, H * W);
+    else if (mode == KP_COMBINE_PRETRAINED) transport_mode_bwd_k<2><<<grid, TPB, 0, st>>>(gphi, phi_s, phi_t, m_s, m_t, d_phi_s, d_phi_t, d_m_s, d_m_t, B, C, K, H * W);
+    else if (mode == KP_COMBINE_LOOP) transport_mode_bwd_k<3><<<grid, TPB, 0, st>>>(gphi, phi_s, phi_t, m_s, m_t, d_phi_s, d_phi_t, d_m_s, d_m_t, B, C, K, H * W);
+    else { kp_set_error("kp_transport_bwd: unknown mode %d (use kp_transport_max_bwd for 'max')", mode); return KP_E_ARG; }
+    return kp_check_launch("transport_bwd");
 }
 
 }  // extern "C"

@@ -3,27 +3,73 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+
+// ---- the 16-bit storage type ("T" of the C ABI when dtype != KP_F32) ------------------------------------------------
+// Every kernel source that touches 16-bit activations / packed weights is compiled TWICE (Makefile): once with bfloat16
+// as the storage type (dtype KP_BF16) and once, with -DKP_F16_BUILD, with IEEE half (dtype KP_F16: 3 more mantissa bits,
+// the reference's apex-O2 storage type; needs loss scaling, keypoints_amd/amp.py).  The kernels are written against
+// h16_t / h2f / f2h / pack_h16x2 / unpack_h16x2 / kp_mfma16 and never look at the bits themselves.  External symbols
+// of those sources carry a per-build suffix (kp_h16_names.h); kp_api.hip holds the dtype dispatch.
+#ifdef KP_F16_BUILD
+#define KP_H16 KP_F16
+#define KP_SFX(n) n##__f16
+typedef _Float16 kp_h16_native;
+#else
+#define KP_H16 KP_BF16
+#define KP_SFX(n) n##__bf16
+typedef __bf16 kp_h16_native;
+#endif
+#ifdef KP_H16_SOURCE
+#include "kp_h16_names.h"   // must precede kp_hip.h: the dtype-taking entry points are declared under their build's name
+#endif
 #include "../../include/kp_hip.h"
 
-typedef uint16_t bf16_t;   // raw bfloat16 bits
+typedef uint16_t h16_t;   // raw bits of the 16-bit storage type
 
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32), which hipcc
-// selects for __bf16 casts -- one instruction per PAIR instead of ~8 VALU ops per value.
-typedef __bf16 kp_bf16x2 __attribute__((ext_vector_type(2)));
+typedef kp_h16_native kp_h16x2 __attribute__((ext_vector_type(2)));
 typedef float kp_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+// conversions are the hardware ones (round to nearest even): v_cvt_pk_bf16_f32 / v_cvt_f16_f32, v_cvt_f32_f16
+__device__ __forceinline__ float h2f(h16_t v) {
+#ifdef KP_F16_BUILD
+    return (float)__builtin_bit_cast(_Float16, v);
+#else
+    return __uint_as_float(((uint32_t)v) << 16);
+#endif
+}
+__device__ __forceinline__ h16_t f2h(float f) { return __builtin_bit_cast(h16_t, (kp_h16_native)f); }
+__device__ __forceinline__ uint32_t pack_h16x2(float lo, float hi) {
     const kp_f32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, kp_bf16x2));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, kp_h16x2));
+}
+__device__ __forceinline__ void unpack_h16x2(uint32_t w, float& lo, float& hi) {
+#ifdef KP_F16_BUILD
+    const kp_h16x2 h = __builtin_bit_cast(kp_h16x2, w);
+    lo = (float)h[0];
+    hi = (float)h[1];
+#else
+    lo = __uint_as_float(w << 16);
+    hi = __uint_as_float(w & 0xffff0000u);
+#endif
+}
+
+// v_mfma_f32_32x32x16_{bf16,f16}: same shape, same rate; which one depends on the build's 16-bit storage type.
+// A8: any 16-byte vector of eight 16-bit values (the kernels keep fragments as raw shorts); C16: 16 x float.
+template <typename A8, typename C16> __device__ __forceinline__ C16 kp_mfma16(A8 a, A8 b, C16 c, int, int, int) {
+    typedef kp_h16_native v8 __attribute__((ext_vector_type(8)));
+    static_assert(sizeof(A8) == 16 && sizeof(C16) == 64, "kp_mfma16: 8 x 16-bit operands, 16 x fp32 accumulator");
+#ifdef KP_F16_BUILD
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+#endif
 }
 
 template <typename T> __device__ __forceinline__ float ld(const T* p);
 template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
-template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <> __device__ __forceinline__ float ld<h16_t>(const h16_t* p) { return h2f(*p); }
 template <typename T> __device__ __forceinline__ void st(T* p, float v);
 template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
-template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <> __device__ __forceinline__ void st<h16_t>(h16_t* p, float v) { *p = f2h(v); }
 
 // 4-wide vector access (16 B fp32 / 8 B bf16); pointer must be aligned accordingly.
 template <typename T> __device__ __forceinline__ void ld4(const T* p, float (&o)[4]);
@@ -31,19 +77,19 @@ template <> __device__ __forceinline__ void ld4<float>(const float* p, float (&o
     float4 v = *reinterpret_cast<const float4*>(p);
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
 }
-template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float (&o)[4]) {
+template <> __device__ __forceinline__ void ld4<h16_t>(const h16_t* p, float (&o)[4]) {
     uint2 v = *reinterpret_cast<const uint2*>(p);
-    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    unpack_h16x2(v.x, o[0], o[1]);
+    unpack_h16x2(v.y, o[2], o[3]);
 }
 template <typename T> __device__ __forceinline__ void st4(T* p, const float (&o)[4]);
 template <> __device__ __forceinline__ void st4<float>(float* p, const float (&o)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
 }
-template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (&o)[4]) {
+template <> __device__ __forceinline__ void st4<h16_t>(h16_t* p, const float (&o)[4]) {
     uint2 v;
-    v.x = pack_bf16x2(o[0], o[1]);
-    v.y = pack_bf16x2(o[2], o[3]);
+    v.x = pack_h16x2(o[0], o[1]);
+    v.y = pack_h16x2(o[2], o[3]);
     *reinterpret_cast<uint2*>(p) = v;
 }
 

@@ -1,0 +1,120 @@
+// Convolution entry points: dispatch between the kernel families of this build's 16-bit storage type (compiled once
+// for bf16 and once for fp16; kp_api.hip holds the public names and the dtype dispatch).
+#include <stdlib.h>
+#include "kp_prof.h"
+
+int kp_conv_fwd_generic(const void*, const void*, const float*, void*, float*, int, int, int, int, int, int, int,
+                        hipStream_t);
+int kp_conv_wgrad_generic(const void*, const void*, float*, int, int, int, int, int, int, int, int, hipStream_t);
+int kp_conv_fwd_mfma(const void*, const void*, const float*, void*, float*, int, int, int, int, int, int,
+                     hipStream_t);   // bf16 only; returns KP_E_UNSUPPORTED when the shape is not eligible
+int kp_conv_wgrad_mfma(const void*, const void*, float*, int, int, int, int, int, int, int, hipStream_t);
+int kp_conv_dgrad_mfma(const void*, const void*, void*, int, int, int, int, int, hipStream_t);
+int kp_conv_wgrad_patch(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
+long long kp_conv_wgrad_patch_partials(int, int, int, int, int, int);
+int kp_conv_small_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
+int kp_conv_small_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
+int kp_conv_first_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
+int kp_conv_first_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
+long long kp_conv_first_wgrad_partials(int, int, int, int, int);
+
+extern int g_kp_wgrad_patch;
+
+static int use_mfma() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("KP_DISABLE_MFMA");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v;
+}
+
+extern "C" {
+
+int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C,
+                int K, int R, int dtype, void* stream) {
+    KP_REQUIRE(x && w && y, "kp_conv_fwd: null pointer");
+    KP_REQUIRE(N > 0 && C > 0 && K > 0 && (R == 1 || R == 3) && Hi >= R && Wi >= R, "kp_conv_fwd: bad dims N=%d Hi=%d Wi=%d C=%d K=%d R=%d", N, Hi, Wi, C, K, R);
+    KP_REQUIRE(dtype == KP_F32 || dtype == KP_H16, "kp_conv_fwd: bad dtype %d", dtype);
+    const double flops = 2.0 * N * (double)(Hi - R + 1) * (Wi - R + 1) * C * K * R * R;
+    const double esz = dtype == KP_H16 ? 2.0 : 4.0;   // algorithmic HBM bytes: input + output + weights, each once
+    const double bytes = esz * ((double)N * Hi * Wi * C + (double)N * (Hi - R + 1) * (Wi - R + 1) * K + (double)R * R * C * K);
+    ProfScope ps(KP_PROF_CONV_GENERIC, flops, (hipStream_t)stream, bytes);
+    if (stats) kp_set_last_rows(((long long)N * (Hi - R + 1) * (Wi - R + 1) + 63) / 64);
+    if (dtype == KP_H16 && use_mfma()) {
+        int rc = kp_conv_fwd_mfma(x, w, bias, y, stats, N, Hi, Wi, C, K, R, (hipStream_t)stream);
+        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_MFMA); return rc; }
+        if (R == 3 && C <= 4) {
+            rc = kp_conv_first_fwd(x, w, bias, y, stats, N, Hi, Wi, C, K, (hipStream_t)stream);
+            if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_FIRST); return rc; }
+        }
+        if (R == 3) {
+            rc = kp_conv_small_fwd(x, w, bias, y, stats, N, Hi, Wi, C, K, (hipStream_t)stream);
+            if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_SMALL); return rc; }
+        }
+    }
+    if (getenv("KP_LOG_GENERIC")) fprintf(stderr, "generic conv: N=%d Hi=%d Wi=%d C=%d K=%d R=%d dtype=%d stats=%d\n", N, Hi, Wi, C, K, R, dtype, stats != nullptr);
+    int rc = kp_conv_fwd_generic(x, w, bias, y, stats, N, Hi, Wi, C, K, R, dtype, (hipStream_t)stream);
+    ps.done(KP_PROF_CONV_GENERIC);
+    return rc;
+}
+
+int kp_conv_dgrad(const void* dy, const void* w_dgrad, void* gx, int N, int H, int W, int K, int C, int dtype,
+                  void* stream) {
+    KP_REQUIRE(dy && w_dgrad && gx, "kp_conv_dgrad: null pointer");
+    KP_REQUIRE(N > 0 && C > 0 && K > 0 && H > 0 && W > 0, "kp_conv_dgrad: bad dims");
+    KP_REQUIRE(dtype == KP_F32 || dtype == KP_H16, "kp_conv_dgrad: bad dtype %d", dtype);
+    if (dtype == KP_H16 && use_mfma()) {
+        const double flops = 2.0 * N * (double)H * W * C * K * 9;
+        const double bytes = 2.0 * ((double)N * (H + 4) * (W + 4) * K + (double)N * (H + 2) * (W + 2) * C + 9.0 * C * K);
+        ProfScope ps(KP_PROF_CONV_MFMA, flops, (hipStream_t)stream, bytes);
+        int rc = kp_conv_dgrad_mfma(dy, w_dgrad, gx, N, H, W, K, C, (hipStream_t)stream);
+        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_MFMA); return rc; }
+        ps.cancel();
+    }
+    return kp_conv_fwd(dy, w_dgrad, nullptr, gx, nullptr, N, H + 4, W + 4, K, C, 3, dtype, stream);
+}
+
+int kp_conv_wgrad_partials(int N, int Ho, int Wo, int C, int K, int R, int dy_pad, int dtype) {
+    if (dtype == KP_H16 && use_mfma() && R == 3 && g_kp_wgrad_patch) {
+        const long long p = kp_conv_wgrad_patch_partials(N, Ho, Wo, C, K, dy_pad);
+        if (p > 0 && p < 0x7fffffffLL) return (int)p;
+    }
+    if (dtype == KP_H16 && use_mfma() && R == 3 && C <= 4) {
+        const long long p = kp_conv_first_wgrad_partials(N, Ho, Wo, C, K);
+        if (p > 0) return (int)p;
+    }
+    return 1;
+}
+
+int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R, int dy_pad,
+                  int dtype, void* stream) {
+    KP_REQUIRE(x && dy && scratch, "kp_conv_wgrad: null pointer");
+    KP_REQUIRE(N > 0 && C > 0 && K > 0 && (R == 1 || R == 3) && Ho > 0 && Wo > 0 && dy_pad >= 0, "kp_conv_wgrad: bad dims");
+    KP_REQUIRE(dtype == KP_F32 || dtype == KP_H16, "kp_conv_wgrad: bad dtype %d", dtype);
+    const double flops = 2.0 * N * (double)Ho * Wo * C * K * R * R;
+    const double wesz = dtype == KP_H16 ? 2.0 : 4.0;
+    const double wbytes = wesz * ((double)N * (Ho + R - 1) * (Wo + R - 1) * C + (double)N * Ho * Wo * K) + 4.0 * R * R * C * K;
+    ProfScope ps(KP_PROF_WGRAD_GENERIC, flops, (hipStream_t)stream, wbytes);
+    if (dtype == KP_H16 && use_mfma()) {
+        int rc = (R == 3 && g_kp_wgrad_patch) ? kp_conv_wgrad_patch(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream)
+                                              : KP_E_UNSUPPORTED;
+        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_WGRAD_MFMA); return rc; }
+        rc = kp_conv_wgrad_mfma(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, (hipStream_t)stream);
+        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_WGRAD_MFMA); return rc; }
+        if (R == 3 && C <= 4) {
+            rc = kp_conv_first_wgrad(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
+            if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_FIRST); return rc; }
+        }
+        if (R == 3) {
+            rc = kp_conv_small_wgrad(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
+            if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_SMALL); return rc; }
+        }
+    }
+    if (getenv("KP_LOG_GENERIC")) fprintf(stderr, "generic wgrad: N=%d Ho=%d Wo=%d C=%d K=%d R=%d dp=%d dtype=%d\n", N, Ho, Wo, C, K, R, dy_pad, dtype);
+    int rc = kp_conv_wgrad_generic(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, dtype, (hipStream_t)stream);
+    ps.done(KP_PROF_WGRAD_GENERIC);
+    return rc;
+}
+
+}  // extern "C"

@@ -44,8 +44,8 @@ __device__ __forceinline__ float reduce8_over64(const float (&v)[8], int lane, i
 }
 
 template <int CIN>
-__global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                         const float* __restrict__ bias, bf16_t* __restrict__ y,
+__global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
+                                                         const float* __restrict__ bias, h16_t* __restrict__ y,
                                                          float* __restrict__ partials, int Hi, int Wi, int K,
                                                          long long M) {
     constexpr int J = 9 * CIN;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const bf16_t* __restric
     const int Ho = Hi - 2, Wo = Wi - 2;
     for (int i = tid; i < J * K; i += TPB) {   // w is [K][J] -> wl[j][k]
         const int k = i / J, j = i - k * J;
-        wl[j * K + k] = bf2f(w[i]);
+        wl[j * K + k] = h2f(w[i]);
     }
     __syncthreads();
     const long long m_wave = (long long)blockIdx.x * TPB + wave * 64;
@@ -69,9 +69,9 @@ __global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const bf16_t* __restric
     float xin[J];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        const bf16_t* xr = x + ((n * Hi + p + r) * Wi + q) * CIN;
+        const h16_t* xr = x + ((n * Hi + p + r) * Wi + q) * CIN;
 #pragma unroll
-        for (int i = 0; i < 3 * CIN; ++i) xin[r * 3 * CIN + i] = bf2f(xr[i]);
+        for (int i = 0; i < 3 * CIN; ++i) xin[r * 3 * CIN + i] = h2f(xr[i]);
     }
     const int CP = K >> 3;                     // 16-byte chunks per pixel
     unsigned char* st = stage + (size_t)wave * 64 * K * 2;
@@ -102,15 +102,15 @@ __global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const bf16_t* __restric
             }
         }
         uint4 pk;
-        pk.x = pack_bf16x2(acc[0], acc[1]);
-        pk.y = pack_bf16x2(acc[2], acc[3]);
-        pk.z = pack_bf16x2(acc[4], acc[5]);
-        pk.w = pack_bf16x2(acc[6], acc[7]);
+        pk.x = pack_h16x2(acc[0], acc[1]);
+        pk.y = pack_h16x2(acc[2], acc[3]);
+        pk.z = pack_h16x2(acc[4], acc[5]);
+        pk.w = pack_h16x2(acc[6], acc[7]);
         const int ch = k0 >> 3;
         *reinterpret_cast<uint4*>(st + (size_t)lane * K * 2 + ((ch ^ (lane & (CP - 1))) << 4)) = pk;
     }
     // coalesced write-out: chunk id = i*64 + lane -> (pixel id / CP, chunk id % CP)
-    bf16_t* yw = y + m_wave * K;
+    h16_t* yw = y + m_wave * K;
     for (int id = lane; id < 64 * CP; id += 64) {
         const int px = id / CP, ch = id - px * CP;
         const uint4 v = *reinterpret_cast<const uint4*>(st + (size_t)px * K * 2 + ((ch ^ (px & (CP - 1))) << 4));
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const bf16_t* __restric
 
 // scratch[k][tap][c] += sum_pixels dy[pixel][k] * x[pixel + tap][c]
 template <int CIN>
-__global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+__global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
                                                            float* __restrict__ scratch, int Ho, int Wo, int K,
                                                            int dy_pad, long long total_rows, int rows_per_block) {
     constexpr int J = 9 * CIN;
@@ -143,14 +143,14 @@ __global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const bf16_t* __restr
         const int p = (int)(row % Ho);
         const long long n = row / Ho;
         // stage input rows p..p+2 as fp32, 4 floats per pixel (channels >= CIN are never read)
-        const bf16_t* xr = x + ((n * Hi + p) * Wi) * CIN;
+        const h16_t* xr = x + ((n * Hi + p) * Wi) * CIN;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
             for (int i = lane; i < Wi * CIN; i += 64) {
                 const int px = i / CIN, c = i - px * CIN;
-                xw[r * rowf + px * 4 + c] = bf2f(xr[r * Wi * CIN + i]);
+                xw[r * rowf + px * 4 + c] = h2f(xr[r * Wi * CIN + i]);
             }
-        const bf16_t* dr = dy + (((n * Hd + p + dy_pad) * Wd) + dy_pad) * (long long)K + k;
+        const h16_t* dr = dy + (((n * Hd + p + dy_pad) * Wd) + dy_pad) * (long long)K + k;
         if (KS == 1 && (Wo & 7) == 0) {
             // one stream per wave (K = 64): UQ pixels per iteration share their UQ+2 window columns (aligned 16-byte
             // broadcast reads) and the UQ dy loads are issued together (the loop is bound by their latency)
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const bf16_t* __restr
             for (int q = 0; q < Wo; q += UQ) {
                 float d[UQ];
 #pragma unroll
-                for (int u = 0; u < UQ; ++u) d[u] = bf2f(dr[(long long)(q + u) * K]);
+                for (int u = 0; u < UQ; ++u) d[u] = h2f(dr[(long long)(q + u) * K]);
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     float4 col[UQ + 2];
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const bf16_t* __restr
         } else {
 #pragma unroll 4
             for (int q = stream; q < Wo; q += KS) {
-                const float d = bf2f(dr[(long long)q * K]);
+                const float d = h2f(dr[(long long)q * K]);
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -235,8 +235,8 @@ __device__ __forceinline__ void group_next(GroupPos& c, int Ho, int Wo) {   // t
 }
 
 template <int CIN>
-__global__ __launch_bounds__(256) void conv3_first_fwd_mfma_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                              const float* __restrict__ bias, bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256) void conv3_first_fwd_mfma_k(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
+                                                              const float* __restrict__ bias, h16_t* __restrict__ y,
                                                               float* __restrict__ partials, int Hi, int Wi,
                                                               long long groups, int gpw) {
     constexpr int J = 9 * CIN, NS = (J + 15) / 16, K = 64, KT = 2;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void conv3_first_fwd_mfma_k(const bf16_t* __re
     if (lane < 4) *reinterpret_cast<uint32_t*>(xs + 3 * F_RS + lane * 4) = 0u;
 
     // weights [K][J] -> A fragments (row = output channel, 8 consecutive reduction indices per lane), once per wave
-    bf16x8 wa[KT][NS];
+    h16x8 wa[KT][NS];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void conv3_first_fwd_mfma_k(const bf16_t* __re
 #pragma unroll
             for (int r = 0; r < 3; ++r) *reinterpret_cast<uint32_t*>(xs + r * F_RS + lane * 4) = xr[r];
         }
-        bf16x8 xb[NS];
+        h16x8 xb[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void conv3_first_fwd_mfma_k(const bf16_t* __re
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[kt][i] = bs[kt][i];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[kt][s], xb[s], acc[kt], 0, 0, 0);
+            for (int s = 0; s < NS; ++s) acc[kt] = kp_mfma16(wa[kt][s], xb[s], acc[kt], 0, 0, 0);
         }
         // statistics (fp32 values before rounding), bf16 pack, transpose through the wave's LDS tile, 1-KiB stores
 #pragma unroll
@@ -328,12 +328,12 @@ __global__ __launch_bounds__(256) void conv3_first_fwd_mfma_k(const bf16_t* __re
                     sq[kt][g4 * 4 + e] = __builtin_fmaf(v[e], v[e], sq[kt][g4 * 4 + e]);
                 }
                 uint2 pk;
-                pk.x = pack_bf16x2(v[0], v[1]);
-                pk.y = pack_bf16x2(v[2], v[3]);
+                pk.x = pack_h16x2(v[0], v[1]);
+                pk.y = pack_h16x2(v[2], v[3]);
                 const int chunk = kt * 4 + g4;
                 *reinterpret_cast<uint2*>(stg + px * (K * 2) + ((chunk ^ (px & 7)) << 4) + h * 8) = pk;
             }
-        bf16_t* yb = y + g * FG * K;
+        h16_t* yb = y + g * FG * K;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = i * 64 + lane, pp = id >> 3, c16 = id & 7;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void conv3_first_fwd_mfma_k(const bf16_t* __re
 // are summed in a fixed order by kp_wgrad_unpack (no atomics: bitwise reproducible).  dy tiles (32 px x 128 B) go to
 // LDS by DMA as they lie and are read with the transpose read (channel-major fragments), the input window as above.
 template <int CIN>
-__global__ __launch_bounds__(1024) void conv3_first_wgrad_mfma_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+__global__ __launch_bounds__(1024) void conv3_first_wgrad_mfma_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
                                                                  float* __restrict__ partial, int Ho, int Wo, int dy_pad,
                                                                  long long groups, int gpw) {
     constexpr int J = 9 * CIN, K = 64, KT = 2, PK = K * 2, NW = 16;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(1024) void conv3_first_wgrad_mfma_k(const bf16_t* _
     uint32_t xr[3] = {0u, 0u, 0u};
     GroupPos c = group_pos(g0 < groups ? g0 : 0, Ho, Wo);   // fetch cursor
     auto fetch = [&](int buf) {
-        const bf16_t* db = dy + (((c.n * Hd + c.p + dy_pad) * Wd) + c.q + dy_pad) * K;
+        const h16_t* db = dy + (((c.n * Hd + c.p + dy_pad) * Wd) + c.q + dy_pad) * K;
         const u32x4 dr = rsrc_words(db);   // asm DMA: the builtin would make every transpose read wait for it (kp_mfma_util.h)
 #pragma unroll
         for (int u = 0; u < 4; ++u) dma16_asm(dr, dyb + buf * DYB + u * 1024, dvoff[u]);
@@ -424,13 +424,13 @@ __global__ __launch_bounds__(1024) void conv3_first_wgrad_mfma_k(const bf16_t* _
             for (int r = 0; r < 3; ++r) *reinterpret_cast<uint32_t*>(xs + r * F_RS + lane * 4) = xr[r];
         }
         if (g + 1 < g1) fetch(buf ^ 1);                       // in flight during this group's reads and MFMAs
-        bf16x8 xb[2];
+        h16x8 xb[2];
 #pragma unroll
         for (int R = 0; R < 2; ++R)
 #pragma unroll
             for (int i = 0; i < 8; ++i) xb[R][i] = *reinterpret_cast<const short*>(xs + xoff + (R * 16 + i) * CIN * 2);
         const unsigned char* tile = dyb + buf * DYB;
-        bf16x8 a[KT][2];
+        h16x8 a[KT][2];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             a[kt][0] = tr_frag<PK, 0>(tile, kbase[kt]);
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(1024) void conv3_first_wgrad_mfma_k(const bf16_t* _
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int R = 0; R < 2; ++R) acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kt][R], xb[R], acc[kt], 0, 0, 0);
+            for (int R = 0; R < 2; ++R) acc[kt] = kp_mfma16(a[kt][R], xb[R], acc[kt], 0, 0, 0);
     }
     // fold the 16 wavefronts in a fixed order; D[k][j]: lane column = j, rows k = 8*(i>>2) + 4*h + (i&3) (+32 kt)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -474,7 +474,7 @@ int kp_conv_first_fwd(const void* x, const void* w, const float* bias, void* y, 
         const unsigned grid = (unsigned)((groups + 4 * gpw - 1) / (4 * gpw));
         if (stats) kp_set_last_rows((long long)grid * 4);
 #define KP_FIRST_FWD_M(CINv)                                                                                       \
-    conv3_first_fwd_mfma_k<CINv><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, stats, \
+    conv3_first_fwd_mfma_k<CINv><<<grid, 256, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, \
                                                        Hi, Wi, groups, gpw)
         switch (C) {
             case 1: KP_FIRST_FWD_M(1); break;
@@ -487,7 +487,7 @@ int kp_conv_first_fwd(const void* x, const void* w, const float* bias, void* y, 
     const size_t lds = (size_t)9 * C * K * sizeof(float) + (size_t)4 * 64 * K * 2;
     const unsigned grid = (unsigned)((M + TPB - 1) / TPB);
 #define KP_FIRST_FWD(CINv)                                                                                          \
-    conv3_first_fwd_k<CINv><<<grid, TPB, lds, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, stats, Hi, \
+    conv3_first_fwd_k<CINv><<<grid, TPB, lds, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, \
                                                     Wi, K, M)
     switch (C) {
         case 1: KP_FIRST_FWD(1); break;
@@ -525,7 +525,7 @@ int kp_conv_first_wgrad(const void* x, const void* dy, float* scratch, int N, in
         long long groups; int gpw; unsigned grid;
         if (first_wgrad_plan(N, Ho, Wo, C, K, groups, gpw, grid)) {
 #define KP_FIRST_WG_M(CINv)                                                                                          \
-    conv3_first_wgrad_mfma_k<CINv><<<grid, 1024, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, scratch, Ho, Wo, dy_pad, \
+    conv3_first_wgrad_mfma_k<CINv><<<grid, 1024, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, \
                                                           groups, gpw)
             switch (C) {
                 case 1: KP_FIRST_WG_M(1); break;
@@ -546,7 +546,7 @@ int kp_conv_first_wgrad(const void* x, const void* dy, float* scratch, int N, in
     if (red > lds) lds = red;
     if (lds > 64 * 1024) return KP_E_UNSUPPORTED;
 #define KP_FIRST_WG(CINv)                                                                                        \
-    conv3_first_wgrad_k<CINv><<<grid, TPB, lds, st>>>((const bf16_t*)x, (const bf16_t*)dy, scratch, Ho, Wo, K,    \
+    conv3_first_wgrad_k<CINv><<<grid, TPB, lds, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, K,    \
                                                       dy_pad, rows, rpb)
     switch (C) {
         case 1: KP_FIRST_WG(1); break;

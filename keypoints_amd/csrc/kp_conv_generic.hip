@@ -227,11 +227,11 @@ int launch_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, i
 int kp_conv_fwd_generic(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi,
                         int C, int K, int R, int dtype, hipStream_t st) {
     return dtype == KP_F32 ? launch_fwd<float>(x, w, bias, y, stats, N, Hi, Wi, C, K, R, st)
-                           : launch_fwd<bf16_t>(x, w, bias, y, stats, N, Hi, Wi, C, K, R, st);
+                           : launch_fwd<h16_t>(x, w, bias, y, stats, N, Hi, Wi, C, K, R, st);
 }
 
 int kp_conv_wgrad_generic(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R,
                           int dy_pad, int dtype, hipStream_t st) {
     return dtype == KP_F32 ? launch_wgrad<float>(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, st)
-                           : launch_wgrad<bf16_t>(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, st);
+                           : launch_wgrad<h16_t>(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, st);
 }

@@ -16,7 +16,7 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(8))) short h16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int BM = 128, BK = 64, TPB = 256;
@@ -91,8 +91,8 @@ __device__ __forceinline__ void pix_decode(long long m, int Ho, int Wo, int grp,
 }
 
 template <int BN, int MODE>
-__global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                         const float* __restrict__ bias, bf16_t* __restrict__ y,
+__global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
+                                                         const float* __restrict__ bias, h16_t* __restrict__ y,
                                                          float* __restrict__ partials, int N, int Hi, int Wi, int C,
                                                          int K, int mtiles, int ktiles) {
     constexpr int WN = BN / 2;            // channels per wave
@@ -195,17 +195,17 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restric
         const unsigned char* sb = smem + buf * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 xf[2], wf[TN];
+            h16x8 xf[2], wf[TN];
             const int ls = kk * 2 + fh;
 #pragma unroll
-            for (int b = 0; b < 2; ++b) xf[b] = *(const bf16x8*)(sb + xoff[b] + ((ls ^ xsw[b]) << 4));
+            for (int b = 0; b < 2; ++b) xf[b] = *(const h16x8*)(sb + xoff[b] + ((ls ^ xsw[b]) << 4));
 #pragma unroll
-            for (int a = 0; a < TN; ++a) wf[a] = *(const bf16x8*)(sb + woff[a] + ((ls ^ wsw[a]) << 4));
+            for (int a = 0; a < TN; ++a) wf[a] = *(const h16x8*)(sb + woff[a] + ((ls ^ wsw[a]) << 4));
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = kp_mfma16(wf[a], xf[b], acc[a][b], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -241,8 +241,8 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const bf16_t* __restric
                 }
                 if (ok) {
                     uint2 pk;
-                    pk.x = pack_bf16x2(v[0], v[1]);
-                    pk.y = pack_bf16x2(v[2], v[3]);
+                    pk.x = pack_h16x2(v[0], v[1]);
+                    pk.y = pack_h16x2(v[2], v[3]);
                     *reinterpret_cast<uint2*>(y + opix * K + kq) = pk;
                 }
             }
@@ -285,15 +285,15 @@ static int launch_linear(const void* x, const void* w, const float* bias, void* 
     if (mtiles * ktiles > 0x7fffffffLL) return KP_E_UNSUPPORTED;
     const unsigned grid = (unsigned)(mtiles * ktiles);
     if (bn == 128)
-        conv3x3_mfma_k<128, MODE><<<grid, TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, stats, N, Hi,
+        conv3x3_mfma_k<128, MODE><<<grid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, N, Hi,
                                                        Wi, C, K, (int)mtiles, ktiles);
     else
-        conv3x3_mfma_k<64, MODE><<<grid, TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, stats, N, Hi,
+        conv3x3_mfma_k<64, MODE><<<grid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, N, Hi,
                                                       Wi, C, K, (int)mtiles, ktiles);
     return kp_check_launch("conv3x3_mfma");
 }
 
-int g_kp_conv_patch = -1;   // kp_config(KP_CFG_CONV_PATCH, v); -1 = read KP_CONV_PATCH from the environment once
+extern int g_kp_conv_patch;   // kp_api.hip: kp_config(KP_CFG_CONV_PATCH, v); -1 = read KP_CONV_PATCH from the environment once
 static int patch_mode() {   // 0 forces the linear implicit-GEMM kernel (A/B measurements)
     if (g_kp_conv_patch < 0) {
         const char* e = getenv("KP_CONV_PATCH");

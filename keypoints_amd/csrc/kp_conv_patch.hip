@@ -35,7 +35,7 @@ constexpr int ROWB = 128;               // bytes per LDS row (64 bf16)
 constexpr int NWBUF = 4;               // weight ring slots (power of two: the slot of a step is a run-time counter)
 
 struct PatchArgs {
-    const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y; float* partials;
+    const h16_t* x; const h16_t* w; const float* bias; h16_t* y; float* partials;
     int Hib, Wib, ioff;   // input buffer rows / cols, offset of the tile domain's patch origin in it
     int Hob, Wob, ooff;   // output buffer rows / cols, offset of the tile domain in it
     int H, W;             // tile domain (multiples of 16)
@@ -164,13 +164,13 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         ws16[a] = (fh ^ ((row >> 1) & 7)) << 4;
     }
 
-    struct Frag { bf16x8 x[2]; bf16x8 w[TN]; };
+    struct Frag { h16x8 x[2]; h16x8 w[TN]; };
     auto load_frag = [&](Frag& f, const unsigned char* xb, const unsigned char* wb, int s, int kk) {
         if (TRACE && (dbg & 64) && (kk & 1)) return;   // ablation: half the LDS fragment reads
 #pragma unroll
-        for (int b = 0; b < 2; ++b) f.x[b] = *(const bf16x8*)(xb + xoff[b] + (xs16[s] ^ (kk << 5)));
+        for (int b = 0; b < 2; ++b) f.x[b] = *(const h16x8*)(xb + xoff[b] + (xs16[s] ^ (kk << 5)));
 #pragma unroll
-        for (int a = 0; a < TN; ++a) f.w[a] = *(const bf16x8*)(wb + woff[a] + (ws16[a] ^ (kk << 5)));
+        for (int a = 0; a < TN; ++a) f.w[a] = *(const h16x8*)(wb + woff[a] + (ws16[a] ^ (kk << 5)));
     };
 
     f32x16 acc[TN][2];
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         for (int a = 0; a < TN; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[a], f.x[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = kp_mfma16(f.w[a], f.x[b], acc[a][b], 0, 0, 0);
     };
 
     // epilogue: D[k_out][pixel]; lane: pixel = fr of fragment b, k_out = 8*(reg>>2) + 4*fh + (reg&3).
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         const long long prow = (long long)t.pt * 4 + wm;   // statistics row of this wave (64 pixels)
         // this wave's 4 x 16 pixel x WN channel output window from one scalar base: stores carry a lane-constant
         // VGPR offset and a scalar (row, column) offset -- no per-store vector address arithmetic
-        bf16_t* ybase = A.y + ((((long long)t.n * A.Hob + t.oy0 + wm * 4 + A.ooff) * A.Wob) + t.ox0 + A.ooff) * (long long)K +
+        h16_t* ybase = A.y + ((((long long)t.n * A.Hob + t.oy0 + wm * 4 + A.ooff) * A.Wob) + t.ox0 + A.ooff) * (long long)K +
                         t.k0 + wn * WN;
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, 0x7ffffffe, 0x00020000);
         if constexpr (STATS) if (!A.compact) {   // per-tile rows: start from zero
@@ -244,8 +244,8 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                         }
                     }
                     uint2 pk;
-                    pk.x = pack_bf16x2(v[0], v[1]);
-                    pk.y = pack_bf16x2(v[2], v[3]);
+                    pk.x = pack_h16x2(v[0], v[1]);
+                    pk.y = pack_h16x2(v[2], v[3]);
                     const int chunk = a * 4 + g;
                     *reinterpret_cast<uint2*>(stg + fr * (WN * 2) + ((chunk ^ (fr & (CPP - 1))) << 4) + fh * 8) = pk;
                 }
@@ -452,7 +452,7 @@ int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* 
     if ((long long)(PW + 1) * Wib * C * 2 >= 0x7fffffffLL || 128LL * 9 * C * 2 + 9LL * C * 2 >= 0x7fffffffLL)
         return KP_E_UNSUPPORTED;
     PatchArgs a;
-    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.partials = stats;
+    a.x = (const h16_t*)x; a.w = (const h16_t*)w; a.bias = bias; a.y = (h16_t*)y; a.partials = stats;
     a.Hib = Hib; a.Wib = Wib; a.ioff = ioff; a.Hob = Hob; a.Wob = Wob; a.ooff = ooff; a.H = H; a.W = W;
     a.C = C; a.K = K;
     { extern int g_kp_debug; extern long long* g_kp_trace; a.dbg = g_kp_debug; a.trace = g_kp_trace; }

@@ -15,7 +15,7 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(8))) short h16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int TPB = 256;
@@ -53,8 +53,8 @@ __device__ __forceinline__ float reduce16_over32(float (&v)[16], int lane, int& 
 
 // CB = C / 16
 template <int CB>
-__global__ __launch_bounds__(TPB) void conv3x3_small_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                       const float* __restrict__ bias, bf16_t* __restrict__ y,
+__global__ __launch_bounds__(TPB) void conv3x3_small_k(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
+                                                       const float* __restrict__ bias, h16_t* __restrict__ y,
                                                        float* __restrict__ partials, int N, int Hi, int Wi, int K,
                                                        long long nseg, int segs_per_row) {
     constexpr int C = CB * 16;
@@ -63,13 +63,13 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_k(const bf16_t* __restrict_
     const int Ho = Hi - 2, Wo = Wi - 2;
 
     // weight fragments: lane (k = fr, half = fh): 8 input channels of W[k][tap][cb*16 + fh*8 ...]; rows k >= K are zero
-    bf16x8 wf[9 * CB];
+    h16x8 wf[9 * CB];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (fr < K) v = *reinterpret_cast<const bf16x8*>(w + ((long long)fr * 9 + t) * C + cb * 16 + fh * 8);
+            h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (fr < K) v = *reinterpret_cast<const h16x8*>(w + ((long long)fr * 9 + t) * C + cb * 16 + fh * 8);
             wf[t * CB + cb] = v;
         }
     float bv[16];
@@ -91,18 +91,18 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_k(const bf16_t* __restrict_
         const int q = sq * 32 + fr;
         const bool ok = q < Wo;
         const int qc = ok ? q : Wo - 1;   // tail lanes load a valid pixel, masked at the store
-        const bf16_t* xp = x + ((n * Hi + p) * Wi + qc) * (long long)C + fh * 8;
+        const h16_t* xp = x + ((n * Hi + p) * Wi + qc) * (long long)C + fh * 8;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        bf16x8 xf[9 * CB];
+        h16x8 xf[9 * CB];
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
-                xf[t * CB + cb] = *reinterpret_cast<const bf16x8*>(xp + ((long long)(t / 3) * Wi + (t % 3)) * C + cb * 16);
+                xf[t * CB + cb] = *reinterpret_cast<const h16x8*>(xp + ((long long)(t / 3) * Wi + (t % 3)) * C + cb * 16);
 #pragma unroll
-        for (int t = 0; t < 9 * CB; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t], xf[t], acc, 0, 0, 0);
+        for (int t = 0; t < 9 * CB; ++t) acc = kp_mfma16(wf[t], xf[t], acc, 0, 0, 0);
         // D[k][px]: lane: pixel = fr, k = 8*(reg>>2) + 4*fh + (reg&3)
         uint32_t pk[8];
 #pragma unroll
@@ -113,12 +113,12 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_k(const bf16_t* __restrict_
                 v[e] = acc[g * 4 + e] + bv[g * 4 + e];
                 if (ok) { ssum[g * 4 + e] += v[e]; ssq[g * 4 + e] += v[e] * v[e]; }
             }
-            pk[2 * g] = pack_bf16x2(v[0], v[1]);
-            pk[2 * g + 1] = pack_bf16x2(v[2], v[3]);
+            pk[2 * g] = pack_h16x2(v[0], v[1]);
+            pk[2 * g + 1] = pack_h16x2(v[2], v[3]);
         }
         // pair the half-waves' 8-byte pieces: after the swaps lanes fh=0 hold channels 8g..8g+7 of chunk g (even g),
         // lanes fh=1 those of chunk g+1
-        bf16_t* yp = y + ((n * Ho + p) * Wo + q) * (long long)K;
+        h16_t* yp = y + ((n * Ho + p) * Wo + q) * (long long)K;
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {
             uint32_t a0 = pk[2 * g], a1 = pk[2 * g + 1], b0 = pk[2 * g + 2], b1 = pk[2 * g + 3];
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_k(const bf16_t* __restrict_
 // runs per pixel across the wave, L1-resident; the 10 loads of an input row serve its 3 column taps.
 // A wavefront walks whole image rows in 16-pixel segments; tail pixels get dy = 0 (and a clamped, finite x).
 template <int K, int C>
-__global__ __launch_bounds__(TPB) void wgrad3x3_small_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+__global__ __launch_bounds__(TPB) void wgrad3x3_small_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
                                                            float* __restrict__ scratch, int Ho, int Wo, int dy_pad,
                                                            long long total_rows, int rows_per_wave) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(TPB) void wgrad3x3_small_k(const bf16_t* __restrict
                 const unsigned v = dr[(long long)(q < Wo ? q : Wo - 1) * K];
                 a16[j] = (q < Wo && fr < K) ? v : 0u;
             }
-            bf16x8 af;
+            h16x8 af;
 #pragma unroll
             for (int j = 0; j < 8; ++j) af[j] = (short)a16[j];
 #pragma unroll
@@ -189,10 +189,10 @@ __global__ __launch_bounds__(TPB) void wgrad3x3_small_k(const bf16_t* __restrict
                 }
 #pragma unroll
                 for (int s_ = 0; s_ < 3; ++s_) {
-                    bf16x8 bfv;
+                    h16x8 bfv;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) bfv[j] = (short)b16[j + s_];
-                    acc[r * 3 + s_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfv, acc[r * 3 + s_], 0, 0, 0);
+                    acc[r * 3 + s_] = kp_mfma16(af, bfv, acc[r * 3 + s_], 0, 0, 0);
                 }
             }
         }
@@ -235,9 +235,9 @@ int kp_conv_small_fwd(const void* x, const void* w, const float* bias, void* y, 
     if (blocks < 1) { if (stats) return KP_E_UNSUPPORTED; blocks = 1; }
     if (stats) kp_set_last_rows(blocks * 4);
     if (C == 16)
-        conv3x3_small_k<1><<<(unsigned)blocks, TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, stats, N, Hi, Wi, K, nseg, spr);
+        conv3x3_small_k<1><<<(unsigned)blocks, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, N, Hi, Wi, K, nseg, spr);
     else
-        conv3x3_small_k<2><<<(unsigned)blocks, TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, stats, N, Hi, Wi, K, nseg, spr);
+        conv3x3_small_k<2><<<(unsigned)blocks, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, N, Hi, Wi, K, nseg, spr);
     return kp_check_launch("conv3x3_small");
 }
 
@@ -249,7 +249,7 @@ int kp_conv_small_wgrad(const void* x, const void* dy, float* scratch, int N, in
     if (rpw < 1) rpw = 1;
     const long long waves = (rows + rpw - 1) / rpw;
     const unsigned grid = (unsigned)((waves + 3) / 4);
-#define KP_SWG(Kv, Cv) wgrad3x3_small_k<Kv, Cv><<<grid, TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, scratch, Ho, Wo, dy_pad, rows, rpw)
+#define KP_SWG(Kv, Cv) wgrad3x3_small_k<Kv, Cv><<<grid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, rows, rpw)
     if (K == 16 && C == 16) KP_SWG(16, 16);
     else if (K == 16) KP_SWG(16, 32);
     else if (C == 16) KP_SWG(32, 16);

@@ -326,7 +326,7 @@ __global__ void scale_k(const float* __restrict__ x, const float* __restrict__ s
 #define DISPATCH_T(dtype, ...)                         \
     do {                                               \
         if ((dtype) == KP_F32) { using T = float; __VA_ARGS__; } \
-        else { using T = bf16_t; __VA_ARGS__; }        \
+        else { using T = h16_t; __VA_ARGS__; }        \
     } while (0)
 
 int kp_head_fwd_fast(const void*, const float*, const float*, float, float*, long long, int, int, int, hipStream_t);
@@ -360,6 +360,7 @@ int kp_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int K, int C, in
     return kp_check_launch("pack_weights");
 }
 
+#ifndef KP_F16_BUILD   // no dtype: defined once, by the bf16 build of this source
 int kp_wgrad_unpack(const float* scratch, int partials, float* dw, int K, int C, int Cp, int R, void* stream) {
     KP_REQUIRE(K > 0 && C > 0 && Cp >= C && (R == 1 || R == 3) && partials >= 1, "kp_wgrad_unpack: bad dims");
     const long long total = (long long)K * Cp * R * R;
@@ -374,12 +375,14 @@ int kp_wgrad_unpack(const float* scratch, int partials, float* dw, int K, int C,
     return kp_check_launch("wgrad_unpack");
 }
 
+#endif
+
 int kp_head_fwd(const void* x, const float* w, const float* bias, float slope, float* out, int N, int H, int W, int C,
                 int K, int dtype, void* stream) {
     KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "kp_head_fwd: bad dims");
     KP_REQUIRE(C <= 2048, "kp_head_fwd: C too large for the LDS tile");
     const long long M = (long long)N * H * W;
-    if (dtype == KP_BF16) {
+    if (dtype == KP_H16) {
         int rc = kp_head_fwd_mfma(x, w, bias, slope, out, M, H * W, C, K, (hipStream_t)stream);
         if (rc != KP_E_UNSUPPORTED) return rc;
         rc = kp_head_fwd_fast(x, w, bias, slope, out, M, H * W, C, K, (hipStream_t)stream);
@@ -396,13 +399,13 @@ int kp_head_bwd(const float* gout, const float* out, const void* x, const float*
     KP_REQUIRE(K <= 256 && C <= 2048, "kp_head_bwd: K <= 256, C <= 2048 supported");
     const long long M = (long long)N * H * W;
     hipStream_t st = (hipStream_t)stream;
-    if (dx && dtype == KP_BF16) {
+    if (dx && dtype == KP_H16) {
         int rc = kp_head_dx_mfma(gout, out, w, slope, dx, M, H * W, C, K, st);
         if (rc == KP_E_UNSUPPORTED) rc = kp_head_dx_fast(gout, out, w, slope, dx, M, H * W, C, K, st);
         if (rc == KP_OK) dx = nullptr;
         else if (rc != KP_E_UNSUPPORTED) return rc;
     }
-    if (dw && dtype == KP_BF16) {
+    if (dw && dtype == KP_H16) {
         int rc = kp_head_dw_mfma(gout, out, x, slope, dw, db, M, H * W, C, K, st);
         if (rc == KP_E_UNSUPPORTED) rc = kp_head_dw_fast(gout, out, x, slope, dw, db, M, H * W, C, K, st);
         if (rc == KP_OK) dw = nullptr;
@@ -425,6 +428,7 @@ int kp_head_bwd(const float* gout, const float* out, const void* x, const float*
     return KP_OK;
 }
 
+#ifndef KP_F16_BUILD   // no dtype: defined once, by the bf16 build of this source
 int kp_l2_loss(const float* x, const float* t, const float* mask, double* loss_sum, float* grad, float scale, size_t n,
                void* stream) {
     KP_REQUIRE(n > 0, "kp_l2_loss: empty");
@@ -447,5 +451,7 @@ int kp_adam_step(float* p, const float* g, float* m, float* v, size_t n, float l
     adam_k<<<cdiv(n, TPB), TPB, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2));
     return kp_check_launch("adam_step");
 }
+
+#endif
 
 }  // extern "C"

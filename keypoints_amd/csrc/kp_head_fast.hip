@@ -14,10 +14,10 @@ namespace {
 constexpr int TPB = 256, V = 8;
 
 __device__ __forceinline__ void unpack8(const uint4 v, float (&o)[V]) {
-    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
-    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
-    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+    unpack_h16x2(v.x, o[0], o[1]);
+    unpack_h16x2(v.y, o[2], o[3]);
+    unpack_h16x2(v.z, o[4], o[5]);
+    unpack_h16x2(v.w, o[6], o[7]);
 }
 
 // Sum over the CV adjacent lanes of a pixel (CV a power of two <= 64): DPP for the steps inside a 16-lane row
@@ -37,7 +37,7 @@ __device__ __forceinline__ float group_sum(float v, int CV) {
 
 // KB = compile-time bound on K (4 or 16); CV = C/8 is a power of two <= 64 (checked by the launcher)
 template <int KB>
-__global__ __launch_bounds__(TPB) void head_fwd_small_k(const bf16_t* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(TPB) void head_fwd_small_k(const h16_t* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float slope,
                                                         float* __restrict__ out, long long M, int HW, int C, int K,
                                                         int ppb) {
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(TPB) void head_fwd_small_k(const bf16_t* __restrict
 template <int KB>
 __global__ __launch_bounds__(TPB) void head_dx_small_k(const float* __restrict__ gout, const float* __restrict__ out,
                                                        const float* __restrict__ w, float slope,
-                                                       bf16_t* __restrict__ dx, long long M, int HW, int C, int K,
+                                                       h16_t* __restrict__ dx, long long M, int HW, int C, int K,
                                                        int ppb) {
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [K][C]
     for (int i = threadIdx.x; i < K * C; i += TPB) wl[i] = w[i];
@@ -104,15 +104,15 @@ __global__ __launch_bounds__(TPB) void head_dx_small_k(const float* __restrict__
             }
         }
         uint4 pk;
-        pk.x = pack_bf16x2(r[0], r[1]); pk.y = pack_bf16x2(r[2], r[3]);
-        pk.z = pack_bf16x2(r[4], r[5]); pk.w = pack_bf16x2(r[6], r[7]);
+        pk.x = pack_h16x2(r[0], r[1]); pk.y = pack_h16x2(r[2], r[3]);
+        pk.z = pack_h16x2(r[4], r[5]); pk.w = pack_h16x2(r[6], r[7]);
         *reinterpret_cast<uint4*>(dx + m * C + cv * V) = pk;
     }
 }
 
 template <int KB>
 __global__ __launch_bounds__(TPB) void head_dw_small_k(const float* __restrict__ gout, const float* __restrict__ out,
-                                                       const bf16_t* __restrict__ x, float slope,
+                                                       const h16_t* __restrict__ x, float slope,
                                                        float* __restrict__ dw, float* __restrict__ db, long long M,
                                                        int HW, int C, int K, int ppb) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [npl][KC][C] (+ [npl][KC] for db)
@@ -189,7 +189,7 @@ int kp_head_fwd_fast(const void* x, const float* w, const float* bias, float slo
     const int npl = TPB / (C / V), ppb = npl * 8;
     const unsigned grid = (unsigned)((M + ppb - 1) / ppb);
     const size_t lds = (size_t)K * C * sizeof(float);
-    KP_HEAD_KB(K, (head_fwd_small_k<KB><<<grid, TPB, lds, st>>>((const bf16_t*)x, w, bias, slope, out, M, HW, C, K, ppb)));
+    KP_HEAD_KB(K, (head_fwd_small_k<KB><<<grid, TPB, lds, st>>>((const h16_t*)x, w, bias, slope, out, M, HW, C, K, ppb)));
     return kp_check_launch("head_fwd_fast");
 }
 
@@ -199,7 +199,7 @@ int kp_head_dx_fast(const float* gout, const float* out, const float* w, float s
     const int npl = TPB / (C / V), ppb = npl * 8;
     const unsigned grid = (unsigned)((M + ppb - 1) / ppb);
     const size_t lds = (size_t)K * C * sizeof(float);
-    KP_HEAD_KB(K, (head_dx_small_k<KB><<<grid, TPB, lds, st>>>(gout, out, w, slope, (bf16_t*)dx, M, HW, C, K, ppb)));
+    KP_HEAD_KB(K, (head_dx_small_k<KB><<<grid, TPB, lds, st>>>(gout, out, w, slope, (h16_t*)dx, M, HW, C, K, ppb)));
     return kp_check_launch("head_dx_fast");
 }
 
@@ -214,6 +214,6 @@ int kp_head_dw_fast(const float* gout, const float* out, const void* x, float sl
     if (ppb < npl) ppb = npl;
     ppb = (ppb + npl - 1) / npl * npl;
     const unsigned grid = (unsigned)((M + ppb - 1) / ppb);
-    KP_HEAD_KB(K, (head_dw_small_k<KB><<<grid, TPB, lds, st>>>(gout, out, (const bf16_t*)x, slope, dw, db, M, HW, C, K, (int)ppb)));
+    KP_HEAD_KB(K, (head_dw_small_k<KB><<<grid, TPB, lds, st>>>(gout, out, (const h16_t*)x, slope, dw, db, M, HW, C, K, (int)ppb)));
     return kp_check_launch("head_dw_fast");
 }

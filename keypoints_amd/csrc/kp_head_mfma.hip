@@ -15,22 +15,24 @@
 namespace {
 
 // 8 fp32 values -> bf16 hi / lo fragments (round-to-nearest-even both times)
-__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+__device__ __forceinline__ void split8(const float (&v)[8], h16x8& hi, h16x8& lo) {
     uint32_t h[4], l[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        h[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-        const float r0 = v[2 * i] - __uint_as_float(h[i] << 16);
-        const float r1 = v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u);
-        l[i] = pack_bf16x2(r0, r1);
+        h[i] = pack_h16x2(v[2 * i], v[2 * i + 1]);
+        float h0, h1;
+        unpack_h16x2(h[i], h0, h1);
+        const float r0 = v[2 * i] - h0;
+        const float r1 = v[2 * i + 1] - h1;
+        l[i] = pack_h16x2(r0, r1);
     }
     const u32x4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
-    hi = __builtin_bit_cast(bf16x8, hv);
-    lo = __builtin_bit_cast(bf16x8, lv);
+    hi = __builtin_bit_cast(h16x8, hv);
+    lo = __builtin_bit_cast(h16x8, lv);
 }
 
-__device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+__device__ __forceinline__ f32x16 mma(h16x8 a, h16x8 b, f32x16 c) {
+    return kp_mfma16(a, b, c, 0, 0, 0);
 }
 
 // rows k of W[K][C] (fp32), 8 consecutive c starting at c0: zero rows beyond K
@@ -47,7 +49,7 @@ __device__ __forceinline__ void load_w8(const float* __restrict__ w, int k, int 
 
 // ---- forward -----------------------------------------------------------------------------------------------------
 template <int KT>   // 32-channel tiles of the output (K <= 32 * KT)
-__global__ __launch_bounds__(256) void head_fwd_mfma_k(const bf16_t* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void head_fwd_mfma_k(const h16_t* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float slope,
                                                        float* __restrict__ out, long long groups, int HW, int C, int K) {
     const int lane = threadIdx.x & 63;
@@ -55,19 +57,19 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_k(const bf16_t* __restrict_
     if (g >= groups) return;
     const int px = lane & 31, h = lane >> 5;
     const long long m0 = g * 32;
-    const bf16_t* xp = x + (m0 + px) * C + h * 8;
+    const h16_t* xp = x + (m0 + px) * C + h * 8;
     f32x16 acc[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[kt][i] = 0.f;
     for (int c0 = 0; c0 < C; c0 += 16) {
-        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(xp + c0);
+        const h16x8 xb = *reinterpret_cast<const h16x8*>(xp + c0);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             float wv[8];
             load_w8(w, kt * 32 + px, K, C, c0 + h * 8, wv);
-            bf16x8 whi, wlo;
+            h16x8 whi, wlo;
             split8(wv, whi, wlo);
             acc[kt] = mma(whi, xb, acc[kt]);
             acc[kt] = mma(wlo, xb, acc[kt]);
@@ -101,7 +103,7 @@ __device__ __forceinline__ void load_dz_px(const float* __restrict__ gout, const
 // ---- input gradient ------------------------------------------------------------------------------------------------
 template <int KS>   // 16-channel reduction slices (K <= 16 * KS)
 __global__ __launch_bounds__(256) void head_dx_mfma_k(const float* __restrict__ gout, const float* __restrict__ out,
-                                                      const float* __restrict__ w, float slope, bf16_t* __restrict__ dx,
+                                                      const float* __restrict__ w, float slope, h16_t* __restrict__ dx,
                                                       long long groups, int HW, int C, int K) {
     const int lane = threadIdx.x & 63;
     const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -109,14 +111,14 @@ __global__ __launch_bounds__(256) void head_dx_mfma_k(const float* __restrict__ 
     const int px = lane & 31, h = lane >> 5;
     const long long m0 = g * 32, n = m0 / HW;
     const int hw = (int)(m0 - n * HW) + px;
-    bf16x8 zhi[KS], zlo[KS];
+    h16x8 zhi[KS], zlo[KS];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
         float v[8];
         load_dz_px(gout, out, n, hw, HW, K, kk * 16 + h * 8, slope, v);
         split8(v, zhi[kk], zlo[kk]);
     }
-    bf16_t* dp = dx + (m0 + px) * C + 4 * h;
+    h16_t* dp = dx + (m0 + px) * C + 4 * h;
     for (int ct = 0; ct < C; ct += 32) {
         f32x16 acc;
 #pragma unroll
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void head_dx_mfma_k(const float* __restrict__ 
                 const int k = kk * 16 + h * 8 + i;
                 wv[i] = k < K ? w[(long long)k * C + ct + px] : 0.f;
             }
-            bf16x8 whi, wlo;
+            h16x8 whi, wlo;
             split8(wv, whi, wlo);
             acc = mma(whi, zhi[kk], acc);
             acc = mma(wlo, zhi[kk], acc);
@@ -140,8 +142,8 @@ __global__ __launch_bounds__(256) void head_dx_mfma_k(const float* __restrict__ 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint2 pk;
-            pk.x = pack_bf16x2(acc[4 * q], acc[4 * q + 1]);
-            pk.y = pack_bf16x2(acc[4 * q + 2], acc[4 * q + 3]);
+            pk.x = pack_h16x2(acc[4 * q], acc[4 * q + 1]);
+            pk.y = pack_h16x2(acc[4 * q + 2], acc[4 * q + 3]);
             *reinterpret_cast<uint2*>(dp + ct + 8 * q) = pk;
         }
     }
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void head_dx_mfma_k(const float* __restrict__ 
 // wavefront = (pixel range, 128 input channels): 4 x KT accumulator tiles; fp32 atomics into dw / db at the end
 template <int KT>
 __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ gout, const float* __restrict__ out,
-                                                      const bf16_t* __restrict__ x, float slope, float* __restrict__ dw,
+                                                      const h16_t* __restrict__ x, float slope, float* __restrict__ dw,
                                                       float* __restrict__ db, long long groups, int gpw, int HW, int C,
                                                       int K) {
     const int lane = threadIdx.x & 63;
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ 
 #pragma unroll
         for (int s = 0; s < 2; ++s) {           // two slices of 16 pixels
             const int p0 = s * 16 + h * 8;       // this lane's 8 consecutive pixels
-            bf16x8 zhi[KT], zlo[KT];
+            h16x8 zhi[KT], zlo[KT];
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
                 const int k = kt * 32 + r;
@@ -199,10 +201,10 @@ __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ 
                 if (cr == 0) bsum[kt] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                 split8(v, zhi[kt], zlo[kt]);
             }
-            const bf16_t* xp = x + (m0 + p0) * C + cr * 128 + r;
+            const h16_t* xp = x + (m0 + p0) * C + cr * 128 + r;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                bf16x8 xb;      // column = input channel cr*128 + t*32 + r, 8 consecutive pixels (stride C)
+                h16x8 xb;      // column = input channel cr*128 + t*32 + r, 8 consecutive pixels (stride C)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) xb[i] = (short)xp[(long long)i * C + t * 32];
 #pragma unroll
@@ -243,8 +245,8 @@ int kp_head_fwd_mfma(const void* x, const float* w, const float* bias, float slo
     if (!mfma_shape(M, HW, C, K) || !aligned16(x, w)) return KP_E_UNSUPPORTED;
     const long long groups = M / 32;
     const unsigned grid = (unsigned)((groups + 3) / 4);
-    if (K <= 32) head_fwd_mfma_k<1><<<grid, 256, 0, st>>>((const bf16_t*)x, w, bias, slope, out, groups, HW, C, K);
-    else head_fwd_mfma_k<2><<<grid, 256, 0, st>>>((const bf16_t*)x, w, bias, slope, out, groups, HW, C, K);
+    if (K <= 32) head_fwd_mfma_k<1><<<grid, 256, 0, st>>>((const h16_t*)x, w, bias, slope, out, groups, HW, C, K);
+    else head_fwd_mfma_k<2><<<grid, 256, 0, st>>>((const h16_t*)x, w, bias, slope, out, groups, HW, C, K);
     return kp_check_launch("head_fwd_mfma");
 }
 
@@ -253,7 +255,7 @@ int kp_head_dx_mfma(const float* gout, const float* out, const float* w, float s
     if (!mfma_shape(M, HW, C, K) || !aligned16(dx)) return KP_E_UNSUPPORTED;
     const long long groups = M / 32;
     const unsigned grid = (unsigned)((groups + 3) / 4);
-#define KP_DX(KSv) head_dx_mfma_k<KSv><<<grid, 256, 0, st>>>(gout, out, w, slope, (bf16_t*)dx, groups, HW, C, K)
+#define KP_DX(KSv) head_dx_mfma_k<KSv><<<grid, 256, 0, st>>>(gout, out, w, slope, (h16_t*)dx, groups, HW, C, K)
     if (K <= 16) KP_DX(1);
     else if (K <= 32) KP_DX(2);
     else if (K <= 48) KP_DX(3);
@@ -273,7 +275,7 @@ int kp_head_dw_mfma(const float* gout, const float* out, const void* x, float sl
     const int gpw = (int)((groups + splits - 1) / splits);
     splits = (groups + gpw - 1) / gpw;
     const unsigned grid = (unsigned)((splits * cranges + 3) / 4);
-    if (K <= 32) head_dw_mfma_k<1><<<grid, 256, 0, st>>>(gout, out, (const bf16_t*)x, slope, dw, db, groups, gpw, HW, C, K);
-    else head_dw_mfma_k<2><<<grid, 256, 0, st>>>(gout, out, (const bf16_t*)x, slope, dw, db, groups, gpw, HW, C, K);
+    if (K <= 32) head_dw_mfma_k<1><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, groups, gpw, HW, C, K);
+    else head_dw_mfma_k<2><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, groups, gpw, HW, C, K);
     return kp_check_launch("head_dw_mfma");
 }

@@ -6,8 +6,8 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(8))) short h16x8;
+typedef __attribute__((ext_vector_type(4))) short h16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -105,12 +105,12 @@ __device__ __forceinline__ int tr_base(int v, int lrow, int colbyte) {
     return lrow * P + ((((colbyte >> 6) ^ blk_swz<P>(row)) << 6) | (colbyte & 63));
 }
 template <int P, int R>
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, const int (&base)[4]) {
-    bf16x8 r;
+__device__ __forceinline__ h16x8 tr_frag(const unsigned char* tile, const int (&base)[4]) {
+    h16x8 r;
     const unsigned char* a = tile + base[R & 3];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(a + (R + 4 * u) * P));
+        h16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(a + (R + 4 * u) * P));
         r[4 * u + 0] = v[0]; r[4 * u + 1] = v[1]; r[4 * u + 2] = v[2]; r[4 * u + 3] = v[3];
     }
     return r;

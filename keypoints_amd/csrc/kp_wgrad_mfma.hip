@@ -14,8 +14,8 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(8))) short h16x8;
+typedef __attribute__((ext_vector_type(4))) short h16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int TPB = 256, PIX = 64;
@@ -31,21 +31,21 @@ template <int P>   // row pitch in bytes (128 or 256): swizzle of the 64-B block
 __device__ __forceinline__ int blk_swz(int row) { return P == 256 ? (row & 3) : ((row >> 1) & 1); }
 
 template <int P>
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int prow, int colbyte) {
+__device__ __forceinline__ h16x8 tr_frag(const unsigned char* tile, int prow, int colbyte) {
     // 8 consecutive pixels (prow..prow+7 handled as two 4-row transpose reads) of this lane's channel
-    bf16x8 r;
+    h16x8 r;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int row = prow + 4 * u;   // row of THIS lane's address (already includes t>>2)
         const int off = row * P + ((((colbyte >> 6) ^ blk_swz<P>(row)) << 6) | (colbyte & 63));
-        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(tile + off));
+        h16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(tile + off));
         r[4 * u + 0] = v[0]; r[4 * u + 1] = v[1]; r[4 * u + 2] = v[2]; r[4 * u + 3] = v[3];
     }
     return r;
 }
 
 template <int TK, int TC>
-__global__ __launch_bounds__(TPB, 2) void wgrad3x3_mfma_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+__global__ __launch_bounds__(TPB, 2) void wgrad3x3_mfma_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
                                                           float* __restrict__ scratch, int Ho, int Wo, int C, int K,
                                                           int dy_pad, int lgWo, int lgHo, int ctiles, int ktiles,
                                                           int stages_per_split, int total_stages) {
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_mfma_k(const bf16_t* __restri
         const unsigned char* sx = sd + DYB;
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss) {
-            bf16x8 af[AK], bfr[AC];
+            h16x8 af[AK], bfr[AC];
 #pragma unroll
             for (int a = 0; a < AK; ++a) af[a] = tr_frag<PK>(sd, ss * 16 + prow0, kcol[a]);
 #pragma unroll
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_mfma_k(const bf16_t* __restri
             for (int a = 0; a < AK; ++a)
 #pragma unroll
                 for (int b = 0; b < AC; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = kp_mfma16(af[a], bfr[b], acc[a][b], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -189,7 +189,7 @@ int kp_conv_wgrad_mfma(const void* x, const void* dy, float* scratch, int N, int
     splits = (total_stages + sps - 1) / sps;
     const unsigned grid = (unsigned)(tiles * splits);
 #define KP_WG_LAUNCH(TKv, TCv)                                                                                      \
-    wgrad3x3_mfma_k<TKv, TCv><<<grid, TPB, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, scratch, Ho, Wo, C, K,     \
+    wgrad3x3_mfma_k<TKv, TCv><<<grid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, C, K,     \
                                                    dy_pad, lgWo, lgHo, ctiles, ktiles, sps, total_stages)
     if (TKs == 128 && TCs == 128) KP_WG_LAUNCH(128, 128);
     else if (TKs == 128) KP_WG_LAUNCH(128, 64);

@@ -23,7 +23,7 @@ constexpr int PH = BH + 2, PWC = BW + 2;       // input patch
 constexpr int PROWS = PH * PWC;                // 180 patch pixels
 
 struct WgArgs {
-    const bf16_t* x; const bf16_t* dy; float* scratch;
+    const h16_t* x; const h16_t* dy; float* scratch;
     int Ho, Wo, C, K, dy_pad;
     int ctiles, ktiles, stages_per_split, total_stages, bx, by, dbg;
     long long partial_stride;   // floats between the partial gradients of consecutive pixel splits (0: one buffer, atomics)
@@ -163,10 +163,10 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_patch_k(const WgArgs A) {
         const unsigned char* sd = smem + buf * STAGE;
         const unsigned char* sx = sd + DYB;
         // walk the 10 patch rows; patch row p meets output rows p, p-1, p-2 through taps r = 0, 1, 2
-        bf16x8 a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0, a2 = a0;   // dY fragments of output rows p, p-1, p-2 (rotating)
+        h16x8 a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0, a2 = a0;   // dY fragments of output rows p, p-1, p-2 (rotating)
         // fragments are read one patch row ahead of their MFMAs, so a wave keeps the matrix pipe fed on its own
         // (the second wave of a SIMD finishes a stage ~2000 cycles after the first and runs alone meanwhile)
-        bf16x8 an = tr_frag<PK, 0>(sd, kbase), bn[3];
+        h16x8 an = tr_frag<PK, 0>(sd, kbase), bn[3];
         bn[0] = tr_frag<PC, 0>(sx, cbase);
         bn[1] = tr_frag<PC, 1>(sx, cbase);
         bn[2] = tr_frag<PC, 2>(sx, cbase);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_patch_k(const WgArgs A) {
             constexpr int p = decltype(pc)::value;
             a2 = a1; a1 = a0;
             if constexpr (p < BH) a0 = an;
-            bf16x8 b[3] = {bn[0], bn[1], bn[2]};
+            h16x8 b[3] = {bn[0], bn[1], bn[2]};
             if constexpr (p + 1 < PH) {
                 if constexpr (p + 1 < BH) an = tr_frag<PK, (p + 1) * BW>(sd, kbase);
                 bn[0] = tr_frag<PC, (p + 1) * PWC + 0>(sx, cbase);
@@ -183,9 +183,9 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_patch_k(const WgArgs A) {
             }
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
-                if constexpr (p < BH) acc[0 * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[s], acc[0 * 3 + s], 0, 0, 0);
-                if constexpr (p >= 1 && p - 1 < BH) acc[1 * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[s], acc[1 * 3 + s], 0, 0, 0);
-                if constexpr (p >= 2) acc[2 * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[s], acc[2 * 3 + s], 0, 0, 0);
+                if constexpr (p < BH) acc[0 * 3 + s] = kp_mfma16(a0, b[s], acc[0 * 3 + s], 0, 0, 0);
+                if constexpr (p >= 1 && p - 1 < BH) acc[1 * 3 + s] = kp_mfma16(a1, b[s], acc[1 * 3 + s], 0, 0, 0);
+                if constexpr (p >= 2) acc[2 * 3 + s] = kp_mfma16(a2, b[s], acc[2 * 3 + s], 0, 0, 0);
             }
             if (loader) {   // two instructions per row from the top: the last one is issued ~3 rows before the stage ends
                 stage_issue(buf ^ 1, std::integral_constant<int, 2 * p>{}, more);
@@ -260,7 +260,7 @@ int kp_conv_wgrad_patch(const void* x, const void* dy, float* scratch, int N, in
     WgArgs a; unsigned grid; long long splits; bool k128;
     int rc = plan(N, Ho, Wo, C, K, dy_pad, a, grid, splits, k128);
     if (rc != KP_OK) return rc;
-    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.scratch = scratch;
+    a.x = (const h16_t*)x; a.dy = (const h16_t*)dy; a.scratch = scratch;
     a.partial_stride = (long long)K * 9 * C;
     { extern int g_kp_debug; extern long long* g_kp_trace; a.dbg = g_kp_debug; a.trace = g_kp_trace; }
     if (k128 && a.trace) wgrad3x3_patch_k<128, 64, true><<<grid, TPB, 0, st>>>(a);

@@ -6,6 +6,8 @@ the C ABI (include/kp_hip.h).  Inputs must live on a HIP device.
     gaussian_like_function                -> functional.py:56-63
     point_map                             -> functional.py:66-72
     transport_max                         -> transporter.py:57-60 (combine_method='max')
+    keypoint_bottleneck                   -> all of the above for both branches of TransporterNet.forward
+                                             (transporter.py:27-32,57-60) in one launch per direction
 """
 from __future__ import annotations
 
@@ -124,3 +126,115 @@ class _TransportMax(torch.autograd.Function):
 def transport_max(phi_s, phi_t, m_s, m_t):
     """phi_s*(1-max_k m_s)*(1-max_k m_t) + phi_t*max_k m_t -> (phi, mask_s, mask_t)."""
     return _TransportMax.apply(phi_s, phi_t, m_s, m_t)
+
+
+class _TransportMode(torch.autograd.Function):
+    """kp_transport_fwd / _bwd: 'sum_and_clamp', 'pretrained_network' and 'loop' (transporter.py:41-55)."""
+
+    @staticmethod
+    def forward(ctx, phi_s, phi_t, m_s, m_t, mode):
+        from .._lib import COMBINE
+        require_device(phi_s, phi_t, m_s, m_t)
+        phi_s, phi_t, m_s, m_t = (f32c(t) for t in (phi_s, phi_t, m_s, m_t))
+        B, C, H, W = phi_s.shape
+        K = m_s.shape[1]
+        if m_s.shape != (B, K, H, W) or m_t.shape != m_s.shape or phi_t.shape != phi_s.shape:
+            raise RuntimeError('transport: feature maps and keypoint maps must share batch and spatial size')
+        phi = torch.empty_like(phi_s)
+        mask_s = torch.empty(B, 1, H, W, device=phi_s.device, dtype=torch.float32)
+        mask_t = torch.empty(B, 1, H, W, device=phi_s.device, dtype=torch.float32)
+        call('kp_transport_fwd', COMBINE[mode], ptr(phi_s), ptr(phi_t), ptr(m_s), ptr(m_t), ptr(phi), ptr(mask_s),
+             ptr(mask_t), B, C, K, H, W, stream_ptr())
+        ctx.save_for_backward(phi_s, phi_t, m_s, m_t)
+        ctx.mode = COMBINE[mode]
+        ctx.mark_non_differentiable(mask_s, mask_t)
+        return phi, mask_s, mask_t
+
+    @staticmethod
+    def backward(ctx, gphi, _gs, _gt):
+        phi_s, phi_t, m_s, m_t = ctx.saved_tensors
+        B, C, H, W = phi_s.shape
+        K = m_s.shape[1]
+        need = ctx.needs_input_grad
+        d_phi_s = torch.empty_like(phi_s) if need[0] else None
+        d_phi_t = torch.empty_like(phi_t) if need[1] else None
+        d_m_s = torch.empty_like(m_s) if need[2] else None
+        d_m_t = torch.empty_like(m_t) if need[3] else None
+        call('kp_transport_bwd', ctx.mode, ptr(f32c(gphi)), ptr(phi_s), ptr(phi_t), ptr(m_s), ptr(m_t), ptr(d_phi_s),
+             ptr(d_phi_t), ptr(d_m_s), ptr(d_m_t), B, C, K, H, W, stream_ptr())
+        return d_phi_s, d_phi_t, d_m_s, d_m_t, None
+
+
+def transport(phi_s, phi_t, m_s, m_t, mode):
+    """TransporterNet.forward's combine step (transporter.py:41-60) for any `combine_method`
+    -> (phi, mask_s, mask_t); gradients flow to all four inputs that require them."""
+    if mode == 'max':
+        return _TransportMax.apply(phi_s, phi_t, m_s, m_t)
+    if mode not in ('sum_and_clamp', 'pretrained_network', 'loop'):
+        raise ValueError(f'unknown combine_method {mode!r}')
+    return _TransportMode.apply(phi_s, phi_t, m_s, m_t, mode)
+
+
+class _KeypointBottleneck(torch.autograd.Function):
+    """kp_keypoint_bottleneck_fwd / _bwd: both branches' spacial_logsoftmax + gaussian_like_function + the 'max'
+    blend as one kernel; the source branch carries no gradient (transporter.py:36-37)."""
+
+    @staticmethod
+    def forward(ctx, heat_s, heat_t, phi_s, phi_t, sigma, eps):
+        require_device(heat_s, heat_t, phi_s, phi_t)
+        heat_s, heat_t, phi_s, phi_t = (f32c(t) for t in (heat_s, heat_t, phi_s, phi_t))
+        B, C, H, W = phi_t.shape
+        K = heat_t.shape[1]
+        if heat_t.shape != (B, K, H, W) or heat_s.shape != heat_t.shape or phi_s.shape != phi_t.shape:
+            raise RuntimeError('keypoint_bottleneck: heat-maps and feature maps must share batch and spatial size')
+        dev = phi_t.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        k = torch.empty(B, K, 2, **f32)
+        p = torch.empty(B, K, H, **f32)
+        q = torch.empty(B, K, W, **f32)
+        m = torch.empty(B, K, H, W, **f32)
+        phi = torch.empty_like(phi_t)
+        mask_s = torch.empty(B, 1, H, W, **f32)
+        mask_t = torch.empty(B, 1, H, W, **f32)
+        arg_t = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
+        call('kp_keypoint_bottleneck_fwd', ptr(heat_s), ptr(heat_t), ptr(phi_s), ptr(phi_t), ptr(k), ptr(p), ptr(q),
+             ptr(m), ptr(phi), ptr(mask_s), ptr(mask_t), ptr(arg_t), B, C, K, H, W, float(sigma), float(eps), stream_ptr())
+        ctx.save_for_backward(phi_s, phi_t, mask_s, mask_t, arg_t, k, p, q)
+        ctx.args = (float(sigma), float(eps))
+        ctx.mark_non_differentiable(p, q, mask_s, mask_t)
+        ctx.set_materialize_grads(False)
+        return phi, k, p, q, m, mask_s, mask_t
+
+    @staticmethod
+    def backward(ctx, gphi, gk, _gp, _gq, gm, _gs, _gt):
+        phi_s, phi_t, mask_s, mask_t, arg_t, k, p, q = ctx.saved_tensors
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            raise NotImplementedError('keypoint_bottleneck: the source branch carries no gradient (transporter.py:36-37); '
+                                      'compose spacial_logsoftmax / gaussian_like_function / transport_max instead')
+        B, C, H, W = phi_t.shape
+        K = k.shape[1]
+        sigma, eps = ctx.args
+        if gphi is None:
+            gphi = torch.zeros_like(phi_t)
+        d_phi_t = torch.empty_like(phi_t)
+        d_heat = torch.empty(B, K, H, W, device=phi_t.device, dtype=torch.float32)
+        call('kp_keypoint_bottleneck_bwd', ptr(f32c(gphi)), ptr(f32c(gk)) if gk is not None else None,
+             ptr(f32c(gm)) if gm is not None else None, ptr(phi_s), ptr(phi_t), ptr(mask_s), ptr(mask_t), ptr(arg_t),
+             ptr(k), ptr(p), ptr(q), ptr(d_phi_t), ptr(d_heat), B, C, K, H, W, sigma, eps, stream_ptr())
+        return None, d_heat, None, d_phi_t, None, None
+
+
+def keypoint_bottleneck(heat_s, heat_t, phi_s, phi_t, sigma=0.1, eps=1e-6):
+    """-> (phi, k_t, (p_t, q_t), m_t, mask_s, mask_t): TransporterNet.forward between the encoders and the decoder
+    for combine_method='max' (transporter.py:27-32,57-60), one launch forward, one backward."""
+    phi, k, p, q, m, mask_s, mask_t = _KeypointBottleneck.apply(heat_s, heat_t, phi_s, phi_t, sigma, eps)
+    return phi, k, (p, q), m, mask_s, mask_t
+
+
+def bottleneck_fusable(H, W, C):
+    """Shapes the fused kernels take (include/kp_hip.h): everything else composes the piecewise kernels."""
+    if H > 256 or W > 256:
+        return False
+    nq = (H * W) // 4 if (H * W) % 4 == 0 else H * W
+    G = min(C, max(1, 1024 // max(1, nq)))
+    return G * H * W <= 16384

@@ -39,7 +39,10 @@ class Container(nn.Module):
         raise NotImplementedError()
 
     def set_precision(self, precision):
-        """'fp32' (strict parity, apex O0) or 'bf16' (mixed precision, fp32 master weights; the O2 role)."""
+        """'fp32' (strict parity, apex O0), 'bf16' or 'fp16' (mixed precision, fp32 master weights; the O2 role --
+        'fp16' is the reference's own type and wants loss scaling: keypoints_amd.amp.scale_loss)."""
+        from ..runtime import precision_dtype
+        precision_dtype(precision)   # raises KeyError on an unknown name
         for m in self.modules():
             if isinstance(m, Unit):
                 m.precision = precision

@@ -26,30 +26,35 @@ class TransporterNet(knn.Container):
         m = self.key2map(k, height=phi.size(2), width=phi.size(3))
         return phi, heatmap, k, p, m
 
+    def _fused_bottleneck_ok(self, phi):
+        return (self.combine_method == 'max' and type(self.ssm) is knn.SpatialLogSoftmax
+                and type(self.key2map) is knn.GaussianLike
+                and MF.bottleneck_fusable(phi.size(2), phi.size(3), phi.size(1)))
+
     def forward(self, xs, xt):
         with shared_packs():   # both branches run on the same weights: pack them once
             with torch.no_grad():   # source branch carries no gradient (transporter.py:36-37)
-                phi_xs, _, _, _, m_xs = self.extract(xs)
-            phi_xt, heatmap_xt, k_xt, p_xt, m_xt = self.extract(xt)
+                phi_xs = self.feature(xs)
+                heatmap_xs = self.keypoint(xs)
+            phi_xt = self.feature(xt)
+            heatmap_xt = self.keypoint(xt)
 
-        mode = self.combine_method
-        if mode == 'max':
-            phi, mask_xs, mask_xt = MF.transport_max(phi_xs, phi_xt, m_xs, m_xt)
-        elif mode == 'sum_and_clamp':
-            mask_xs = m_xs.sum(dim=1, keepdim=True).clamp(0.0, 1.0)
-            mask_xt = m_xt.sum(dim=1, keepdim=True).clamp(0.0, 1.0)
-            phi = phi_xs * (1 - mask_xs) * (1 - mask_xt) + phi_xt * mask_xt
-        elif mode == 'pretrained_network':
-            mask_xs, mask_xt = m_xs, m_xt
-            phi = phi_xs * (1 - mask_xs) * (1 - mask_xt) + phi_xt * mask_xt
-        elif mode == 'loop':
-            phi = phi_xs
-            for i in range(k_xt.size(1)):
-                mask_xs, mask_xt = m_xs[:, i:i + 1], m_xt[:, i:i + 1]
-                phi = phi * (1 - mask_xs) * (1 - mask_xt) + phi_xt * mask_xt
-        else:
-            raise ValueError(f'unknown combine_method {mode!r}')
+        if self._fused_bottleneck_ok(phi_xt):
+            # ssm + key2map of both branches and the 'max' blend: one kernel forward, one backward
+            phi, k_xt, p_xt, m_xt, mask_xs, mask_xt = MF.keypoint_bottleneck(
+                heatmap_xs, heatmap_xt, phi_xs, phi_xt, sigma=self.key2map.sigma)
+            x_t = self.decoder(phi)
+            return x_t, phi, k_xt, m_xt, p_xt, heatmap_xt, mask_xs, mask_xt
 
+        with torch.no_grad():
+            k_xs, _ = self.ssm(heatmap_xs, probs=True)
+            m_xs = self.key2map(k_xs, height=phi_xs.size(2), width=phi_xs.size(3))
+        k_xt, p_xt = self.ssm(heatmap_xt, probs=True)
+        m_xt = self.key2map(k_xt, height=phi_xt.size(2), width=phi_xt.size(3))
+
+        # 'max' on shapes the fused kernel does not take, and the three other combine modes: one blend kernel each
+        # way (kp_transport_max_* / kp_transport_*), forward and backward
+        phi, mask_xs, mask_xt = MF.transport(phi_xs, phi_xt, m_xs, m_xt, self.combine_method)
         x_t = self.decoder(phi)
         return x_t, phi, k_xt, m_xt, p_xt, heatmap_xt, mask_xs, mask_xt
 
@@ -99,16 +104,36 @@ class TransporterMap(knn.Container):
         self.map.save(directory + '/map')
 
 
+def make_mapper(keypoints, model_type='MAPPER', load=None):
+    """The keypoint-map -> mask network that mapper.py:50-52 trains: Unit(keypoints -> 1) over vgg_cfg[model_type],
+    wrapped as TransporterMap (checkpoint layout `<dir>/map/*.mdl`)."""
+    mapper = TransporterMap(knn.Unit(keypoints, 1, vgg.make_layers(vgg.vgg_cfg[model_type])), init_weights=load is None)
+    if load is not None:
+        mapper.load(load)
+    return mapper
+
+
 def make(type, in_channels, z_channels, keypoints, combine_mode='max', load=None, transfer_load=None,
-         map_device=None):
+         map_device=None, mapper_load=None, mapper_type='MAPPER'):
     """Same wiring and construction order as transporter.py:112-138 (so one torch seed gives the
-    same initial weights as the reference): LeakyReLU encoder / keypoint cores, ReLU decoder core."""
+    same initial weights as the reference): LeakyReLU encoder / keypoint cores, ReLU decoder core.
+
+    combine_mode='pretrained_network' wires what the reference defines but never connects (MaskMaker,
+    transporter.py:83-92 + the mapper of mapper.py:50-52): key2map = MaskMaker(pretrained mapper) turns the keypoints
+    into ONE mask channel through point_map and the frozen mapper network; `mapper_load` names its checkpoint
+    directory (None: a freshly initialised mapper, for tests).  Built after the three Units, so the seed-for-seed
+    weight reproduction of the reference's construction order is unaffected."""
     leaky = dict(nonlinearity=nn.LeakyReLU, nonlinearity_kwargs={'inplace': True})
     encoder = knn.Unit(in_channels, z_channels, vgg.make_layers(vgg.vgg_cfg[type], **leaky))
     decoder = knn.Unit(z_channels, in_channels, vgg.make_layers(vgg.decoder_cfg[type]))
     keypoint = knn.Unit(in_channels, keypoints, vgg.make_layers(vgg.vgg_cfg[type], **leaky))
     net = TransporterNet(encoder, keypoint, knn.GaussianLike(sigma=0.1), decoder, init_weights=True,
                          combine_method=combine_mode)
+    if combine_mode == 'pretrained_network':
+        mapper = make_mapper(keypoints, mapper_type, mapper_load)
+        for p in mapper.parameters():
+            p.requires_grad_(False)
+        net.key2map = MaskMaker(mapper.eval())
     if load is not None:
         net.load(load, map_device)
     if transfer_load is not None:

@@ -58,6 +58,7 @@ class FusedAdam:
         self._units = []
         self._loose = []
         self._state = {}
+        self.scaler = None   # keypoints_amd.amp.LossScaler for the fp16 mode (amp.initialize attaches it)
         if modules is not None:
             self.bind(modules)
 
@@ -108,14 +109,24 @@ class FusedAdam:
         b1, b2 = self.betas
         bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
         st = stream_ptr()
-        for m, flat, em, ev in self._units:
-            g = m.grad_arena().flat
-            call('kp_adam_step', ptr(flat), ptr(g), ptr(em), ptr(ev), flat.numel(), self.lr, b1, b2, self.eps, bc1, bc2, st)
+        work = [(flat, m.grad_arena().flat, em, ev) for m, flat, em, ev in self._units]
         for p in self._loose:
             if p.grad is None:
                 continue
             require_device(p)
             stt = self._state.setdefault(id(p), (torch.zeros_like(p.data), torch.zeros_like(p.data)))
-            g = f32c(p.grad)
-            call('kp_adam_step', ptr(p.data), ptr(g), ptr(stt[0]), ptr(stt[1]), p.numel(), self.lr, b1, b2, self.eps,
-                 bc1, bc2, st)
+            work.append((p.data, f32c(p.grad), stt[0], stt[1]))
+        if self.scaler is None:
+            for w, g, em, ev in work:
+                call('kp_adam_step', ptr(w), ptr(g), ptr(em), ptr(ev), w.numel(), self.lr, b1, b2, self.eps, bc1, bc2, st)
+            return
+        # fp16 mode: gradients carry the loss scale.  Flag inf / nan anywhere, then every arena either takes the
+        # un-scaled Adam update or (overflow) is left alone, then the scale adapts -- all on the device, no host read.
+        sc = self.scaler
+        for w, g, em, ev in work:
+            call('kp_amp_check', ptr(g), g.numel(), ptr(sc.state), st)
+        call('kp_amp_prepare', ptr(sc.state), b1, b2, st)
+        for w, g, em, ev in work:
+            call('kp_adam_step_scaled', ptr(w), ptr(g), ptr(em), ptr(ev), w.numel(), self.lr, b1, b2, self.eps,
+                 ptr(sc.state), st)
+        call('kp_amp_update', ptr(sc.state), sc.growth_factor, sc.backoff_factor, sc.growth_interval, sc.max_scale, st)

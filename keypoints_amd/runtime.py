@@ -5,10 +5,11 @@ import torch
 
 from . import _lib
 
-_DTYPES = {'fp32': (torch.float32, _lib.KP_F32), 'bf16': (torch.bfloat16, _lib.KP_BF16)}
+_DTYPES = {'fp32': (torch.float32, _lib.KP_F32), 'bf16': (torch.bfloat16, _lib.KP_BF16), 'fp16': (torch.float16, _lib.KP_F16)}
 
-# storage type of activations / packed weights inside Units; fp32 = strict-parity mode
-# (apex opt_level O0), bf16 = mixed precision with fp32 master weights (the O2 role).
+# storage type of activations / packed weights inside Units; fp32 = strict-parity mode (apex opt_level O0);
+# bf16 / fp16 = mixed precision with fp32 master weights (the O2 role).  fp16 is the reference's own 16-bit type
+# (3 more mantissa bits than bf16: 8x tighter parity) and, like there, is trained with loss scaling (keypoints_amd.amp).
 _default_precision = 'fp32'
 
 

@@ -156,7 +156,7 @@ class UnitFunction(torch.autograd.Function):
         # An odd input width (KeyNet decoder: z + K = 74 channels, keynet.py:55) is zero-padded to a multiple of 64
         # so that the bf16 MFMA kernels take the first layer; its weights are zero-padded to match.
         Cp0 = Cin
-        if (first['kind'] == 'conv3' and unit.precision == 'bf16' and Cin > 4 and Cin % 64 != 0 and Cin not in (16, 32)
+        if (first['kind'] == 'conv3' and unit.precision in ('bf16', 'fp16') and Cin > 4 and Cin % 64 != 0 and Cin not in (16, 32)
                 and first['conv'].out_channels % 64 == 0):   # (16 / 32 channels have their own kernels)
             Cp0 = (Cin + 63) // 64 * 64
         a = torch.empty(N, H + 2 * pad0, W + 2 * pad0, Cp0, device=dev, dtype=tdt)

@@ -92,6 +92,12 @@ def bf16_storage(t: Tensor) -> Tensor:
     return t + (t.detach().to(torch.bfloat16).to(t.dtype) - t.detach())
 
 
+def fp16_storage(t: Tensor) -> Tensor:
+    """Straight-through IEEE-half rounding: the same emulation for the HIP path's precision 'fp16' (the reference's own
+    apex-O2 storage type)."""
+    return t + (t.detach().to(torch.float16).to(t.dtype) - t.detach())
+
+
 def unit_forward(plan: List[dict], P: Params, prefix: str, x: Tensor,
                  buffers: Optional[Params] = None, training: bool = True, quant=None) -> Tensor:
     """`knn.Unit.forward` (knn.py:127-130) on the CPU.

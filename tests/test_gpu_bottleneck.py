@@ -81,8 +81,12 @@ def test_combine_modes_in_net(golden, mode):
     t = {n: torch.tensor(z[n], device='cuda') for n in ('phi_s', 'phi_t', 'm_s', 'm_t')}
     ms, mt = (t['m_s'], t['m_t']) if mode != 'pretrained_network' else (t['m_s'][:, :1], t['m_t'][:, :1])
     k = torch.zeros(2, 5, 2, device='cuda')
-    seq = iter([(t['phi_s'], None, k, None, ms), (t['phi_t'], None, k, None, mt)])
-    net.extract = lambda x: next(seq)
+    # stand-ins for the sub-networks: feature / keypoint return the stored tensors, key2map the stored maps
+    feats, maps = iter([t['phi_s'], t['phi_t']]), iter([ms, mt])
+    net.feature = lambda x: next(feats)
+    net.keypoint = lambda x: torch.zeros(2, 5, 8, 8, device='cuda')
+    net.ssm = lambda h, probs=False: (k, None)
+    net.key2map = lambda kk, height, width: next(maps)
     res = net.forward(None, None)
     close(res[1], z[f'{mode}.phi']); close(res[6], z[f'{mode}.mask_s']); close(res[7], z[f'{mode}.mask_t'])
 

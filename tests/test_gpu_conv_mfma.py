@@ -259,38 +259,53 @@ def test_conv_full_size_against_gpu_fp32(C, K, H):
     w = (torch.randn(K, 3, 3, C, device='cuda', generator=g) * (2.0 / (9 * C)) ** 0.5).bfloat16()
     bias = torch.randn(K, device='cuda', generator=g)
     st = stream_ptr()
-    y = torch.empty(N, H, H, K, device='cuda', dtype=torch.bfloat16)
-    stats = torch.empty(N * H * H // 64, 2, K, device='cuda')
+    # every output buffer starts as NaN: a tile the persistent scheduler skips, or writes twice wrongly, cannot pass
+    y = torch.full((N, H, H, K), float('nan'), device='cuda', dtype=torch.bfloat16)
+    stats = torch.full((N * H * H // 64, 2, K), float('nan'), device='cuda')
     call('kp_conv_fwd', ptr(x), ptr(w), ptr(bias), ptr(y), ptr(stats), N, H + 2, H + 2, C, K, 3, _lib.KP_BF16, st)
     rows = _lib.last_rows()
     xf, wf = x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2)
     ref = F.conv2d(xf, wf, bias).permute(0, 2, 3, 1)
     got = y.float()
     assert torch.isfinite(got).all()
-    assert ((got - ref).abs() <= 2 ** -7 * ref.abs() + 2e-3).float().mean().item() > 0.9995
+    # ALL elements within one bf16 ulp (2^-7 relative) of the fp32 result + fp32 summation-order noise; 99.95 % within
+    # half an ulp (the rest are sums that land on the other side of a rounding boundary)
+    err = (got - ref).abs()
+    assert float((err - (2 ** -7 * ref.abs() + 2e-4)).max()) <= 0, float(err.max())
+    assert (err <= 2 ** -8 * ref.abs() + 2e-4).float().mean().item() > 0.9995
+    # BatchNorm sums per channel: one missing 16x16 tile shifts sum(y^2) by ~256 * E[y^2] = 1.2e-4 of the total
     s = stats[:rows].double().sum(0)
+    assert torch.isfinite(s).all()
     flat = ref.double().reshape(-1, K)
-    assert (s[0] - flat.sum(0)).abs().max().item() <= 1e-3 * flat.abs().sum(0).max().item()
-    assert (s[1] - (flat ** 2).sum(0)).abs().max().item() <= 1e-3 * (flat ** 2).sum(0).max().item()
-    del ref, got, flat
+    assert float(((s[0] - flat.sum(0)).abs() / flat.abs().sum(0)).max()) <= 2e-5
+    assert float(((s[1] - (flat ** 2).sum(0)).abs() / (flat ** 2).sum(0)).max()) <= 2e-5
+    del ref, got, flat, err
     # backward: dy with a zero border of 2
     dyi = torch.randn(N, H, H, K, device='cuda', generator=g).bfloat16()
     dy = torch.zeros(N, H + 4, H + 4, K, device='cuda', dtype=torch.bfloat16)
     dy[:, 2:-2, 2:-2] = dyi
     wd = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()            # [C][3][3][K], rotated by 180 degrees
-    gx = torch.empty(N, H + 2, H + 2, C, device='cuda', dtype=torch.bfloat16)
+    gx = torch.full((N, H + 2, H + 2, C), float('nan'), device='cuda', dtype=torch.bfloat16)
     call('kp_conv_dgrad', ptr(dy), ptr(wd), ptr(gx), N, H, H, K, C, _lib.KP_BF16, st)
-    gref = torch.nn.grad.conv2d_input(xf.shape, wf, dyi.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    # gradient over the PADDED input domain = full correlation of dy with the rotated weights
+    gref = torch.nn.grad.conv2d_input((N, C, H + 2, H + 2), wf, dyi.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
     gg = gx.float()
-    assert ((gg - gref).abs() <= 2 ** -7 * gref.abs() + 2e-3).float().mean().item() > 0.9995
-    del gref, gg
+    assert torch.isfinite(gg).all()
+    err = (gg - gref).abs()
+    assert float((err - (2 ** -7 * gref.abs() + 2e-4)).max()) <= 0, float(err.max())
+    assert (err <= 2 ** -8 * gref.abs() + 2e-4).float().mean().item() > 0.9995
+    del gref, gg, err
     parts = _lib.lib().kp_conv_wgrad_partials(N, H, H, C, K, 3, 2, _lib.KP_BF16)
-    scratch = torch.zeros(parts, K, 3, 3, C, device='cuda') if parts == 1 else torch.empty(parts, K, 3, 3, C, device='cuda')
+    scratch = torch.zeros(parts, K, 3, 3, C, device='cuda') if parts == 1 else \
+        torch.full((parts, K, 3, 3, C), float('nan'), device='cuda')
     call('kp_conv_wgrad', ptr(x), ptr(dy), ptr(scratch), N, H, H, C, K, 3, 2, _lib.KP_BF16, st)
     dw = torch.zeros(K, C, 3, 3, device='cuda')
     call('kp_wgrad_unpack', ptr(scratch), parts, ptr(dw), K, C, C, 3, st)
     wref = torch.nn.grad.conv2d_weight(xf, wf.shape, dyi.float().permute(0, 3, 1, 2))
+    assert torch.isfinite(dw).all()
     assert ((dw - wref).norm() / wref.norm()).item() < 2e-4
+    # every entry: a pixel block dropped from one (k, c) pair moves that entry by ~1/sqrt(blocks) of its size
+    assert float((dw - wref).abs().max()) <= 2e-3 * float(wref.abs().max())
 
 
 def test_first_layer_full_size_against_gpu_fp32():

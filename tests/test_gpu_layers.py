@@ -15,7 +15,7 @@ def relerr(a, b):
     return np.abs(a - b).max() / max(1e-12, np.abs(b).max())
 
 
-@pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('bf16', 3e-2)])
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('bf16', 3e-2), ('fp16', 4e-3)])
 @pytest.mark.parametrize('tag,cin,cout,tail,slope', [('in3', 3, 64, None, 0.01), ('c64', 32, 64, 'M', 0.01),
                                                       ('dec', 32, 16, 'U', 0.0), ('odd', 5, 7, None, 0.01)])
 def test_block_against_golden(golden, tag, cin, cout, tail, slope, precision, tol):
@@ -93,7 +93,10 @@ def test_block_against_golden(golden, tag, cin, cout, tail, slope, precision, to
     call('kp_conv_fwd', ptr(dy), ptr(wd), None, ptr(gx), None, N, H + 4, W + 4, K, C, 3, code, st)
     dx = torch.empty(N, C, H, W, device=dev)
     call('kp_nhwc_grad_to_nchw', ptr(gx), ptr(dx), N, C, C, H, W, 1, code, st)
-    gt = tol * 5
+    # gradient sums of this 512-pixel block: in the 16-bit modes one pre-activation that crosses LeakyReLU's kink (or one
+    # max-pool window that resolves differently) under the storage rounding of y moves a per-channel sum by several
+    # per cent, whatever the mantissa width -- the bound there is for such single flips, not for rounding
+    gt = tol * 5 if precision == 'fp32' else 0.15
     assert relerr(dgamma, z[f'{tag}.dgamma']) < gt and relerr(dbeta, z[f'{tag}.dbeta']) < gt
     assert relerr(dw, z[f'{tag}.dweight']) < gt
     assert relerr(dx, z[f'{tag}.dx']) < gt
@@ -101,7 +104,7 @@ def test_block_against_golden(golden, tag, cin, cout, tail, slope, precision, to
     assert np.abs(z[f'{tag}.dbias']).max() < 1e-4 * np.abs(z[f'{tag}.dweight']).max() + 1e-5
 
 
-@pytest.mark.parametrize('precision,tol', [('fp32', 1e-5), ('bf16', 2e-2)])
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-5), ('bf16', 2e-2), ('fp16', 2.5e-3)])
 def test_head_against_golden(golden, precision, tol):
     from keypoints_amd._lib import call, ptr
     from keypoints_amd.runtime import precision_dtype, stream_ptr
@@ -122,8 +125,20 @@ def test_head_against_golden(golden, precision, tol):
     dxn = torch.empty(N, H, W, C, device=dev, dtype=tdt)
     dw = torch.zeros(K, C, device=dev); db = torch.zeros(K, device=dev)
     call('kp_head_bwd', ptr(gout), ptr(out), ptr(a), ptr(wt), 0.01, ptr(dxn), ptr(dw), ptr(db), N, H, W, C, K, code, st)
-    assert relerr(dxn.float().permute(0, 3, 1, 2), z['head.dx']) < tol
-    assert relerr(dw.view(K, C, 1, 1), z['head.dweight']) < tol and relerr(db, z['head.dbias']) < tol
+    if precision == 'fp32':
+        ref_dx, ref_dw, ref_db = z['head.dx'], z['head.dweight'], z['head.dbias']
+    else:
+        # 16-bit storage of x moves pre-activations that sit within rounding of 0 across LeakyReLU's kink (the golden
+        # data has one at 1e-6): the gradient there legitimately switches between slope and 1.  The backward is
+        # therefore judged against torch autograd on the SAME rounded activation (kernel arithmetic, not the kink).
+        af = a.float().permute(0, 3, 1, 2).requires_grad_(True)
+        wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        yr = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(af, wr, br), 0.01)
+        assert relerr(out, yr.detach().cpu().numpy()) < 1e-5
+        yr.backward(gout)
+        ref_dx, ref_dw, ref_db = af.grad.cpu().numpy(), wr.grad.cpu().numpy(), br.grad.cpu().numpy()
+    assert relerr(dxn.float().permute(0, 3, 1, 2), ref_dx) < tol
+    assert relerr(dw.view(K, C, 1, 1), ref_dw) < tol and relerr(db, ref_db) < tol
 
 
 @pytest.mark.parametrize('N,H,W,C,K', [(2, 16, 16, 64, 3), (1, 8, 8, 512, 10), (3, 5, 7, 16, 1), (2, 32, 32, 128, 16),
