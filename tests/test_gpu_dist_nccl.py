@@ -1,0 +1,88 @@
+"""The data-parallel reducer over RCCL (torch.distributed backend 'nccl') on the one GPU a test box has: world size 1,
+but the real code path -- RCCL communicator, async all-reduce pieces on RCCL's stream launched from the backward hooks of a
+real Transporter backward, finish() joining them before Adam (keypoints_amd/dist.py).  World-size-2 semantics (averaging,
+piece bookkeeping, bf16 transport, no_sync, checkpoint broadcast) are covered on CPU over gloo (tests/test_dist_gloo.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.fixture()
+def nccl_world1():
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    yield
+    dist.destroy_process_group()
+
+
+def _step(net, opt, xs, xt, reducer=None):
+    import keypoints_amd as ka
+    opt.zero_grad()
+    loss = ka.l2_reconstruction_loss(net(xs, xt)[0], xt)
+    loss.backward()
+    issued = None
+    if reducer is not None:
+        issued = reducer.pieces_issued
+        reducer.finish()
+    opt.step()
+    return loss, issued
+
+
+@pytest.mark.parametrize('transport', ['fp32', 'bf16'])
+def test_grad_reducer_nccl_world1_real_backward(nccl_world1, transport):
+    import keypoints_amd as ka
+    from keypoints_amd.dist import GradReducer
+    from keypoints_amd.models import transporter
+    g = torch.Generator().manual_seed(3)
+    xs = torch.rand(8, 3, 128, 128, generator=g).cuda()
+    xt = torch.rand(8, 3, 128, 128, generator=g).cuda()
+    nets = []
+    for with_dp in (False, True):
+        torch.manual_seed(11)
+        net = transporter.make('F', 3, 64, 10).cuda().set_precision('bf16')
+        opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
+        red = GradReducer(net, transport=transport) if with_dp else None
+        if red is not None:
+            assert all(red._split[id(u)] is not None for u in red.units)      # model F: every Unit sends its tail early
+        for _ in range(2):
+            loss, issued = _step(net, opt, xs, xt, red)
+        if red is not None:
+            assert issued == 2 * len(red.units), issued                        # two pieces per Unit, all before finish()
+            assert not red._pending and red.pieces_issued == 0
+            # a second backward into in-flight arenas is refused ...
+            opt.zero_grad()
+            ka.l2_reconstruction_loss(net(xs, xt)[0], xt).backward()
+            with pytest.raises(RuntimeError, match='no_sync'):
+                ka.l2_reconstruction_loss(net(xs, xt)[0], xt).backward()
+            for work, _, _ in red._pending:
+                work.wait()
+            torch.cuda.synchronize()
+            red._pending.clear(); red._early.clear(); red._done.clear(); red.pieces_issued = 0
+            red.detach()
+        nets.append((net, float(loss)))
+    (ref, l0), (dp, l1) = nets
+    if transport == 'fp32':
+        # AVG over one rank is the identity, so the DP step IS the non-DP step -- up to the run-to-run noise of the
+        # step itself: the 1x1 heads accumulate their weight gradient with fp32 atomics (kp_head_*.hip), so two runs of
+        # the same step differ in the last bits of those tensors; the 3x3 layers' gradients are bitwise reproducible.
+        assert abs(l0 - l1) <= 1e-5 * abs(l0)
+        for (n, a), (_, b) in zip(ref.named_parameters(), dp.named_parameters()):
+            assert float((a - b).abs().max()) <= 2.01e-4, n
+        exact = [n for (n, a), (_, b) in zip(ref.named_parameters(), dp.named_parameters()) if torch.equal(a, b)]
+        assert len(exact) >= 0.5 * len(list(ref.parameters())), len(exact)
+    else:                       # gradients went through bf16 on the wire: 2^-9 relative per element
+        assert abs(l0 - l1) <= 1e-3 * abs(l0)
+        for (n, a), (_, b) in zip(ref.named_parameters(), dp.named_parameters()):
+            assert float((a - b).abs().max()) <= 2.01e-4, n          # Adam steps of lr = 1e-4 in the worst case flip sign

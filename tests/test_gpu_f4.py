@@ -97,7 +97,7 @@ def _write_ckpt(z, root):
     for unit in ('encoder', 'decoder'):
         os.makedirs(os.path.join(root, unit), exist_ok=True)
         for blk in ('in_block', 'core', 'out_block'):
-            sd = OrderedDict((k, torch.tensor(z[f'ckpt.{unit}.{blk}.{k}'])) for k in z[f'files.{unit}.{blk}'])
+            sd = OrderedDict((str(k), torch.tensor(z[f'ckpt.{unit}.{blk}.{k}'])) for k in z[f'files.{unit}.{blk}'])
             torch.save(sd, os.path.join(root, unit, blk + '.mdl'))
 
 
@@ -119,7 +119,7 @@ def test_autoencoder_loads_reference_checkpoint_and_transfers(golden, tmp_path):
     for unit in ('encoder', 'decoder'):
         for blk in ('in_block', 'core', 'out_block'):
             sd = torch.load(os.path.join(out, unit, blk + '.mdl'))
-            assert list(sd.keys()) == list(z[f'files.{unit}.{blk}'])
+            assert list(sd.keys()) == [str(k) for k in z[f'files.{unit}.{blk}']]
             for k, v in sd.items():
                 assert np.array_equal(v.cpu().numpy(), z[f'ckpt.{unit}.{blk}.{k}']), (unit, blk, k)
     torch.manual_seed(8)
