@@ -35,7 +35,15 @@ __device__ __forceinline__ float group_sum(float v, int CV) {
     return v;
 }
 
-// KB = compile-time bound on K (4 or 16); CV = C/8 is a power of two <= 64 (checked by the launcher)
+// KB = compile-time bound on K (4 or 16); CV = C/8 is a power of two <= 64 (checked by the launcher).
+// All three kernels keep the thread's weight columns (or accumulators) in registers, are branch-free over k (rows
+// k >= K are zero-padded: a `k < K` test inside the unrolled loop put every strided gout / out load behind its own
+// s_waitcnt, 16 serialised round trips per pixel), issue every load of an iteration before the first use, and walk TWO
+// pixels per iteration.  Pixel indices fit 32 bits (checked by the launcher), so the per-pixel (image, offset) split is a
+// 32-bit division.
+constexpr int PIX = 2;   // pixels in flight per thread
+
+// forward: weights in LDS (the register-resident variant measured slower: 173 VGPRs at KB = 16)
 template <int KB>
 __global__ __launch_bounds__(TPB) void head_fwd_small_k(const h16_t* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float slope,
@@ -74,39 +82,67 @@ __global__ __launch_bounds__(TPB) void head_fwd_small_k(const h16_t* __restrict_
     }
 }
 
+// dz[k] of one pixel: all 2*KB strided loads issued back to back (rows k >= K re-read row K-1 and are zeroed)
+template <int KB>
+__device__ __forceinline__ void load_dz(const float* __restrict__ gout, const float* __restrict__ out, int m, int HW, int K,
+                                        float slope, float (&dz)[KB]) {
+    float g[KB], o[KB];
+    if (m < 0) {
+#pragma unroll
+        for (int k = 0; k < KB; ++k) dz[k] = 0.f;
+        return;
+    }
+    const int n = m / HW, hw = m - n * HW;
+    const long long base = ((long long)n * K) * HW + hw;
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        const long long idx = base + (long long)(k < K ? k : K - 1) * HW;
+        g[k] = gout[idx];
+        o[k] = out[idx];
+    }
+#pragma unroll
+    for (int k = 0; k < KB; ++k) dz[k] = k < K ? g[k] * act_grad(o[k], slope) : 0.f;
+}
+
 template <int KB>
 __global__ __launch_bounds__(TPB) void head_dx_small_k(const float* __restrict__ gout, const float* __restrict__ out,
                                                        const float* __restrict__ w, float slope,
                                                        h16_t* __restrict__ dx, long long M, int HW, int C, int K,
                                                        int ppb) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [K][C]
-    for (int i = threadIdx.x; i < K * C; i += TPB) wl[i] = w[i];
-    __syncthreads();
     const int CV = C / V, cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
-    const long long m0 = (long long)blockIdx.x * ppb;
-    for (int i = pl; i < ppb; i += npl) {
-        const long long m = m0 + i;
-        if (m >= M) break;
-        const long long n = m / HW, hw = m - n * HW;
-        float r[V];
+    float wr[KB][V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) r[e] = 0.f;
+    for (int k = 0; k < KB; ++k)
 #pragma unroll
-        for (int k = 0; k < KB; ++k) {
-            if (k < K) {
-                const long long idx = (n * K + k) * HW + hw;
-                const float dz = gout[idx] * act_grad(out[idx], slope);
-                const float4 w0 = *reinterpret_cast<const float4*>(wl + k * C + cv * V);
-                const float4 w1 = *reinterpret_cast<const float4*>(wl + k * C + cv * V + 4);
-                r[0] = fmaf(dz, w0.x, r[0]); r[1] = fmaf(dz, w0.y, r[1]); r[2] = fmaf(dz, w0.z, r[2]);
-                r[3] = fmaf(dz, w0.w, r[3]); r[4] = fmaf(dz, w1.x, r[4]); r[5] = fmaf(dz, w1.y, r[5]);
-                r[6] = fmaf(dz, w1.z, r[6]); r[7] = fmaf(dz, w1.w, r[7]);
-            }
+        for (int e = 0; e < V; e += 4) {
+            const float4 q = k < K ? *reinterpret_cast<const float4*>(w + k * C + cv * V + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wr[k][e] = q.x; wr[k][e + 1] = q.y; wr[k][e + 2] = q.z; wr[k][e + 3] = q.w;
         }
-        uint4 pk;
-        pk.x = pack_h16x2(r[0], r[1]); pk.y = pack_h16x2(r[2], r[3]);
-        pk.z = pack_h16x2(r[4], r[5]); pk.w = pack_h16x2(r[6], r[7]);
-        *reinterpret_cast<uint4*>(dx + m * C + cv * V) = pk;
+    const int m0 = (int)((long long)blockIdx.x * ppb), Mi = (int)M;
+    for (int i = pl; i < ppb; i += PIX * npl) {
+        float dz[PIX][KB];
+        int m[PIX];
+#pragma unroll
+        for (int u = 0; u < PIX; ++u) {
+            m[u] = m0 + i + u * npl;
+            if (!(i + u * npl < ppb && m[u] < Mi)) m[u] = -1;
+            load_dz<KB>(gout, out, m[u], HW, K, slope, dz[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < PIX; ++u) {
+            if (m[u] < 0) continue;
+            float r[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) r[e] = 0.f;
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+#pragma unroll
+                for (int e = 0; e < V; ++e) r[e] = fmaf(dz[u][k], wr[k][e], r[e]);
+            uint4 pk;
+            pk.x = pack_h16x2(r[0], r[1]); pk.y = pack_h16x2(r[2], r[3]);
+            pk.z = pack_h16x2(r[4], r[5]); pk.w = pack_h16x2(r[6], r[7]);
+            *reinterpret_cast<uint4*>(dx + (long long)m[u] * C + cv * V) = pk;
+        }
     }
 }
 
@@ -124,21 +160,26 @@ __global__ __launch_bounds__(TPB) void head_dw_small_k(const float* __restrict__
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[k][e] = 0.f;
     }
-    const long long m0 = (long long)blockIdx.x * ppb;
-    for (int i = pl; i < ppb; i += npl) {
-        const long long m = m0 + i;
-        if (m >= M) break;
-        const long long n = m / HW, hw = m - n * HW;
-        float xv[V];
-        unpack8(*reinterpret_cast<const uint4*>(x + m * C + cv * V), xv);
+    const int m0 = (int)((long long)blockIdx.x * ppb), Mi = (int)M;
+    for (int i = pl; i < ppb; i += PIX * npl) {
+        float dz[PIX][KB];
+        uint4 raw[PIX];
 #pragma unroll
-        for (int k = 0; k < KB; ++k) {
-            if (k < K) {
-                const long long idx = (n * K + k) * HW + hw;
-                const float dz = gout[idx] * act_grad(out[idx], slope);
-                dbs[k] += dz;
+        for (int u = 0; u < PIX; ++u) {
+            int m = m0 + i + u * npl;
+            if (!(i + u * npl < ppb && m < Mi)) m = -1;
+            raw[u] = m >= 0 ? *reinterpret_cast<const uint4*>(x + (long long)m * C + cv * V) : make_uint4(0, 0, 0, 0);
+            load_dz<KB>(gout, out, m, HW, K, slope, dz[u]);
+        }
 #pragma unroll
-                for (int e = 0; e < V; ++e) acc[k][e] = fmaf(dz, xv[e], acc[k][e]);
+        for (int u = 0; u < PIX; ++u) {
+            float xv[V];
+            unpack8(raw[u], xv);
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                dbs[k] += dz[u][k];
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[k][e] = fmaf(dz[u][k], xv[e], acc[k][e]);
             }
         }
     }
@@ -185,7 +226,7 @@ bool small_shape(int C, int K) {
 
 int kp_head_fwd_fast(const void* x, const float* w, const float* bias, float slope, float* out, long long M, int HW,
                      int C, int K, hipStream_t st) {
-    if (!small_shape(C, K)) return KP_E_UNSUPPORTED;
+    if (!small_shape(C, K) || M >= (1LL << 31)) return KP_E_UNSUPPORTED;
     const int npl = TPB / (C / V), ppb = npl * 8;
     const unsigned grid = (unsigned)((M + ppb - 1) / ppb);
     const size_t lds = (size_t)K * C * sizeof(float);
@@ -195,17 +236,20 @@ int kp_head_fwd_fast(const void* x, const float* w, const float* bias, float slo
 
 int kp_head_dx_fast(const float* gout, const float* out, const float* w, float slope, void* dx, long long M, int HW,
                     int C, int K, hipStream_t st) {
-    if (!small_shape(C, K)) return KP_E_UNSUPPORTED;
-    const int npl = TPB / (C / V), ppb = npl * 8;
+    if (!small_shape(C, K) || M >= (1LL << 31)) return KP_E_UNSUPPORTED;
+    // the register-resident weights are loaded once per thread: 8..32 pixels per thread, at least ~2048 workgroups
+    const int npl = TPB / (C / V);
+    long long per = M / ((long long)npl * 2048);
+    per = per < 8 ? 8 : (per > 32 ? 32 : per);
+    const int ppb = npl * (int)per;
     const unsigned grid = (unsigned)((M + ppb - 1) / ppb);
-    const size_t lds = (size_t)K * C * sizeof(float);
-    KP_HEAD_KB(K, (head_dx_small_k<KB><<<grid, TPB, lds, st>>>(gout, out, w, slope, (h16_t*)dx, M, HW, C, K, ppb)));
+    KP_HEAD_KB(K, (head_dx_small_k<KB><<<grid, TPB, 0, st>>>(gout, out, w, slope, (h16_t*)dx, M, HW, C, K, ppb)));
     return kp_check_launch("head_dx_fast");
 }
 
 int kp_head_dw_fast(const float* gout, const float* out, const void* x, float slope, float* dw, float* db, long long M,
                     int HW, int C, int K, hipStream_t st) {
-    if (!small_shape(C, K)) return KP_E_UNSUPPORTED;
+    if (!small_shape(C, K) || M >= (1LL << 31)) return KP_E_UNSUPPORTED;
     const int npl = TPB / (C / V);
     const size_t lds = ((size_t)npl * 4 * C + (size_t)npl * 4) * sizeof(float);   // KC = 4 channels per reduction pass
     if (lds > 64 * 1024) return KP_E_UNSUPPORTED;
