@@ -7,6 +7,14 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _exact_reference_conv():
+    """The GPU reference convolutions run on torch's native im2col + GEMM path (MIOpen off): exact fp32 arithmetic, and
+    no per-shape kernel search (the MIOpen search alone took 85 s for the 256 -> 128 @ 128x128 reference)."""
+    with torch.backends.cudnn.flags(enabled=False):
+        yield
+
 SHAPES = [  # N, Ho, Wo, C, K, with_stats
     (2, 16, 16, 64, 64, True), (2, 8, 8, 128, 128, True), (1, 32, 32, 64, 256, True),
     (1, 8, 24, 64, 128, True),          # M = 192: masked half tile
