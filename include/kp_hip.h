@@ -44,9 +44,14 @@ extern "C" {
 
 int kp_version(void);
 const char* kp_last_error(void);
-/* Number of leading rows of the partial-sum buffer that the most recent kp_conv_fwd (stats != NULL) or
- * kp_bn_act_bwd_reduce call of this thread wrote.  Only those rows are defined; pass the value on to
- * kp_bn_finalize / kp_bn_bwd_finalize.  It never exceeds the documented buffer size (ceil(N*Ho*Wo/64) and N*H rows). */
+/* How many leading rows of the partial-sum buffer a kp_conv_fwd (stats != NULL) / kp_bn_act_bwd_reduce call of this
+ * shape writes: a pure function of the arguments and the device (the persistent kernels write a few rows per workgroup).
+ * Only those rows are defined; pass the value on to kp_bn_finalize / kp_bn_bwd_finalize.  Never more than the
+ * documented buffer size (ceil(N*Ho*Wo/64) and N*H rows).  Nothing is launched.  < 0: KP_E_*. */
+long long kp_conv_fwd_stats_rows(int N, int Hi, int Wi, int C, int K, int R, int dtype);
+long long kp_bn_bwd_rows(int gp, int tail, int N, int H, int W, int C, int dtype);
+/* Legacy side channel (thread-local): the row count of this thread's most recent statistics-producing call.  Equal to
+ * what the two functions above return for that call's shape; new code should use those. */
 long long kp_last_rows(void);
 /* number of CUs of the current device (for grid sizing by host code) */
 int kp_device_cus(void);

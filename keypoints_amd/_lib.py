@@ -62,7 +62,7 @@ SIGNATURES = {
     'kp_prof_collect': [_i, _p, _p, _p],
     'kp_prof_bytes': [_i, _p],
 }
-PLAIN = {'kp_conv_wgrad_partials': ([_i] * 8, _i), 'kp_last_rows': ([], _ll), 'kp_bn_ws_doubles': ([_i], _i), 'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
+PLAIN = {'kp_conv_wgrad_partials': ([_i] * 8, _i), 'kp_conv_fwd_stats_rows': ([_i] * 7, _ll), 'kp_bn_bwd_rows': ([_i] * 7, _ll), 'kp_last_rows': ([], _ll), 'kp_bn_ws_doubles': ([_i], _i), 'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
 
 _lib = None
 

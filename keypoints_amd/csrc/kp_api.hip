@@ -13,6 +13,9 @@ int kp_bottleneck_fused_bwd(const float*, const float*, const float*, const floa
 static thread_local char g_err[512] = "";
 static thread_local long long g_last_rows = 0;
 void kp_set_last_rows(long long r) { g_last_rows = r; }
+static thread_local int g_query = 0;
+int kp_query_mode() { return g_query; }
+void kp_set_query_mode(int on) { g_query = on; }
 long long* g_kp_trace = nullptr;   // kp_config_ptr(KP_CFG_TRACE, dev_ptr): s_memtime trace buffer (512 x i64) or NULL
 int g_kp_wgrad_patch = 1;   // kp_config(KP_CFG_WGRAD_PATCH, v)
 int g_kp_bn_fast = 1;       // kp_config(KP_CFG_BN_FAST, v)
@@ -173,5 +176,23 @@ KP_DISPATCH(kp_head_fwd, (const void* x, const float* w, const float* bias, floa
             (x, w, bias, slope, out, N, H, W, C, K, dtype, stream))
 KP_DISPATCH(kp_head_bwd, (const float* gout, const float* out, const void* x, const float* w, float slope, void* dx, float* dw, float* db, int N, int H, int W, int C, int K, int dtype, void* stream),
             (gout, out, x, w, slope, dx, dw, db, N, H, W, C, K, dtype, stream))
+
+/* Row counts as pure functions of the shape (and the device): the public dispatch runs in query mode -- every launcher
+ * records its row count and returns before launching.  Replaces the kp_last_rows() side channel. */
+long long kp_conv_fwd_stats_rows(int N, int Hi, int Wi, int C, int K, int R, int dtype) {
+    kp_set_query_mode(1);
+    float dummy;   // non-NULL stats: the launchers only look at the pointer's truth value in query mode
+    const int rc = kp_conv_fwd(nullptr, nullptr, nullptr, nullptr, &dummy, N, Hi, Wi, C, K, R, dtype, nullptr);
+    kp_set_query_mode(0);
+    return rc == KP_OK ? kp_last_rows() : (long long)rc;
+}
+
+long long kp_bn_bwd_rows(int gp, int tail, int N, int H, int W, int C, int dtype) {
+    kp_set_query_mode(1);
+    const int rc = kp_bn_act_bwd_reduce(nullptr, gp, tail, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr,
+                                        N, H, W, C, dtype, nullptr);
+    kp_set_query_mode(0);
+    return rc == KP_OK ? kp_last_rows() : (long long)rc;
+}
 
 }  // extern "C"

@@ -586,8 +586,8 @@ int kp_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
 int kp_bn_act_bwd_reduce(const void* gsrc, int gp, int tail, const unsigned char* argmax, const void* y,
                          const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
                          float* partials, int N, int H, int W, int C, int dtype, void* stream) {
-    KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && gp >= 0 && (tail == 0 || tail == 1) && partials, "kp_bn_act_bwd_reduce: bad args");
-    KP_REQUIRE(tail == 0 || argmax != nullptr, "kp_bn_act_bwd_reduce: maxpool needs argmax");
+    KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && gp >= 0 && (tail == 0 || tail == 1) && (partials || kp_query_mode()), "kp_bn_act_bwd_reduce: bad args");
+    KP_REQUIRE(tail == 0 || argmax != nullptr || kp_query_mode(), "kp_bn_act_bwd_reduce: maxpool needs argmax");
     BnP bn{mean, invstd, gamma, beta};
     const unsigned grid = (unsigned)((long long)N * H);
     hipStream_t st = (hipStream_t)stream;
@@ -597,6 +597,7 @@ int kp_bn_act_bwd_reduce(const void* gsrc, int gp, int tail, const unsigned char
         if (rc != KP_E_UNSUPPORTED) return rc;
     }
     kp_set_last_rows((long long)N * H);
+    KP_QUERY_RETURN();
     KP_BN_DISPATCH(dtype, C, (bn_bwd_reduce_k<T, V><<<grid, TPB, (size_t)TPB * 2 * V * sizeof(float), st>>>((const T*)gsrc, gp, tail, argmax, (const T*)y, bn, slope, partials, H, W, C)));
     return kp_check_launch("bn_bwd_reduce");
 }

@@ -721,6 +721,7 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
         const int prpb = rows_per_block(prows, (W / 2) * (C / V) * 4, kp_device_cus());
         const unsigned pgrid = (unsigned)((prows + prpb - 1) / prpb);
         if (mode == 0) kp_set_last_rows(pgrid);
+        KP_QUERY_RETURN();
 #define KP_BWDP(GPv, MODEv)                                                                                               \
     bn_bwd_pool_fast_k<GPv, MODEv><<<pgrid, TPB, 0, st>>>((const h16_t*)gsrc, argmax, (const h16_t*)y, bn, slope, partials, \
                                                          sums, (h16_t*)dy, dp, N, H, W, C, prows, prpb)
@@ -733,6 +734,7 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
     const int rpb = rows_per_block(rows, W * (C / V), kp_device_cus());
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
     if (mode == 0) kp_set_last_rows(grid);
+    KP_QUERY_RETURN();
 #define KP_BWD(POOLv, GPv, MODEv)                                                                                    \
     bn_bwd_fast_k<POOLv, GPv, MODEv><<<grid, TPB, 0, st>>>((const h16_t*)gsrc, argmax, (const h16_t*)y, bn, slope,  \
                                                            partials, sums, (h16_t*)dy, dp, N, H, W, C, rows, rpb)

@@ -124,6 +124,14 @@ __device__ __forceinline__ float ruler_at(int i, int n) {
 void kp_set_error(const char* fmt, ...);
 int kp_check_launch(const char* what);
 void kp_set_last_rows(long long rows);   // see kp_last_rows() in kp_hip.h
+// Query mode (kp_conv_fwd_stats_rows / kp_bn_bwd_rows): the dispatch runs as usual, every launcher records its row count
+// and returns before launching anything.  Thread-local, set and cleared inside ONE public call.
+int kp_query_mode();
+void kp_set_query_mode(int on);
+#define KP_QUERY_RETURN()            \
+    do {                             \
+        if (kp_query_mode()) return KP_OK; \
+    } while (0)
 
 #define KP_REQUIRE(cond, ...)                 \
     do {                                      \

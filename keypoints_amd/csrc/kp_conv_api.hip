@@ -33,7 +33,7 @@ extern "C" {
 
 int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C,
                 int K, int R, int dtype, void* stream) {
-    KP_REQUIRE(x && w && y, "kp_conv_fwd: null pointer");
+    KP_REQUIRE(kp_query_mode() || (x && w && y), "kp_conv_fwd: null pointer");
     KP_REQUIRE(N > 0 && C > 0 && K > 0 && (R == 1 || R == 3) && Hi >= R && Wi >= R, "kp_conv_fwd: bad dims N=%d Hi=%d Wi=%d C=%d K=%d R=%d", N, Hi, Wi, C, K, R);
     KP_REQUIRE(dtype == KP_F32 || dtype == KP_H16, "kp_conv_fwd: bad dtype %d", dtype);
     const double flops = 2.0 * N * (double)(Hi - R + 1) * (Wi - R + 1) * C * K * R * R;

@@ -473,6 +473,7 @@ int kp_conv_first_fwd(const void* x, const void* w, const float* bias, void* y, 
         const int gpw = 8;
         const unsigned grid = (unsigned)((groups + 4 * gpw - 1) / (4 * gpw));
         if (stats) kp_set_last_rows((long long)grid * 4);
+        KP_QUERY_RETURN();
 #define KP_FIRST_FWD_M(CINv)                                                                                       \
     conv3_first_fwd_mfma_k<CINv><<<grid, 256, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, \
                                                        Hi, Wi, groups, gpw)
@@ -484,6 +485,7 @@ int kp_conv_first_fwd(const void* x, const void* w, const float* bias, void* y, 
 #undef KP_FIRST_FWD_M
         return kp_check_launch("conv3_first_fwd_mfma");
     }
+    KP_QUERY_RETURN();   // (statistics rows of the VALU kernel: the per-64-pixel default set by kp_conv_fwd)
     const size_t lds = (size_t)9 * C * K * sizeof(float) + (size_t)4 * 64 * K * 2;
     const unsigned grid = (unsigned)((M + TPB - 1) / TPB);
 #define KP_FIRST_FWD(CINv)                                                                                          \

@@ -191,6 +191,7 @@ __global__ __launch_bounds__(TPB) void conv_wgrad_generic(const T* __restrict__ 
 template <typename T>
 int launch_fwd(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C,
                int K, int R, hipStream_t st) {
+    KP_QUERY_RETURN();
     const long long M = (long long)N * (Hi - R + 1) * (Wi - R + 1);
     dim3 grid(cdiv(M, BM), cdiv(K, BN));
     if (R == 3)

@@ -268,6 +268,7 @@ int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* 
 template <int MODE>
 static int launch_linear(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi,
                          int C, int K, hipStream_t st) {
+    KP_QUERY_RETURN();   // statistics rows of the linear kernel: the per-64-pixel default set by kp_conv_fwd
     const int Ho = Hi - 2, Wo = Wi - 2;
     long long M, mtiles;
     if (MODE == 2) {

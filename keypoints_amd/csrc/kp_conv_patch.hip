@@ -470,6 +470,7 @@ int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* 
     if (grid > need) grid = need;
     a.compact = (stats && ptiles >= grid && ((grid / 8) % a.ktiles) == 0) ? 1 : 0;
     if (stats) kp_set_last_rows(a.compact ? (long long)grid * 4 : ptiles * 4);
+    KP_QUERY_RETURN();
     if ((a.trace || a.dbg) && bn == 128 && stats) conv3x3_patch_k<128, true, true><<<grid, TPB, 0, st>>>(a);
     else if (bn == 128 && stats) conv3x3_patch_k<128, true, false><<<grid, TPB, 0, st>>>(a);
     else if (bn == 128) conv3x3_patch_k<128, false, false><<<grid, TPB, 0, st>>>(a);

@@ -234,6 +234,7 @@ int kp_conv_small_fwd(const void* x, const void* w, const float* bias, void* y, 
     if (stats && blocks * 4 > max_rows) blocks = max_rows / 4;
     if (blocks < 1) { if (stats) return KP_E_UNSUPPORTED; blocks = 1; }
     if (stats) kp_set_last_rows(blocks * 4);
+    KP_QUERY_RETURN();
     if (C == 16)
         conv3x3_small_k<1><<<(unsigned)blocks, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, N, Hi, Wi, K, nseg, spr);
     else

@@ -12,7 +12,7 @@ void kp_prof_event_release(hipEvent_t e);
 
 struct ProfScope {
     bool on; ProfRec r; hipStream_t st;
-    ProfScope(int family, double flops, hipStream_t s, double bytes = 0.0) : on(g_prof_on), st(s) {
+    ProfScope(int family, double flops, hipStream_t s, double bytes = 0.0) : on(g_prof_on && !kp_query_mode()), st(s) {
         if (!on) return;
         r.family = family; r.flops = flops; r.bytes = bytes; r.e0 = kp_prof_event(); r.e1 = kp_prof_event();
         (void)hipEventRecord(r.e0, st);

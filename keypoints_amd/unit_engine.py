@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import call, last_rows, ptr
+from ._lib import call, ptr
 from .runtime import f32c, precision_dtype, require_device, stream_ptr
 
 TAILS = {None: _lib.TAIL_NONE, 'M': _lib.TAIL_MAXPOOL2, 'U': _lib.TAIL_UPSAMPLE2}
@@ -184,6 +184,7 @@ class UnitFunction(torch.autograd.Function):
             training = bn is not None and bn.training
             stats = torch.empty((N * H * W + 63) // 64, 2, K, device=dev, dtype=torch.float32) if training else None
             call('kp_conv_fwd', ptr(a), ptr(wf), ptr(conv.bias), ptr(y), ptr(stats), N, H + 2, W + 2, C, K, 3, code, st)
+            srows = _lib.lib().kp_conv_fwd_stats_rows(N, H + 2, W + 2, C, K, 3, code) if training else 0
             mean = invstd = None
             if bn is not None:
                 if training:
@@ -198,7 +199,7 @@ class UnitFunction(torch.autograd.Function):
                     else:
                         mom = float(bn.momentum)
                     ws = torch.empty(128 * K, device=dev, dtype=torch.float64)
-                    call('kp_bn_finalize', ptr(stats), last_rows(), ptr(ws), ptr(mean), ptr(invstd),
+                    call('kp_bn_finalize', ptr(stats), srows, ptr(ws), ptr(mean), ptr(invstd),
                          ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
                          ptr(bn.num_batches_tracked) if track else None, mom, float(bn.eps), N * H * W, K, st)
                 else:
@@ -280,7 +281,8 @@ class UnitFunction(torch.autograd.Function):
                 dgam, dbet = None, (ptr(gv[id(conv.bias)]) if conv.bias is not None else None)
             sums = torch.empty(2 * K, device=dev, dtype=torch.float32)
             ws = torch.empty(128 * K, device=dev, dtype=torch.float64)
-            call('kp_bn_bwd_finalize', ptr(partials), ptr(ws), last_rows(), K, ptr(sums), dgam, dbet, st)
+            prows = _lib.lib().kp_bn_bwd_rows(gp, tcode, N, H, W, K, code)
+            call('kp_bn_bwd_finalize', ptr(partials), ptr(ws), prows, K, ptr(sums), dgam, dbet, st)
             need_dx = idx > 0 or need_x
             dp = 2 if need_dx else 0
             dy = torch.empty(N, H + 2 * dp, W + 2 * dp, K, device=dev, dtype=tdt)

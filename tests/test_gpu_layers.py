@@ -190,3 +190,38 @@ def test_wgrad_unpack(P, K, Cd, Cp, R):
     call('kp_wgrad_unpack', ptr(sd), P, ptr(dw), K, Cd, Cp, R, stream_ptr())
     err = (dw.double().cpu() - ref).abs().max().item()
     assert err <= 1e-5 * ref.abs().max().item() + 1e-6, err
+
+
+def test_row_count_queries_match_the_launches():
+    """kp_conv_fwd_stats_rows / kp_bn_bwd_rows (pure functions of the shape: nothing launched) return exactly the number
+    of partial-sum rows the corresponding launch writes -- for every kernel family the dispatch can pick (LDS-patch
+    persistent, linear implicit GEMM, first layer MFMA / VALU, small-channel, generic fp32; fast and general BN)."""
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, last_rows, ptr
+    from keypoints_amd.runtime import precision_dtype, stream_ptr
+    L = _lib.lib()
+    st = stream_ptr()
+    for (N, H, W, C, K, prec) in [(4, 32, 32, 64, 128, 'bf16'), (128, 16, 16, 512, 512, 'fp16'), (2, 24, 40, 64, 64, 'bf16'),
+                                   (8, 128, 128, 3, 64, 'bf16'), (2, 20, 20, 3, 64, 'bf16'), (16, 84, 84, 16, 32, 'fp16'),
+                                   (2, 16, 16, 5, 7, 'fp32'), (2, 16, 16, 64, 64, 'fp32')]:
+        tdt, code = precision_dtype(prec)
+        x = torch.randn(N, H + 2, W + 2, C, device='cuda').to(tdt)
+        w = torch.randn(K, 3, 3, C, device='cuda').to(tdt)
+        y = torch.empty(N, H, W, K, device='cuda', dtype=tdt)
+        stats = torch.empty((N * H * W + 63) // 64, 2, K, device='cuda')
+        q = L.kp_conv_fwd_stats_rows(N, H + 2, W + 2, C, K, 3, code)
+        call('kp_conv_fwd', ptr(x), ptr(w), None, ptr(y), ptr(stats), N, H + 2, W + 2, C, K, 3, code, st)
+        assert 0 < q == last_rows() <= stats.shape[0], (N, H, W, C, K, prec, q, last_rows())
+    for (N, H, W, C, tail, gp, prec) in [(8, 32, 32, 128, 0, 1, 'bf16'), (8, 32, 32, 128, 1, 1, 'fp16'), (2, 16, 16, 7, 0, 0, 'fp32'),
+                                          (128, 64, 64, 256, 0, 0, 'bf16'), (3, 8, 8, 512, 1, 0, 'bf16')]:
+        tdt, code = precision_dtype(prec)
+        Hs, Ws = (H // 2, W // 2) if tail else (H, W)
+        g = torch.randn(N, Hs + 2 * gp, Ws + 2 * gp, C, device='cuda').to(tdt)
+        yv = torch.randn(N, H, W, C, device='cuda').to(tdt)
+        am = torch.randint(0, 4, (N, Hs, Ws, C), device='cuda', dtype=torch.uint8) if tail else None
+        vec = [torch.rand(C, device='cuda') + 0.5 for _ in range(4)]
+        partials = torch.empty(N * H, 2, C, device='cuda')
+        q = L.kp_bn_bwd_rows(gp, tail, N, H, W, C, code)
+        call('kp_bn_act_bwd_reduce', ptr(g), gp, tail, ptr(am), ptr(yv), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]),
+             0.01, ptr(partials), N, H, W, C, code, st)
+        assert 0 < q == last_rows() <= N * H, (N, H, W, C, tail, gp, prec, q, last_rows())
