@@ -178,9 +178,13 @@ int kp_upsample2_bwd(const void* gsrc, int gp, void* g, int N, int H, int W, int
 /* x: [N][H][W][C] T (no border); w fp32 [K][C]; out fp32 NCHW [N][K][H][W]. */
 int kp_head_fwd(const void* x, const float* w, const float* bias, float slope, float* out,
                 int N, int H, int W, int C, int K, int dtype, void* stream);
-/* gout/out fp32 NCHW; dx [N][H][W][C] T (may be NULL); dw [K][C] +=, db [K] += (fp32). */
+/* gout/out fp32 NCHW; dx [N][H][W][C] T (may be NULL); dw [K][C] +=, db [K] += (fp32).
+ * ws: fp32 workspace of kp_head_bwd_ws_floats(...) floats (contents irrelevant) -> the weight / bias gradient is reduced
+ * in two stages with a fixed summation order (one partial gradient per workgroup, then their sum): bitwise reproducible.
+ * ws == NULL: one stage with fp32 atomics (faster by a few microseconds, run-to-run differences in the last bits). */
+long long kp_head_bwd_ws_floats(int N, int H, int W, int C, int K, int dtype);
 int kp_head_bwd(const float* gout, const float* out, const void* x, const float* w, float slope,
-                void* dx, float* dw, float* db, int N, int H, int W, int C, int K, int dtype, void* stream);
+                void* dx, float* dw, float* db, float* ws, int N, int H, int W, int C, int K, int dtype, void* stream);
 
 /* ---- keypoint bottleneck (keypoints/models/functional.py) --------------- */
 /* heat fp32 [BK][H][W] -> k [BK][2] (y,x), p [BK][H], q [BK][W].

@@ -174,8 +174,13 @@ KP_DISPATCH(kp_upsample2_bwd, (const void* gsrc, int gp, void* g, int N, int H, 
             (gsrc, gp, g, N, H, W, C, dtype, stream))
 KP_DISPATCH(kp_head_fwd, (const void* x, const float* w, const float* bias, float slope, float* out, int N, int H, int W, int C, int K, int dtype, void* stream),
             (x, w, bias, slope, out, N, H, W, C, K, dtype, stream))
-KP_DISPATCH(kp_head_bwd, (const float* gout, const float* out, const void* x, const float* w, float slope, void* dx, float* dw, float* db, int N, int H, int W, int C, int K, int dtype, void* stream),
-            (gout, out, x, w, slope, dx, dw, db, N, H, W, C, K, dtype, stream))
+KP_DISPATCH(kp_head_bwd, (const float* gout, const float* out, const void* x, const float* w, float slope, void* dx, float* dw, float* db, float* ws, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (gout, out, x, w, slope, dx, dw, db, ws, N, H, W, C, K, dtype, stream))
+long long kp_head_bwd_ws_floats__bf16(int, int, int, int, int, int);
+long long kp_head_bwd_ws_floats__f16(int, int, int, int, int, int);
+long long kp_head_bwd_ws_floats(int N, int H, int W, int C, int K, int dtype) {
+    return dtype == KP_F16 ? kp_head_bwd_ws_floats__f16(N, H, W, C, K, dtype) : kp_head_bwd_ws_floats__bf16(N, H, W, C, K, dtype);
+}
 
 /* Row counts as pure functions of the shape (and the device): the public dispatch runs in query mode -- every launcher
  * records its row count and returns before launching.  Replaces the kp_last_rows() side channel. */

@@ -218,7 +218,8 @@ constexpr int HPAIRS = 32;   // (k,c) pairs per thread in the head wgrad
 template <typename T>
 __global__ __launch_bounds__(TPB) void head_bwd_dw_k(const float* __restrict__ gout, const float* __restrict__ out,
                                                      const T* __restrict__ x, float slope, float* __restrict__ dw,
-                                                     float* __restrict__ db, long long M, int HW, int C, int K) {
+                                                     float* __restrict__ db, float* __restrict__ ws, long long M,
+                                                     int HW, int C, int K) {
     extern __shared__ float sm[];   // dz [HPB][K] then xs [HPB][C]
     float* dz = sm;
     float* xs = sm + HPB * K;
@@ -266,9 +267,44 @@ __global__ __launch_bounds__(TPB) void head_bwd_dw_k(const float* __restrict__ g
 #pragma unroll
     for (int i = 0; i < HPAIRS; ++i) {
         const long long pr = pair0 + threadIdx.x + (long long)i * TPB;
-        if (pr < npairs) atomicAdd(dw + pr, acc[i]);
+        if (pr < npairs) {
+            if (ws) ws[(long long)blockIdx.x * (npairs + K) + pr] = acc[i];   // this workgroup column's partial
+            else atomicAdd(dw + pr, acc[i]);
+        }
     }
-    if (blockIdx.y == 0 && threadIdx.x < K && db) atomicAdd(db + threadIdx.x, dbacc);
+    if (blockIdx.y == 0 && threadIdx.x < K) {
+        if (ws) ws[(long long)blockIdx.x * (npairs + K) + npairs + threadIdx.x] = dbacc;
+        else if (db) atomicAdd(db + threadIdx.x, dbacc);
+    }
+}
+
+// dw[i] += sum_p ws[p][i], db[k] += sum_p ws[p][K*C + k], p ascending: the fixed-order second stage of the head's
+// weight gradient (first stage: one partial per workgroup / pixel split, plain stores)
+__global__ __launch_bounds__(TPB) void head_dw_reduce_k(const float* __restrict__ ws, int P, long long n, long long KC,
+                                                        float* __restrict__ dw, float* __restrict__ db) {
+    // a workgroup owns 16 consecutive elements (one 64-byte sector per partial); 16 lanes of partials per element,
+    // each summing p = pl, pl + 16, ... in order, then the 16 lane sums in order: a fixed summation tree
+    __shared__ float red[16][17];
+    const int e = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const long long i = (long long)blockIdx.x * 16 + e;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+        int p = pl;
+        for (; p + 48 < P; p += 64) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += ws[(long long)(p + 16 * u) * n + i];
+        }
+        for (int u = 0; p < P; p += 16, ++u) s[u & 3] += ws[(long long)p * n + i];
+    }
+    red[pl][e] = ((s[0] + s[1]) + s[2]) + s[3];
+    __syncthreads();
+    if (pl == 0 && i < n) {
+        float tot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot += red[r][e];
+        if (i < KC) dw[i] += tot;
+        else if (db) db[i - KC] += tot;
+    }
 }
 
 // ---------------------------------------------------------------- loss / Adam
@@ -332,9 +368,11 @@ __global__ void scale_k(const float* __restrict__ x, const float* __restrict__ s
 int kp_head_fwd_fast(const void*, const float*, const float*, float, float*, long long, int, int, int, hipStream_t);
 int kp_head_fwd_mfma(const void*, const float*, const float*, float, float*, long long, int, int, int, hipStream_t);
 int kp_head_dx_mfma(const float*, const float*, const float*, float, void*, long long, int, int, int, hipStream_t);
-int kp_head_dw_mfma(const float*, const float*, const void*, float, float*, float*, long long, int, int, int, hipStream_t);
+int kp_head_dw_mfma(const float*, const float*, const void*, float, float*, float*, float*, long long, int, int, int, hipStream_t);
+long long kp_head_dw_parts_mfma(long long, int, int, int);
+long long kp_head_dw_parts_fast(long long, int, int);
 int kp_head_dx_fast(const float*, const float*, const float*, float, void*, long long, int, int, int, hipStream_t);
-int kp_head_dw_fast(const float*, const float*, const void*, float, float*, float*, long long, int, int, int, hipStream_t);
+int kp_head_dw_fast(const float*, const float*, const void*, float, float*, float*, float*, long long, int, int, int, hipStream_t);
 
 extern "C" {
 
@@ -393,8 +431,24 @@ int kp_head_fwd(const void* x, const float* w, const float* bias, float slope, f
     return kp_check_launch("head_fwd");
 }
 
+// partial gradients (workspace rows of K*C + K floats) the weight-gradient kernel of this shape writes in deterministic mode
+static long long head_dw_parts(long long M, int HW, int C, int K, int dtype) {
+    if (dtype == KP_H16) {
+        long long p = kp_head_dw_parts_mfma(M, HW, C, K);
+        if (p <= 0) p = kp_head_dw_parts_fast(M, C, K);
+        if (p > 0) return p;
+    }
+    const long long tiles = (M + HPB - 1) / HPB;
+    return tiles < 512 ? tiles : 512;
+}
+
+long long kp_head_bwd_ws_floats(int N, int H, int W, int C, int K, int dtype) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return KP_E_ARG;
+    return head_dw_parts((long long)N * H * W, H * W, C, K, dtype) * ((long long)K * C + K);
+}
+
 int kp_head_bwd(const float* gout, const float* out, const void* x, const float* w, float slope, void* dx, float* dw,
-                float* db, int N, int H, int W, int C, int K, int dtype, void* stream) {
+                float* db, float* ws, int N, int H, int W, int C, int K, int dtype, void* stream) {
     KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "kp_head_bwd: bad dims");
     KP_REQUIRE(K <= 256 && C <= 2048, "kp_head_bwd: K <= 256, C <= 2048 supported");
     const long long M = (long long)N * H * W;
@@ -405,9 +459,11 @@ int kp_head_bwd(const float* gout, const float* out, const void* x, const float*
         if (rc == KP_OK) dx = nullptr;
         else if (rc != KP_E_UNSUPPORTED) return rc;
     }
+    const long long parts = (dw && ws) ? head_dw_parts(M, H * W, C, K, dtype) : 0;
+    float* const dw_out = dw;
     if (dw && dtype == KP_H16) {
-        int rc = kp_head_dw_mfma(gout, out, x, slope, dw, db, M, H * W, C, K, st);
-        if (rc == KP_E_UNSUPPORTED) rc = kp_head_dw_fast(gout, out, x, slope, dw, db, M, H * W, C, K, st);
+        int rc = kp_head_dw_mfma(gout, out, x, slope, dw, db, ws, M, H * W, C, K, st);
+        if (rc == KP_E_UNSUPPORTED) rc = kp_head_dw_fast(gout, out, x, slope, dw, db, ws, M, H * W, C, K, st);
         if (rc == KP_OK) dw = nullptr;
         else if (rc != KP_E_UNSUPPORTED) return rc;
     }
@@ -422,8 +478,14 @@ int kp_head_bwd(const float* gout, const float* out, const void* x, const float*
         const unsigned gx = (unsigned)(tiles < 512 ? tiles : 512);
         const unsigned gy = cdiv((long long)K * C, (long long)TPB * HPAIRS);
         const size_t smem = (size_t)HPB * (K + C) * sizeof(float);
-        DISPATCH_T(dtype, head_bwd_dw_k<T><<<dim3(gx, gy), TPB, smem, st>>>(gout, out, (const T*)x, slope, dw, db, M, H * W, C, K));
-        return kp_check_launch("head_bwd_dw");
+        DISPATCH_T(dtype, head_bwd_dw_k<T><<<dim3(gx, gy), TPB, smem, st>>>(gout, out, (const T*)x, slope, dw, db, ws, M, H * W, C, K));
+        int rc = kp_check_launch("head_bwd_dw");
+        if (rc) return rc;
+    }
+    if (parts > 0) {   // deterministic mode: sum the partial gradients in a fixed order
+        const long long n = (long long)K * C + K;
+        head_dw_reduce_k<<<cdiv(n, 16), TPB, 0, st>>>(ws, (int)parts, n, (long long)K * C, dw_out, db);
+        return kp_check_launch("head_dw_reduce");
     }
     return KP_OK;
 }

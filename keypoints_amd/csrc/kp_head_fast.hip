@@ -149,8 +149,9 @@ __global__ __launch_bounds__(TPB) void head_dx_small_k(const float* __restrict__
 template <int KB>
 __global__ __launch_bounds__(TPB) void head_dw_small_k(const float* __restrict__ gout, const float* __restrict__ out,
                                                        const h16_t* __restrict__ x, float slope,
-                                                       float* __restrict__ dw, float* __restrict__ db, long long M,
-                                                       int HW, int C, int K, int ppb) {
+                                                       float* __restrict__ dw, float* __restrict__ db,
+                                                       float* __restrict__ ws, long long M, int HW, int C, int K,
+                                                       int ppb) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [npl][KC][C] (+ [npl][KC] for db)
     const int CV = C / V, cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
     float acc[KB][V], dbs[KB];
@@ -201,12 +202,14 @@ __global__ __launch_bounds__(TPB) void head_dw_small_k(const float* __restrict__
         for (int i = threadIdx.x; i < kn * C; i += TPB) {
             float s = 0.f;
             for (int r2 = 0; r2 < npl; ++r2) s += red[(size_t)r2 * KC * C + i];
-            unsafeAtomicAdd(dw + (size_t)k0 * C + i, s);
+            if (ws) ws[(size_t)blockIdx.x * ((size_t)K * C + K) + (size_t)k0 * C + i] = s;   // this workgroup's partial
+            else unsafeAtomicAdd(dw + (size_t)k0 * C + i, s);
         }
-        if (db && threadIdx.x < kn) {
+        if ((db || ws) && threadIdx.x < kn) {
             float s = 0.f;
             for (int r2 = 0; r2 < npl; ++r2) s += rdb[r2 * KC + threadIdx.x];
-            unsafeAtomicAdd(db + k0 + threadIdx.x, s);
+            if (ws) ws[(size_t)blockIdx.x * ((size_t)K * C + K) + (size_t)K * C + k0 + threadIdx.x] = s;
+            else unsafeAtomicAdd(db + k0 + threadIdx.x, s);
         }
     }
 }
@@ -247,17 +250,27 @@ int kp_head_dx_fast(const float* gout, const float* out, const float* w, float s
     return kp_check_launch("head_dx_fast");
 }
 
-int kp_head_dw_fast(const float* gout, const float* out, const void* x, float slope, float* dw, float* db, long long M,
-                    int HW, int C, int K, hipStream_t st) {
-    if (!small_shape(C, K) || M >= (1LL << 31)) return KP_E_UNSUPPORTED;
+// workgroups (= partial gradients in deterministic mode) of the small-shape weight-gradient kernel; 0: not its shape
+static long long dw_fast_plan(long long M, int C, int K, long long& ppb) {
+    if (!small_shape(C, K) || M >= (1LL << 31)) return 0;
     const int npl = TPB / (C / V);
     const size_t lds = ((size_t)npl * 4 * C + (size_t)npl * 4) * sizeof(float);   // KC = 4 channels per reduction pass
-    if (lds > 64 * 1024) return KP_E_UNSUPPORTED;
-    // ~2048 workgroups, each a contiguous run of pixels
-    long long ppb = (M + 2047) / 2048;
+    if (lds > 64 * 1024) return 0;
+    ppb = (M + 2047) / 2048;                    // ~2048 workgroups, each a contiguous run of pixels
     if (ppb < npl) ppb = npl;
     ppb = (ppb + npl - 1) / npl * npl;
-    const unsigned grid = (unsigned)((M + ppb - 1) / ppb);
-    KP_HEAD_KB(K, (head_dw_small_k<KB><<<grid, TPB, lds, st>>>(gout, out, (const h16_t*)x, slope, dw, db, M, HW, C, K, (int)ppb)));
+    return (M + ppb - 1) / ppb;
+}
+long long kp_head_dw_parts_fast(long long M, int C, int K) { long long ppb; return dw_fast_plan(M, C, K, ppb); }
+
+int kp_head_dw_fast(const float* gout, const float* out, const void* x, float slope, float* dw, float* db, float* ws,
+                    long long M, int HW, int C, int K, hipStream_t st) {
+    long long ppb;
+    const long long parts = dw_fast_plan(M, C, K, ppb);
+    if (parts <= 0) return KP_E_UNSUPPORTED;
+    const int npl = TPB / (C / V);
+    const size_t lds = ((size_t)npl * 4 * C + (size_t)npl * 4) * sizeof(float);
+    const unsigned grid = (unsigned)parts;
+    KP_HEAD_KB(K, (head_dw_small_k<KB><<<grid, TPB, lds, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, M, HW, C, K, (int)ppb)));
     return kp_check_launch("head_dw_fast");
 }

@@ -12,6 +12,10 @@
 // gradient gives dZ^T fragments (8 consecutive pixels of one channel) as two 16-byte loads.  No LDS, no barriers.
 #include "kp_mfma_util.h"
 
+#ifndef KP_HEAD_DET_SPLITS
+#define KP_HEAD_DET_SPLITS 128   // pixel splits (= partial gradients in the workspace) of the deterministic weight gradient
+#endif
+
 namespace {
 
 // 8 fp32 values -> bf16 hi / lo fragments (round-to-nearest-even both times)
@@ -154,8 +158,8 @@ __global__ __launch_bounds__(256) void head_dx_mfma_k(const float* __restrict__ 
 template <int KT>
 __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ gout, const float* __restrict__ out,
                                                       const h16_t* __restrict__ x, float slope, float* __restrict__ dw,
-                                                      float* __restrict__ db, long long groups, int gpw, int HW, int C,
-                                                      int K) {
+                                                      float* __restrict__ db, float* __restrict__ ws, long long groups,
+                                                      int gpw, int HW, int C, int K) {
     const int lane = threadIdx.x & 63;
     const int cranges = C / 128;
     const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -223,14 +227,21 @@ __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int k = kt * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
-                if (k < K) unsafeAtomicAdd(dw + (long long)k * C + cr * 128 + t * 32 + r, acc[kt][t][i]);
+                if (k < K) {
+                    const long long e = (long long)k * C + cr * 128 + t * 32 + r;
+                    if (ws) ws[sp * ((long long)K * C + K) + e] = acc[kt][t][i];   // this pixel split's partial (plain store)
+                    else unsafeAtomicAdd(dw + e, acc[kt][t][i]);
+                }
             }
-    if (db && cr == 0) {
+    if ((db || ws) && cr == 0) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             const float tot = bsum[kt] + __shfl_xor(bsum[kt], 32, 64);   // the two 8-pixel halves
             const int k = kt * 32 + r;
-            if (h == 0 && k < K) unsafeAtomicAdd(db + k, tot);
+            if (h == 0 && k < K) {
+                if (ws) ws[sp * ((long long)K * C + K) + (long long)K * C + k] = tot;
+                else unsafeAtomicAdd(db + k, tot);
+            }
         }
     }
 }
@@ -264,18 +275,29 @@ int kp_head_dx_mfma(const float* gout, const float* out, const float* w, float s
     return kp_check_launch("head_dx_mfma");
 }
 
-int kp_head_dw_mfma(const float* gout, const float* out, const void* x, float slope, float* dw, float* db, long long M,
-                    int HW, int C, int K, hipStream_t st) {
+// pixel splits of the weight-gradient kernel for this shape (0: not an MFMA shape).  Deterministic mode (a workspace of
+// one partial gradient per split) caps them so that the workspace stays small.
+static long long dw_mfma_plan(long long M, int HW, int C, int K, bool det, int& gpw) {
+    if (!mfma_shape(M, HW, C, K)) return 0;
+    const long long groups = M / 32;
+    const int cranges = C / 128;
+    long long splits = 2048 / cranges;          // ~2048 wavefronts: pixel splits x channel ranges
+    if (det && splits > KP_HEAD_DET_SPLITS) splits = KP_HEAD_DET_SPLITS;
+    if (splits > groups) splits = groups;
+    gpw = (int)((groups + splits - 1) / splits);
+    return (groups + gpw - 1) / gpw;
+}
+long long kp_head_dw_parts_mfma(long long M, int HW, int C, int K) { int gpw; return dw_mfma_plan(M, HW, C, K, true, gpw); }
+
+int kp_head_dw_mfma(const float* gout, const float* out, const void* x, float slope, float* dw, float* db, float* ws,
+                    long long M, int HW, int C, int K, hipStream_t st) {
     if (!mfma_shape(M, HW, C, K) || !aligned16(gout, out)) return KP_E_UNSUPPORTED;
     const long long groups = M / 32;
     const int cranges = C / 128;
-    // ~2048 wavefronts: pixel splits x channel ranges
-    long long splits = 2048 / cranges;
-    if (splits > groups) splits = groups;
-    const int gpw = (int)((groups + splits - 1) / splits);
-    splits = (groups + gpw - 1) / gpw;
+    int gpw;
+    const long long splits = dw_mfma_plan(M, HW, C, K, ws != nullptr, gpw);
     const unsigned grid = (unsigned)((splits * cranges + 3) / 4);
-    if (K <= 32) head_dw_mfma_k<1><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, groups, gpw, HW, C, K);
-    else head_dw_mfma_k<2><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, groups, gpw, HW, C, K);
+    if (K <= 32) head_dw_mfma_k<1><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, groups, gpw, HW, C, K);
+    else head_dw_mfma_k<2><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, groups, gpw, HW, C, K);
     return kp_check_launch("head_dw_mfma");
 }

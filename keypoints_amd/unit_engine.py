@@ -254,8 +254,10 @@ class UnitFunction(torch.autograd.Function):
         hconv = head['conv']
         has_body = len(plan) > 1
         g = torch.empty(N, Hh, Wh, Ch, device=dev, dtype=tdt) if (has_body or need_x) else None
+        # the workspace makes the head's weight gradient a fixed-order two-stage sum (bitwise reproducible step)
+        hws = torch.empty(_lib.lib().kp_head_bwd_ws_floats(N, Hh, Wh, Ch, Kout, code), device=dev, dtype=torch.float32)
         call('kp_head_bwd', ptr(gout), ptr(out), ptr(a_last), ptr(hconv.weight), head['slope'], ptr(g),
-             ptr(gv[id(hconv.weight)]), ptr(gv[id(hconv.bias)]) if hconv.bias is not None else None,
+             ptr(gv[id(hconv.weight)]), ptr(gv[id(hconv.bias)]) if hconv.bias is not None else None, ptr(hws),
              N, Hh, Wh, Ch, Kout, code, st)
         gp = 0   # border width of g (0 = plain, 1 = padded-domain gradient that still needs folding)
         for idx in range(len(saved) - 1, -1, -1):

@@ -124,7 +124,7 @@ def test_head_against_golden(golden, precision, tol):
     gout = torch.tensor(z['head.w'], device=dev)
     dxn = torch.empty(N, H, W, C, device=dev, dtype=tdt)
     dw = torch.zeros(K, C, device=dev); db = torch.zeros(K, device=dev)
-    call('kp_head_bwd', ptr(gout), ptr(out), ptr(a), ptr(wt), 0.01, ptr(dxn), ptr(dw), ptr(db), N, H, W, C, K, code, st)
+    call('kp_head_bwd', ptr(gout), ptr(out), ptr(a), ptr(wt), 0.01, ptr(dxn), ptr(dw), ptr(db), None, N, H, W, C, K, code, st)
     if precision == 'fp32':
         ref_dx, ref_dw, ref_db = z['head.dx'], z['head.dweight'], z['head.dbias']
     else:
@@ -170,7 +170,7 @@ def test_head_small_k_bf16(N, H, W, C, K):
     assert (out.cpu() - ref.detach()).abs().max().item() < 1e-4 * ref.abs().max().item() + 1e-5
     dx = torch.full((N, H, W, C), float('nan'), device='cuda', dtype=torch.bfloat16)
     dw = torch.zeros(K, C, device='cuda'); db = torch.zeros(K, device='cuda')
-    call('kp_head_bwd', ptr(gd), ptr(out), ptr(ad), ptr(wd), 0.01, ptr(dx), ptr(dw), ptr(db), N, H, W, C, K, _lib.KP_BF16, st)
+    call('kp_head_bwd', ptr(gd), ptr(out), ptr(ad), ptr(wd), 0.01, ptr(dx), ptr(dw), ptr(db), None, N, H, W, C, K, _lib.KP_BF16, st)
     assert relerr(dx.float(), af.grad.numpy()) < 1e-2
     assert relerr(dw, wr.grad.numpy()) < 1e-4 and relerr(db, br.grad.numpy()) < 1e-4
 

@@ -453,3 +453,34 @@ def test_layer_done_hook_sees_final_gradients():
     assert final.abs().sum().item() > 0
     for idx, (off, snap) in snaps.items():
         assert torch.equal(snap, final[off:]), idx
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_train_step_is_bitwise_reproducible(precision):
+    """(16-bit modes: the strict-fp32 parity mode runs the generic VALU kernels, whose weight gradient still accumulates
+    with fp32 atomics.)  Two runs of the same two train steps (model F, 8 pairs) give bit-identical parameters, BatchNorm buffers and Adam
+    state: every reduction on the path has a fixed order (BatchNorm sums: per-workgroup partial rows + fp64 tree; 3x3
+    weight gradients: per-split partials summed in order; 1x1 heads: per-workgroup partials summed in order -- the fp32
+    atomics round 1 used there are gone; the keypoint bottleneck: fixed trees)."""
+    import keypoints_amd as ka
+    from keypoints_amd.models import transporter
+    g = torch.Generator().manual_seed(3)
+    xs = torch.rand(8, 3, 128, 128, generator=g).cuda()
+    xt = torch.rand(8, 3, 128, 128, generator=g).cuda()
+    states = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        net = transporter.make('F', 3, 64, 10).cuda().set_precision(precision)
+        opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
+        if precision == 'fp16':
+            opt.scaler = ka.amp.LossScaler('cuda')
+        for _ in range(2):
+            opt.zero_grad()
+            loss = ka.l2_reconstruction_loss(net(xs, xt)[0], xt)
+            with ka.amp.scale_loss(loss, opt) as scaled:
+                scaled.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        states.append({k: v.clone() for k, v in net.state_dict().items()})
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k

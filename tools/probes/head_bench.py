@@ -25,8 +25,15 @@ for (N, H, C, K) in [(256, 84, 32, 16), (256, 84, 32, 4), (256, 84, 16, 1), (128
     dx = torch.empty_like(x); dw = torch.zeros(K, C, device='cuda'); db = torch.zeros(K, device='cuda')
     st = stream_ptr()
     tf = timeit(lambda: call('kp_head_fwd', ptr(x), ptr(w), ptr(b), 0.01, ptr(out), N, H, H, C, K, 1, st))
-    tdx = timeit(lambda: call('kp_head_bwd', ptr(g), ptr(out), ptr(x), ptr(w), 0.01, ptr(dx), None, None, N, H, H, C, K, 1, st))
-    tdw = timeit(lambda: call('kp_head_bwd', ptr(g), ptr(out), ptr(x), ptr(w), 0.01, None, ptr(dw), ptr(db), N, H, H, C, K, 1, st))
+    tdx = timeit(lambda: call('kp_head_bwd', ptr(g), ptr(out), ptr(x), ptr(w), 0.01, ptr(dx), None, None, None, N, H, H, C, K, 1, st))
+    tdw = timeit(lambda: call('kp_head_bwd', ptr(g), ptr(out), ptr(x), ptr(w), 0.01, None, ptr(dw), ptr(db), None, N, H, H, C, K, 1, st))
+    ws = torch.empty(_lib.lib().kp_head_bwd_ws_floats(N, H, H, C, K, 1), device='cuda')
+    tdet = timeit(lambda: call('kp_head_bwd', ptr(g), ptr(out), ptr(x), ptr(w), 0.01, None, ptr(dw), ptr(db), ptr(ws), N, H, H, C, K, 1, st))
+    d1 = torch.zeros(K, C, device='cuda'); d2 = torch.zeros(K, C, device='cuda'); b1 = torch.zeros(K, device='cuda'); b2 = torch.zeros(K, device='cuda')
+    call('kp_head_bwd', ptr(g), ptr(out), ptr(x), ptr(w), 0.01, None, ptr(d1), ptr(b1), ptr(ws), N, H, H, C, K, 1, st)
+    call('kp_head_bwd', ptr(g), ptr(out), ptr(x), ptr(w), 0.01, None, ptr(d2), ptr(b2), ptr(ws), N, H, H, C, K, 1, st)
+    d0 = torch.zeros(K, C, device='cuda'); call('kp_head_bwd', ptr(g), ptr(out), ptr(x), ptr(w), 0.01, None, ptr(d0), None, None, N, H, H, C, K, 1, st)
+    print(f'   deterministic dw {tdet:.0f} us, ws {ws.numel()*4/1e6:.1f} MB, bitwise repeat {torch.equal(d1, d2) and torch.equal(b1, b2)}, vs atomics rel {float((d1-d0).norm()/d0.norm()):.1e}')
     M = N * H * H
     bx, bo = M * C * 2, M * K * 4
     print(f'N={N} H={H} C={C} K={K}: fwd {tf:.0f} us ({(bx+bo)/tf/1e6:.2f} TB/s)  dx {tdx:.0f} us ({(bx+2*bo)/tdx/1e6:.2f} TB/s)  dw {tdw:.0f} us ({(bx+2*bo)/tdw/1e6:.2f} TB/s)', flush=True)

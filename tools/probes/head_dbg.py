@@ -14,7 +14,7 @@ for precision in ('fp32','bf16','fp16'):
     gout=torch.tensor(z['head.w'],device='cuda')
     dxn=torch.full((N,H,W,C),float('nan'),device='cuda',dtype=tdt)
     dw=torch.zeros(K,C,device='cuda'); db=torch.zeros(K,device='cuda')
-    call('kp_head_bwd',ptr(gout),ptr(out),ptr(a),ptr(wt),0.01,ptr(dxn),ptr(dw),ptr(db),N,H,W,C,K,code,st)
+    call('kp_head_bwd',ptr(gout),ptr(out),ptr(a),ptr(wt),0.01,ptr(dxn),ptr(dw),ptr(db),None,N,H,W,C,K,code,st)
     got=dxn.float().permute(0,3,1,2).cpu().numpy(); ref=z['head.dx']
     err=np.abs(got-ref); i=np.unravel_index(err.argmax(),err.shape)
     print(precision,'dx maxerr',err.max(),'at',i,'got',got[i],'ref',ref[i],'refmax',np.abs(ref).max(), 'out there', out[i[0],:,i[2],i[3]].cpu().numpy(), 'refy', z['head.y'][i[0],:,i[2],i[3]])
