@@ -17,6 +17,7 @@ int kp_conv_small_wgrad(const void*, const void*, float*, int, int, int, int, in
 int kp_conv_first_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
 int kp_conv_first_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 long long kp_conv_first_wgrad_partials(int, int, int, int, int);
+long long kp_conv_small_wgrad_partials(int, int, int, int, int);
 
 extern int g_kp_wgrad_patch;
 
@@ -82,6 +83,10 @@ int kp_conv_wgrad_partials(int N, int Ho, int Wo, int C, int K, int R, int dy_pa
     }
     if (dtype == KP_H16 && use_mfma() && R == 3 && C <= 4) {
         const long long p = kp_conv_first_wgrad_partials(N, Ho, Wo, C, K);
+        if (p > 0) return (int)p;
+    }
+    if (dtype == KP_H16 && use_mfma() && R == 3) {
+        const long long p = kp_conv_small_wgrad_partials(N, Ho, Wo, C, K);
         if (p > 0) return (int)p;
     }
     return 1;

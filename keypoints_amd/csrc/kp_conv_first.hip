@@ -123,6 +123,7 @@ template <int CIN>
 __global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
                                                            float* __restrict__ scratch, int Ho, int Wo, int K,
                                                            int dy_pad, long long total_rows, int rows_per_block) {
+    // every workgroup leaves ITS partial gradient in scratch[blockIdx.x][K][J] (plain stores; kp_wgrad_unpack adds them in order)
     constexpr int J = 9 * CIN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const h16_t* __restri
             }
         }
     }
-    // fold the pixel streams (lanes k, k+K, ...), then the 4 wavefronts, then one atomic per (k, j) per block
+    // fold the pixel streams (lanes k, k+K, ...), then the 4 wavefronts
     for (int o = K; o < 64; o <<= 1)
 #pragma unroll
         for (int j = 0; j < J; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const h16_t* __restri
     __syncthreads();
     for (int i = tid; i < K * J; i += TPB) {
         const float s = red[i] + red[K * J + i] + red[2 * K * J + i] + red[3 * K * J + i];
-        unsafeAtomicAdd(scratch + i, s);                      // scratch is [K][9][CIN] = [K][J]
+        scratch[(long long)blockIdx.x * K * J + i] = s;       // a partial is [K][9][CIN] = [K][J]
     }
 }
 
@@ -515,9 +516,25 @@ static bool first_wgrad_plan(int N, int Ho, int Wo, int C, int K, long long& gro
     return true;
 }
 
+// VALU kernel: workgroups (= partial gradients), 0 if the shape is not taken
+static unsigned first_wgrad_valu_plan(int N, int Ho, int Wo, int C, int K, int& rpb, size_t& lds) {
+    if (C < 1 || C > 4 || !(K == 16 || K == 32 || K == 64)) return 0;
+    const long long rows = (long long)N * Ho;
+    rpb = (int)((rows + 511) / 512);            // <= 512 workgroups
+    if (rpb < 4) rpb = 4;
+    rpb = (rpb + 3) / 4 * 4;
+    lds = (size_t)4 * 3 * (Wo + 2) * 4 * sizeof(float);
+    const size_t red = (size_t)4 * K * 9 * C * sizeof(float);
+    if (red > lds) lds = red;
+    if (lds > 64 * 1024) return 0;
+    return (unsigned)((rows + rpb - 1) / rpb);
+}
+
 long long kp_conv_first_wgrad_partials(int N, int Ho, int Wo, int C, int K) {
     long long groups; int gpw; unsigned grid;
-    return first_wgrad_plan(N, Ho, Wo, C, K, groups, gpw, grid) ? (long long)grid : 0;
+    if (first_wgrad_plan(N, Ho, Wo, C, K, groups, gpw, grid)) return (long long)grid;
+    int rpb; size_t lds;
+    return first_wgrad_valu_plan(N, Ho, Wo, C, K, rpb, lds);
 }
 
 int kp_conv_first_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K,
@@ -539,14 +556,9 @@ int kp_conv_first_wgrad(const void* x, const void* dy, float* scratch, int N, in
         }
     }
     const long long rows = (long long)N * Ho;
-    int rpb = (int)((rows + 1023) / 1024);
-    if (rpb < 4) rpb = 4;
-    rpb = (rpb + 3) / 4 * 4;
-    const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
-    size_t lds = (size_t)4 * 3 * (Wo + 2) * 4 * sizeof(float);
-    const size_t red = (size_t)4 * K * 9 * C * sizeof(float);
-    if (red > lds) lds = red;
-    if (lds > 64 * 1024) return KP_E_UNSUPPORTED;
+    int rpb; size_t lds;
+    const unsigned grid = first_wgrad_valu_plan(N, Ho, Wo, C, K, rpb, lds);
+    if (!grid) return KP_E_UNSUPPORTED;
 #define KP_FIRST_WG(CINv)                                                                                        \
     conv3_first_wgrad_k<CINv><<<grid, TPB, lds, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, K,    \
                                                       dy_pad, rows, rpb)

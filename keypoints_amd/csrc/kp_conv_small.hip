@@ -148,7 +148,7 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_k(const h16_t* __restrict__
 template <int K, int C>
 __global__ __launch_bounds__(TPB) void wgrad3x3_small_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
                                                            float* __restrict__ scratch, int Ho, int Wo, int dy_pad,
-                                                           long long total_rows, int rows_per_wave) {
+                                                           long long total_rows, int rows_per_wave, long long pstride) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 31, h = lane >> 5;
     const int Hi = Ho + 2, Wi = Wo + 2, Hd = Ho + 2 * dy_pad, Wd = Wo + 2 * dy_pad;
@@ -197,7 +197,8 @@ __global__ __launch_bounds__(TPB) void wgrad3x3_small_k(const h16_t* __restrict_
             }
         }
     }
-    // D[k][c]: lane col = c (fr), rows k = (i&3) + 8*(i>>2) + 4*h.  Sum the 4 wavefronts per tap through LDS, then atomics.
+    // D[k][c]: lane col = c (fr), rows k = (i&3) + 8*(i>>2) + 4*h.  Sum the 4 wavefronts per tap through LDS; the workgroup's
+    // sum is ITS partial gradient (plain stores into scratch[blockIdx.x]; kp_wgrad_unpack adds the partials in order).
     __shared__ float red[4][16][64];
     for (int t = 0; t < 9; ++t) {
         __syncthreads();
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(TPB) void wgrad3x3_small_k(const h16_t* __restrict_
                 const int k = (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (k < K && fr < C) {
                     const float s = ((red[0][i][lane] + red[1][i][lane]) + red[2][i][lane]) + red[3][i][lane];
-                    unsafeAtomicAdd(scratch + ((long long)k * 9 + t) * C + fr, s);
+                    scratch[(long long)blockIdx.x * pstride + ((long long)k * 9 + t) * C + fr] = s;
                 }
             }
         }
@@ -242,15 +243,24 @@ int kp_conv_small_fwd(const void* x, const void* w, const float* bias, void* y, 
     return kp_check_launch("conv3x3_small");
 }
 
-int kp_conv_small_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int dy_pad,
-                        hipStream_t st) {
-    if (!small_ch(C) || !small_ch(K)) return KP_E_UNSUPPORTED;
+// workgroups of the weight-gradient kernel = partial gradients in its scratch (0: not a small-channel shape)
+static unsigned small_wgrad_plan(int N, int Ho, int C, int K, int& rpw) {
+    if (!small_ch(C) || !small_ch(K)) return 0;
     const long long rows = (long long)N * Ho;
-    int rpw = (int)((rows + 2047) / 2048);      // ~2048 wavefronts (512 workgroups), each a contiguous run of rows
+    rpw = (int)((rows + 2047) / 2048);          // ~2048 wavefronts (512 workgroups), each a contiguous run of rows
     if (rpw < 1) rpw = 1;
     const long long waves = (rows + rpw - 1) / rpw;
-    const unsigned grid = (unsigned)((waves + 3) / 4);
-#define KP_SWG(Kv, Cv) wgrad3x3_small_k<Kv, Cv><<<grid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, rows, rpw)
+    return (unsigned)((waves + 3) / 4);
+}
+long long kp_conv_small_wgrad_partials(int N, int Ho, int Wo, int C, int K) { int rpw; (void)Wo; return small_wgrad_plan(N, Ho, C, K, rpw); }
+
+int kp_conv_small_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int dy_pad,
+                        hipStream_t st) {
+    int rpw;
+    const unsigned grid = small_wgrad_plan(N, Ho, C, K, rpw);
+    if (!grid) return KP_E_UNSUPPORTED;
+    const long long rows = (long long)N * Ho;
+#define KP_SWG(Kv, Cv) wgrad3x3_small_k<Kv, Cv><<<grid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, rows, rpw, (long long)Kv * 9 * Cv)
     if (K == 16 && C == 16) KP_SWG(16, 16);
     else if (K == 16) KP_SWG(16, 32);
     else if (C == 16) KP_SWG(32, 16);

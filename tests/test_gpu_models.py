@@ -456,21 +456,23 @@ def test_layer_done_hook_sees_final_gradients():
 
 
 @pytest.mark.parametrize('precision', ['bf16', 'fp16'])
-def test_train_step_is_bitwise_reproducible(precision):
+@pytest.mark.parametrize('model', ['F', 'VGG_PONG_LAYERNECK'])
+def test_train_step_is_bitwise_reproducible(precision, model):
     """(16-bit modes: the strict-fp32 parity mode runs the generic VALU kernels, whose weight gradient still accumulates
-    with fp32 atomics.)  Two runs of the same two train steps (model F, 8 pairs) give bit-identical parameters, BatchNorm buffers and Adam
+    with fp32 atomics.)  Two runs of the same two train steps (model F and the Pong-class net, 8 pairs) give bit-identical parameters, BatchNorm buffers and Adam
     state: every reduction on the path has a fixed order (BatchNorm sums: per-workgroup partial rows + fp64 tree; 3x3
     weight gradients: per-split partials summed in order; 1x1 heads: per-workgroup partials summed in order -- the fp32
     atomics round 1 used there are gone; the keypoint bottleneck: fixed trees)."""
     import keypoints_amd as ka
     from keypoints_amd.models import transporter
     g = torch.Generator().manual_seed(3)
-    xs = torch.rand(8, 3, 128, 128, generator=g).cuda()
-    xt = torch.rand(8, 3, 128, 128, generator=g).cuda()
+    cin, z, K, size = (3, 64, 10, 128) if model == 'F' else (1, 16, 4, 84)
+    xs = torch.rand(8, cin, size, size, generator=g).cuda()
+    xt = torch.rand(8, cin, size, size, generator=g).cuda()
     states = []
     for _ in range(2):
         torch.manual_seed(11)
-        net = transporter.make('F', 3, 64, 10).cuda().set_precision(precision)
+        net = transporter.make(model, cin, z, K).cuda().set_precision(precision)
         opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
         if precision == 'fp16':
             opt.scaler = ka.amp.LossScaler('cuda')
