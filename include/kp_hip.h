@@ -126,10 +126,12 @@ int kp_conv_dgrad(const void* dy, const void* w_dgrad, void* gx, int N, int H, i
 /* Weight gradient: sum_p scratch[p][k][r][s][c] (+)= sum_{n,p,q} dy[n][p][q][k] * x[n][p+r][q+s][c]
  * x: [N][Ho+R-1][Wo+R-1][C] T; dy: interior of [N][Ho+2*dy_pad][Wo+2*dy_pad][K] T.
  * P = kp_conv_wgrad_partials(same shape arguments) tells the scratch protocol of this shape:
- *   P == 1: scratch fp32 [K][R][R][C], ZEROED by the caller, accumulated with hardware fp32 atomics;
- *   P  > 1: scratch fp32 [P][K][R][R][C], no zeroing needed: every partial is fully written by the workgroups of one
- *           pixel split (3x3 MFMA kernel) or by one workgroup (image-sized first layer) with plain stores, and
- *           kp_wgrad_unpack sums them in a fixed order (bitwise reproducible). */
+ *   P == 1: scratch fp32 [K][R][R][C], ZEROED by the caller (the per-tap MFMA fallback accumulates into it with fp32
+ *           atomics; a single-split launch of any other kernel overwrites it);
+ *   P  > 1: scratch fp32 [P][K][R][R][C], no zeroing needed: every partial is fully written with plain stores by the
+ *           workgroups of one pixel split (3x3 MFMA tap-reuse kernel, generic kernel) or by one workgroup (first-layer and
+ *           small-channel kernels), and kp_wgrad_unpack sums them in a fixed order (bitwise reproducible).  Every shape
+ *           of the BASELINE networks, in every precision, takes this protocol. */
 int kp_conv_wgrad_partials(int N, int Ho, int Wo, int C, int K, int R, int dy_pad, int dtype);
 int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R,
                   int dy_pad, int dtype, void* stream);

@@ -18,6 +18,8 @@ int kp_conv_first_fwd(const void*, const void*, const float*, void*, float*, int
 int kp_conv_first_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 long long kp_conv_first_wgrad_partials(int, int, int, int, int);
 long long kp_conv_small_wgrad_partials(int, int, int, int, int);
+long long kp_conv_wgrad_generic_partials(int, int, int, int, int, int);
+int kp_conv_wgrad_mfma_accepts(int, int, int, int, int, int);
 
 extern int g_kp_wgrad_patch;
 
@@ -89,7 +91,10 @@ int kp_conv_wgrad_partials(int N, int Ho, int Wo, int C, int K, int R, int dy_pa
         const long long p = kp_conv_small_wgrad_partials(N, Ho, Wo, C, K);
         if (p > 0) return (int)p;
     }
-    return 1;
+    // the per-tap MFMA fallback (kp_wgrad_mfma.hip: 64-multiples the tap-reuse kernel declines): one zeroed buffer, atomics
+    if (dtype == KP_H16 && use_mfma() && kp_conv_wgrad_mfma_accepts(N, Ho, Wo, C, K, R)) return 1;
+    const long long p = kp_conv_wgrad_generic_partials(N, Ho, Wo, C, K, R);
+    return p < 0x7fffffffLL ? (int)p : 1;
 }
 
 int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R, int dy_pad,

@@ -183,7 +183,8 @@ __global__ __launch_bounds__(TPB) void conv_wgrad_generic(const T* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = c0 + tx * 4 + j;
-            if (c < C) atomicAdd(scratch + ((long long)k * R * R + tap) * C + c, acc[i][j]);
+            // this pixel split's partial gradient (plain store: every (k, tap, c) of a partial has exactly one writer)
+            if (c < C) scratch[(long long)blockIdx.z * K * R * R * C + ((long long)k * R * R + tap) * C + c] = acc[i][j];
         }
     }
 }
@@ -201,18 +202,24 @@ int launch_fwd(const void* x, const void* w, const float* bias, void* y, float* 
     return kp_check_launch("conv_valid_generic");
 }
 
-template <typename T>
-int launch_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R, int dy_pad,
-                 hipStream_t st) {
+// pixel splits of the weight-gradient launch = partial gradients in its scratch
+static long long wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, long long& ppb) {
     const long long M = (long long)N * Ho * Wo;
     const int ctiles = (C + BN - 1) / BN, ktiles = (K + BM - 1) / BM;
     const long long tiles = (long long)ctiles * ktiles * R * R;
-    // aim for ~2048 blocks; at least 256 pixels per block so the atomics stay a small fraction
-    long long splits = (2048 + tiles - 1) / tiles;
-    long long ppb = (M + splits - 1) / splits;
+    long long splits = (2048 + tiles - 1) / tiles;     // aim for ~2048 blocks, at least 256 pixels per block
+    ppb = (M + splits - 1) / splits;
     if (ppb < 256) ppb = 256;
     ppb = (ppb + 15) / 16 * 16;
-    splits = (M + ppb - 1) / ppb;
+    return (M + ppb - 1) / ppb;
+}
+
+template <typename T>
+int launch_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R, int dy_pad,
+                 hipStream_t st) {
+    const int ctiles = (C + BN - 1) / BN, ktiles = (K + BM - 1) / BM;
+    long long ppb;
+    const long long splits = wgrad_plan(N, Ho, Wo, C, K, R, ppb);
     dim3 grid((unsigned)(ctiles * R * R), (unsigned)ktiles, (unsigned)splits);
     if (R == 3)
         conv_wgrad_generic<T, 3><<<grid, TPB, 0, st>>>((const T*)x, (const T*)dy, scratch, N, Ho, Wo, C, K, dy_pad,
@@ -229,6 +236,11 @@ int kp_conv_fwd_generic(const void* x, const void* w, const float* bias, void* y
                         int C, int K, int R, int dtype, hipStream_t st) {
     return dtype == KP_F32 ? launch_fwd<float>(x, w, bias, y, stats, N, Hi, Wi, C, K, R, st)
                            : launch_fwd<h16_t>(x, w, bias, y, stats, N, Hi, Wi, C, K, R, st);
+}
+
+long long kp_conv_wgrad_generic_partials(int N, int Ho, int Wo, int C, int K, int R) {
+    long long ppb;
+    return wgrad_plan(N, Ho, Wo, C, K, R, ppb);
 }
 
 int kp_conv_wgrad_generic(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R,

@@ -172,12 +172,18 @@ int ilog2_exact(int v) {
 
 }  // namespace
 
+// shapes this per-tap kernel takes (one zeroed scratch buffer, fp32 atomics): also asked by kp_conv_wgrad_partials
+int kp_conv_wgrad_mfma_accepts(int N, int Ho, int Wo, int C, int K, int R) {
+    if (R != 3 || C % 64 != 0 || K % 64 != 0) return 0;
+    const long long M = (long long)N * Ho * Wo;
+    return ilog2_exact(Wo) >= 0 && ilog2_exact(Ho) >= 0 && M % PIX == 0 && M < (1LL << 31);
+}
+
 int kp_conv_wgrad_mfma(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R,
                        int dy_pad, hipStream_t st) {
-    if (R != 3 || C % 64 != 0 || K % 64 != 0) return KP_E_UNSUPPORTED;
+    if (!kp_conv_wgrad_mfma_accepts(N, Ho, Wo, C, K, R)) return KP_E_UNSUPPORTED;
     const int lgWo = ilog2_exact(Wo), lgHo = ilog2_exact(Ho);
     const long long M = (long long)N * Ho * Wo;
-    if (lgWo < 0 || lgHo < 0 || M % PIX != 0 || M >= (1LL << 31)) return KP_E_UNSUPPORTED;
     const int TKs = (K % 128 == 0) ? 128 : 64, TCs = (C % 128 == 0) ? 128 : 64;
     const int ktiles = K / TKs, ctiles = C / TCs;
     const int total_stages = (int)(M / PIX);

@@ -455,11 +455,10 @@ def test_layer_done_hook_sees_final_gradients():
         assert torch.equal(snap, final[off:]), idx
 
 
-@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+@pytest.mark.parametrize('precision', ['bf16', 'fp16', 'fp32'])
 @pytest.mark.parametrize('model', ['F', 'VGG_PONG_LAYERNECK'])
 def test_train_step_is_bitwise_reproducible(precision, model):
-    """(16-bit modes: the strict-fp32 parity mode runs the generic VALU kernels, whose weight gradient still accumulates
-    with fp32 atomics.)  Two runs of the same two train steps (model F and the Pong-class net, 8 pairs) give bit-identical parameters, BatchNorm buffers and Adam
+    """Two runs of the same two train steps (model F and the Pong-class net, 8 pairs) give bit-identical parameters, BatchNorm buffers and Adam
     state: every reduction on the path has a fixed order (BatchNorm sums: per-workgroup partial rows + fp64 tree; 3x3
     weight gradients: per-split partials summed in order; 1x1 heads: per-workgroup partials summed in order -- the fp32
     atomics round 1 used there are gone; the keypoint bottleneck: fixed trees)."""
