@@ -243,6 +243,16 @@ def main():
                 roofline['bottleneck'] = dict(bytes=bk['algorithmic_bytes_per_launch'], us=bk['avg_us'],
                                               GBps=bk['algorithmic_gbs'], frac_of_hbm_peak=bk['algorithmic_gbs'] / PEAK_HBM_GBS)
         what = 'Transporter' if args.net == 'transporter' else 'KeyNet+TPS' if not args.no_augment else 'KeyNet'
+        if args.net == 'keynet':
+            cfg_name = 'BASELINE config 3 shape'
+        elif args.model_type == 'F' and args.size == 128 and args.model_keypoints == 10:
+            cfg_name = 'BASELINE config 4 shape'
+        elif args.model_type == 'F' and args.size == 256 and args.model_keypoints == 30:
+            cfg_name = 'BASELINE config 5 shape'
+        elif args.model_type == 'VGG_PONG_LAYERNECK' and args.size == 84 and args.model_keypoints == 4:
+            cfg_name = 'BASELINE config 2 shape'
+        else:
+            cfg_name = 'custom shape'
         line = dict(metric=f'image-pairs/sec (train step) {what} {args.size}x{args.size} K={args.model_keypoints}', value=value,
                     unit='image-pairs/sec', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_step,
                     ms_per_step_median_hipevent=median_ms, ms_per_step_min_hipevent=step_ms[0],
@@ -250,7 +260,7 @@ def main():
                     dtype={'bf16': 'bf16', 'fp16': 'fp16', 'fp32': 'f32'}[args.precision], data='synthetic',
                     config=dict(workload=f'{what} {args.model_type} {args.size}x{args.size}x'
                                          f'{args.model_in_channels} K={args.model_keypoints}, '
-                                         f'{B} pairs/GPU (BASELINE config {4 if args.net == "transporter" else 3} shape), '
+                                         f'{B} pairs/GPU ({cfg_name}), '
                                          f'{"augment+" if args.net == "keynet" and not args.no_augment else ""}fwd+loss+bwd+Adam',
                                 global_batch=B * world, per_gpu_batch=B, parallelism=f'dp{world}',
                                 gflop_per_pair=flop_pair / 1e9, loss=float(loss.item())),

@@ -41,12 +41,17 @@ int kp_check_launch(const char* what) {
 #include "kp_prof.h"
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
+std::mutex g_prof_mu;
 static std::vector<hipEvent_t> g_event_pool;
 hipEvent_t kp_prof_event() {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
-void kp_prof_event_release(hipEvent_t e) { g_event_pool.push_back(e); }
+void kp_prof_event_release(hipEvent_t e) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_event_pool.push_back(e);
+}
 
 int g_kp_conv_patch = -1;   // kp_config(KP_CFG_CONV_PATCH, v); -1 = kp_conv_mfma reads KP_CONV_PATCH from the environment once
 
@@ -79,6 +84,7 @@ int kp_config_ptr(int key, void* value) {
 }
 
 int kp_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) { g_event_pool.push_back(r.e0); g_event_pool.push_back(r.e1); }
     g_prof.clear();
     g_prof_on = on != 0;
@@ -86,6 +92,7 @@ int kp_prof_enable(int on) {
 }
 
 int kp_prof_collect(int family, double* ms, double* flops, long long* launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     double t = 0.0, f = 0.0; long long n = 0;
     for (auto& r : g_prof) {
         if (r.family != family) continue;
@@ -101,6 +108,7 @@ int kp_prof_collect(int family, double* ms, double* flops, long long* launches) 
 }
 
 int kp_prof_bytes(int family, double* bytes) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     double b = 0.0;
     for (auto& r : g_prof)
         if (r.family == family) b += r.bytes;

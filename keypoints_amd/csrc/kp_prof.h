@@ -1,12 +1,14 @@
 // In-library kernel timing (bench.py's roofline leg): HIP events recorded on the launch stream right around a kernel
 // family's launches; kp_prof_collect() synchronises them after the timed region.  Storage lives in kp_api.hip.
 #pragma once
+#include <mutex>
 #include <vector>
 #include "kp_common.h"
 
 struct ProfRec { int family; double flops, bytes; hipEvent_t e0, e1; };
 extern bool g_prof_on;
 extern std::vector<ProfRec> g_prof;
+extern std::mutex g_prof_mu;   // guards g_prof and the event pool: launches may come from several host threads
 hipEvent_t kp_prof_event();
 void kp_prof_event_release(hipEvent_t e);
 
@@ -26,6 +28,7 @@ struct ProfScope {
         if (!on) return;
         r.family = family;
         (void)hipEventRecord(r.e1, st);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
         g_prof.push_back(r);
     }
 };
