@@ -50,6 +50,10 @@ def parse():
                     help='extra steps AFTER the timed region with a HIP-event pair around every convolution / bottleneck '
                          'launch (the roofline leg); 0 = skip')
     ap.add_argument('--out', default='', help='also write the JSON line to this file')
+    ap.add_argument('--dp-overlap', type=int, default=0,
+                    help='N > 1: 1 = all-reduce each gradient piece from the backward hooks (overlapped with the backward); '
+                         '0 (default) = reduce the arenas back to back after the backward: ~1 ms exposed, but no RCCL kernel '
+                         'shares CUs with the statically partitioned persistent MFMA kernels (DESIGN.md section 6)')
     ap.add_argument('--net', default='transporter', choices=['transporter', 'keynet'],
                     help="'keynet' = BASELINE config 3 (KeyNet + TPS/rotation augmentation); not the headline metric")
     ap.add_argument('--no-augment', action='store_true', help='keynet: skip the TPS/rotation augmentation')
@@ -128,7 +132,7 @@ def main():
     opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
     if args.precision == 'fp16':   # the reference's O2 recipe: fp16 storage + dynamic loss scaling (transporter.py:51,84-86)
         opt.scaler = ka.amp.LossScaler(dev)
-    reducer = GradReducer(net) if world > 1 else None
+    reducer = GradReducer(net, overlap=bool(args.dp_overlap)) if world > 1 else None
 
     g = torch.Generator().manual_seed(1234 + rank)
     B = args.batch
@@ -263,6 +267,7 @@ def main():
                                          f'{B} pairs/GPU ({cfg_name}), '
                                          f'{"augment+" if args.net == "keynet" and not args.no_augment else ""}fwd+loss+bwd+Adam',
                                 global_batch=B * world, per_gpu_batch=B, parallelism=f'dp{world}',
+                                dp_overlap=bool(args.dp_overlap) if world > 1 else None,
                                 gflop_per_pair=flop_pair / 1e9, loss=float(loss.item())),
                     roofline=roofline)
         if world == 1 and not args.no_cpu_baseline and args.net == 'transporter':

@@ -30,8 +30,12 @@ import torch.distributed as dist
 
 class GradReducer:
     def __init__(self, root: torch.nn.Module, group=None, broadcast_init: bool = True, tail_fraction: float = 0.6,
-                 transport: str = 'fp32'):
-        """transport: 'fp32' (exact mean of the fp32 gradients) or 'bf16' (each piece is rounded to bf16 for the wire
+                 transport: str = 'fp32', overlap: bool = True):
+        """overlap: True -- pieces are all-reduced from the backward hooks, concurrently with the rest of the backward;
+        False -- the hooks only note which arenas are final and `finish()` reduces them back to back (the exchange is then
+        fully exposed, ~1 ms for model F over xGMI, but no RCCL kernel ever shares the CUs with the persistent MFMA
+        kernels, whose tile partition is static: see DESIGN.md section 6).
+        transport: 'fp32' (exact mean of the fp32 gradients) or 'bf16' (each piece is rounded to bf16 for the wire
         and the reduction: half the xGMI bytes, gradient error 2^-9 relative per element -- SURVEY.md 8e option)."""
         from .models.knn import Unit
         if transport not in ('fp32', 'bf16'):
@@ -40,6 +44,8 @@ class GradReducer:
         self.group = group
         self.world = dist.get_world_size(group)
         self.transport = transport
+        self.overlap = overlap
+        self._ready = []     # overlap=False: arena slices noted by the hooks, reduced in finish()
         self.units: List[Unit] = [m for m in root.modules() if isinstance(m, Unit)]
         self._pending = []   # (work, fp32 arena slice, wire tensor or None)
         self._avg = dist.get_backend(group) == 'nccl'   # RCCL has ncclAvg; gloo sums then scales
@@ -81,11 +87,18 @@ class GradReducer:
             self._sync = prev
 
     def _reduce(self, t) -> None:
+        if not self.overlap:
+            self._ready.append(t)
+            self.pieces_issued += 1
+            return
+        self._launch(t)
+        self.pieces_issued += 1
+
+    def _launch(self, t) -> None:
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         wire = t.to(torch.bfloat16) if self.transport == 'bf16' else None
         work = dist.all_reduce(wire if wire is not None else t, op=op, group=self.group, async_op=True)
         self._pending.append((work, t, wire))
-        self.pieces_issued += 1
 
     def _check_not_in_flight(self, unit) -> None:
         if id(unit) in self._done or id(unit) in self._early:
@@ -99,7 +112,7 @@ class GradReducer:
             return
         if id(unit) in self._done:
             self._check_not_in_flight(unit)
-        sp = self._split.get(id(unit))
+        sp = self._split.get(id(unit)) if self.overlap else None   # overlap=False: one all-reduce per whole arena
         if sp is not None and idx == sp[0]:
             self._check_not_in_flight(unit)
             self._early.add(id(unit))
@@ -124,6 +137,9 @@ class GradReducer:
         a disjoint arena slice, reduced and scaled exactly once."""
         if self._early:
             raise RuntimeError('GradReducer.finish(): a Unit sent its arena tail but never finished its backward')
+        for t in self._ready:
+            self._launch(t)
+        self._ready.clear()
         for work, flat, wire in self._pending:
             work.wait()
             if wire is not None:

@@ -94,6 +94,17 @@ def _worker(rank, world, port, q):
         expect16 = torch.linspace(-1, 1, arena.flat.numel()) * (sum(range(1, world + 1)) / world)
         bf_ok = float((arena.flat - expect16).abs().max()) <= 2 ** -7 and arena.flat.dtype == torch.float32
 
+        # (4b) overlap=False: the hooks send nothing, finish() reduces the same pieces back to back
+        red_late = GradReducer(net, broadcast_init=False, overlap=False)
+        arena.flat.fill_(float(rank + 1))
+        for idx in range(len(u.plan()) - 2, -1, -1):
+            u._layer_done(idx)
+        u._after_backward()
+        late_ok = len(red_late._pending) == 0 and len(red_late._ready) == red_late.pieces_issued == 1   # the whole arena, once
+        red_late.finish()
+        late_ok = late_ok and torch.allclose(arena.flat, torch.full_like(arena.flat, sum(range(1, world + 1)) / world))
+        late_ok = late_ok and not red_late._ready and not red_late._pending
+
         # (5) checkpoint: per-rank BatchNorm buffers -> rank 0's on every rank, rank 0 writes the reference's layout
         import tempfile
         for b in net.buffers():
@@ -104,8 +115,8 @@ def _worker(rank, world, port, q):
         buf_ok = all(float(b.float().mean()) == 3.0 for b in net.buffers() if b.dtype.is_floating_point)
         wrote = os.path.exists(os.path.join(d, 'encoder', 'core.mdl'))
         buf_ok = buf_ok and (wrote == (rank == 0))
-        q.put((rank, same_init, ok and raised and acc_ok and bf_ok and buf_ok, pending_after,
-               dict(base=ok, raised=raised, acc=acc_ok, bf16=bf_ok, save=buf_ok)))
+        q.put((rank, same_init, ok and raised and acc_ok and bf_ok and buf_ok and late_ok, pending_after,
+               dict(base=ok, raised=raised, acc=acc_ok, bf16=bf_ok, save=buf_ok, late=late_ok)))
     finally:
         dist.destroy_process_group()
 
