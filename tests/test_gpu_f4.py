@@ -135,3 +135,39 @@ def test_autoencoder_loads_reference_checkpoint_and_transfers(golden, tmp_path):
             assert np.array_equal(sd[n].numpy(), ref), n
         else:
             close(sd[n], ref, atol=1e-7)
+
+
+def test_amp_initialize_mirrors_the_reference_recipe():
+    """`amp.initialize(net, optim, opt_level=...)` + `with amp.scale_loss(loss, optim)` (transporter.py:51,84-86) on the
+    native implementation: O0 -> strict fp32 Units and no scaler (scale_loss is the identity), O2 -> fp16 Units with a
+    dynamic scaler, loss_scale=<number> -> a static one; three steps of each run and lower the loss."""
+    import keypoints_amd as ka
+    from keypoints_amd import amp
+    from keypoints_amd.models import knn, transporter
+    g = torch.Generator().manual_seed(5)
+    xs = (torch.rand(8, 1, 32, 32, generator=g) * 2 - 1).cuda()
+    xt = (torch.rand(8, 1, 32, 32, generator=g) * 2 - 1).cuda()
+    for opt_level, loss_scale, want in (('O0', 'dynamic', 'fp32'), ('O2', 'dynamic', 'fp16'), ('O1', 128.0, 'fp16')):
+        torch.manual_seed(2)
+        net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 3).cuda()
+        opt = ka.FusedAdam(net.parameters(), lr=1e-3).bind(net)
+        net, opt = amp.initialize(net, opt, opt_level=opt_level, loss_scale=loss_scale)
+        assert all(m.precision == want for m in net.modules() if isinstance(m, knn.Unit))
+        assert (opt.scaler is None) == (want == 'fp32')
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            loss = ka.l2_reconstruction_loss(net(xs, xt)[0], xt)
+            with amp.scale_loss(loss, opt) as scaled_loss:
+                if opt.scaler is None:
+                    assert scaled_loss is loss
+                else:
+                    assert abs(float(scaled_loss) - float(loss) * opt.scaler.scale) <= 1e-3 * abs(float(scaled_loss))
+                scaled_loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        assert losses[-1] < losses[0], losses
+        if opt.scaler is not None:
+            assert opt.scaler.steps_skipped == 0 and opt.scaler.adam_steps == 3
+            if loss_scale != 'dynamic':
+                assert opt.scaler.scale == 128.0
