@@ -62,6 +62,16 @@ int kp_device_cus(void);
 int kp_config(int key, int value);
 #define KP_CFG_WGRAD_PATCH 3  /* 1 (default): tap-reuse weight-gradient kernel where eligible; 0: per-tap kernel */
 #define KP_CFG_BN_FAST 4      /* 1 (default): multi-row unrolled bf16 BatchNorm/activation kernels; 0: general kernels */
+#define KP_CFG_WALK 5         /* memory walk order of the passes, a mask of KP_WALK_* (default KP_WALK_DEFAULT; 0 = every pass front to back,
+                               * plain loads).  Changes no result except the summation order of the fp32 BatchNorm partials. */
+#define KP_WALK_CONV_LINEAR 1     /* persistent 3x3 kernels take their tiles in ONE front over the batch (step i of the grid covers
+                                   * tile ids [i*grid, (i+1)*grid)) instead of eight per-XCD ranges */
+#define KP_WALK_FWD_REVERSE 2     /* kp_bn_act_fwd sweeps the conv output back to front (last-written images first) */
+#define KP_WALK_REDUCE_REVERSE 4  /* kp_bn_act_bwd_reduce sweeps the incoming gradient back to front; the apply pass then runs front to back */
+#define KP_WALK_APPLY_REVERSE 8   /* kp_bn_act_bwd_apply back to front (measurement only) */
+#define KP_WALK_STREAM_LOADS 128  /* the BatchNorm passes read with non-temporal loads (nothing re-reads their inputs soon) */
+#define KP_WALK_DEFAULT (KP_WALK_CONV_LINEAR | KP_WALK_FWD_REVERSE | KP_WALK_REDUCE_REVERSE | KP_WALK_STREAM_LOADS)
+#define KP_CFG_CUS 6          /* CU budget the persistent kernels size their grids to (launches on a CU-masked stream); 0 = whole device */
 #define KP_CFG_TRACE 2        /* device buffer of 512 int64: s_memtime stamps of workgroup 0 of the patch conv kernel */
 int kp_config_ptr(int key, void* value);
 

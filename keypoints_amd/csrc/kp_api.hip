@@ -19,6 +19,11 @@ void kp_set_query_mode(int on) { g_query = on; }
 long long* g_kp_trace = nullptr;   // kp_config_ptr(KP_CFG_TRACE, dev_ptr): s_memtime trace buffer (512 x i64) or NULL
 int g_kp_wgrad_patch = 1;   // kp_config(KP_CFG_WGRAD_PATCH, v)
 int g_kp_bn_fast = 1;       // kp_config(KP_CFG_BN_FAST, v)
+// Memory walk order of the passes (kp_common.h: KP_WALK_*; kp_config(KP_CFG_WALK, mask), 0 = every pass front to back):
+// a pass that follows a producer sweeps the producer's output back to front, so that it starts on what is still in the
+// 256 MiB Infinity Cache, and reads what nobody re-reads soon with streaming loads
+int g_kp_walk = KP_WALK_DEFAULT;
+int g_kp_cus = 0;     // kp_config(KP_CFG_CUS, n): CU budget that persistent kernels size their grids to (0 = the whole device)
 int g_kp_debug = 0;   // kp_config(KP_CFG_DEBUG, mask): kernel ablation switches for measurements
 
 void kp_set_error(const char* fmt, ...) {
@@ -62,15 +67,21 @@ long long kp_last_rows(void) { return g_last_rows; }
 const char* kp_last_error(void) { return g_err; }
 
 int kp_device_cus(void) {
+    if (g_kp_cus > 0) return g_kp_cus;
+    static int cached = 0;
+    if (cached > 0) return cached;
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    cached = n;
     return n;
 }
 
 int kp_config(int key, int value) {
     if (key == KP_CFG_CONV_PATCH) { g_kp_conv_patch = value ? 1 : 0; return KP_OK; }
     if (key == KP_CFG_DEBUG) { g_kp_debug = value; return KP_OK; }
+    if (key == KP_CFG_WALK) { g_kp_walk = value; return KP_OK; }
+    if (key == KP_CFG_CUS) { g_kp_cus = value > 0 ? value : 0; return KP_OK; }
     if (key == KP_CFG_BN_FAST) { g_kp_bn_fast = value ? 1 : 0; return KP_OK; }
     if (key == KP_CFG_WGRAD_PATCH) { g_kp_wgrad_patch = value ? 1 : 0; return KP_OK; }
     kp_set_error("kp_config: unknown key %d", key);

@@ -52,18 +52,27 @@ __device__ __forceinline__ uint4 pack8(const float (&o)[V]) {
     return v;
 }
 __device__ __forceinline__ uint4 ldv(const h16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// streaming load: the line is not kept in the caches behind it (last use of the data for a long time)
+__device__ __forceinline__ uint4 ldv_nt(const h16_t* p, int nt) {
+    if (!nt) return ldv(p);
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void stv(h16_t* p, const uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ---- forward, tail none: out[n][i][j] = act(bn(y[n][clamp(i-p)][clamp(j-p)])) ------------------------------
 __global__ __launch_bounds__(TPB) void bn_act_fwd_none_fast_k(const h16_t* __restrict__ y, BnP bn, float slope,
                                                               h16_t* __restrict__ out, int p, int H, int W, int C,
-                                                              long long total_rows, int rpb) {
+                                                              long long total_rows, int rpb, int walk) {
     const int CV = C / V, Hp = H + 2 * p, Wp = W + 2 * p;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
     const int c = cv * V;
     BnC k; k.load(bn, c);
-    const long long r0 = (long long)blockIdx.x * rpb;
+    const unsigned bid = (walk & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int nt = walk & 2;
+    const long long r0 = (long long)bid * rpb;
     for (int rr = 0; rr < rpb; ++rr) {
         const long long row = r0 + rr;
         if (row >= total_rows) break;
@@ -77,7 +86,7 @@ __global__ __launch_bounds__(TPB) void bn_act_fwd_none_fast_k(const h16_t* __res
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int j = j0 + u * npl;
-                if (j < Wp) raw[u] = ldv(yr + (long long)clampi(j - p, 0, W - 1) * C);
+                if (j < Wp) raw[u] = ldv_nt(yr + (long long)clampi(j - p, 0, W - 1) * C, nt);
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
@@ -109,14 +118,16 @@ template <int TAIL>
 __global__ __launch_bounds__(TPB) void bn_act_fwd_tail_fast_k(const h16_t* __restrict__ y, BnP bn, float slope,
                                                               h16_t* __restrict__ out, int p,
                                                               unsigned char* __restrict__ argmax, int H, int W, int C,
-                                                              long long total_rows, int rpb) {
+                                                              long long total_rows, int rpb, int walk) {
     constexpr int U2 = 2;   // output pixels in flight per thread (8 loads)
     const int Ho = TAIL == 1 ? H / 2 : 2 * H, Wo = TAIL == 1 ? W / 2 : 2 * W;
     const int CV = C / V, Hp = Ho + 2 * p, Wp = Wo + 2 * p;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
     const int c = cv * V;
     BnC k; k.load(bn, c);
-    const long long r0 = (long long)blockIdx.x * rpb;
+    const unsigned bid = (walk & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int nt = walk & 2;
+    const long long r0 = (long long)bid * rpb;
     for (int rr = 0; rr < rpb; ++rr) {
         const long long row = r0 + rr;
         if (row >= total_rows) break;
@@ -147,10 +158,10 @@ __global__ __launch_bounds__(TPB) void bn_act_fwd_tail_fast_k(const h16_t* __res
                     int wa, wb;
                     if (TAIL == 1) { wa = 2 * ow; wb = 2 * ow + 1; lw0[u] = lw1[u] = 0.f; }
                     else { int w0, wp; bilin(ow, W, Wo, w0, wp, lw0[u], lw1[u]); wa = w0; wb = w0 + wp; }
-                    raw[u][0] = ldv(y0 + (long long)wa * C);
-                    raw[u][1] = ldv(y0 + (long long)wb * C);
-                    raw[u][2] = ldv(y1 + (long long)wa * C);
-                    raw[u][3] = ldv(y1 + (long long)wb * C);
+                    raw[u][0] = ldv_nt(y0 + (long long)wa * C, nt);
+                    raw[u][1] = ldv_nt(y0 + (long long)wb * C, nt);
+                    raw[u][2] = ldv_nt(y1 + (long long)wa * C, nt);
+                    raw[u][3] = ldv_nt(y1 + (long long)wb * C, nt);
                 }
             }
 #pragma unroll
@@ -203,13 +214,15 @@ __global__ __launch_bounds__(TPB) void bn_act_fwd_tail_fast_k(const h16_t* __res
 // at odd paddings / image ends) takes the direct path.
 __global__ __launch_bounds__(TPB) void bn_act_fwd_up_fast_k(const h16_t* __restrict__ y, BnP bn, float slope,
                                                             h16_t* __restrict__ out, int p, int H, int W, int C,
-                                                            long long total_rows, int rpb) {
+                                                            long long total_rows, int rpb, int walk) {
     const int Ho = 2 * H, Wo = 2 * W;
     const int CV = C / V, Hp = Ho + 2 * p, Wp = Wo + 2 * p, HB = (Hp + 1) / 2, WB = (Wp + 1) / 2;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
     const int c = cv * V;
     BnC k; k.load(bn, c);
-    const long long r0 = (long long)blockIdx.x * rpb;
+    const unsigned bid = (walk & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int nt = walk & 2;
+    const long long r0 = (long long)bid * rpb;
     for (int rr = 0; rr < rpb; ++rr) {
         const long long row = r0 + rr;              // block row: (n, bi)
         if (row >= total_rows) break;
@@ -229,8 +242,8 @@ __global__ __launch_bounds__(TPB) void bn_act_fwd_up_fast_k(const h16_t* __restr
             const int cA = ww0[0], cB = cA + 1 < W ? cA + 1 : W - 1;
             float s[2][2][V];   // activated sources [row A/B][col A/B]
             {
-                const uint4 rAA = ldv(yA + (long long)cA * C), rAB = ldv(yA + (long long)cB * C);
-                const uint4 rBA = ldv(yB + (long long)cA * C), rBB = ldv(yB + (long long)cB * C);
+                const uint4 rAA = ldv_nt(yA + (long long)cA * C, nt), rAB = ldv_nt(yA + (long long)cB * C, nt);
+                const uint4 rBA = ldv_nt(yB + (long long)cA * C, nt), rBB = ldv_nt(yB + (long long)cB * C, nt);
                 float v[V];
                 unpack8(rAA, v);
 #pragma unroll
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_fast_k(const h16_t* __restrict__ g
                                                      const h16_t* __restrict__ y, BnP bn, float slope,
                                                      float* __restrict__ partials, const float* __restrict__ sums,
                                                      h16_t* __restrict__ dy, int dp, int N, int H, int W, int C,
-                                                     long long total_rows, int rpb) {
+                                                     long long total_rows, int rpb, int walk) {
     const int CV = C / V;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
     const int c = cv * V;
@@ -336,7 +349,9 @@ __global__ __launch_bounds__(TPB) void bn_bwd_fast_k(const h16_t* __restrict__ g
         }
     }
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    const long long r0 = (long long)blockIdx.x * rpb;
+    const unsigned bid = (walk & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int nt = walk & 2;
+    const long long r0 = (long long)bid * rpb;
     for (int rr = 0; rr < rpb; ++rr) {
         const long long row = r0 + rr;
         if (row >= total_rows) break;
@@ -369,8 +384,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_fast_k(const h16_t* __restrict__ g
                 const int w = w0 + u * npl;
                 if (w < W) {
                     const int sw = POOL ? (w >> 1) : w;
-                    graw[u] = ldv(g_centre<GP>(gsrc, n, sh, sw, Hs, Ws, C) + c);
-                    yraw[u] = ldv(yr + (long long)w * C);
+                    graw[u] = ldv_nt(g_centre<GP>(gsrc, n, sh, sw, Hs, Ws, C) + c, nt);
+                    yraw[u] = ldv_nt(yr + (long long)w * C, nt);
                     if (POOL) amraw[u] = *reinterpret_cast<const uint2*>(argmax + ((n * Hs + sh) * Ws + sw) * (long long)C + c);
                 }
             }
@@ -431,8 +446,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_fast_k(const h16_t* __restrict__ g
                     a += red[(r2 * CV + cv) * 2 * V + e];
                     b += red[(r2 * CV + cv) * 2 * V + V + e];
                 }
-                partials[((long long)blockIdx.x * 2 + 0) * C + c + e] = a;
-                partials[((long long)blockIdx.x * 2 + 1) * C + c + e] = b;
+                partials[((long long)bid * 2 + 0) * C + c + e] = a;
+                partials[((long long)bid * 2 + 1) * C + c + e] = b;
             }
         }
     }
@@ -447,7 +462,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_pool_fast_k(const h16_t* __restric
                                                           const h16_t* __restrict__ y, BnP bn, float slope,
                                                           float* __restrict__ partials, const float* __restrict__ sums,
                                                           h16_t* __restrict__ dy, int dp, int N, int H, int W, int C,
-                                                          long long total_rows, int rpb) {
+                                                          long long total_rows, int rpb, int walk) {
     constexpr int U2 = MODE == 0 ? 1 : 2;   // reduce: occupancy beats loads in flight (measured 212 -> 192 us), apply: the reverse
     const int CV = C / V;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
@@ -466,7 +481,9 @@ __global__ __launch_bounds__(TPB) void bn_bwd_pool_fast_k(const h16_t* __restric
         }
     }
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    const long long r0 = (long long)blockIdx.x * rpb;
+    const unsigned bid = (walk & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int nt = walk & 2;
+    const long long r0 = (long long)bid * rpb;
     for (int rr = 0; rr < rpb; ++rr) {
         const long long row = r0 + rr;
         if (row >= total_rows) break;
@@ -496,12 +513,12 @@ __global__ __launch_bounds__(TPB) void bn_bwd_pool_fast_k(const h16_t* __restric
             for (int u = 0; u < U2; ++u) {
                 const int sw = w0 + u * npl;
                 if (sw < Ws) {
-                    graw[u] = ldv(g_centre<GP>(gsrc, n, sh, sw, Hs, Ws, C) + c);
+                    graw[u] = ldv_nt(g_centre<GP>(gsrc, n, sh, sw, Hs, Ws, C) + c, nt);
                     amraw[u] = *reinterpret_cast<const uint2*>(argmax + ((n * Hs + sh) * Ws + sw) * (long long)C + c);
-                    yraw[u][0] = ldv(y0 + (long long)(2 * sw) * C);
-                    yraw[u][1] = ldv(y0 + (long long)(2 * sw + 1) * C);
-                    yraw[u][2] = ldv(y1 + (long long)(2 * sw) * C);
-                    yraw[u][3] = ldv(y1 + (long long)(2 * sw + 1) * C);
+                    yraw[u][0] = ldv_nt(y0 + (long long)(2 * sw) * C, nt);
+                    yraw[u][1] = ldv_nt(y0 + (long long)(2 * sw + 1) * C, nt);
+                    yraw[u][2] = ldv_nt(y1 + (long long)(2 * sw) * C, nt);
+                    yraw[u][3] = ldv_nt(y1 + (long long)(2 * sw + 1) * C, nt);
                 }
             }
 #pragma unroll
@@ -562,8 +579,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_pool_fast_k(const h16_t* __restric
                     a += red[(r2 * CV + cv) * 2 * V + e];
                     b += red[(r2 * CV + cv) * 2 * V + V + e];
                 }
-                partials[((long long)blockIdx.x * 2 + 0) * C + c + e] = a;
-                partials[((long long)blockIdx.x * 2 + 1) * C + c + e] = b;
+                partials[((long long)bid * 2 + 0) * C + c + e] = a;
+                partials[((long long)bid * 2 + 1) * C + c + e] = b;
             }
         }
     }
@@ -687,6 +704,8 @@ int kp_bn_act_fwd_fast(const void* y, const float* mean, const float* invstd, co
                        hipStream_t st) {
     if (!fast_shape(C)) return KP_E_UNSUPPORTED;
     if (tail == KP_TAIL_MAXPOOL2 && ((H | W) & 1)) return KP_E_UNSUPPORTED;
+    extern int g_kp_walk;
+    const int walk = ((g_kp_walk & KP_WALK_FWD_REVERSE) ? 1 : 0) | ((g_kp_walk & KP_WALK_STREAM_LOADS) ? 2 : 0);
     BnP bn{mean, invstd, gamma, beta};
     const int Ho = tail == KP_TAIL_MAXPOOL2 ? H / 2 : (tail == KP_TAIL_UPSAMPLE2 ? 2 * H : H);
     const int Wo = tail == KP_TAIL_MAXPOOL2 ? W / 2 : (tail == KP_TAIL_UPSAMPLE2 ? 2 * W : W);
@@ -695,15 +714,15 @@ int kp_bn_act_fwd_fast(const void* y, const float* mean, const float* invstd, co
     const int rpb = rows_per_block(rows, (Wo + 2 * out_pad) * (C / V) * work, kp_device_cus());
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
     if (tail == KP_TAIL_NONE)
-        bn_act_fwd_none_fast_k<<<grid, TPB, 0, st>>>((const h16_t*)y, bn, slope, (h16_t*)out, out_pad, H, W, C, rows, rpb);
+        bn_act_fwd_none_fast_k<<<grid, TPB, 0, st>>>((const h16_t*)y, bn, slope, (h16_t*)out, out_pad, H, W, C, rows, rpb, walk);
     else if (tail == KP_TAIL_MAXPOOL2)
-        bn_act_fwd_tail_fast_k<1><<<grid, TPB, 0, st>>>((const h16_t*)y, bn, slope, (h16_t*)out, out_pad, argmax, H, W, C, rows, rpb);
+        bn_act_fwd_tail_fast_k<1><<<grid, TPB, 0, st>>>((const h16_t*)y, bn, slope, (h16_t*)out, out_pad, argmax, H, W, C, rows, rpb, walk);
     else {
         const int HB = (Ho + 2 * out_pad + 1) / 2, WB = (Wo + 2 * out_pad + 1) / 2;
         const long long brows = (long long)N * HB;
         const int brpb = rows_per_block(brows, WB * (C / V) * 4, kp_device_cus());
         bn_act_fwd_up_fast_k<<<(unsigned)((brows + brpb - 1) / brpb), TPB, 0, st>>>((const h16_t*)y, bn, slope, (h16_t*)out,
-                                                                                  out_pad, H, W, C, brows, brpb);
+                                                                                  out_pad, H, W, C, brows, brpb, walk);
     }
     return kp_check_launch("bn_act_fwd_fast");
 }
@@ -715,6 +734,8 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
     if (!(tail == KP_TAIL_NONE || tail == KP_TAIL_MAXPOOL2) || gp < 0 || gp > 1 || !fast_shape(C)) return KP_E_UNSUPPORTED;
     if (tail == KP_TAIL_MAXPOOL2 && ((H | W) & 1)) return KP_E_UNSUPPORTED;
     BnP bn{mean, invstd, gamma, beta};
+    extern int g_kp_walk;
+    const int walk = ((g_kp_walk & (mode ? KP_WALK_APPLY_REVERSE : KP_WALK_REDUCE_REVERSE)) ? 1 : 0) | ((g_kp_walk & KP_WALK_STREAM_LOADS) ? 2 : 0);
     const int pool = tail == KP_TAIL_MAXPOOL2;
     if (pool) {   // walk pooled rows
         const long long prows = (long long)N * (H / 2);
@@ -724,7 +745,7 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
         KP_QUERY_RETURN();
 #define KP_BWDP(GPv, MODEv)                                                                                               \
     bn_bwd_pool_fast_k<GPv, MODEv><<<pgrid, TPB, 0, st>>>((const h16_t*)gsrc, argmax, (const h16_t*)y, bn, slope, partials, \
-                                                         sums, (h16_t*)dy, dp, N, H, W, C, prows, prpb)
+                                                         sums, (h16_t*)dy, dp, N, H, W, C, prows, prpb, walk)
         if (mode == 0) { if (gp) KP_BWDP(1, 0); else KP_BWDP(0, 0); }
         else { if (gp) KP_BWDP(1, 1); else KP_BWDP(0, 1); }
 #undef KP_BWDP
@@ -737,7 +758,7 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
     KP_QUERY_RETURN();
 #define KP_BWD(POOLv, GPv, MODEv)                                                                                    \
     bn_bwd_fast_k<POOLv, GPv, MODEv><<<grid, TPB, 0, st>>>((const h16_t*)gsrc, argmax, (const h16_t*)y, bn, slope,  \
-                                                           partials, sums, (h16_t*)dy, dp, N, H, W, C, rows, rpb)
+                                                           partials, sums, (h16_t*)dy, dp, N, H, W, C, rows, rpb, walk)
     if (mode == 0) {
         if (pool) { if (gp) KP_BWD(1, 1, 0); else KP_BWD(1, 0, 0); }
         else { if (gp) KP_BWD(0, 1, 0); else KP_BWD(0, 0, 0); }

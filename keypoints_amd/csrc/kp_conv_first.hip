@@ -507,8 +507,8 @@ static bool first_wgrad_plan(int N, int Ho, int Wo, int C, int K, long long& gro
     const long long M = (long long)N * Ho * Wo;
     if (!(K == 64 && C >= 1 && C <= 3 && Wo % FG == 0 && M >= 65536)) return false;
     groups = M / FG;
-    static int cus = 0;
-    if (!cus) { cus = kp_device_cus(); if (cus <= 0) cus = 256; }
+    int cus = kp_device_cus();   // (the CU budget of the launching lane: kp_config(KP_CFG_CUS))
+    if (cus <= 0) cus = 256;
     long long per_wg = (groups + cus - 1) / cus;            // one workgroup (160 KB of LDS) per CU
     gpw = (int)((per_wg + 15) / 16);
     if (gpw < 1) gpw = 1;

@@ -40,6 +40,7 @@ struct PatchArgs {
     int Hob, Wob, ooff;   // output buffer rows / cols, offset of the tile domain in it
     int H, W;             // tile domain (multiples of 16)
     int C, K, ktiles, ntiles, dbg;
+    int linear;           // 1: tile ids in time order (step i of the grid covers ids [i*grid, (i+1)*grid)); 0: 8 XCD ranges
     int compact;          // 1: BN partial sums are accumulated per workgroup (rows = 4 * grid); 0: 4 rows per pixel tile
     long long* trace;     // optional: s_memtime stamps of workgroup 0 / wave 0 (512 entries), measurement only
 };
@@ -76,8 +77,9 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     //      round-robin, so the workgroups of an XCD work on neighbouring tiles at the same time (L2 reuse)
     const int per_xcd = gridDim.x >> 3, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int Q = (A.ntiles + 7) >> 3;
-    const int tile_hi = (xcd + 1) * Q < A.ntiles ? (xcd + 1) * Q : A.ntiles;
-    int tile = xcd * Q + jb;
+    const int tile_hi = A.linear ? A.ntiles : ((xcd + 1) * Q < A.ntiles ? (xcd + 1) * Q : A.ntiles);
+    const int tstride = A.linear ? (int)gridDim.x : per_xcd;   // ids between two consecutive tiles of a workgroup
+    int tile = A.linear ? xcd * per_xcd + jb : xcd * Q + jb;
     if (STATS && A.compact) {   // this workgroup's 4 rows: zero everywhere, its own k-tile columns are set at the end
         float* rowp = A.partials + (long long)blockIdx.x * 4 * 2 * K;
         for (int i = tid; i < 4 * 2 * K; i += TPB) rowp[i] = 0.f;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         return t;
     };
     // a workgroup's next tile is per_xcd ids further: add the mixed-radix digits of that stride with carries
-    const int d_kt = per_xcd % A.ktiles, d_pt = per_xcd / A.ktiles;
+    const int d_kt = tstride % A.ktiles, d_pt = tstride / A.ktiles;
     const int d_tx = d_pt % tiles_x, d_ty = (d_pt / tiles_x) % tiles_y, d_n = d_pt / (tiles_x * tiles_y);
     auto advance = [&](const TileRef& c) {
         TileRef t;
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     bool after_epi = false;
 
     while (true) {
-        const int ntile_id = tile + per_xcd;
+        const int ntile_id = tile + tstride;
         const bool has_next = ntile_id < tile_hi;
         TileRef nxt = cur;
         __amdgpu_buffer_rsrc_t xrn = xr, wrn = wr;
@@ -456,13 +458,14 @@ int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* 
     a.Hib = Hib; a.Wib = Wib; a.ioff = ioff; a.Hob = Hob; a.Wob = Wob; a.ooff = ooff; a.H = H; a.W = W;
     a.C = C; a.K = K;
     { extern int g_kp_debug; extern long long* g_kp_trace; a.dbg = g_kp_debug; a.trace = g_kp_trace; }
+    { extern int g_kp_walk; a.linear = (g_kp_walk & KP_WALK_CONV_LINEAR) ? 1 : 0; }
     const long long ptiles = (long long)N * (H / TS) * (W / TS);
     const int bn = (K % 128 == 0) ? 128 : 64;
     a.ktiles = K / bn;
     if (ptiles * a.ktiles > 0x7fffffffLL) return KP_E_UNSUPPORTED;
     a.ntiles = (int)(ptiles * a.ktiles);
-    static int cus = 0;
-    if (!cus) { cus = kp_device_cus(); if (cus <= 0) cus = 256; }
+    int cus = kp_device_cus();   // (the CU budget of the launching lane: kp_config(KP_CFG_CUS))
+    if (cus <= 0) cus = 256;
     // one persistent workgroup per CU (134 KB of LDS each), a multiple of the 8 XCDs
     int grid = (cus / 8) * 8;
     if (grid < 8) grid = 8;

@@ -235,8 +235,8 @@ static int plan(int N, int Ho, int Wo, int C, int K, int dy_pad, WgArgs& a, unsi
     const int TKs = k128 ? 128 : 64, TCs = k128 ? 64 : 128;
     a.ktiles = K / TKs; a.ctiles = C / TCs;
     const long long tiles = (long long)a.ktiles * a.ctiles;
-    static int cus = 0;
-    if (!cus) { cus = kp_device_cus(); if (cus <= 0) cus = 256; }
+    int cus = kp_device_cus();   // (the CU budget of the launching lane: kp_config(KP_CFG_CUS))
+    if (cus <= 0) cus = 256;
     // one workgroup per CU (>= 112 KB of LDS each); split the pixel blocks so that the grid fills the chip
     splits = (cus + tiles - 1) / tiles;
     if (splits > total / 4) splits = total / 4;

@@ -1,0 +1,135 @@
+"""Every architecture of the reference's tables that has both an encoder and a decoder entry (vgg.py:48-70: A, F, VGG_PONG,
+VGG_PONG_TRIVIAL, VGG_PONG_LAYERNECK, VGG_PACMAN, VGG_PACMAN_2) as a Transporter, plus the encoder-only tables (B, D, E,
+MAPPER) as single Units: one train step in strict fp32 against the oracle (pinned to the reference by tests/golden), and the
+16-bit modes against the same.  These nets walk kernel paths the two BASELINE architectures do not: a pool / upsample tail
+on the LAST 3x3 layer (A), pools between 16-channel layers, 64-channel MFMA layers at tiny sizes, an 8-channel Unit."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# (A and F shrink the image 32x / 8x: sizes chosen so that the deepest BatchNorm layers still see >= 256 samples per channel)
+# COND: how much wider the bounds of a case are than those of the shallow Pong-class nets.  A (13 BatchNorm layers down
+# to 4x4 maps, 256 samples per channel) and F (8x8, 512 samples) at these test sizes amplify ANY fp32 rounding
+# difference layer by layer: the oracle's own fp32 run sits 6e-5 / 2e-5 rel-L2 from its fp64 run on x_t there, the HIP
+# fp32 path (different summation order) 2.2e-4 / 7e-5 (tools/probes/type_dbg.py).  The BASELINE-size cases with
+# well-conditioned statistics are held to the tight bounds in test_gpu_fullsize.py.
+COND = {'A': 4.0, 'F': 2.0}
+CASES = [('A', 3, 16, 4, 128, 16), ('F', 3, 32, 5, 64, 8), ('VGG_PONG', 1, 16, 3, 32, 6), ('VGG_PONG_TRIVIAL', 1, 16, 3, 32, 6),
+         ('VGG_PONG_LAYERNECK', 1, 16, 3, 32, 6), ('VGG_PACMAN', 3, 16, 4, 32, 6), ('VGG_PACMAN_2', 3, 16, 4, 32, 6)]
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize('typ,cin,z,K,size,B', CASES)
+def test_transporter_type_fp32_train_step_vs_oracle(typ, cin, z, K, size, B):
+    import keypoints_amd as ka
+    from keypoints_amd.models import transporter
+    from oracle import kp_oracle as O
+    plans = O.transporter_plans(typ, cin, z, K)
+    P, Bf = O.init_params(plans, seed=7)
+    g = torch.Generator().manual_seed(8)
+    xs = torch.rand(B, cin, size, size, generator=g)
+    xt = torch.rand(B, cin, size, size, generator=g)
+    net = transporter.make(typ, cin, z, K)
+    net.load_state_dict({**P, **Bf}, strict=True)
+    net = net.cuda().set_precision('fp32')
+    opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
+    opt.zero_grad()
+    out = net(xs.cuda(), xt.cuda())
+    loss = ka.l2_reconstruction_loss(out[0], xt.cuda())
+    loss.backward()
+    G = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+    opt.step()
+    oP = {k: v.double() for k, v in P.items()}
+    oB = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in Bf.items()}
+    oloss, oout, oG = O.transporter_train_step(plans, oP, oB, {}, xs.double(), xt.double())
+    c = COND.get(typ, 1.0)
+    assert abs(float(loss.detach()) - float(oloss)) <= c * 1e-5 * abs(float(oloss))
+    assert float((out[0].detach().cpu().double() - oout[0]).abs().max()) <= c * 1.5e-4 * float(oout[0].abs().max())
+    assert float((out[2].detach().cpu().double() - oout[2]).abs().max()) <= c * 5e-5   # (2e-5 at BASELINE sizes; these nets are tiny)
+    assert out[0].shape == xt.shape and out[3].shape[1] == K
+    noise = {f"{n}.{s['key']}.bias" for n, pl in plans.items() for s in pl if s['op'] == 'conv3'}
+    errs = {n: rel(G[n], oG[n]) for n in G if n not in noise and float(oG[n].norm()) > 0}
+    worst = max(errs.values())
+    assert worst <= c * 2e-2 and np.median(list(errs.values())) <= c * 5e-3, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    sd = net.state_dict()
+    for n, b in oB.items():
+        if not n.endswith('num_batches_tracked'):
+            assert float((sd[n].cpu().double() - b).abs().max()) <= c * 2e-5 * max(1.0, float(b.abs().max())), n
+
+
+@pytest.mark.parametrize('precision,tol', [('bf16', 0.25), ('fp16', 0.04)])
+@pytest.mark.parametrize('typ,cin,z,K,size,B', CASES)
+def test_transporter_type_16bit_tracks_fp32(typ, cin, z, K, size, B, precision, tol):
+    """The same nets in the 16-bit modes against the HIP fp32 run (small batches at random init: loose bounds; the point
+    is that every kernel path of these shapes runs and lands in the right place)."""
+    import keypoints_amd as ka
+    from keypoints_amd.models import transporter
+    g = torch.Generator().manual_seed(8)
+    xs = torch.rand(B, cin, size, size, generator=g).cuda()
+    xt = torch.rand(B, cin, size, size, generator=g).cuda()
+    res = {}
+    for prec in ('fp32', precision):
+        torch.manual_seed(3)
+        net = transporter.make(typ, cin, z, K).cuda().set_precision(prec)
+        opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
+        if prec == 'fp16':
+            opt.scaler = ka.amp.LossScaler('cuda')
+        for attempt in range(12):   # fp16: an initial scale of 2^16 may overflow on these tiny nets -> skipped step, scale halves
+            opt.zero_grad()
+            out = net(xs, xt)
+            loss = ka.l2_reconstruction_loss(out[0], xt)
+            with ka.amp.scale_loss(loss, opt) as scaled:
+                scaled.backward()
+            skipped = opt.scaler.steps_skipped if opt.scaler is not None else 0
+            opt.step()
+            if opt.scaler is None or opt.scaler.steps_skipped == skipped:
+                break
+        assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+        if opt.scaler is not None:
+            assert opt.scaler.adam_steps == 1
+        res[prec] = (float(loss), out[0].detach(), out[2].detach())
+    l32, x32, k32 = res['fp32']
+    l16, x16, k16 = res[precision]
+    c = COND.get(typ, 1.0)
+    assert abs(l16 - l32) <= 0.05 * abs(l32)
+    assert rel(x16, x32) <= min(1.0, c * 1.5 * tol) and float((k16 - k32).abs().max()) <= c * tol
+
+
+@pytest.mark.parametrize('typ,cin,cout,size', [('B', 3, 8, 128), ('D', 3, 8, 128), ('E', 3, 8, 128), ('MAPPER', 4, 1, 32)])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_encoder_only_tables_as_units(typ, cin, cout, size, precision):
+    """knn.Unit over the encoder-only tables (B / D / E: VGG-11/13/16/19-style stacks; MAPPER: the 8-channel net of
+    mapper.py:50-52), forward + backward against the oracle's unit_forward + autograd."""
+    import torch.nn as nn
+    from keypoints_amd.models import knn, vgg
+    from oracle import kp_oracle as O
+    torch.manual_seed(5)
+    leaky = dict(nonlinearity=nn.LeakyReLU, nonlinearity_kwargs={'inplace': True})
+    unit = knn.Unit(cin, cout, vgg.make_layers(vgg.vgg_cfg[typ], **leaky))
+    box = knn.Container(); box.u = unit; box._initialize_weights()
+    P = {'u.' + k: v.detach().clone() for k, v in unit.state_dict().items() if 'running' not in k and 'num_batches' not in k}
+    plan = O.unit_plan(O.ENCODER_CORES[typ], cin, cout, O.LEAKY)
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(8, cin, size, size, generator=g)
+    w = torch.randn(8, cout, *([size // 2 ** sum(1 for t in O.ENCODER_CORES[typ] if t == 'M')] * 2), generator=g)
+    unit = unit.cuda(); unit.precision = precision
+    xd = x.cuda().requires_grad_(True)
+    y = unit(xd)
+    assert y.shape == w.shape
+    (y * w.cuda()).sum().backward()
+    oP = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    ox = x.double().requires_grad_(True)
+    oy = O.unit_forward(plan, oP, 'u', ox)
+    (oy * w.double()).sum().backward()
+    tol = 2e-4 if precision == 'fp32' else 0.25
+    assert rel(y, oy) <= tol
+    # 13-19 BatchNorm layers deep: the reference's own fp32-vs-fp64 gradient noise is ~5e-3 here
+    assert rel(xd.grad, ox.grad) <= (2e-2 if precision == 'fp32' else 1.2)
+    gw = unit.in_block[1].weight.grad
+    assert rel(gw, oP['u.in_block.1.weight'].grad) <= (2e-2 if precision == 'fp32' else 1.2)
