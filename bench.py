@@ -60,6 +60,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=16)
     ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="N > 1: 'nccl' (= RCCL, the measured path); 'gloo' only to exercise the multi-rank code path on a box with "
+                         'fewer GPUs than ranks (ranks then share devices; the number is not a scaling result)')
     ap.add_argument('--lib', default='', help='development: time another build of libkp_hip.so (A/B on one box)')
     return ap.parse_args()
 
@@ -105,11 +108,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU fallback)'
+    if args.backend == 'gloo':
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group('gloo')
 
     import keypoints_amd as ka
     from keypoints_amd import _lib

@@ -81,3 +81,29 @@ def test_grad_reducer_nccl_world1_real_backward(nccl_world1, transport):
         assert abs(l0 - l1) <= 1e-3 * abs(l0)
         for (n, a), (_, b) in zip(ref.named_parameters(), dp.named_parameters()):
             assert float((a - b).abs().max()) <= 2.01e-4, n          # Adam steps of lr = 1e-4 in the worst case flip sign
+
+
+@pytest.mark.parametrize('overlap', [0, 1])
+def test_bench_two_ranks_share_the_gpu_over_gloo(overlap):
+    """The driver's N > 1 launch line (torch.distributed.run, one process per rank, barrier + max-over-ranks timing, rank 0
+    prints the JSON line) on the one GPU of a test box: two ranks share cuda:0 and exchange gradients over gloo
+    (`bench.py --backend gloo`; the reported number is not a scaling result).  Everything but the RCCL transport is the path
+    of `bench.py --gpus 2`: sharded batch, GradReducer hooks (both modes), Adam on identical averaged gradients."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--batch', '16', '--backend', 'gloo', '--dp-overlap', str(overlap), '--profile-steps', '0']
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 alone reports
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['config']['global_batch'] == 32 and rec['config']['parallelism'] == 'dp2'
+    assert rec['config']['dp_overlap'] is bool(overlap) and rec['scaling'] == 'weak'
+    assert rec['value'] > 0 and 0 < rec['config']['loss'] < 10 and 'cpu_baseline' not in rec
