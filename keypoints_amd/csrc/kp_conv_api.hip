@@ -20,6 +20,10 @@ long long kp_conv_first_wgrad_partials(int, int, int, int, int);
 long long kp_conv_small_wgrad_partials(int, int, int, int, int);
 long long kp_conv_wgrad_generic_partials(int, int, int, int, int, int);
 int kp_conv_wgrad_mfma_accepts(int, int, int, int, int, int);
+// strict fp32 on the matrix cores (kp_conv_f32.hip, v_mfma_f32_32x32x2_f32): 3x3, C % 16 == 0, K % 64 == 0
+int kp_conv_fwd_f32mfma(const float*, const float*, const float*, float*, float*, int, int, int, int, int, hipStream_t);
+long long kp_conv_wgrad_f32mfma_partials(int, int, int, int, int);
+int kp_conv_wgrad_f32mfma(const float*, const float*, float*, int, int, int, int, int, int, hipStream_t);
 
 extern int g_kp_wgrad_patch;
 
@@ -55,6 +59,10 @@ int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, float*
             rc = kp_conv_small_fwd(x, w, bias, y, stats, N, Hi, Wi, C, K, (hipStream_t)stream);
             if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_SMALL); return rc; }
         }
+    }
+    if (dtype == KP_F32 && R == 3 && use_mfma()) {
+        int rc = kp_conv_fwd_f32mfma((const float*)x, (const float*)w, bias, (float*)y, stats, N, Hi, Wi, C, K, (hipStream_t)stream);
+        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_GENERIC); return rc; }
     }
     if (getenv("KP_LOG_GENERIC")) fprintf(stderr, "generic conv: N=%d Hi=%d Wi=%d C=%d K=%d R=%d dtype=%d stats=%d\n", N, Hi, Wi, C, K, R, dtype, stats != nullptr);
     int rc = kp_conv_fwd_generic(x, w, bias, y, stats, N, Hi, Wi, C, K, R, dtype, (hipStream_t)stream);
@@ -93,6 +101,10 @@ int kp_conv_wgrad_partials(int N, int Ho, int Wo, int C, int K, int R, int dy_pa
     }
     // the per-tap MFMA fallback (kp_wgrad_mfma.hip: 64-multiples the tap-reuse kernel declines): one zeroed buffer, atomics
     if (dtype == KP_H16 && use_mfma() && kp_conv_wgrad_mfma_accepts(N, Ho, Wo, C, K, R)) return 1;
+    if (dtype == KP_F32 && R == 3 && use_mfma()) {
+        const long long p = kp_conv_wgrad_f32mfma_partials(N, Ho, Wo, C, K);
+        if (p > 0 && p < 0x7fffffffLL) return (int)p;
+    }
     const long long p = kp_conv_wgrad_generic_partials(N, Ho, Wo, C, K, R);
     return p < 0x7fffffffLL ? (int)p : 1;
 }
@@ -120,6 +132,10 @@ int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, 
             rc = kp_conv_small_wgrad(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
             if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_SMALL); return rc; }
         }
+    }
+    if (dtype == KP_F32 && R == 3 && use_mfma()) {
+        int rc = kp_conv_wgrad_f32mfma((const float*)x, (const float*)dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
+        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_WGRAD_GENERIC); return rc; }
     }
     if (getenv("KP_LOG_GENERIC")) fprintf(stderr, "generic wgrad: N=%d Ho=%d Wo=%d C=%d K=%d R=%d dp=%d dtype=%d\n", N, Ho, Wo, C, K, R, dy_pad, dtype);
     int rc = kp_conv_wgrad_generic(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, dtype, (hipStream_t)stream);
