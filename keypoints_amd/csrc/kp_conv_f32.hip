@@ -21,6 +21,7 @@
 //       reduction steps = 16 pixels; A = dy^T and B = x are read from pixel-major LDS tiles with ds_read_b32 (a lane
 //       reads ONE channel of pixel p or p + 1: 32 consecutive floats per half wave, conflict free); every split writes its
 //       own partial gradient with plain stores (kp_wgrad_unpack sums them in a fixed order: deterministic).
+#include <stdlib.h>
 #include "kp_mfma_util.h"
 
 namespace {
@@ -171,10 +172,13 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_f32_mfma_k(const float* __rest
 
 // scratch[split][k][tap][c] = sum over the split's pixels of dy[m][k] * x[pix(m) + tap][c]
 constexpr int PB = 16;     // pixels per reduction step
-template <int TK, int TC>
+// ROWT: Wo % 16 == 0 -- a 16-pixel step never leaves its image row, so a step's two row bases are scalars and a
+// thread's offsets constants (the general path recomputes (n, p, q) per load: ~250 instructions per step)
+template <int TK, int TC, bool ROWT>
 __global__ __launch_bounds__(TPB, 2) void wgrad3x3_f32_mfma_k(const float* __restrict__ x, const float* __restrict__ dy,
                                                                float* __restrict__ scratch, int Ho, int Wo, int C, int K,
-                                                               int dy_pad, int ctiles, long long M, long long ppb) {
+                                                               int dy_pad, int ctiles, int ktiles, int splits, long long M,
+                                                               long long ppb) {
     constexpr int AK = TK / 64, AC = TC / 64;      // 32-wide MFMA tiles per wave along k / c
     __shared__ __attribute__((aligned(16))) float Ds[2][PB][TK];
     __shared__ __attribute__((aligned(16))) float Xs[2][PB][TC];
@@ -182,10 +186,19 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_f32_mfma_k(const float* __res
     const int wk = wave >> 1, wc = wave & 1;
     const int fr = lane & 31, fh = lane >> 5;
     const int Hi = Ho + 2, Wi = Wo + 2, Hd = Ho + 2 * dy_pad, Wd = Wo + 2 * dy_pad;
-    const int tap = blockIdx.x / ctiles, c0 = (blockIdx.x - tap * ctiles) * TC;
-    const int k0 = blockIdx.y * TK;
+    // XCD-aware order: the T = 9 * ctiles * ktiles workgroups of ONE pixel split run on one XCD (blockIdx % 8) at the same
+    // time and walk the split's pixels in step, so each 16-pixel slice of dy / x is fetched into that XCD's L2 once and
+    // re-read from there by the other taps / tiles (round-robin placement of a (tap, tile, split) grid had every XCD fetch
+    // every slice: the kernel ran at the pace of the memory-side traffic)
+    const int T = 9 * ctiles * ktiles;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int split = (jb / T) * 8 + xcd, tile = jb % T;
+    if (split >= splits) return;
+    const int kt = tile / (9 * ctiles), tx = tile - kt * 9 * ctiles;
+    const int tap = tx / ctiles, c0 = (tx - tap * ctiles) * TC;
+    const int k0 = kt * TK;
     const int r = tap / 3, sx = tap - 3 * r;
-    const long long mbeg = (long long)blockIdx.z * ppb;
+    const long long mbeg = (long long)split * ppb;
     const long long mend = mbeg + ppb < M ? mbeg + ppb : M;
 
     // loader role: float4 id = tid + 256 * i over a [PB][TK or TC] tile.  The pixel coordinates of a step's first pixel
@@ -204,7 +217,23 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_f32_mfma_k(const float* __res
         q = bq + pr; p = bp; n = bn;
         while (q >= Wo) { q -= Wo; if (++p == Ho) { p = 0; ++n; } }
     };
+    int doff[LD], xoff[LX];
+#pragma unroll
+    for (int i = 0; i < LD; ++i) { const int id = tid + TPB * i; doff[i] = (id / (TK / 4)) * K + (id % (TK / 4)) * 4; }
+#pragma unroll
+    for (int i = 0; i < LX; ++i) { const int id = tid + TPB * i; xoff[i] = (id / (TC / 4)) * C + (id % (TC / 4)) * 4; }
     auto gload = [&](long long mb) {
+        if constexpr (ROWT) {
+            const float* dyrow = dy + ((bn * Hd + bp + dy_pad) * Wd + bq + dy_pad) * (long long)K + k0;
+            const float* xrow = x + ((bn * Hi + bp + r) * Wi + bq + sx) * (long long)C + c0;
+#pragma unroll
+            for (int i = 0; i < LD; ++i) rd[i] = *reinterpret_cast<const f32x4*>(dyrow + doff[i]);
+#pragma unroll
+            for (int i = 0; i < LX; ++i) rx[i] = *reinterpret_cast<const f32x4*>(xrow + xoff[i]);
+            bq += PB;
+            if (bq >= Wo) { bq = 0; if (++bp == Ho) { bp = 0; ++bn; } }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < LD; ++i) {
             const int id = tid + TPB * i, pr = id / (TK / 4), col = (id % (TK / 4)) * 4;
@@ -259,25 +288,32 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_f32_mfma_k(const float* __res
     for (long long mb = mbeg; mb < mend; mb += PB) {
         const bool more = mb + PB < mend;
         if (more) gload(mb + PB);
+        float df[2][AK], xf[2][AC];
+#pragma unroll
+        for (int a = 0; a < AK; ++a) df[0][a] = Ds[buf][fh][wk * (TK / 2) + a * 32 + fr];
+#pragma unroll
+        for (int b = 0; b < AC; ++b) xf[0][b] = Xs[buf][fh][wc * (TC / 2) + b * 32 + fr];
 #pragma unroll
         for (int pp = 0; pp < PB; pp += 2) {
-            float df[AK], xf[AC];
+            const int cur = (pp >> 1) & 1, nxt = cur ^ 1;
+            if (pp + 2 < PB) {
 #pragma unroll
-            for (int a = 0; a < AK; ++a) df[a] = Ds[buf][pp + fh][wk * (TK / 2) + a * 32 + fr];
+                for (int a = 0; a < AK; ++a) df[nxt][a] = Ds[buf][pp + 2 + fh][wk * (TK / 2) + a * 32 + fr];
 #pragma unroll
-            for (int b = 0; b < AC; ++b) xf[b] = Xs[buf][pp + fh][wc * (TC / 2) + b * 32 + fr];
+                for (int b = 0; b < AC; ++b) xf[nxt][b] = Xs[buf][pp + 2 + fh][wc * (TC / 2) + b * 32 + fr];
+            }
 #pragma unroll
             for (int a = 0; a < AK; ++a)
 #pragma unroll
                 for (int b = 0; b < AC; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(df[a], xf[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(df[cur][a], xf[cur][b], acc[a][b], 0, 0, 0);
         }
         if (more) lstore(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
     // D[k][c]: lane: c = fr, k = 8 * (reg >> 2) + 4 * fh + (reg & 3); plain stores, every element has one writer
-    float* out = scratch + (long long)blockIdx.z * K * 9 * C;
+    float* out = scratch + (long long)split * K * 9 * C;
 #pragma unroll
     for (int a = 0; a < AK; ++a)
 #pragma unroll
@@ -290,17 +326,137 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_f32_mfma_k(const float* __res
             }
 }
 
+// Three taps of one filter row per workgroup (Wo % 16 == 0, K % 128 == 0, C % 64 == 0): the 16-pixel dy slice is staged
+// once for the taps s = 0, 1, 2, whose x operands are the same 18-pixel slice of the padded input row read at a shift --
+// 12.6 KB of L2 -> LDS traffic per 48 MFMAs per wave instead of 16 KB per 32.  Workgroup = filter row r x 128 output
+// channels x 64 input channels x one pixel split; wave tile 64 k x 32 c x 3 taps (6 accumulators).
+__global__ __launch_bounds__(TPB, 2) void wgrad3x3_f32_row3_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ scratch, int Ho, int Wo, int C, int K,
+                                                               int dy_pad, int ctiles, int ktiles, int splits, long long M,
+                                                               long long ppb) {
+    constexpr int TK = 128, TC = 64;
+    __shared__ __attribute__((aligned(16))) float Ds[2][PB][TK];
+    __shared__ __attribute__((aligned(16))) float Xs[2][PB + 2][TC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wc = wave & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int Hi = Ho + 2, Wi = Wo + 2, Hd = Ho + 2 * dy_pad, Wd = Wo + 2 * dy_pad;
+    const int T = 3 * ctiles * ktiles;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int split = (jb / T) * 8 + xcd, tile = jb % T;
+    if (split >= splits) return;
+    const int kt = tile / (3 * ctiles), tx = tile - kt * 3 * ctiles;
+    const int r = tx / ctiles, c0 = (tx - r * ctiles) * TC;
+    const int k0 = kt * TK;
+    const long long mbeg = (long long)split * ppb;
+    const long long mend = mbeg + ppb < M ? mbeg + ppb : M;
+
+    int bq = (int)(mbeg % Wo), bp; long long bn;
+    { const long long t = mbeg / Wo; bp = (int)(t % Ho); bn = t / Ho; }
+    // loaders: dy 16 x 128 floats = 512 float4 (2 per thread), x 18 x 64 floats = 288 float4 (1 per thread + 1 for 32 threads)
+    const int doff0 = (tid >> 5) * K + (tid & 31) * 4, doff1 = doff0 + 8 * K;
+    const int xr0 = tid >> 4, xc = (tid & 15) * 4;
+    const int xoff0 = xr0 * C + xc, xoff1 = (xr0 + 16) * C + xc;
+    const bool x2 = tid < 32;
+    f32x4 rd[2], rx[2];
+    auto gload = [&]() {
+        const float* dyrow = dy + ((bn * Hd + bp + dy_pad) * Wd + bq + dy_pad) * (long long)K + k0;
+        const float* xrow = x + ((bn * Hi + bp + r) * Wi + bq) * (long long)C + c0;
+        rd[0] = *reinterpret_cast<const f32x4*>(dyrow + doff0);
+        rd[1] = *reinterpret_cast<const f32x4*>(dyrow + doff1);
+        rx[0] = *reinterpret_cast<const f32x4*>(xrow + xoff0);
+        if (x2) rx[1] = *reinterpret_cast<const f32x4*>(xrow + xoff1);
+        bq += PB;
+        if (bq >= Wo) { bq = 0; if (++bp == Ho) { bp = 0; ++bn; } }
+    };
+    auto lstore = [&](int buf) {
+        *reinterpret_cast<f32x4*>(&Ds[buf][tid >> 5][(tid & 31) * 4]) = rd[0];
+        *reinterpret_cast<f32x4*>(&Ds[buf][(tid >> 5) + 8][(tid & 31) * 4]) = rd[1];
+        *reinterpret_cast<f32x4*>(&Xs[buf][xr0][xc]) = rx[0];
+        if (x2) *reinterpret_cast<f32x4*>(&Xs[buf][xr0 + 16][xc]) = rx[1];
+    };
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][t][i] = 0.f;
+    gload();
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (long long mb = mbeg; mb < mend; mb += PB) {
+        const bool more = mb + PB < mend;
+        if (more) gload();
+        // fragments of pixel pair pp + 2 are read while the MFMAs of pair pp issue (two register sets)
+        float df[2][2], xf[2][3];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) df[0][a] = Ds[buf][fh][wk * 64 + a * 32 + fr];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) xf[0][t] = Xs[buf][fh + t][wc * 32 + fr];
+#pragma unroll
+        for (int pp = 0; pp < PB; pp += 2) {
+            const int cur = (pp >> 1) & 1, nxt = cur ^ 1;
+            if (pp + 2 < PB) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) df[nxt][a] = Ds[buf][pp + 2 + fh][wk * 64 + a * 32 + fr];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) xf[nxt][t] = Xs[buf][pp + 2 + fh + t][wc * 32 + fr];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(df[cur][a], xf[cur][t], acc[a][t], 0, 0, 0);
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* out = scratch + (long long)split * K * 9 * C;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = k0 + wk * 64 + a * 32 + 8 * (i >> 2) + 4 * fh + (i & 3);
+                const int c = c0 + wc * 32 + fr;
+                out[((long long)k * 9 + r * 3 + t) * C + c] = acc[a][t][i];
+            }
+}
+
 bool fwd_ok(int N, int Hi, int Wi, int C, int K) {
     return C % BKC == 0 && K % 64 == 0 && Hi >= 3 && Wi >= 3 && (long long)N * Hi * Wi * C < (1LL << 40);
 }
 
-// pixel splits of the weight gradient: fill the chip with ~4 workgroups per CU, at least 512 pixels per split
+// pixel splits of the weight gradient: ONE resident round of workgroups (4 per CU: 117 VGPRs, 32 KB of LDS) -- the work per
+// workgroup is uniform, so tiles x splits just above the resident count would leave a second, nearly empty round --
+// and at least 512 pixels per split
+bool wgrad_row3(int Wo, int C, int K) { return Wo % PB == 0 && K % 128 == 0 && C % 64 == 0; }
+
 long long wgrad_plan(int N, int Ho, int Wo, int C, int K, long long& ppb, int& tk, int& tc) {
     const long long M = (long long)N * Ho * Wo;
     tk = K % 128 == 0 ? 128 : 64;
     tc = C % 128 == 0 ? 128 : 64;
-    const long long tiles = 9LL * (K / tk) * (C / tc);
-    long long splits = (1024 + tiles - 1) / tiles;
+    long long tiles = 9LL * (K / tk) * (C / tc);
+    if (wgrad_row3(Wo, C, K)) { tc = 64; tiles = 3LL * (K / 128) * (C / 64); }
+    // resident workgroups of the kernel this shape takes (occupancy query, once per kernel)
+    static int slots_row3 = 0, slots_gen = 0;
+    int& slots = wgrad_row3(Wo, C, K) ? slots_row3 : slots_gen;
+    if (!slots) {
+        int per_cu = 0;
+        const hipError_t e = wgrad_row3(Wo, C, K)
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad3x3_f32_row3_k, TPB, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad3x3_f32_mfma_k<128, 128, true>, TPB, 0);
+        int cus = kp_device_cus();
+        if (cus <= 0) cus = 256;
+        slots = (e == hipSuccess && per_cu > 0 ? per_cu : 3) * cus;
+        if (getenv("KP_LOG_GENERIC")) fprintf(stderr, "fp32 wgrad: %d resident workgroups per CU (row3 %d)\n", per_cu, (int)wgrad_row3(Wo, C, K));
+    }
+    long long splits = slots / tiles;
+    if (splits < 1) splits = 1;
     ppb = (M + splits - 1) / splits;
     if (ppb < 512) ppb = 512;
     ppb = (ppb + PB - 1) / PB * PB;
@@ -340,11 +496,23 @@ int kp_conv_wgrad_f32mfma(const float* x, const float* dy, float* scratch, int N
     if (C % 64 != 0 || K % 64 != 0 || Ho < 1 || Wo < 1) return KP_E_UNSUPPORTED;
     long long ppb; int tk, tc;
     const long long splits = wgrad_plan(N, Ho, Wo, C, K, ppb, tk, tc);
-    if (splits > 65535) return KP_E_UNSUPPORTED;
     const long long M = (long long)N * Ho * Wo;
-    const int ctiles = C / tc;
-    const dim3 grid((unsigned)(9 * ctiles), (unsigned)(K / tk), (unsigned)splits);
-#define KP_WG32(TKv, TCv) wgrad3x3_f32_mfma_k<TKv, TCv><<<grid, TPB, 0, st>>>(x, dy, scratch, Ho, Wo, C, K, dy_pad, ctiles, M, ppb)
+    const int ctiles = C / tc, ktiles = K / tk;
+    if (wgrad_row3(Wo, C, K)) {
+        const long long blocks3 = (splits + 7) / 8 * 8 * 3LL * ctiles * ktiles;
+        if (blocks3 >= (1LL << 31)) return KP_E_UNSUPPORTED;
+        wgrad3x3_f32_row3_k<<<(unsigned)blocks3, TPB, 0, st>>>(x, dy, scratch, Ho, Wo, C, K, dy_pad, ctiles, ktiles, (int)splits, M, ppb);
+        return kp_check_launch("wgrad3x3_f32_row3");
+    }
+    const long long blocks = (splits + 7) / 8 * 8 * 9LL * ctiles * ktiles;
+    if (blocks >= (1LL << 31)) return KP_E_UNSUPPORTED;
+    const unsigned grid = (unsigned)blocks;
+    const bool rowt = Wo % PB == 0;   // (then M and every split are multiples of 16 pixels as well)
+#define KP_WG32(TKv, TCv)                                                                                                  \
+    do {                                                                                                                   \
+        if (rowt) wgrad3x3_f32_mfma_k<TKv, TCv, true><<<grid, TPB, 0, st>>>(x, dy, scratch, Ho, Wo, C, K, dy_pad, ctiles, ktiles, (int)splits, M, ppb);  \
+        else wgrad3x3_f32_mfma_k<TKv, TCv, false><<<grid, TPB, 0, st>>>(x, dy, scratch, Ho, Wo, C, K, dy_pad, ctiles, ktiles, (int)splits, M, ppb);     \
+    } while (0)
     if (tk == 128 && tc == 128) KP_WG32(128, 128);
     else if (tk == 128) KP_WG32(128, 64);
     else if (tc == 128) KP_WG32(64, 128);
