@@ -186,34 +186,46 @@ __global__ __launch_bounds__(TPB) void bn_reduce_finalize_k(const float* __restr
 // 1024-thread workgroup per 16 channels, 32 row lanes x (16 sum | 16 sumsq) columns, 8 independent loads in flight
 // per lane; the 32 lanes are folded through LDS in index order (deterministic).  (A "last workgroup finalizes"
 // two-stage kernel was measured 5x slower: device-scope fences between XCDs cost more than the second launch.)
-template <int MODE>
+// CPW = channels per workgroup (16, 8 or 4): narrow layers get as many workgroups as wide ones (a 64-channel layer with
+// 8192 partial rows on 4 workgroups of 16 channels took 26 us, four times the 512-channel case).
+template <int MODE, int CPW>
 __global__ __launch_bounds__(1024) void bn_reduce_finalize_wide_k(const float* __restrict__ partials, long long rows, int C,
                                                                   float* __restrict__ o0, float* __restrict__ o1,
                                                                   float* __restrict__ r0p, float* __restrict__ r1p,
                                                                   long long* __restrict__ nbt, float momentum, float eps,
                                                                   long long count) {
-    const int cl = threadIdx.x & 15, which = (threadIdx.x >> 4) & 1, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 16 + cl;
+    constexpr int RL = 1024 / (2 * CPW);   // row lanes
+    const int cl = threadIdx.x & (CPW - 1), which = (threadIdx.x / CPW) & 1, rl = threadIdx.x / (2 * CPW);
+    const int c = blockIdx.x * CPW + cl;
     double s = 0.0;
     if (c < C) {
         const float* col = partials + (long long)which * C + c;
         const long long stride = 2LL * C;
         long long r = rl;
-        for (; r + 7 * 32 < rows; r += 8 * 32) {
+        for (; r + 7 * RL < rows; r += 8 * RL) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = col[(r + 32 * u) * stride];
+            for (int u = 0; u < 8; ++u) v[u] = col[(r + RL * u) * stride];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += (double)v[u];
         }
-        for (; r < rows; r += 32) s += (double)col[r * stride];
+        for (; r < rows; r += RL) s += (double)col[r * stride];
     }
-    __shared__ double red[32][32];
-    red[rl][threadIdx.x & 31] = s;
+    __shared__ double red[RL][2 * CPW];
+    red[rl][threadIdx.x & (2 * CPW - 1)] = s;
     __syncthreads();
-    if (threadIdx.x < 16 && c < C) {
+    // fold the row lanes in index order (deterministic): 8 partial chains per column, then their sum
+    __shared__ double red2[8][2 * CPW];
+    if (threadIdx.x < 8 * 2 * CPW) {
+        const int col2 = threadIdx.x % (2 * CPW), part = threadIdx.x / (2 * CPW);
+        double a = 0.0;
+        for (int r = part * (RL / 8); r < (part + 1) * (RL / 8); ++r) a += red[r][col2];
+        red2[part][col2] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < CPW && c < C) {
         double sum = 0.0, sq = 0.0;
-        for (int r = 0; r < 32; ++r) { sum += red[r][cl]; sq += red[r][16 + cl]; }
+        for (int r = 0; r < 8; ++r) { sum += red2[r][cl]; sq += red2[r][CPW + cl]; }
         if (MODE == 0) {
             const double mu = sum / (double)count;
             double var = sq / (double)count - mu * mu;
@@ -553,8 +565,10 @@ int kp_bn_finalize(const float* stats, long long rows, double* ws, float* save_m
         return kp_check_launch("bn_reduce_finalize");
     }
     if (rows <= WIDE_ROWS) {
-        bn_reduce_finalize_wide_k<0><<<cdiv(C, 16), 1024, 0, st>>>(stats, rows, C, save_mean, save_invstd, running_mean,
-                                                                   running_var, num_batches_tracked, momentum, eps, count);
+#define KP_WIDE0(CPWv) bn_reduce_finalize_wide_k<0, CPWv><<<cdiv(C, CPWv), 1024, 0, st>>>(stats, rows, C, save_mean, save_invstd, running_mean, \
+                                                                               running_var, num_batches_tracked, momentum, eps, count)
+        if (C >= 256) KP_WIDE0(16); else if (C >= 128) KP_WIDE0(8); else KP_WIDE0(4);
+#undef KP_WIDE0
         return kp_check_launch("bn_reduce_finalize_wide");
     }
     int rc = reduce_rows(stats, ws, rows, 2 * C, st);
@@ -613,8 +627,10 @@ int kp_bn_bwd_finalize(const float* partials, double* ws, long long rows, int C,
         return kp_check_launch("bn_bwd_reduce_finalize");
     }
     if (rows <= WIDE_ROWS) {
-        bn_reduce_finalize_wide_k<1><<<cdiv(C, 16), 1024, 0, st>>>(partials, rows, C, sums, nullptr, dbeta, dgamma, nullptr,
-                                                                   0.f, 0.f, 1);
+#define KP_WIDE1(CPWv) bn_reduce_finalize_wide_k<1, CPWv><<<cdiv(C, CPWv), 1024, 0, st>>>(partials, rows, C, sums, nullptr, dbeta, dgamma, \
+                                                                               nullptr, 0.f, 0.f, 1)
+        if (C >= 256) KP_WIDE1(16); else if (C >= 128) KP_WIDE1(8); else KP_WIDE1(4);
+#undef KP_WIDE1
         return kp_check_launch("bn_bwd_reduce_finalize_wide");
     }
     int rc = reduce_rows(partials, ws, rows, 2 * C, st);

@@ -62,7 +62,7 @@ int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, float*
     }
     if (dtype == KP_F32 && R == 3 && use_mfma()) {
         int rc = kp_conv_fwd_f32mfma((const float*)x, (const float*)w, bias, (float*)y, stats, N, Hi, Wi, C, K, (hipStream_t)stream);
-        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_GENERIC); return rc; }
+        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_F32MFMA); return rc; }
     }
     if (getenv("KP_LOG_GENERIC")) fprintf(stderr, "generic conv: N=%d Hi=%d Wi=%d C=%d K=%d R=%d dtype=%d stats=%d\n", N, Hi, Wi, C, K, R, dtype, stats != nullptr);
     int rc = kp_conv_fwd_generic(x, w, bias, y, stats, N, Hi, Wi, C, K, R, dtype, (hipStream_t)stream);
@@ -135,7 +135,7 @@ int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, 
     }
     if (dtype == KP_F32 && R == 3 && use_mfma()) {
         int rc = kp_conv_wgrad_f32mfma((const float*)x, (const float*)dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
-        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_WGRAD_GENERIC); return rc; }
+        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_WGRAD_F32MFMA); return rc; }
     }
     if (getenv("KP_LOG_GENERIC")) fprintf(stderr, "generic wgrad: N=%d Ho=%d Wo=%d C=%d K=%d R=%d dp=%d dtype=%d\n", N, Ho, Wo, C, K, R, dy_pad, dtype);
     int rc = kp_conv_wgrad_generic(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, dtype, (hipStream_t)stream);
