@@ -247,6 +247,11 @@ def main():
                             pmc_effective_clock_ghz=pmc['effective_clock_ghz'] if pmc else None,
                             avg_launch_us=dom[1]['avg_us'], launches_per_step=dom[1]['launches_per_step'])
         if roofline is not None:
+            prop = torch.cuda.get_device_properties(dev)
+            roofline.update(peak_source='/opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters): ~2.5 PFLOP/s dense bf16/fp16 MFMA, '
+                                        '157.3 TFLOP/s fp32 matrix, 8 TB/s HBM3E (spec), 256 CUs at 2.4 GHz',
+                            device=dict(name=prop.name, arch=getattr(prop, 'gcnArchName', ''), cus=prop.multi_processor_count,
+                                        hbm_gib=round(prop.total_memory / 2 ** 30, 1)))
             roofline.update(step_tflops=value / world * flop_pair / 1e12, step_frac=value / world * flop_pair / 1e12 / peak,
                             measured='HIP events around each launch on the launch stream, '
                                      f'{args.profile_steps} steps after the timed region', kernels=fam)
