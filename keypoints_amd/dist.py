@@ -30,13 +30,16 @@ import torch.distributed as dist
 
 class GradReducer:
     def __init__(self, root: torch.nn.Module, group=None, broadcast_init: bool = True, tail_fraction: float = 0.6,
-                 transport: str = 'fp32', overlap: bool = True):
+                 transport: str = 'fp32', overlap: bool = True, sync_bn: bool = False):
         """overlap: True -- pieces are all-reduced from the backward hooks, concurrently with the rest of the backward;
         False -- the hooks only note which arenas are final and `finish()` reduces them back to back (the exchange is then
         fully exposed, ~1 ms for model F over xGMI, but no RCCL kernel ever shares the CUs with the persistent MFMA
         kernels, whose tile partition is static: see DESIGN.md section 6).
         transport: 'fp32' (exact mean of the fp32 gradients) or 'bf16' (each piece is rounded to bf16 for the wire
-        and the reduction: half the xGMI bytes, gradient error 2^-9 relative per element -- SURVEY.md 8e option)."""
+        and the reduction: half the xGMI bytes, gradient error 2^-9 relative per element -- SURVEY.md 8e option).
+        sync_bn: BatchNorm batch statistics (forward) and the two backward sums are all-reduced per layer, i.e. the ranks
+        normalise with the statistics of the GLOBAL batch: the DP step then equals the single-process step on the
+        concatenated batch (non-default option; one small synchronous all-reduce per layer and direction)."""
         from .models.knn import Unit
         if transport not in ('fp32', 'bf16'):
             raise ValueError("transport must be 'fp32' or 'bf16'")
@@ -60,6 +63,7 @@ class GradReducer:
         for u in self.units:
             u.after_backward = self._on_unit_backward
             u.layer_done = self._on_layer_done
+            u.sync_bn = (group, self.world) if sync_bn and self.world > 1 else None
             self._split[id(u)] = self._choose_split(u, tail_fraction)
 
     @staticmethod
@@ -168,3 +172,4 @@ class GradReducer:
         for u in self.units:
             u.after_backward = None
             u.layer_done = None
+            u.sync_bn = None

@@ -89,6 +89,7 @@ class Unit(nn.Module):
         self._arena = None
         self.after_backward = None   # optional hook(unit): data-parallel gradient reduction hangs here
         self.layer_done = None       # optional hook(unit, idx): the gradients of plan steps >= idx are final
+        self.sync_bn = None          # (process group, world size): BatchNorm batch statistics over all ranks (dist.GradReducer(sync_bn=True))
 
     # -- HIP execution -------------------------------------------------------------------------
     def plan(self):

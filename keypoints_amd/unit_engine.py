@@ -130,6 +130,18 @@ class GradArena:
             p.grad = self.views[id(p)]
 
 
+def _allreduce_rows(rows: torch.Tensor, group) -> torch.Tensor:
+    """SyncBN (non-default): per-channel partial sums [R][2][K] (fp32) of this rank -> the sum over all ranks as
+    TWO fp32 rows (high part, remainder) of the fp64 total, so that the fp64 finalize kernels lose nothing to the fp32
+    transport format.  Tiny tensors (2 K doubles per layer); the all-reduce is synchronous on the launch stream."""
+    import torch.distributed as dist
+    tot = rows.double().sum(0)
+    dist.all_reduce(tot, group=group)
+    hi = tot.float()
+    lo = (tot - hi.double()).float()
+    return torch.stack((hi, lo)).contiguous()
+
+
 def _tail_dims(H, W, tail):
     if tail == 'M':
         return H // 2, W // 2
@@ -199,9 +211,13 @@ class UnitFunction(torch.autograd.Function):
                     else:
                         mom = float(bn.momentum)
                     ws = torch.empty(128 * K, device=dev, dtype=torch.float64)
+                    count = N * H * W
+                    sync = unit.sync_bn
+                    if sync is not None:   # batch statistics over the ranks' shards together (world x count samples)
+                        stats, srows, count = _allreduce_rows(stats[:srows], sync[0]), 2, count * sync[1]
                     call('kp_bn_finalize', ptr(stats), srows, ptr(ws), ptr(mean), ptr(invstd),
                          ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
-                         ptr(bn.num_batches_tracked) if track else None, mom, float(bn.eps), N * H * W, K, st)
+                         ptr(bn.num_batches_tracked) if track else None, mom, float(bn.eps), count, K, st)
                 else:
                     if record:
                         raise NotImplementedError('backward through eval-mode BatchNorm is not implemented')
@@ -285,6 +301,14 @@ class UnitFunction(torch.autograd.Function):
             ws = torch.empty(128 * K, device=dev, dtype=torch.float64)
             prows = _lib.lib().kp_bn_bwd_rows(gp, tcode, N, H, W, K, code)
             call('kp_bn_bwd_finalize', ptr(partials), ptr(ws), prows, K, ptr(sums), dgam, dbet, st)
+            sync = unit.sync_bn if bn is not None else None
+            if sync is not None:
+                # dgamma / dbeta above are this rank's sums (the gradient all-reduce averages them like every other
+                # gradient); the apply pass needs the sums over ALL ranks, and divides by its own N*H*W: hand it the
+                # global sums scaled by 1 / world
+                g2rows = _allreduce_rows(partials[:prows], sync[0])
+                call('kp_bn_bwd_finalize', ptr(g2rows), ptr(ws), 2, K, ptr(sums), None, None, st)
+                sums = sums * (1.0 / sync[1])
             need_dx = idx > 0 or need_x
             dp = 2 if need_dx else 0
             dy = torch.empty(N, H + 2 * dp, W + 2 * dp, K, device=dev, dtype=tdt)

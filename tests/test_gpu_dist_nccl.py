@@ -108,3 +108,27 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(overlap):
     assert rec['config']['dp_overlap'] is bool(overlap) and rec['scaling'] == 'weak'
     import math
     assert rec['value'] > 0 and rec['config']['loss'] > 0 and math.isfinite(rec['config']['loss']) and 'cpu_baseline' not in rec
+
+
+@pytest.mark.parametrize('typ,size', [('VGG_PONG_LAYERNECK', 32), ('VGG_PACMAN_2', 32)])
+def test_sync_bn_equals_the_concatenated_batch(typ, size):
+    """GradReducer(sync_bn=True): two ranks (sharing the GPU, gloo) each run half of a batch; with the BatchNorm
+    statistics and backward sums all-reduced per layer, loss, averaged gradients, updated parameters and running
+    statistics equal those of ONE process on the whole batch (fp32: to rounding)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', KP_SYNCBN_TYPE=typ, KP_SYNCBN_SIZE=str(size))
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'tests', 'dist_syncbn_worker.py')]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('SYNCBN ')]
+    assert len(line) == 1, out.stdout[-2000:]
+    rec = json.loads(line[0][7:])
+    assert abs(rec['loss_dp'] - rec['loss_ref']) <= 2e-6 * abs(rec['loss_ref']), rec
+    assert rec['worst_grad'] <= 2e-4, rec       # fp32 summation order differs between the two runs
+    assert rec['params'] <= 1e-5 and rec['buffers'] <= 1e-5, rec
