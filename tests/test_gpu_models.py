@@ -485,3 +485,36 @@ def test_train_step_is_bitwise_reproducible(precision, model):
         states.append({k: v.clone() for k, v in net.state_dict().items()})
     for k in states[0]:
         assert torch.equal(states[0][k], states[1][k]), k
+
+
+def test_memory_walk_order_changes_nothing_but_the_partial_sum_order():
+    """KP_CFG_WALK: the default order (conv tiles in one front, BatchNorm passes back to front, streaming
+    loads) against every pass front to back -- same step, up to the order in which the fp32 BatchNorm partials are summed."""
+    import keypoints_amd as ka
+    from keypoints_amd import _lib
+    from keypoints_amd.models import transporter
+    g = torch.Generator().manual_seed(3)
+    xs = torch.rand(16, 3, 64, 64, generator=g).cuda()
+    xt = torch.rand(16, 3, 64, 64, generator=g).cuda()
+    res = []
+    try:
+        for mask in (0, None):
+            if mask is not None:
+                _lib.call('kp_config', 5, mask)
+            torch.manual_seed(11)
+            net = transporter.make('F', 3, 32, 5).cuda().set_precision('bf16')
+            opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
+            opt.zero_grad()
+            out = net(xs, xt)
+            loss = ka.l2_reconstruction_loss(out[0], xt)
+            loss.backward()
+            res.append((float(loss.detach()), out[0].detach().float(), out[2].detach(),
+                        torch.cat([p.grad.flatten() for p in net.parameters()])))
+            _lib.call('kp_config', 5, 1 | 2 | 4 | 128)   # KP_WALK_DEFAULT
+    finally:
+        _lib.call('kp_config', 5, 1 | 2 | 4 | 128)
+    (l0, x0, k0, g0), (l1, x1, k1, g1) = res
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    assert float((x0 - x1).abs().max()) <= 2e-2 * float(x0.abs().max())     # a bf16 ulp here and there after 25 layers
+    assert float((k0 - k1).abs().max()) <= 2e-3
+    assert float((g0 - g1).norm() / g0.norm()) <= 2e-2
