@@ -69,8 +69,18 @@ int kp_config(int key, int value);
 #define KP_WALK_FWD_REVERSE 2     /* kp_bn_act_fwd sweeps the conv output back to front (last-written images first) */
 #define KP_WALK_REDUCE_REVERSE 4  /* kp_bn_act_bwd_reduce sweeps the incoming gradient back to front; the apply pass then runs front to back */
 #define KP_WALK_APPLY_REVERSE 8   /* kp_bn_act_bwd_apply back to front (measurement only) */
+/* 4 instead of 8 channels per thread (8-byte lanes, about half the registers, twice the waves per SIMD) for one class of
+ * BatchNorm passes each: */
+#define KP_WALK_V4_FWD_NONE 0x200
+#define KP_WALK_V4_FWD_POOL 0x400
+#define KP_WALK_V4_FWD_UP 0x800
+#define KP_WALK_V4_REDUCE 0x1000
+#define KP_WALK_V4_APPLY 0x2000
+#define KP_WALK_V4_POOL_REDUCE 0x4000
+#define KP_WALK_V4_POOL_APPLY 0x8000
 #define KP_WALK_STREAM_LOADS 128  /* the BatchNorm passes read with non-temporal loads (nothing re-reads their inputs soon) */
-#define KP_WALK_DEFAULT (KP_WALK_CONV_LINEAR | KP_WALK_FWD_REVERSE | KP_WALK_REDUCE_REVERSE | KP_WALK_STREAM_LOADS)
+#define KP_WALK_V4_ALL 0xfe00
+#define KP_WALK_DEFAULT (KP_WALK_CONV_LINEAR | KP_WALK_FWD_REVERSE | KP_WALK_REDUCE_REVERSE | KP_WALK_STREAM_LOADS | KP_WALK_V4_ALL)
 #define KP_CFG_CUS 6          /* CU budget the persistent kernels size their grids to (launches on a CU-masked stream); 0 = whole device */
 #define KP_CFG_TRACE 2        /* device buffer of 512 int64: s_memtime stamps of workgroup 0 of the patch conv kernel */
 int kp_config_ptr(int key, void* value);

@@ -22,7 +22,11 @@ int g_kp_bn_fast = 1;       // kp_config(KP_CFG_BN_FAST, v)
 // Memory walk order of the passes (kp_common.h: KP_WALK_*; kp_config(KP_CFG_WALK, mask), 0 = every pass front to back):
 // a pass that follows a producer sweeps the producer's output back to front, so that it starts on what is still in the
 // 256 MiB Infinity Cache, and reads what nobody re-reads soon with streaming loads
-int g_kp_walk = KP_WALK_DEFAULT;
+static int walk_default() {   // KP_WALK=<mask> in the environment overrides the default (A/B runs of whole test files)
+    const char* e = getenv("KP_WALK");
+    return e ? (int)strtol(e, nullptr, 0) : KP_WALK_DEFAULT;
+}
+int g_kp_walk = walk_default();
 int g_kp_cus = 0;     // kp_config(KP_CFG_CUS, n): CU budget that persistent kernels size their grids to (0 = the whole device)
 int g_kp_debug = 0;   // kp_config(KP_CFG_DEBUG, mask): kernel ablation switches for measurements
 

@@ -510,9 +510,9 @@ def test_memory_walk_order_changes_nothing_but_the_partial_sum_order():
             loss.backward()
             res.append((float(loss.detach()), out[0].detach().float(), out[2].detach(),
                         torch.cat([p.grad.flatten() for p in net.parameters()])))
-            _lib.call('kp_config', 5, 1 | 2 | 4 | 128)   # KP_WALK_DEFAULT
+            _lib.call('kp_config', 5, 1 | 2 | 4 | 128 | 0xfe00)   # KP_WALK_DEFAULT
     finally:
-        _lib.call('kp_config', 5, 1 | 2 | 4 | 128)
+        _lib.call('kp_config', 5, 1 | 2 | 4 | 128 | 0xfe00)
     (l0, x0, k0, g0), (l1, x1, k1, g1) = res
     assert abs(l0 - l1) <= 1e-5 * abs(l0)
     assert float((x0 - x1).abs().max()) <= 2e-2 * float(x0.abs().max())     # a bf16 ulp here and there after 25 layers

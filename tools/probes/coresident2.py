@@ -10,6 +10,9 @@ if len(sys.argv) > 1:
 from keypoints_amd._lib import call, ptr
 
 N = 128; bf = torch.bfloat16; dev = 'cuda'
+if os.environ.get('KP_WALK'):
+    call('kp_config', 5, int(os.environ['KP_WALK'], 0))
+REDUCE_ONLY = os.environ.get('BN_LANE', 'full') == 'reduce'
 hi = torch.cuda.Stream(priority=-1)
 lo = torch.cuda.Stream(priority=0)
 
@@ -35,6 +38,8 @@ def case(C, K, H, C2, H2):
         s = st.cuda_stream
         call('kp_bn_act_bwd_reduce', ptr(g2), 1, 0, None, ptr(y2), ptr(mean), ptr(inv), ptr(ga), ptr(be), 0.01, ptr(part), N, H2, H2, C2, 1, s)
         call('kp_bn_bwd_finalize', ptr(part), ptr(ws), prows, C2, ptr(sums), ptr(dgam), ptr(dbet), s)
+        if REDUCE_ONLY:
+            return
         call('kp_bn_act_bwd_apply', ptr(g2), 1, 0, None, ptr(y2), ptr(mean), ptr(inv), ptr(ga), ptr(be), 0.01, ptr(sums), ptr(dy2), 2,
              N, H2, H2, C2, 1, s)
 
