@@ -122,6 +122,10 @@ int kp_nhwc_grad_to_nchw(const void* gsrc, float* dst, int N, int C, int Cp, int
 /* fp32 [K][C][R][R] (nn.Conv2d.weight) -> T [K][R][R][Cp] (forward operand) and,
  * if w_dgrad != NULL, T [Cp][R][R][K] with the taps flipped (dgrad operand); channels C..Cp-1 are zero. */
 int kp_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int K, int C, int Cp, int R, int dtype, void* stream);
+/* The same for n <= 24 3x3 layers in ONE launch (all layers of a knn.Unit): host arrays of the per-layer arguments;
+ * w_dgrad[i] may be NULL. */
+int kp_pack_weights_batch(int n, const float* const* w, void* const* w_fwd, void* const* w_dgrad, const int* K, const int* C,
+                          const int* Cp, int dtype, void* stream);
 /* dw[K][C][R][R] += sum_p transpose(scratch[p][K][R][R][Cp])[.., :C]   (fp32; p < partials summed in a fixed order) */
 int kp_wgrad_unpack(const float* scratch, int partials, float* dw, int K, int C, int Cp, int R, void* stream);
 

@@ -23,6 +23,7 @@ SIGNATURES = {
     'kp_nchw_to_nhwc': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'kp_nhwc_grad_to_nchw': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'kp_pack_weights': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    'kp_pack_weights_batch': [_i, _p, _p, _p, _p, _p, _p, _i, _p],
     'kp_wgrad_unpack': [_p, _i, _p, _i, _i, _i, _i, _p],
     'kp_conv_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'kp_conv_dgrad': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

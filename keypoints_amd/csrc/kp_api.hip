@@ -179,6 +179,8 @@ KP_DISPATCH(kp_nhwc_grad_to_nchw, (const void* gsrc, float* dst, int N, int C, i
             (gsrc, dst, N, C, Cp, H, W, pad, dtype, stream))
 KP_DISPATCH(kp_pack_weights, (const float* w, void* w_fwd, void* w_dgrad, int K, int C, int Cp, int R, int dtype, void* stream),
             (w, w_fwd, w_dgrad, K, C, Cp, R, dtype, stream))
+KP_DISPATCH(kp_pack_weights_batch, (int n, const float* const* w, void* const* w_fwd, void* const* w_dgrad, const int* K, const int* C, const int* Cp, int dtype, void* stream),
+            (n, w, w_fwd, w_dgrad, K, C, Cp, dtype, stream))
 KP_DISPATCH(kp_conv_fwd, (const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C, int K, int R, int dtype, void* stream),
             (x, w, bias, y, stats, N, Hi, Wi, C, K, R, dtype, stream))
 KP_DISPATCH(kp_conv_dgrad, (const void* dy, const void* w_dgrad, void* gx, int N, int H, int W, int K, int C, int dtype, void* stream),

@@ -69,6 +69,31 @@ __global__ void pack_weights_k(const float* __restrict__ w, T* __restrict__ wf, 
     if (wd) st<T>(wd + (((long long)c * R + (R - 1 - r)) * R + (R - 1 - s)) * K + k, v);
 }
 
+// All 3x3 layers of a Unit in ONE launch (a Unit forward packed its 8-9 layers with as many ~12 us launches).
+constexpr int PACK_MAX = 24;
+struct PackBatch {
+    const float* w[PACK_MAX]; void* wf[PACK_MAX]; void* wd[PACK_MAX];
+    int K[PACK_MAX], C[PACK_MAX], Cp[PACK_MAX];
+    unsigned first_block[PACK_MAX + 1];
+    int n;
+};
+template <typename T>
+__global__ void pack_weights_batch_k(const PackBatch B) {
+    int l = 0;
+    while (l + 1 < B.n && blockIdx.x >= B.first_block[l + 1]) ++l;   // (uniform; n <= 24)
+    const int K = B.K[l], C = B.C[l], Cp = B.Cp[l];
+    const long long total = (long long)K * 9 * Cp;
+    const long long t = (long long)(blockIdx.x - B.first_block[l]) * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c = (int)(t % Cp);
+    const int s = (int)((t / Cp) % 3);
+    const int r = (int)((t / ((long long)Cp * 3)) % 3);
+    const int k = (int)(t / ((long long)Cp * 9));
+    const float v = c < C ? B.w[l][(((long long)k * C + c) * 3 + r) * 3 + s] : 0.f;
+    st<T>((T*)B.wf[l] + t, v);
+    if (B.wd[l]) st<T>((T*)B.wd[l] + (((long long)c * 3 + (2 - r)) * 3 + (2 - s)) * K + k, v);
+}
+
 // dw[k][c][r][s] += sum_p scratch[p][k][r][s][c].  A workgroup = 64 element groups (VEC consecutive c of one
 // (k, r, s) of the scratch layout: coalesced 16-byte lanes) x 4 partial lanes; lane q sums the partials p = q, q+4, ...
 // (4 loads in flight), the 4 lanes are combined through LDS in a fixed order -> deterministic.
@@ -396,6 +421,23 @@ int kp_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int K, int C, in
     const long long total = (long long)K * Cp * R * R;
     DISPATCH_T(dtype, pack_weights_k<T><<<cdiv(total, TPB), TPB, 0, (hipStream_t)stream>>>(w, (T*)w_fwd, (T*)w_dgrad, K, C, Cp, R));
     return kp_check_launch("pack_weights");
+}
+
+int kp_pack_weights_batch(int n, const float* const* w, void* const* w_fwd, void* const* w_dgrad, const int* K, const int* C,
+                          const int* Cp, int dtype, void* stream) {
+    KP_REQUIRE(n >= 1 && n <= PACK_MAX && w && w_fwd && w_dgrad && K && C && Cp, "kp_pack_weights_batch: bad args (1 <= n <= %d)", PACK_MAX);
+    PackBatch B;
+    B.n = n;
+    unsigned blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        KP_REQUIRE(K[i] > 0 && C[i] > 0 && Cp[i] >= C[i] && w[i] && w_fwd[i], "kp_pack_weights_batch: bad layer %d", i);
+        B.w[i] = w[i]; B.wf[i] = w_fwd[i]; B.wd[i] = w_dgrad[i]; B.K[i] = K[i]; B.C[i] = C[i]; B.Cp[i] = Cp[i];
+        B.first_block[i] = blocks;
+        blocks += cdiv((size_t)K[i] * 9 * Cp[i], TPB);
+    }
+    B.first_block[n] = blocks;
+    DISPATCH_T(dtype, pack_weights_batch_k<T><<<blocks, TPB, 0, (hipStream_t)stream>>>(B));
+    return kp_check_launch("pack_weights_batch");
 }
 
 #ifndef KP_F16_BUILD   // no dtype: defined once, by the bf16 build of this source

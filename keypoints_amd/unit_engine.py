@@ -64,6 +64,38 @@ def _slope_of(act: nn.Module) -> float:
     raise NotImplementedError(f'activation {type(act).__name__} has no HIP kernel (ReLU / LeakyReLU only)')
 
 
+def _pack_unit(plan, Cin, Cp0, record, dev, tdt, code, st):
+    """Packed copies (compute type, tap-major) of every 3x3 weight of a Unit: `[K][3][3][C]` for the forward and, when a
+    backward may follow (or the packs are shared across calls), `[C][3][3][K]` flipped for the data gradient.  Layers whose
+    packs are not in the shared store yet are packed by ONE kp_pack_weights_batch launch."""
+    import ctypes
+    out, todo = [], []
+    C = Cin
+    for idx, stp in enumerate(plan[:-1]):
+        conv = stp['conv']
+        K, Cl = conv.out_channels, C
+        Cp = Cp0 if idx == 0 else C
+        pkey = (id(conv.weight), Cp, code)
+        ent = _PACKS.get(pkey) if _PACKS is not None else None
+        if ent is None or (record and ent[1] is None):
+            wf = torch.empty(K, 3, 3, Cp, device=dev, dtype=tdt)
+            wd = torch.empty(Cp, 3, 3, K, device=dev, dtype=tdt) if (record or _PACKS is not None) else None
+            ent = (wf, wd)
+            todo.append((conv.weight, wf, wd, K, Cl, Cp))
+            if _PACKS is not None:
+                _PACKS[pkey] = ent
+        out.append(ent)
+        C = K
+    for i in range(0, len(todo), 24):
+        part = todo[i:i + 24]
+        n = len(part)
+        vp, ia = ctypes.c_void_p * n, ctypes.c_int * n
+        call('kp_pack_weights_batch', n, vp(*[ptr(t[0]) for t in part]), vp(*[ptr(t[1]) for t in part]),
+             vp(*[ptr(t[2]) for t in part]), ia(*[t[3] for t in part]), ia(*[t[4] for t in part]), ia(*[t[5] for t in part]),
+             code, st)
+    return out
+
+
 def build_plan(blocks: List[nn.Sequential]) -> List[dict]:
     """Group the flat module list of in_block + core + out_block into kernel steps."""
     mods = [m for b in blocks for m in b]
@@ -174,6 +206,7 @@ class UnitFunction(torch.autograd.Function):
         a = torch.empty(N, H + 2 * pad0, W + 2 * pad0, Cp0, device=dev, dtype=tdt)
         call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, Cin, Cp0, H, W, pad0, code, st)
         saved = []
+        packs = _pack_unit(plan, Cin, Cp0, record, dev, tdt, code, st)
         C = Cin
         for idx, stp in enumerate(plan[:-1]):
             conv, bn = stp['conv'], stp['bn']
@@ -182,16 +215,7 @@ class UnitFunction(torch.autograd.Function):
                 raise RuntimeError(f'channel mismatch: conv expects {conv.in_channels}, got {C}')
             Cl = C                       # logical input channels of this layer (the conv's)
             C = Cp0 if idx == 0 else C   # physical channels of `a`
-            pkey = (id(conv.weight), C, code)
-            ent = _PACKS.get(pkey) if _PACKS is not None else None
-            if ent is None or (record and ent[1] is None):
-                wf = torch.empty(K, 3, 3, C, device=dev, dtype=tdt)
-                wd = torch.empty(C, 3, 3, K, device=dev, dtype=tdt) if (record or _PACKS is not None) else None
-                call('kp_pack_weights', ptr(conv.weight), ptr(wf), ptr(wd), K, Cl, C, 3, code, st)
-                if _PACKS is not None:
-                    _PACKS[pkey] = (wf, wd)
-            else:
-                wf, wd = ent
+            wf, wd = packs[idx]
             y = torch.empty(N, H, W, K, device=dev, dtype=tdt)
             training = bn is not None and bn.training
             stats = torch.empty((N * H * W + 63) // 64, 2, K, device=dev, dtype=torch.float32) if training else None
