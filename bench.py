@@ -63,6 +63,9 @@ def parse():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="N > 1: 'nccl' (= RCCL, the measured path); 'gloo' only to exercise the multi-rank code path on a box with "
                          'fewer GPUs than ranks (ranks then share devices; the number is not a scaling result)')
+    ap.add_argument('--streams', type=int, default=1,
+                    help='1 (default): weight gradients and the keypoint encoder run on side HIP streams beside the main chain '
+                         '(DESIGN.md 3.8); 0: every kernel on one stream, in program order')
     ap.add_argument('--lib', default='', help='development: time another build of libkp_hip.so (A/B on one box)')
     return ap.parse_args()
 
@@ -127,6 +130,7 @@ def main():
     from keypoints_amd.models import transporter
     from keypoints_amd.flops import conv_flops_per_pair
 
+    ka.set_multi_stream(bool(args.streams))
     torch.manual_seed(0)
     if args.net == 'keynet':
         from keypoints_amd.models import keynet
@@ -213,6 +217,9 @@ def main():
                                  algorithmic_gbs=by.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0)
         _lib.call('kp_prof_enable', 0)
 
+    if os.environ.get('KP_MEMSTATS'):
+        ms_ = torch.cuda.memory_stats()
+        print('memstats', {k: ms_[k] for k in ('num_device_alloc', 'num_device_free', 'num_alloc_retries', 'reserved_bytes.all.peak')}, file=sys.stderr)
     if rank == 0:
         flop_pair = conv_flops_per_pair(net, args.size, args.size)
         ms_step = 1e3 * elapsed / args.steps

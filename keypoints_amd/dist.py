@@ -27,6 +27,8 @@ from typing import List
 import torch
 import torch.distributed as dist
 
+from . import runtime
+
 
 class GradReducer:
     def __init__(self, root: torch.nn.Module, group=None, broadcast_init: bool = True, tail_fraction: float = 0.6,
@@ -139,6 +141,7 @@ class GradReducer:
     def finish(self) -> None:
         """Join every outstanding gradient all-reduce (call between backward() and optimiser.step()).  Every piece is
         a disjoint arena slice, reduced and scaled exactly once."""
+        runtime.join_side_streams()
         if self._early:
             raise RuntimeError('GradReducer.finish(): a Unit sent its arena tail but never finished its backward')
         for t in self._ready:

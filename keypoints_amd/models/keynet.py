@@ -3,6 +3,7 @@
 import torch
 import torch.nn as nn
 
+from .. import runtime
 from . import knn, vgg
 
 
@@ -18,8 +19,11 @@ class KeyNet(knn.Container):
             self._initialize_weights()
 
     def forward(self, x, x_t):
-        z = self.encoder(x)
-        heatmap = self.keypoint(x_t)
+        with runtime.fork('chain', x_t) as side:   # two independent encoders: the keypoint one on a side stream
+            with side:
+                heatmap = self.keypoint(x_t)
+                side.outputs(heatmap)
+            z = self.encoder(x)
         k, p = self.ssm(heatmap, probs=True)
         m = self.key2map(k, height=z.size(2), width=z.size(3))
         x_t = self.decoder(torch.cat((z, m), dim=1))

@@ -9,6 +9,7 @@ from typing import Iterable, List
 
 import torch
 
+from . import runtime
 from ._lib import call, ptr
 from .runtime import f32c, require_device, stream_ptr
 
@@ -98,6 +99,7 @@ class FusedAdam:
 
     @torch.no_grad()
     def step(self):
+        runtime.join_side_streams()   # (a backward joins them itself when it ends; this is for hand-driven Units)
         if not self._units and not self._loose:
             self._loose = list(self.params)
         self.step_count += 1

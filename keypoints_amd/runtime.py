@@ -45,3 +45,112 @@ def f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
+
+
+# ---- stream-level concurrency -----------------------------------------------------------------------
+# The step alternates matrix-core kernels (power / MFMA bound) with HBM-bound BatchNorm passes; kernels of INDEPENDENT
+# chains share the CUs when they are on different HIP streams (whatever fits beside the resident workgroups runs there):
+# a Unit's weight gradients go to a side stream of the stream its backward runs on, and the Transporter's keypoint
+# encoder runs on a side stream of the feature encoder's.  Results do not depend on it (every kernel is deterministic).
+_multi_stream = True
+_side_streams = {}     # (device index, parent stream id, role) -> torch.cuda.Stream
+_used = set()          # side streams with work the parent has not waited for yet
+_callback_queued = False
+
+
+def set_multi_stream(on: bool) -> None:
+    """Switch the side streams off (every kernel of the step then runs on torch's current stream, in program order)."""
+    global _multi_stream
+    _multi_stream = bool(on)
+
+
+def multi_stream() -> bool:
+    return _multi_stream and not torch.cuda.is_current_stream_capturing()
+
+
+def side_stream(role: str) -> torch.cuda.Stream:
+    """The side stream `role` of torch's current stream (created on first use)."""
+    cur = torch.cuda.current_stream()
+    key = (cur.device.index, cur.stream_id, role)
+    s = _side_streams.get(key)
+    if s is None:
+        s = _side_streams[key] = torch.cuda.Stream(device=cur.device)
+    _used.add(s)
+    return s
+
+
+def join_side_streams() -> None:
+    """torch's current stream waits for everything enqueued on any side stream so far."""
+    global _callback_queued
+    _callback_queued = False
+    if not _used:
+        return
+    cur = torch.cuda.current_stream()
+    for s in list(_used):
+        if s.device == cur.device:
+            cur.wait_stream(s)
+            _used.discard(s)
+
+
+def join_after_backward() -> None:
+    """Called from inside a backward node: when the autograd pass ends, the stream that called backward() waits for the
+    side streams (the engine runs its final callbacks under the caller's current stream), so `p.grad`, the optimiser
+    and the gradient reducer see finished arenas without knowing about the streams."""
+    global _callback_queued
+    _used.add(torch.cuda.current_stream())   # the stream this node runs on (that of its forward)
+    if not _callback_queued:
+        _callback_queued = True
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+
+
+_held = {}   # side stream -> tensors its last block handed to the parent stream
+
+
+class fork:
+    """`with fork(role, *inputs) as side:` -- inside, `with side:` runs a block on the side stream `role` of the current
+    stream (after everything enqueued so far); leaving the outer block makes the current stream wait for it.
+    The caching allocator recycles a block in the order of the stream it was allocated on, so tensors that cross streams
+    are kept referenced until the other stream is known to be past them: `inputs` (read by the side block) live in the
+    caller's frame until the join; what the side block hands back (`side.outputs(...)`) is held until the NEXT fork of
+    this side stream has waited for the parent.  (`tensor.record_stream` is the allocator's own mechanism for this; with
+    it the step time jumped to 160-220 ms at random.)
+    With the side streams switched off (or under stream capture) `with side:` runs the block in place."""
+
+    def __init__(self, role, *inputs):
+        self._role, self._inputs = role, [t for t in inputs if t is not None and t.is_cuda]
+        self._stream = None
+
+    def __enter__(self):
+        if self._inputs and multi_stream():
+            self._cur = torch.cuda.current_stream()
+            self._stream = side_stream(self._role)
+            self._stream.wait_stream(self._cur)
+            _held.pop(self._stream, None)   # the parent's readers of the previous outputs are behind this wait
+        return _SideBlock(self)
+
+    def __exit__(self, *exc):
+        if self._stream is not None:
+            self._cur.wait_stream(self._stream)
+            _used.discard(self._stream)
+        self._inputs = None
+        return False
+
+
+class _SideBlock:
+    def __init__(self, owner):
+        self._o = owner
+
+    def __enter__(self):
+        if self._o._stream is not None:
+            self._ctx = torch.cuda.stream(self._o._stream)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._o._stream is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+    def outputs(self, *tensors):
+        if self._o._stream is not None:
+            _held[self._o._stream] = tensors

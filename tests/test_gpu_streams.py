@@ -1,0 +1,85 @@
+"""Stream-level concurrency of the train step: weight gradients on a side stream of the Unit's backward,
+the keypoint encoder on a side stream of the feature encoder's.  It changes WHEN kernels run, never what they compute."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(net_kind, streams, steps=3, accumulate=False):
+    import keypoints_amd as ka
+    from keypoints_amd.models import transporter, keynet
+    ka.set_multi_stream(streams)
+    try:
+        g = torch.Generator().manual_seed(5)
+        # (128 x 128: every layer on the deterministic kernels, as in test_train_step_is_bitwise_reproducible)
+        xs = torch.rand(8, 3, 128, 128, generator=g).cuda()
+        xt = torch.rand(8, 3, 128, 128, generator=g).cuda()
+        torch.manual_seed(11)
+        if net_kind == 'keynet':
+            class A: model_type, model_in_channels, model_z_channels, model_keypoints = 'F', 3, 32, 5
+            net = keynet.make(A()).cuda().set_precision('bf16')
+        else:
+            net = transporter.make('F', 3, 32, 5).cuda().set_precision('bf16')
+        opt = ka.FusedAdam(net.parameters(), lr=1e-3).bind(net)
+        losses = []
+        for _ in range(steps):
+            opt.zero_grad()
+            loss = ka.l2_reconstruction_loss(net(xs, xt)[0], xt)
+            loss.backward()
+            if accumulate:   # a second backward into the same arenas before the optimiser step
+                ka.l2_reconstruction_loss(net(xt, xs)[0], xs).backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        grads = torch.cat([p.grad.flatten() for p in net.parameters()]).clone()
+        return torch.stack(losses), {k: v.clone() for k, v in net.state_dict().items()}, grads
+    finally:
+        ka.set_multi_stream(True)
+
+
+@pytest.mark.parametrize('net_kind', ['transporter', 'keynet'])
+@pytest.mark.parametrize('accumulate', [False, True])
+def test_side_streams_change_nothing(net_kind, accumulate):
+    """Three train steps with the side streams on and off: losses, gradients of the last step, parameters and BatchNorm
+    buffers are bit-identical (also with two backwards accumulating into the arenas per step)."""
+    l0, s0, g0 = _run(net_kind, False, accumulate=accumulate)
+    l1, s1, g1 = _run(net_kind, True, accumulate=accumulate)
+    assert torch.equal(l0, l1)
+    assert torch.equal(g0, g1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+
+
+def test_gradients_are_final_when_backward_returns():
+    """`p.grad` read on the caller's stream right after backward() (no optimiser, no synchronize in between) sees the
+    finished arenas: the autograd pass joins the side streams when it ends."""
+    import keypoints_amd as ka
+    from keypoints_amd.models import transporter
+    g = torch.Generator().manual_seed(5)
+    xs = torch.rand(16, 3, 128, 128, generator=g).cuda()
+    xt = torch.rand(16, 3, 128, 128, generator=g).cuda()
+    outs = []
+    for streams in (False, True, True):
+        ka.set_multi_stream(streams)
+        torch.manual_seed(11)
+        net = transporter.make('F', 3, 32, 5).cuda().set_precision('bf16')
+        ka.l2_reconstruction_loss(net(xs, xt)[0], xt).backward()
+        # consumer kernels enqueued immediately on the current stream
+        outs.append(torch.stack([p.grad.double().abs().sum() for p in net.parameters()]))
+    ka.set_multi_stream(True)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_extractor_graph_capture_ignores_side_streams():
+    """Under stream capture (the inference extractor's HIP graph) everything stays on the capturing stream."""
+    from keypoints_amd import runtime
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        x = torch.zeros(4, device='cuda')
+        with torch.cuda.graph(g, stream=s):
+            assert not runtime.multi_stream()
+            x += 1
+    assert runtime.multi_stream()

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Concurrency report from a rocprofv3 kernel trace (`--kernel-trace --output-format csv`): how much of the wall time has
+matrix-core kernels running, HBM-bound passes running, both at once, or nothing.
+python tools/overlap_report.py <..._kernel_trace.csv> [skip_fraction]"""
+import csv, sys, collections
+
+MFMA = ('conv3x3_patch_k', 'wgrad3x3_patch_k', 'conv3x3_mfma_k', 'wgrad3x3_mfma_k', 'conv3x3_f32', 'wgrad3x3_f32')
+
+
+def main():
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+    ev = []
+    for r in rows:
+        name = r['Kernel_Name']
+        kind = 0 if any(m in name for m in MFMA) else 1
+        ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), kind, name))
+    ev.sort()
+    t0, t1 = ev[0][0], max(e[1] for e in ev)
+    lo = t0 + (t1 - t0) * skip          # analyse the tail of the run (steady-state steps)
+    hi = t1 - (t1 - t0) * 0.02
+    pts = []
+    for s, e, k, _ in ev:
+        if e <= lo or s >= hi:
+            continue
+        s = max(s, lo); e = min(e, hi)
+        pts.append((s, 1, k)); pts.append((e, -1, k))
+    pts.sort()
+    cnt = [0, 0]
+    acc = collections.Counter()
+    prev = lo
+    for t, d, k in pts:
+        state = ('mfma' if cnt[0] else '') + ('+' if cnt[0] and cnt[1] else '') + ('hbm' if cnt[1] else '') or 'idle'
+        acc[state] += t - prev
+        prev = t
+        cnt[k] += d
+    tot = sum(acc.values())
+    for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
+        print(f'{k:10s} {v / 1e6:9.3f} ms  {100 * v / tot:5.1f} %')
+    dur = collections.Counter(); n = collections.Counter()
+    for s, e, k, name in ev:
+        if e > lo:
+            short = name.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+            dur[short] += e - s; n[short] += 1
+    print('sum of kernel durations / wall:', round(sum(dur.values()) / tot, 3))
+    for k, v in dur.most_common(14):
+        print(f'  {k[:60]:60s} {n[k]:5d} {v / 1e6:8.3f} ms  avg {v / n[k] / 1e3:7.1f} us')
+
+
+if __name__ == '__main__':
+    main()
