@@ -197,8 +197,9 @@ def main():
 
     # ---- the roofline leg, OUTSIDE the timed region: a few more steps with an event pair around every convolution /
     # bottleneck launch on its launch stream
-    fam = {}
-    if args.profile_steps > 0:
+    def profile_leg():
+        """--profile-steps more steps with an event pair around every convolution / bottleneck launch -> per-family table"""
+        table = {}
         barrier()
         _lib.call('kp_prof_enable', 1)
         for _ in range(args.profile_steps):
@@ -210,12 +211,24 @@ def main():
             by = ctypes.c_double()
             _lib.call('kp_prof_bytes', fid, ctypes.addressof(by))
             if n.value:
-                fam[name] = dict(ms_per_step=ms.value / args.profile_steps, launches_per_step=n.value / args.profile_steps,
-                                 avg_us=1e3 * ms.value / n.value,
-                                 tflops=fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0,
-                                 flop_per_launch=fl.value / n.value, algorithmic_bytes_per_launch=by.value / n.value,
-                                 algorithmic_gbs=by.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0)
+                table[name] = dict(ms_per_step=ms.value / args.profile_steps, launches_per_step=n.value / args.profile_steps,
+                                   avg_us=1e3 * ms.value / n.value,
+                                   tflops=fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0,
+                                   flop_per_launch=fl.value / n.value, algorithmic_bytes_per_launch=by.value / n.value,
+                                   algorithmic_gbs=by.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0)
         _lib.call('kp_prof_enable', 0)
+        return table
+
+    # `fam`: the launches as the timed region runs them.  With the side streams on, a launch shares the chip with
+    # kernels of other streams for part of its life (its event pair then spans more than its own work); `fam_alone` is
+    # the same table from steps with every kernel on ONE stream, i.e. each launch with the chip to itself.
+    fam, fam_alone = {}, {}
+    if args.profile_steps > 0:
+        fam = profile_leg()
+        if args.streams:
+            ka.set_multi_stream(False)
+            fam_alone = profile_leg()
+            ka.set_multi_stream(True)
 
     if os.environ.get('KP_MEMSTATS'):
         ms_ = torch.cuda.memory_stats()
@@ -224,6 +237,12 @@ def main():
         flop_pair = conv_flops_per_pair(net, args.size, args.size)
         ms_step = 1e3 * elapsed / args.steps
         value = B * world / (elapsed / args.steps)
+        # the roofline of a KERNEL is quoted from the launches that had the chip to themselves (`fam_alone`, one stream);
+        # the same launches as the timed region runs them (side streams: shared chip, queueing inside the event pair)
+        # are reported next to it under `roofline.concurrent`
+        fam_conc = fam if fam_alone else {}
+        if fam_alone:
+            fam = fam_alone
         dom = max(fam.items(), key=lambda kv: kv[1]['ms_per_step']) if fam else (None, None)
         peak = PEAK_BF16_TFLOPS if args.precision != 'fp32' else PEAK_F32_TFLOPS
         # HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the
@@ -261,7 +280,17 @@ def main():
                                         hbm_gib=round(prop.total_memory / 2 ** 30, 1)))
             roofline.update(step_tflops=value / world * flop_pair / 1e12, step_frac=value / world * flop_pair / 1e12 / peak,
                             measured='HIP events around each launch on the launch stream, '
-                                     f'{args.profile_steps} steps after the timed region', kernels=fam)
+                                     f'{args.profile_steps} steps after the timed region', kernels=fam,
+                            streams=('the timed steps run with side streams (DESIGN.md 3.8); achieved / frac / kernels are from '
+                                     'profile steps with every kernel on ONE stream (a launch has the chip to itself, comparable '
+                                     'with a rocprofv3 trace of `--streams 0`); `concurrent` = the same launches in profile steps '
+                                     'with the side streams on, where an event pair also spans the time a launch shares the '
+                                     'chip with, or queues behind, kernels of other streams') if args.streams else 'one stream')
+            if fam_conc and dom[0] in fam_conc:
+                dc = fam_conc[dom[0]]
+                ach = dc['algorithmic_gbs'] if hbm else dc['tflops']
+                roofline['concurrent'] = dict(achieved=ach, frac=ach / (PEAK_HBM_GBS if hbm else peak), avg_launch_us=dc['avg_us'],
+                                              kernels=fam_conc)
             if 'keypoint_bottleneck' in fam:   # the bottleneck is HBM / latency class: report its GB/s
                 bk = fam['keypoint_bottleneck']
                 roofline['bottleneck'] = dict(bytes=bk['algorithmic_bytes_per_launch'], us=bk['avg_us'],
@@ -287,7 +316,7 @@ def main():
                                          f'{B} pairs/GPU ({cfg_name}), '
                                          f'{"augment+" if args.net == "keynet" and not args.no_augment else ""}fwd+loss+bwd+Adam',
                                 global_batch=B * world, per_gpu_batch=B, parallelism=f'dp{world}',
-                                dp_overlap=bool(args.dp_overlap) if world > 1 else None,
+                                dp_overlap=bool(args.dp_overlap) if world > 1 else None, side_streams=bool(args.streams),
                                 gflop_per_pair=flop_pair / 1e9, loss=float(loss.item())),
                     roofline=roofline)
         if world == 1 and not args.no_cpu_baseline and args.net == 'transporter':

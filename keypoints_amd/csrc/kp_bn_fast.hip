@@ -15,7 +15,10 @@
 
 namespace {
 
-constexpr int TPB = 256, UNR = 4;
+#ifndef KP_UNR
+#define KP_UNR 4   // vectors in flight per thread in the forward no-tail pass (build-time knob for tools/probes)
+#endif
+constexpr int TPB = 256, UNR = KP_UNR;
 constexpr int UNB = 4;   // pixels in flight per thread in the backward kernels (2 and 1 measured slower)
 constexpr int UNB4 = 4;  // the same for the 4-channel variants
 

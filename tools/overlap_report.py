@@ -16,9 +16,15 @@ def main():
         kind = 0 if any(m in name for m in MFMA) else 1
         ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), kind, name))
     ev.sort()
-    t0, t1 = ev[0][0], max(e[1] for e in ev)
-    lo = t0 + (t1 - t0) * skip          # analyse the tail of the run (steady-state steps)
-    hi = t1 - (t1 - t0) * 0.02
+    # window = whole train steps: from the first to the last loss kernel of the second half of the run (one per step)
+    marks = [e[0] for e in ev if 'l2_loss_k' in e[3]]
+    marks = marks[len(marks) // 2:]
+    if len(marks) >= 2:
+        lo, hi = marks[0], marks[-1]
+        print(f'{len(marks) - 1} steps, {(hi - lo) / (len(marks) - 1) / 1e6:.3f} ms per step under the profiler')
+    else:
+        t0, t1 = ev[0][0], max(e[1] for e in ev)
+        lo, hi = t0 + (t1 - t0) * skip, t1
     pts = []
     for s, e, k, _ in ev:
         if e <= lo or s >= hi:
