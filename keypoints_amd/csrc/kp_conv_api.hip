@@ -99,8 +99,11 @@ int kp_conv_wgrad_partials(int N, int Ho, int Wo, int C, int K, int R, int dy_pa
         const long long p = kp_conv_small_wgrad_partials(N, Ho, Wo, C, K);
         if (p > 0) return (int)p;
     }
-    // the per-tap MFMA fallback (kp_wgrad_mfma.hip: 64-multiples the tap-reuse kernel declines): one zeroed buffer, atomics
-    if (dtype == KP_H16 && use_mfma() && kp_conv_wgrad_mfma_accepts(N, Ho, Wo, C, K, R)) return 1;
+    // the per-tap MFMA fallback (kp_wgrad_mfma.hip: 64-multiples the tap-reuse kernel declines): one partial per pixel split
+    if (dtype == KP_H16 && use_mfma()) {
+        const int p = kp_conv_wgrad_mfma_accepts(N, Ho, Wo, C, K, R);
+        if (p > 0) return p;
+    }
     if (dtype == KP_F32 && R == 3 && use_mfma()) {
         const long long p = kp_conv_wgrad_f32mfma_partials(N, Ho, Wo, C, K);
         if (p > 0 && p < 0x7fffffffLL) return (int)p;

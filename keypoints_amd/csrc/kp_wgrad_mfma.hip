@@ -8,8 +8,9 @@
 // block, lane t supplying the address of (row t/4, 8-byte chunk t%4).
 // Workgroup tile TK x TC channels (64 or 128 each), 64 pixels per stage, 2x2 wavefronts, double-buffered
 // LDS; 64-byte blocks of every LDS row are XOR-swizzled by the pixel row so the 4 rows of a transpose
-// read fall on 4 different bank groups (conflict-free).  Split over pixels across workgroups; partial
-// tiles are added with hardware fp32 atomics.
+// read fall on 4 different bank groups (conflict-free).  Split over pixels across workgroups; every split
+// stores its tile into ITS OWN partial gradient (scratch[split][K][9][C], plain stores, nothing to zero), which
+// kp_wgrad_unpack sums in a fixed order: deterministic like the tap-reuse kernel (this one used fp32 atomics).
 #include "kp_common.h"
 
 namespace {
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_mfma_k(const h16_t* __restric
     }
 
     // D[k][c]: lane col = c (lane&31), rows k = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float* part = scratch + (long long)sp * K * 9 * C;
 #pragma unroll
     for (int a = 0; a < AK; ++a)
 #pragma unroll
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(TPB, 2) void wgrad3x3_mfma_k(const h16_t* __restric
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int kk = kb + (i & 3) + 8 * (i >> 2);
-                unsafeAtomicAdd(scratch + ((long long)kk * 9 + tap) * C + cc, acc[a][b][i]);
+                part[((long long)kk * 9 + tap) * C + cc] = acc[a][b][i];
             }
         }
 }
@@ -172,27 +174,40 @@ int ilog2_exact(int v) {
 
 }  // namespace
 
-// shapes this per-tap kernel takes (one zeroed scratch buffer, fp32 atomics): also asked by kp_conv_wgrad_partials
+// shapes this per-tap kernel takes; the pixel splits (= partial gradient buffers) of a shape: also asked by
+// kp_conv_wgrad_partials
+namespace {
+struct WgPlan { int TKs, TCs, ktiles, ctiles, total_stages, sps; long long tiles, splits; };
+WgPlan wg_plan(int N, int Ho, int Wo, int C, int K) {
+    WgPlan p;
+    const long long M = (long long)N * Ho * Wo;
+    p.TKs = (K % 128 == 0) ? 128 : 64; p.TCs = (C % 128 == 0) ? 128 : 64;
+    p.ktiles = K / p.TKs; p.ctiles = C / p.TCs;
+    p.total_stages = (int)(M / PIX);
+    p.tiles = 9LL * p.ktiles * p.ctiles;
+    long long splits = (1536 + p.tiles - 1) / p.tiles;
+    if (splits > p.total_stages / 8) splits = p.total_stages / 8;
+    if (splits < 1) splits = 1;
+    p.sps = (int)((p.total_stages + splits - 1) / splits);
+    p.splits = (p.total_stages + p.sps - 1) / p.sps;   // every split has at least one stage: every partial is written
+    return p;
+}
+}  // namespace
+
 int kp_conv_wgrad_mfma_accepts(int N, int Ho, int Wo, int C, int K, int R) {
     if (R != 3 || C % 64 != 0 || K % 64 != 0) return 0;
     const long long M = (long long)N * Ho * Wo;
-    return ilog2_exact(Wo) >= 0 && ilog2_exact(Ho) >= 0 && M % PIX == 0 && M < (1LL << 31);
+    if (!(ilog2_exact(Wo) >= 0 && ilog2_exact(Ho) >= 0 && M % PIX == 0 && M < (1LL << 31))) return 0;
+    return (int)wg_plan(N, Ho, Wo, C, K).splits;
 }
 
 int kp_conv_wgrad_mfma(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R,
                        int dy_pad, hipStream_t st) {
     if (!kp_conv_wgrad_mfma_accepts(N, Ho, Wo, C, K, R)) return KP_E_UNSUPPORTED;
     const int lgWo = ilog2_exact(Wo), lgHo = ilog2_exact(Ho);
-    const long long M = (long long)N * Ho * Wo;
-    const int TKs = (K % 128 == 0) ? 128 : 64, TCs = (C % 128 == 0) ? 128 : 64;
-    const int ktiles = K / TKs, ctiles = C / TCs;
-    const int total_stages = (int)(M / PIX);
-    const long long tiles = 9LL * ktiles * ctiles;
-    long long splits = (1536 + tiles - 1) / tiles;
-    if (splits > total_stages / 8) splits = total_stages / 8;
-    if (splits < 1) splits = 1;
-    const int sps = (int)((total_stages + splits - 1) / splits);
-    splits = (total_stages + sps - 1) / sps;
+    const WgPlan pl = wg_plan(N, Ho, Wo, C, K);
+    const int TKs = pl.TKs, TCs = pl.TCs, ktiles = pl.ktiles, ctiles = pl.ctiles, total_stages = pl.total_stages, sps = pl.sps;
+    const long long tiles = pl.tiles, splits = pl.splits;
     const unsigned grid = (unsigned)(tiles * splits);
 #define KP_WG_LAUNCH(TKv, TCv)                                                                                      \
     wgrad3x3_mfma_k<TKv, TCv><<<grid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, C, K,     \

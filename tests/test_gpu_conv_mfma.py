@@ -70,6 +70,8 @@ WG_SHAPES = [  # N, Ho, Wo, C, K, dy_pad
     # tap-reuse kernel (kp_wgrad_patch.hip): (128 x 64) and (64 x 128) gradient blocks, odd split counts
     (3, 32, 32, 128, 128, 2), (2, 16, 32, 128, 64, 2), (1, 64, 64, 256, 64, 0), (5, 16, 16, 64, 512, 2),
     (2, 24, 48, 64, 128, 2),
+    # per-tap fallback (kp_wgrad_mfma.hip: maps smaller than the tap-reuse kernel's blocks), several pixel splits
+    (32, 8, 8, 512, 512, 2), (64, 4, 4, 512, 256, 2), (16, 8, 8, 64, 64, 0),
 ]
 
 
@@ -105,6 +107,31 @@ def test_conv_wgrad_mfma(N, Ho, Wo, C, K, dp):
     err = (got - ref).abs().max().item()
     assert err <= 2e-5 * ref.abs().max().item() * (N * Ho * Wo) ** 0.5 + 1e-4, (err, ref.abs().max().item())
     assert ((got - ref).norm() / ref.norm()).item() < 1e-5
+
+
+def test_wgrad_fallback_is_bitwise_repeatable():
+    """The per-tap fallback kernel leaves one partial gradient per pixel split (no fp32 atomics any more): two runs give
+    the same bits, every partial buffer is written completely."""
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    N, Ho, Wo, C, K, dp = 32, 8, 8, 512, 512, 2
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, Ho + 2, Wo + 2, C, generator=g).bfloat16().cuda()
+    dy = torch.zeros(N, Ho + 2 * dp, Wo + 2 * dp, K, dtype=torch.bfloat16)
+    dy[:, dp:dp + Ho, dp:dp + Wo] = torch.randn(N, Ho, Wo, K, generator=g).bfloat16()
+    dy = dy.cuda()
+    parts = _lib.lib().kp_conv_wgrad_partials(N, Ho, Wo, C, K, 3, dp, _lib.KP_BF16)
+    assert parts > 1
+    outs = []
+    for _ in range(3):
+        scratch = torch.full((parts, K, 3, 3, C), float('nan'), device='cuda')
+        call('kp_conv_wgrad', ptr(x), ptr(dy), ptr(scratch), N, Ho, Wo, C, K, 3, dp, _lib.KP_BF16, stream_ptr())
+        gw = torch.zeros(K, C, 3, 3, device="cuda")   # kp_wgrad_unpack ACCUMULATES into the gradient arena
+        call('kp_wgrad_unpack', ptr(scratch), parts, ptr(gw), K, C, C, 3, stream_ptr())
+        assert torch.isfinite(scratch).all()
+        outs.append(gw)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 FIRST_SHAPES = [  # N, Ho, Wo, C, K
