@@ -54,6 +54,9 @@ def parse():
                     help='N > 1: 1 = all-reduce each gradient piece from the backward hooks (overlapped with the backward); '
                          '0 (default) = reduce the arenas back to back after the backward: ~1 ms exposed, but no RCCL kernel '
                          'shares CUs with the statically partitioned persistent MFMA kernels (DESIGN.md section 6)')
+    ap.add_argument('--comm', default='torch', choices=['torch', 'native'],
+                    help="N > 1: 'torch' = torch.distributed all-reduces (ProcessGroupNCCL = RCCL); 'native' = the C ABI's own RCCL "
+                         "communicator (kp_comm_*), torch.distributed only carries its unique id")
     ap.add_argument('--net', default='transporter', choices=['transporter', 'keynet'],
                     help="'keynet' = BASELINE config 3 (KeyNet + TPS/rotation augmentation); not the headline metric")
     ap.add_argument('--no-augment', action='store_true', help='keynet: skip the TPS/rotation augmentation')
@@ -144,7 +147,7 @@ def main():
     opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
     if args.precision == 'fp16':   # the reference's O2 recipe: fp16 storage + dynamic loss scaling (transporter.py:51,84-86)
         opt.scaler = ka.amp.LossScaler(dev)
-    reducer = GradReducer(net, overlap=bool(args.dp_overlap)) if world > 1 else None
+    reducer = GradReducer(net, overlap=bool(args.dp_overlap), comm=args.comm) if world > 1 else None
 
     g = torch.Generator().manual_seed(1234 + rank)
     B = args.batch

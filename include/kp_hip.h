@@ -313,6 +313,22 @@ int kp_adam_step_scaled(float* p, const float* g, float* m, float* v, size_t n, 
 int kp_amp_update(double* state, float growth_factor, float backoff_factor, int growth_interval, float max_scale,
                   void* stream);
 
+/* ---- gradient exchange of the data-parallel step (SURVEY.md 8b "kp_comm_init/destroy/allreduce", 8e) ---------------
+ * The reference has no distributed code; these calls are what a DDP wrapper around transporter.py:79-89 would do between
+ * `loss.backward()` and `optim.step()`: one all-reduce (average) of each flat gradient arena over the ranks (RCCL over
+ * xGMI), and a broadcast of parameters / BatchNorm buffers from one rank.  RCCL is bound at run time: kp_comm_available()
+ * is 0 (and the other calls return KP_E_ARG with text) in a process that has no librccl.
+ * One communicator per process and GPU: kp_comm_init binds it to the CURRENT HIP device; `id128` = the 128 bytes rank 0
+ * got from kp_comm_unique_id, carried to the other ranks by the launcher (any side channel).  Collectives are enqueued on
+ * `stream` in place (buf is input and output), never synchronise; every rank must issue the same calls in the same order.
+ * dtype: KP_F32 / KP_BF16 / KP_F16 = element type of buf.  average != 0: sum / world (ncclAvg). */
+int kp_comm_available(void);
+int kp_comm_unique_id(void* id128);
+int kp_comm_init(const void* id128, int rank, int world, void** comm);
+int kp_comm_allreduce(void* comm, void* buf, size_t count, int dtype, int average, void* stream);
+int kp_comm_broadcast(void* comm, void* buf, size_t count, int dtype, int root, void* stream);
+int kp_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,18 +27,70 @@ from typing import List
 import torch
 import torch.distributed as dist
 
-from . import runtime
+from . import _lib, runtime
+
+
+class NativeComm:
+    """The RCCL communicator behind the C ABI (`kp_comm_*`, include/kp_hip.h): the gradient exchange without
+    torch.distributed in the data path.  torch.distributed (any backend) is only the side channel that carries rank 0's
+    128-byte unique id to the other ranks; collectives then run on a communication stream of this object, ordered
+    against the compute stream with events.  One per process (= per GPU); bound to the current device."""
+
+    _DT = {torch.float32: _lib.KP_F32, torch.bfloat16: _lib.KP_BF16, torch.float16: _lib.KP_F16}
+
+    def __init__(self, group=None):
+        import ctypes
+        if not _lib.lib().kp_comm_available():
+            raise RuntimeError('NativeComm: no RCCL library in this process (librccl.so)')
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        buf = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.call('kp_comm_unique_id', buf)
+        box = [bytes(buf.raw) if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        h = ctypes.c_void_p()
+        _lib.call('kp_comm_init', box[0], self.rank, self.world, ctypes.byref(h))
+        self._h = h
+        self.stream = torch.cuda.Stream()
+
+    class _Work:
+        def __init__(self, ev):
+            self._ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self._ev)
+
+    def all_reduce(self, t: torch.Tensor, average: bool = True):
+        """In-place all-reduce of a contiguous tensor, asynchronous to the caller's stream: everything enqueued there so
+        far happens before it; `.wait()` of the returned object orders the caller's stream behind it."""
+        self.stream.wait_stream(torch.cuda.current_stream())
+        _lib.call('kp_comm_allreduce', self._h, t.data_ptr(), t.numel(), self._DT[t.dtype], int(average), self.stream.cuda_stream)
+        ev = torch.cuda.Event(); ev.record(self.stream)
+        return NativeComm._Work(ev)
+
+    def broadcast(self, t: torch.Tensor, src: int = 0) -> None:
+        st = torch.cuda.current_stream()
+        _lib.call('kp_comm_broadcast', self._h, t.data_ptr(), t.numel(), self._DT[t.dtype], src, st.cuda_stream)
+
+    def close(self) -> None:
+        if self._h is not None:
+            torch.cuda.synchronize()
+            _lib.call('kp_comm_destroy', self._h)
+            self._h = None
 
 
 class GradReducer:
     def __init__(self, root: torch.nn.Module, group=None, broadcast_init: bool = True, tail_fraction: float = 0.6,
-                 transport: str = 'fp32', overlap: bool = True, sync_bn: bool = False):
+                 transport: str = 'fp32', overlap: bool = True, sync_bn: bool = False, comm: str = 'torch'):
         """overlap: True -- pieces are all-reduced from the backward hooks, concurrently with the rest of the backward;
         False -- the hooks only note which arenas are final and `finish()` reduces them back to back (the exchange is then
         fully exposed, ~1 ms for model F over xGMI, but no RCCL kernel ever shares the CUs with the persistent MFMA
         kernels, whose tile partition is static: see DESIGN.md section 6).
         transport: 'fp32' (exact mean of the fp32 gradients) or 'bf16' (each piece is rounded to bf16 for the wire
         and the reduction: half the xGMI bytes, gradient error 2^-9 relative per element -- SURVEY.md 8e option).
+        comm: 'torch' -- the all-reduces go through torch.distributed (ProcessGroupNCCL = RCCL on ROCm, or gloo);
+        'native' -- through the C ABI's own RCCL communicator (`NativeComm`, kp_comm_*: SURVEY.md 8b), fp32 / bf16 parameters
+        and gradients only; torch.distributed then only carries the communicator's unique id at construction.
         sync_bn: BatchNorm batch statistics (forward) and the two backward sums are all-reduced per layer, i.e. the ranks
         normalise with the statistics of the GLOBAL batch: the DP step then equals the single-process step on the
         concatenated batch (non-default option; one small synchronous all-reduce per layer and direction)."""
@@ -53,12 +105,15 @@ class GradReducer:
         self._ready = []     # overlap=False: arena slices noted by the hooks, reduced in finish()
         self.units: List[Unit] = [m for m in root.modules() if isinstance(m, Unit)]
         self._pending = []   # (work, fp32 arena slice, wire tensor or None)
-        self._avg = dist.get_backend(group) == 'nccl'   # RCCL has ncclAvg; gloo sums then scales
+        if comm not in ('torch', 'native'):
+            raise ValueError("comm must be 'torch' or 'native'")
+        self.native = NativeComm(group) if comm == 'native' else None
+        self._avg = self.native is not None or dist.get_backend(group) == 'nccl'   # RCCL has ncclAvg; gloo sums then scales
         self._sync = True
         self.pieces_issued = 0   # since the last finish() (tests / diagnostics)
         if broadcast_init:
             for t in list(root.parameters()) + list(root.buffers()):
-                dist.broadcast(t.data, src=0, group=group)
+                self._bcast(t.data)
         self._split = {}      # id(unit) -> (plan step index, arena offset): the tail from there on is reduced early
         self._early = set()   # units whose tail piece is already in flight this step
         self._done = set()    # units whose whole arena is in flight this step
@@ -100,10 +155,19 @@ class GradReducer:
         self._launch(t)
         self.pieces_issued += 1
 
+    def _bcast(self, t, src: int = 0) -> None:
+        if self.native is not None and t.dtype in NativeComm._DT and t.is_contiguous():
+            self.native.broadcast(t, src)
+        else:   # (num_batches_tracked is int64: RCCL types of the C ABI are the float ones)
+            dist.broadcast(t, src=src, group=self.group)
+
     def _launch(self, t) -> None:
-        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         wire = t.to(torch.bfloat16) if self.transport == 'bf16' else None
-        work = dist.all_reduce(wire if wire is not None else t, op=op, group=self.group, async_op=True)
+        if self.native is not None:
+            work = self.native.all_reduce(wire if wire is not None else t, average=True)
+        else:
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            work = dist.all_reduce(wire if wire is not None else t, op=op, group=self.group, async_op=True)
         self._pending.append((work, t, wire))
 
     def _check_not_in_flight(self, unit) -> None:
@@ -161,7 +225,7 @@ class GradReducer:
         """BatchNorm running statistics are per-rank (each rank normalises its own shard); before a checkpoint every
         rank takes rank `src`'s buffers, so that what is saved -- and what every rank continues from -- is one state."""
         for b in self.root.buffers():
-            dist.broadcast(b.data, src=src, group=self.group)
+            self._bcast(b.data, src)
 
     def save(self, directory: str) -> None:
         """Checkpoint under DP: buffers from rank 0 to everyone, then rank 0 writes `root.save(directory)`
@@ -172,6 +236,9 @@ class GradReducer:
         dist.barrier(group=self.group)
 
     def detach(self) -> None:
+        if self.native is not None:
+            self.native.close()
+            self.native = None
         for u in self.units:
             u.after_backward = None
             u.layer_done = None

@@ -132,3 +132,44 @@ def test_sync_bn_equals_the_concatenated_batch(typ, size):
     assert abs(rec['loss_dp'] - rec['loss_ref']) <= 2e-6 * abs(rec['loss_ref']), rec
     assert rec['worst_grad'] <= 2e-4, rec       # fp32 summation order differs between the two runs
     assert rec['params'] <= 1e-5 and rec['buffers'] <= 1e-5, rec
+
+
+def test_native_comm_world1(nccl_world1):
+    """kp_comm_* (the C ABI's own RCCL communicator) on the one GPU of the box: unique id, init, in-place
+    all-reduce (average / sum, fp32 and bf16), broadcast, destroy -- and the reducer on it through a real backward:
+    with one rank the averaged gradient is the gradient, so the step equals the non-DP step bit for bit."""
+    import keypoints_amd as ka
+    from keypoints_amd import _lib
+    from keypoints_amd.dist import GradReducer, NativeComm
+    from keypoints_amd.models import transporter
+    assert _lib.lib().kp_comm_available() == 1
+    comm = NativeComm()
+    for dt in (torch.float32, torch.bfloat16):
+        t = torch.randn(1 << 20, device='cuda').to(dt)
+        ref = t.clone()
+        comm.all_reduce(t, average=True).wait()
+        comm.all_reduce(t, average=False).wait()
+        comm.broadcast(t, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(t, ref)
+    comm.close()
+
+    g = torch.Generator().manual_seed(3)
+    xs = torch.rand(8, 3, 128, 128, generator=g).cuda()
+    xt = torch.rand(8, 3, 128, 128, generator=g).cuda()
+    nets = []
+    for mode in (None, 'overlap', 'after'):
+        torch.manual_seed(11)
+        net = transporter.make('F', 3, 64, 10).cuda().set_precision('bf16')
+        opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
+        red = GradReducer(net, comm='native', overlap=(mode == 'overlap')) if mode else None
+        for _ in range(2):
+            loss, issued = _step(net, opt, xs, xt, red)
+        if red is not None:
+            assert issued == (2 if mode == 'overlap' else 1) * len(red.units)
+            torch.cuda.synchronize()
+            red.detach()
+        nets.append(net)
+    for other in nets[1:]:
+        for (n, a), (_, b) in zip(nets[0].named_parameters(), other.named_parameters()):
+            assert torch.equal(a, b), n
