@@ -133,6 +133,10 @@ def main():
     from keypoints_amd.models import transporter
     from keypoints_amd.flops import conv_flops_per_pair
 
+    if world > torch.cuda.device_count():
+        # ranks share a device (the one-GPU exercise of the launch path, --backend gloo): two processes with five HIP
+        # streams each oversubscribe the hardware queues and the driver time-slices them (measured: 0.9 s per step)
+        args.streams = 0
     ka.set_multi_stream(bool(args.streams))
     torch.manual_seed(0)
     if args.net == 'keynet':

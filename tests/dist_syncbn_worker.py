@@ -13,6 +13,8 @@ import keypoints_amd as ka
 from keypoints_amd.dist import GradReducer
 from keypoints_amd.models import transporter
 
+ka.set_multi_stream(False)   # both ranks share the test box's one GPU: side streams of two processes oversubscribe its queues
+
 
 def make(seed):
     torch.manual_seed(seed)
