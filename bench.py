@@ -69,6 +69,10 @@ def parse():
     ap.add_argument('--streams', type=int, default=1,
                     help='1 (default): weight gradients and the keypoint encoder run on side HIP streams beside the main chain '
                          '(DESIGN.md 3.8); 0: every kernel on one stream, in program order')
+    ap.add_argument('--graph', type=int, default=0,
+                    help='1: replay the whole train step as one HIP graph (keypoints_amd.graph.GraphedTrainStep): a 2.5x for the '
+                         'Pong-class nets at the reference batch sizes, where ~140 launches of a few us set the pace; slower than '
+                         'the eager multi-stream step for model F')
     ap.add_argument('--lib', default='', help='development: time another build of libkp_hip.so (A/B on one box)')
     return ap.parse_args()
 
@@ -174,6 +178,16 @@ def main():
         opt.step()
         return loss
 
+    eager_step = step
+    if args.graph:
+        # the whole step as one HIP graph launch (keypoints_amd/graph.py): for launch-bound nets / batch sizes.  The batch is
+        # copied into the graph's input buffers every step, as a training loop would; the roofline legs run eagerly.
+        assert world == 1 and args.net == 'transporter', '--graph: single-GPU Transporter step only'
+        gstep = ka.graph.GraphedTrainStep(net, opt, None, (xs, xt), warmup=2)
+
+        def step():
+            return gstep(xs, xt)
+
     for _ in range(args.warmup):
         step()
 
@@ -210,7 +224,7 @@ def main():
         barrier()
         _lib.call('kp_prof_enable', 1)
         for _ in range(args.profile_steps):
-            step()
+            eager_step()
         barrier()
         for fid, name in FAMILIES.items():
             ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
@@ -323,7 +337,7 @@ def main():
                                          f'{B} pairs/GPU ({cfg_name}), '
                                          f'{"augment+" if args.net == "keynet" and not args.no_augment else ""}fwd+loss+bwd+Adam',
                                 global_batch=B * world, per_gpu_batch=B, parallelism=f'dp{world}',
-                                dp_overlap=bool(args.dp_overlap) if world > 1 else None, side_streams=bool(args.streams),
+                                dp_overlap=bool(args.dp_overlap) if world > 1 else None, side_streams=bool(args.streams), hip_graph=bool(args.graph),
                                 gflop_per_pair=flop_pair / 1e9, loss=float(loss.item())),
                     roofline=roofline)
         if world == 1 and not args.no_cpu_baseline and args.net == 'transporter':

@@ -6,6 +6,7 @@ from . import data_augments, tps  # noqa: F401
 from .optim import FusedAdam, l2_reconstruction_loss  # noqa: F401
 from . import inference  # noqa: F401
 from . import amp  # noqa: F401
+from . import graph  # noqa: F401
 
 
 def install_as_keypoints():

@@ -91,7 +91,7 @@ def scale_loss(loss, optimizer):
     """`with amp.scale_loss(loss, optim) as scaled_loss: scaled_loss.backward()` (transporter.py:84-86).  Without a
     scaler on the optimizer (fp32 / bf16 modes) the loss passes through unchanged."""
     scaler = getattr(optimizer, 'scaler', None)
-    if scaler is None:
+    if scaler is None or getattr(scaler, 'unit', False):   # (unit: constant scale 1, keypoints_amd.graph)
         yield loss
     else:
         yield _ScaleLoss.apply(loss, scaler.scale_tensor())

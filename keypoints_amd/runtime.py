@@ -54,8 +54,8 @@ def f32c(t: torch.Tensor) -> torch.Tensor:
 # encoder runs on a side stream of the feature encoder's.  Results do not depend on it (every kernel is deterministic).
 _multi_stream = True
 _side_streams = {}     # (device index, parent stream id, role) -> torch.cuda.Stream
-_used = set()          # side streams with work the parent has not waited for yet
-_callback_queued = False
+_parents = {}          # side stream -> the stream it was forked from
+_used = set()          # side streams with work their parent has not waited for yet
 
 
 def set_multi_stream(on: bool) -> None:
@@ -64,8 +64,13 @@ def set_multi_stream(on: bool) -> None:
     _multi_stream = bool(on)
 
 
-def multi_stream() -> bool:
-    return _multi_stream and not torch.cuda.is_current_stream_capturing()
+_disabled_roles = set()   # measurement / debugging: side-stream roles ('wgrad', 'chain') that stay on the parent stream
+
+
+def multi_stream(role: str = None) -> bool:
+    # (under stream capture -- the inference extractor's graph, keypoints_amd.graph -- the side streams join the capture
+    #  when they wait for the capturing stream and become parallel branches of the graph)
+    return _multi_stream and role not in _disabled_roles
 
 
 def side_stream(role: str) -> torch.cuda.Stream:
@@ -75,32 +80,42 @@ def side_stream(role: str) -> torch.cuda.Stream:
     s = _side_streams.get(key)
     if s is None:
         s = _side_streams[key] = torch.cuda.Stream(device=cur.device)
+        _parents[s] = cur
     _used.add(s)
     return s
 
 
+def nested_fork_under_capture() -> bool:
+    """True when torch's current stream is itself a side stream and a stream capture is in progress on it."""
+    cur = torch.cuda.current_stream()
+    return cur in _parents and torch.cuda.is_current_stream_capturing()
+
+
 def join_side_streams() -> None:
-    """torch's current stream waits for everything enqueued on any side stream so far."""
-    global _callback_queued
-    _callback_queued = False
+    """torch's current stream waits for everything enqueued on any side stream so far (optimiser / reducer entry: a no-op
+    after a backward, which joins on its own -- see join_after_backward)."""
     if not _used:
         return
     cur = torch.cuda.current_stream()
     for s in list(_used):
         if s.device == cur.device:
-            cur.wait_stream(s)
+            if s != cur:
+                cur.wait_stream(s)
             _used.discard(s)
 
 
 def join_after_backward() -> None:
-    """Called from inside a backward node: when the autograd pass ends, the stream that called backward() waits for the
-    side streams (the engine runs its final callbacks under the caller's current stream), so `p.grad`, the optimiser
-    and the gradient reducer see finished arenas without knowing about the streams."""
-    global _callback_queued
-    _used.add(torch.cuda.current_stream())   # the stream this node runs on (that of its forward)
-    if not _callback_queued:
-        _callback_queued = True
-        torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+    """Called at the end of a Unit's backward, on the stream the autograd engine runs it on (= the stream of its forward).
+    If that is a side stream, the stream it was forked from waits for it here: by the time `backward()` returns, that
+    wait is enqueued, so whatever the caller enqueues next on the forward's stream (`p.grad`, the optimiser, the gradient
+    reducer) sees finished arenas.  (An engine callback -- `queue_callback` -- would be the general hook, but it runs on
+    the engine's worker thread, whose thread-local current stream is the legacy default stream: waiting THERE on a
+    capturing stream aborts the capture of keypoints_amd.graph.)"""
+    cur = torch.cuda.current_stream()
+    parent = _parents.get(cur)
+    if parent is not None:
+        parent.wait_stream(cur)
+        _used.discard(cur)
 
 
 _held = {}   # side stream -> tensors its last block handed to the parent stream
@@ -121,7 +136,7 @@ class fork:
         self._stream = None
 
     def __enter__(self):
-        if self._inputs and multi_stream():
+        if self._inputs and multi_stream(self._role):
             self._cur = torch.cuda.current_stream()
             self._stream = side_stream(self._role)
             self._stream.wait_stream(self._cur)

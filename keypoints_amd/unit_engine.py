@@ -289,7 +289,9 @@ class UnitFunction(torch.autograd.Function):
         arena = unit.grad_arena()
         arena.attach(params)
         cur = torch.cuda.current_stream()
-        side = runtime.side_stream('wgrad') if runtime.multi_stream() else None
+        side = runtime.side_stream('wgrad') if runtime.multi_stream('wgrad') else None
+        if side is not None and runtime.nested_fork_under_capture():
+            side = None   # (a side stream OF a side stream inside a stream capture crashes hipStreamEndCapture, ROCm 7.0)
         keep = []
         gv = arena.views
         need_x = ctx.needs_input_grad[0]

@@ -72,14 +72,42 @@ def test_gradients_are_final_when_backward_returns():
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
-def test_extractor_graph_capture_ignores_side_streams():
-    """Under stream capture (the inference extractor's HIP graph) everything stays on the capturing stream."""
-    from keypoints_amd import runtime
-    s = torch.cuda.Stream()
-    with torch.cuda.stream(s):
-        g = torch.cuda.CUDAGraph()
-        x = torch.zeros(4, device='cuda')
-        with torch.cuda.graph(g, stream=s):
-            assert not runtime.multi_stream()
-            x += 1
-    assert runtime.multi_stream()
+@pytest.mark.parametrize('model', ['F', 'VGG_PONG_LAYERNECK'])
+def test_graphed_train_step_equals_eager(model):
+    """keypoints_amd.graph.GraphedTrainStep: the whole step (zero_grad, forward, loss, backward with its side streams as
+    graph branches, Adam with device-resident step count) captured once and replayed on fresh batches gives the same
+    parameters, bit for bit, as the eager loop on the same batches."""
+    import keypoints_amd as ka
+    from keypoints_amd.models import transporter
+    cin, z, K, size, B = (3, 64, 10, 128, 8) if model == 'F' else (1, 16, 4, 84, 32)
+    g = torch.Generator().manual_seed(7)
+    batches = [(torch.rand(B, cin, size, size, generator=g).cuda(), torch.rand(B, cin, size, size, generator=g).cuda())
+               for _ in range(6)]
+
+    def build():
+        torch.manual_seed(11)
+        net = transporter.make(model, cin, z, K).cuda().set_precision('bf16')
+        opt = ka.FusedAdam(net.parameters(), lr=1e-3).bind(net)
+        return net, opt
+
+    net_g, opt_g = build()
+    step = ka.graph.GraphedTrainStep(net_g, opt_g, None, batches[0], warmup=2)   # 2 warm-up steps train on batch 0 (the capture itself runs nothing)
+    losses_g = [step(xs, xt).clone() for xs, xt in batches[1:]]
+
+    net_e, opt_e = build()
+    opt_e.scaler = ka.amp.LossScaler('cuda', init_scale=1.0, growth_factor=1.0, backoff_factor=1.0, growth_interval=1 << 30,
+                                     max_scale=1.0)
+    opt_e.scaler.unit = True
+    losses_e = []
+    for i, (xs, xt) in enumerate([batches[0]] * 2 + batches[1:]):
+        opt_e.zero_grad()
+        loss = ka.l2_reconstruction_loss(net_e(xs, xt)[0], xt)
+        loss.backward()
+        opt_e.step()
+        if i >= 2:
+            losses_e.append(loss.detach().clone())
+    torch.cuda.synchronize()
+    assert torch.equal(torch.stack(losses_g), torch.stack(losses_e))
+    for (n, a), (_, b) in zip(net_g.state_dict().items(), net_e.state_dict().items()):
+        assert torch.equal(a, b), n
+    assert opt_g.scaler.adam_steps == 7 and opt_g.scaler.steps_skipped == 0
