@@ -111,3 +111,37 @@ def test_graphed_train_step_equals_eager(model):
     for (n, a), (_, b) in zip(net_g.state_dict().items(), net_e.state_dict().items()):
         assert torch.equal(a, b), n
     assert opt_g.scaler.adam_steps == 7 and opt_g.scaler.steps_skipped == 0
+
+
+def test_graphed_train_step_fp16_dynamic_loss_scale():
+    """The fp16 recipe (dynamic loss scaling, overflow check, skipped steps) lives on the device, so it replays inside the
+    graph: same parameters and scaler state as the eager loop, including a step that overflows and is skipped."""
+    import keypoints_amd as ka
+    from keypoints_amd.models import transporter
+    g = torch.Generator().manual_seed(7)
+    batches = [(torch.rand(8, 3, 128, 128, generator=g).cuda(), torch.rand(8, 3, 128, 128, generator=g).cuda()) for _ in range(5)]
+    batches[3] = (batches[3][0] * 3e4, batches[3][1] * 3e4)   # a batch that overflows fp16 activations: the step must be skipped
+
+    def build():
+        torch.manual_seed(11)
+        net = transporter.make('F', 3, 64, 10).cuda()
+        opt = ka.FusedAdam(net.parameters(), lr=1e-3)
+        net, opt = ka.amp.initialize(net, opt, opt_level='O2')
+        return net, opt.bind(net)
+
+    net_g, opt_g = build()
+    step = ka.graph.GraphedTrainStep(net_g, opt_g, None, batches[0], warmup=2)
+    for xs, xt in batches[1:]:
+        step(xs, xt)
+    net_e, opt_e = build()
+    for xs, xt in [batches[0]] * 2 + batches[1:]:
+        opt_e.zero_grad()
+        loss = ka.l2_reconstruction_loss(net_e(xs, xt)[0], xt)
+        with ka.amp.scale_loss(loss, opt_e) as scaled:
+            scaled.backward()
+        opt_e.step()
+    torch.cuda.synchronize()
+    assert torch.equal(opt_g.scaler.state, opt_e.scaler.state)
+    assert opt_g.scaler.steps_skipped >= 1
+    for (n, a), (_, b) in zip(net_g.state_dict().items(), net_e.state_dict().items()):
+        assert torch.equal(a, b), n
