@@ -64,7 +64,9 @@ def set_multi_stream(on: bool) -> None:
     _multi_stream = bool(on)
 
 
-_disabled_roles = set()   # measurement / debugging: side-stream roles ('wgrad', 'chain') that stay on the parent stream
+import os as _os
+# measurement / debugging: side-stream roles ('wgrad', 'chain', 'ring') that stay on the parent stream (KP_NO_ROLES=a,b)
+_disabled_roles = set(filter(None, _os.environ.get('KP_NO_ROLES', '').split(',')))
 
 
 def multi_stream(role: str = None) -> bool:
