@@ -45,7 +45,7 @@ def main():
         print(f'{k:10s} {v / 1e6:9.3f} ms  {100 * v / tot:5.1f} %')
     dur = collections.Counter(); n = collections.Counter()
     for s, e, k, name in ev:
-        if e > lo:
+        if e > lo and s < hi:
             short = name.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
             dur[short] += e - s; n[short] += 1
     print('sum of kernel durations / wall:', round(sum(dur.values()) / tot, 3))
