@@ -111,6 +111,57 @@ def cpu_baseline(args):
                        f'timed steps, torch CPU {torch.get_num_threads()} threads')
 
 
+class PowerSampler:
+    """Socket power and shader clock of this rank's GPU while the timed steps run, from the amdgpu hwmon files
+    (power1_input [uW], power1_cap [uW], freq1_input [Hz] = sclk), sampled every 10 ms by a host thread.  The matrix-core
+    kernels of this step run at the package power cap with the clock throttled below the 2.4 GHz the peak figures assume
+    (DESIGN.md section 3): the numbers are reported next to the roofline so that `frac` can be read against them.
+    Silent (None) where the files are not readable."""
+
+    def __init__(self, dev):
+        import glob
+        import threading
+        self.samples, self.cap, self._stop, self._dir = [], None, threading.Event(), None
+        try:
+            prop = torch.cuda.get_device_properties(dev)
+            want = f'{prop.pci_domain_id:04x}:{prop.pci_bus_id:02x}:{prop.pci_device_id:02x}'
+            for card in glob.glob('/sys/class/drm/card*/device'):
+                if os.path.basename(os.path.realpath(card)).lower().startswith(want):
+                    hw = glob.glob(os.path.join(card, 'hwmon', 'hwmon*'))
+                    if hw and os.path.exists(os.path.join(hw[0], 'power1_input')):
+                        self._dir = hw[0]
+            if self._dir:
+                self.cap = int(open(os.path.join(self._dir, 'power1_cap')).read()) / 1e6
+        except Exception:
+            self._dir = None
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        pw, fq = os.path.join(self._dir, 'power1_input'), os.path.join(self._dir, 'freq1_input')
+        while not self._stop.is_set():
+            try:
+                self.samples.append((int(open(pw).read()) / 1e6, int(open(fq).read()) / 1e6))
+            except Exception:
+                pass
+            time.sleep(0.01)
+
+    def start(self):
+        if self._dir:
+            self._thread.start()
+
+    def stop(self):
+        if not self._dir:
+            return None
+        self._stop.set()
+        self._thread.join(timeout=1.0)
+        if not self.samples:
+            return None
+        w = [s[0] for s in self.samples]; f = [s[1] for s in self.samples]
+        return dict(avg_socket_w=sum(w) / len(w), max_socket_w=max(w), cap_w=self.cap, avg_sclk_mhz=sum(f) / len(f),
+                    min_sclk_mhz=min(f), samples=len(w), nominal_sclk_mhz=2400,
+                    source='amdgpu hwmon power1_input / power1_cap / freq1_input of this GPU, 10 ms period, timed region only')
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -202,6 +253,9 @@ def main():
     # kp_* call is enqueued on), from which the per-step median comes
     barrier()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    power = PowerSampler(dev) if rank == 0 else None
+    if power is not None:
+        power.start()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -209,6 +263,7 @@ def main():
         marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    power = power.stop() if power is not None else None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -307,6 +362,11 @@ def main():
                                      'with a rocprofv3 trace of `--streams 0`); `concurrent` = the same launches in profile steps '
                                      'with the side streams on, where an event pair also spans the time a launch shares the '
                                      'chip with, or queues behind, kernels of other streams') if args.streams else 'one stream')
+            # the chip's state during the timed steps: at the package power cap the shader clock sits well below the 2.4 GHz
+            # behind `peak`; frac_at_measured_clock = achieved / (peak x measured clock / 2.4 GHz)
+            roofline['power'] = power
+            if power and not hbm and power.get('avg_sclk_mhz'):
+                roofline['frac_at_measured_clock'] = roofline['frac'] / (power['avg_sclk_mhz'] / 2400.0)
             if fam_conc and dom[0] in fam_conc:
                 dc = fam_conc[dom[0]]
                 ach = dc['algorithmic_gbs'] if hbm else dc['tflops']
