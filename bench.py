@@ -36,8 +36,9 @@ HBM_BOUND = {'conv_first_16bit', 'conv_small_16bit', 'keypoint_bottleneck'}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=10,
+                    help='untimed steps before the timed ones (the package takes ~10 steps = 0.3 s to settle at its power cap)')
     ap.add_argument('--batch', type=int, default=128, help='image pairs per GPU')
     ap.add_argument('--size', type=int, default=128)
     ap.add_argument('--model_type', default='F')
