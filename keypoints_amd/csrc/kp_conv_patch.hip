@@ -298,6 +298,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
             ++tri;
         }
     };
+    float dummy[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};   // TRACE build only (see dbg & 0x700)
     const int nchunks = C / 64;
     TileRef cur = decode(tile);
     __amdgpu_buffer_rsrc_t xr = x_rsrc(cur), wr = w_rsrc(cur);
@@ -375,6 +376,16 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                 stamp();
                 __builtin_amdgcn_sched_barrier(0);
 
+                // (measurement build: dbg & 0x100 / 0x200 / 0x400 add 24 / 48 / 96 dependent-free fp32 FMAs per step and wave --
+                //  what a BatchNorm-apply of the patch fused into this loop would issue -- to see whether the power-limited loop
+                //  has the issue slots for them: tools/probes/valu_in_loop.py)
+                if constexpr (TRACE) {
+                    const int reps = ((dbg >> 8) & 1) * 1 + ((dbg >> 9) & 1) * 2 + ((dbg >> 10) & 1) * 4;
+                    for (int rr = 0; rr < reps; ++rr) {
+#pragma unroll
+                        for (int q = 0; q < 24; ++q) dummy[q & 7] = __builtin_fmaf(dummy[q & 7], 1.0001f, dummy[(q + 3) & 7]);
+                    }
+                }
                 // -- second half: kk = 2 MFMAs first (keeps the matrix pipe fed while the DMA instructions issue)
                 mma(f2);
                 __builtin_amdgcn_sched_barrier(0);
@@ -438,6 +449,8 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
             }
         }
     }
+    if constexpr (TRACE) if ((dbg & 0x700) && dummy[0] + dummy[1] + dummy[2] + dummy[3] + dummy[4] + dummy[5] + dummy[6] + dummy[7] == 12345.678f)
+        A.partials[0] = dummy[0];   // keeps the measurement FMAs alive
     if constexpr (TRACE) if (tracing && lane == 0)
         for (int i = 0; i < 512; ++i) A.trace[i] = i < tri ? reinterpret_cast<long long*>(smem + OFF_TRACE)[i] : 0;
 }
