@@ -163,3 +163,23 @@ def test_flop_accounting_matches_survey():
     assert f == O.conv_flops_per_pair(O.transporter_plans('F', 3, 64, 10), 128, 128)
     kn = keynet.make(types.SimpleNamespace(model_type='F', model_in_channels=3, model_z_channels=64, model_keypoints=10))
     assert conv_flops_per_pair(kn, 128, 128) == O.conv_flops_per_pair(O.keynet_plans('F', 3, 64, 10), 128, 128, transporter=False)
+
+
+def test_side_stream_helpers_are_inert_without_a_device():
+    """runtime.fork / join_side_streams touch no HIP API when nothing lives on a device: the CPU-side uses of
+    the host engine (plan building, reducer bookkeeping over gloo) never initialise HIP through them."""
+    import torch
+    from keypoints_amd import runtime
+    x = torch.zeros(2, 3)
+    order = []
+    with runtime.fork('chain', x) as side:
+        with side:
+            order.append('side')
+            side.outputs(x)
+        order.append('main')
+    runtime.join_side_streams()
+    assert order == ['side', 'main'] and not runtime._used and not runtime._held
+    runtime.set_multi_stream(False)
+    assert not runtime.multi_stream() and not runtime.multi_stream('wgrad')
+    runtime.set_multi_stream(True)
+    assert runtime.multi_stream('chain')
