@@ -8,6 +8,7 @@ launch.  The side streams of the step (runtime.fork / side_stream) become parall
     step = keypoints_amd.graph.GraphedTrainStep(net, optim, loss_fn, (xs, xt))     # warm-up steps (these TRAIN) + capture (runs nothing)
     for xs, xt in loader:
         loss = step(xs, xt)          # copies the batch into the graph's input buffers, replays, returns the loss tensor
+                                     # (a static buffer: the next call overwrites it -- clone() to keep a value)
 
 Frozen at capture: input shapes, the precision mode, every hyper-parameter that reaches a kernel as a scalar argument
 (learning rate, betas, eps) -- build a new GraphedTrainStep to change one.  Not for the data-parallel reducer (its
