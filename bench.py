@@ -365,6 +365,8 @@ def main():
                                      'chip with, or queues behind, kernels of other streams') if args.streams else 'one stream')
             # the chip's state during the timed steps: at the package power cap the shader clock sits well below the 2.4 GHz
             # behind `peak`; frac_at_measured_clock = achieved / (peak x measured clock / 2.4 GHz)
+            if power:
+                power['joules_per_step'] = power['avg_socket_w'] * ms_step * 1e-3   # the step is energy-limited
             roofline['power'] = power
             if power and not hbm and power.get('avg_sclk_mhz'):
                 roofline['frac_at_measured_clock'] = roofline['frac'] / (power['avg_sclk_mhz'] / 2400.0)
