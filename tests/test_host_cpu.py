@@ -183,3 +183,32 @@ def test_side_stream_helpers_are_inert_without_a_device():
     assert not runtime.multi_stream() and not runtime.multi_stream('wgrad')
     runtime.set_multi_stream(True)
     assert runtime.multi_stream('chain')
+
+
+def test_overlap_report_on_a_synthetic_trace(tmp_path, capsys):
+    """tools/overlap_report.py (the concurrency evidence of DESIGN 3.8) on a hand-made kernel trace: two steps delimited by
+    loss kernels, one MFMA kernel overlapping an HBM pass for half of its duration."""
+    import csv, importlib.util, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = [('l2_loss_k', 0, 10), ('l2_loss_k', 1000, 1010), ('l2_loss_k', 2000, 2010), ('conv3x3_patch_k<128, true, false>(x)', 2100, 2500),
+            ('v4::bn_bwd_fast_k<0, 1, 1>(y)', 2300, 2700), ('l2_loss_k', 3000, 3010)]
+    f = tmp_path / 't_kernel_trace.csv'
+    with open(f, 'w', newline='') as fh:
+        w = csv.writer(fh)
+        w.writerow(['Kernel_Name', 'Start_Timestamp', 'End_Timestamp'])
+        for r in rows:
+            w.writerow(r)
+    spec = importlib.util.spec_from_file_location('overlap_report', os.path.join(root, 'tools', 'overlap_report.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    old = sys.argv
+    sys.argv = ['overlap_report.py', str(f)]
+    try:
+        mod.main()
+    finally:
+        sys.argv = old
+    out = capsys.readouterr().out
+    assert '1 steps' in out                       # window: second half of the loss kernels = [2000, 3000]
+    lines = {ln.split()[0]: float(ln.split()[-2]) for ln in out.splitlines() if ln.split() and ln.split()[0] in ('mfma', 'hbm', 'mfma+hbm', 'idle')}
+    assert lines['mfma+hbm'] == 20.0 and lines['mfma'] == 20.0 and abs(lines['hbm'] - 21.0) < 1e-6 and abs(lines['idle'] - 39.0) < 1e-6
+    sys.argv = old

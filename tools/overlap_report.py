@@ -40,6 +40,7 @@ def main():
         acc[state] += t - prev
         prev = t
         cnt[k] += d
+    acc[('mfma' if cnt[0] else '') + ('+' if cnt[0] and cnt[1] else '') + ('hbm' if cnt[1] else '') or 'idle'] += hi - prev
     tot = sum(acc.values())
     for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
         print(f'{k:10s} {v / 1e6:9.3f} ms  {100 * v / tot:5.1f} %')
