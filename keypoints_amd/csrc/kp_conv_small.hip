@@ -16,7 +16,9 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) short h16x8;
+typedef __attribute__((ext_vector_type(4))) short h16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+#define LDS_AS __attribute__((address_space(3)))
 
 constexpr int TPB = 256;
 
@@ -62,16 +64,22 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_k(const h16_t* __restrict__
     const int fr = lane & 31, fh = lane >> 5;
     const int Ho = Hi - 2, Wo = Wi - 2;
 
-    // weight fragments: lane (k = fr, half = fh): 8 input channels of W[k][tap][cb*16 + fh*8 ...]; rows k >= K are zero
-    h16x8 wf[9 * CB];
+    // weight fragments: lane (k = fr, half = fh): 8 input channels of W[k][tap][cb*16 + fh*8 ...]; rows k >= K are zero.
+    // They live in LDS (one copy per workgroup, read back lane-linear: conflict-free), not in 36 / 72 registers: 94-96 VGPRs
+    // instead of 128 / 164, i.e. 4-5 waves per SIMD instead of 2-3 for a kernel whose pace is load latency x occupancy
+    // (config 2: 5.85 -> 5.5 ms per step).
+    __shared__ h16x8 swf[9 * CB][64];
+    if (wave == 0) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (fr < K) v = *reinterpret_cast<const h16x8*>(w + ((long long)fr * 9 + t) * C + cb * 16 + fh * 8);
-            wf[t * CB + cb] = v;
-        }
+            for (int cb = 0; cb < CB; ++cb) {
+                h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (fr < K) v = *reinterpret_cast<const h16x8*>(w + ((long long)fr * 9 + t) * C + cb * 16 + fh * 8);
+                swf[t * CB + cb][lane] = v;
+            }
+    }
+    __syncthreads();
     float bv[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_k(const h16_t* __restrict__
             for (int cb = 0; cb < CB; ++cb)
                 xf[t * CB + cb] = *reinterpret_cast<const h16x8*>(xp + ((long long)(t / 3) * Wi + (t % 3)) * C + cb * 16);
 #pragma unroll
-        for (int t = 0; t < 9 * CB; ++t) acc = kp_mfma16(wf[t], xf[t], acc, 0, 0, 0);
+        for (int t = 0; t < 9 * CB; ++t) acc = kp_mfma16(swf[t][lane], xf[t], acc, 0, 0, 0);
         // D[k][px]: lane: pixel = fr, k = 8*(reg>>2) + 4*fh + (reg&3)
         uint32_t pk[8];
 #pragma unroll
@@ -218,7 +226,151 @@ __global__ __launch_bounds__(TPB) void wgrad3x3_small_k(const h16_t* __restrict_
     }
 }
 
+// The same weight gradient with the operands staged through LDS.  The kernel above gathers every MFMA fragment with 2-byte
+// GLOBAL loads (38 per 9 MFMAs, ~64 texture-unit cycles each: 169 us per 16 -> 32 layer of the Pong decoder at 256 x 84 x 84,
+// where the data takes 50 us).  Here a workgroup copies a band of R image rows -- R + 2 input rows, R gradient rows, 16-byte
+// loads, zero-filled to whole 16-pixel segments -- into LDS once, and its four wavefronts take the (row, segment) items of
+// the band, every fragment = two hardware transpose reads (ds_read_b64_tr_b16) of the pixel-major rows: 20 LDS reads per
+// 9 MFMAs and no packing arithmetic.  <= 76 KB per workgroup: two per CU, one stages while the other multiplies.  Same per-workgroup partial
+// gradients, same order of the reductions inside a workgroup as above is NOT kept (items go round-robin over the waves): results
+// differ from the kernel above in the last bits, and are bitwise repeatable.
+constexpr int WG_LDS = 77824;
+constexpr int SL = 12;   // 16-byte chunks per thread and tensor in one band (256 threads x 12 x 16 B = 48 KB of each)
+template <int K, int C>
+__global__ __launch_bounds__(TPB) void wgrad3x3_small_band_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
+                                                             float* __restrict__ scratch, int Ho, int Wo, int dy_pad, int R,
+                                                             int bands_per_img, long long total_bands, long long pstride) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WG_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, h = lane >> 5;
+    const int Hi = Ho + 2, Wi = Wo + 2, Hd = Ho + 2 * dy_pad, Wd = Wo + 2 * dy_pad;
+    const int Wp = (Wo + 15) & ~15, XP = Wp + 2, nseg = Wp / 16;
+    const int xrow_b = XP * C * 2, drow_b = Wp * K * 2;            // LDS bytes per staged row (multiples of 16)
+    unsigned char* xl = smem;                                       // [(R + 2)][XP][C]
+    unsigned char* dl = smem + (size_t)(R + 2) * xrow_b;            // [R][Wp][K]
+    // transpose-read lane roles: t = lane & 15 -> (pixel t / 4, chunk t % 4); g = bit 4 -> 16-channel half; lane / 32 -> pixels 8..15
+    const int t16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int trow = 8 * h + (t16 >> 2);
+    const int chunkb = (16 * g16 + (t16 & 3) * 4) * 2;
+    const bool kval = 16 * g16 < K, cval = 16 * g16 < C;      // the upper half does not exist in a 16-channel tensor: zero fragment
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    for (long long band = blockIdx.x; band < total_bands; band += gridDim.x) {
+        const long long n = band / bands_per_img;
+        const int p0 = (int)(band % bands_per_img) * R;
+        const int rows = Ho - p0 < R ? Ho - p0 : R;
+        __syncthreads();   // the previous band's fragments have been read
+        // ---- stage: input rows p0 .. p0 + rows + 1 (Wi pixels each, zero-filled to XP), gradient rows (Wo pixels, zero-filled
+        //      to Wp).  ALL of a thread's 16-byte loads are issued before its first LDS store (<= SL chunks per thread and
+        //      tensor: a loop of load -> store pairs serialises the HBM latency, ~20 round trips per band); chunk -> (row,
+        //      column) by carries, no divisions.
+        {
+            const int xc = xrow_b / 16, xvalid = Wi * C * 2 / 16, xtot = (rows + 2) * xc;
+            const int dc = drow_b / 16, dvalid = Wo * K * 2 / 16, dtot = rows * dc;
+            const unsigned char* xg = (const unsigned char*)x + (((n * Hi + p0) * Wi) * (long long)C) * 2;
+            const unsigned char* dg = (const unsigned char*)dy + ((((n * Hd + p0 + dy_pad) * Wd) + dy_pad) * (long long)K) * 2;
+            const int xrow_g = Wi * C * 2, drow_g = Wd * K * 2;
+            const int xdr = TPB / xc, xdc = TPB % xc, ddr = TPB / dc, ddc = TPB % dc;
+            // (two rounds -- input rows, then gradient rows -- of SL registers-quads each: both tensors in flight at once
+            //  need 96 staging registers on top of the 144 accumulators and spill)
+            uint4 sb[SL];
+            int r = tid / xc, c16 = tid % xc;
+#pragma unroll
+            for (int u = 0; u < SL; ++u) {
+                sb[u] = make_uint4(0, 0, 0, 0);
+                if (tid + u * TPB < xtot && c16 < xvalid) sb[u] = *reinterpret_cast<const uint4*>(xg + (long long)r * xrow_g + c16 * 16);
+                r += xdr; c16 += xdc;
+                if (c16 >= xc) { c16 -= xc; ++r; }
+            }
+#pragma unroll
+            for (int u = 0; u < SL; ++u)
+                if (tid + u * TPB < xtot) *reinterpret_cast<uint4*>(xl + (tid + u * TPB) * 16) = sb[u];
+            __builtin_amdgcn_sched_barrier(0);
+            int r2 = tid / dc, d16 = tid % dc;
+#pragma unroll
+            for (int u = 0; u < SL; ++u) {
+                sb[u] = make_uint4(0, 0, 0, 0);
+                if (tid + u * TPB < dtot && d16 < dvalid) sb[u] = *reinterpret_cast<const uint4*>(dg + (long long)r2 * drow_g + d16 * 16);
+                r2 += ddr; d16 += ddc;
+                if (d16 >= dc) { d16 -= dc; ++r2; }
+            }
+#pragma unroll
+            for (int u = 0; u < SL; ++u)
+                if (tid + u * TPB < dtot) *reinterpret_cast<uint4*>(dl + (tid + u * TPB) * 16) = sb[u];
+        }
+        __syncthreads();
+        // ---- multiply: items (row, 16-pixel segment) round-robin over the four wavefronts.  A fragment (lane: channel
+        //      lane % 32, 8 consecutive pixels 8 * (lane / 32) ..) is two ds_read_b64_tr_b16: per 16-lane group the
+        //      instruction hands lane i the 4 rows of column i of a [4 pixels][16 channels] block, lane t supplying the
+        //      address of (pixel t / 4, 4-channel chunk t % 4).  Pixel rows are C * 2 (K * 2) bytes apart: the four rows of
+        //      a block fall on disjoint banks.
+        for (int item = wave; item < rows * nseg; item += 4) {
+            const int r = item / nseg, sg = item - r * nseg;
+            const int prow = sg * 16 + trow;
+            h16x8 af = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (kval) {
+                const unsigned char* a = dl + r * drow_b + prow * (K * 2) + chunkb;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const h16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(a + 4 * u * (K * 2)));
+                    af[4 * u + 0] = v[0]; af[4 * u + 1] = v[1]; af[4 * u + 2] = v[2]; af[4 * u + 3] = v[3];
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {
+                const unsigned char* b = xl + (r + rr) * xrow_b + prow * (C * 2) + chunkb;
+#pragma unroll
+                for (int s_ = 0; s_ < 3; ++s_) {
+                    h16x8 bfv = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (cval) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const h16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + (s_ + 4 * u) * (C * 2)));
+                            bfv[4 * u + 0] = v[0]; bfv[4 * u + 1] = v[1]; bfv[4 * u + 2] = v[2]; bfv[4 * u + 3] = v[3];
+                        }
+                    }
+                    acc[rr * 3 + s_] = kp_mfma16(af, bfv, acc[rr * 3 + s_], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // D[k][c]: lane col = c (fr), rows k = (i&3) + 8*(i>>2) + 4*h.  The four wavefronts are summed per tap through LDS (fixed
+    // order); the workgroup's sum is ITS partial gradient (kp_wgrad_unpack adds the partials in order).
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(smem);
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[t][i];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (k < K && fr < C) {
+                    const float s = ((red[0][i][lane] + red[1][i][lane]) + red[2][i][lane]) + red[3][i][lane];
+                    scratch[(long long)blockIdx.x * pstride + ((long long)k * 9 + t) * C + fr] = s;
+                }
+            }
+        }
+    }
+}
+
 bool small_ch(int v) { return v == 16 || v == 32; }
+
+// band plan of the LDS-staged weight gradient: rows per band (0: the rows do not fit -- use the gather kernel), grid
+static int small_band_rows(int Ho, int Wo, int C, int K) {
+    const int Wp = (Wo + 15) & ~15;
+    const long long xrow = (long long)(Wp + 2) * C * 2, drow = (long long)Wp * K * 2;
+    long long R = (WG_LDS - 2 * xrow) / (xrow + drow);
+    if (R > Ho) R = Ho;
+    if (R > 16) R = 16;
+    while (R >= 1 && ((R + 2) * xrow > (long long)SL * TPB * 16 || R * drow > (long long)SL * TPB * 16)) --R;
+    return R < 1 ? 0 : (int)R;
+}
 
 }  // namespace
 
@@ -244,6 +396,16 @@ int kp_conv_small_fwd(const void* x, const void* w, const float* bias, void* y, 
 }
 
 // workgroups of the weight-gradient kernel = partial gradients in its scratch (0: not a small-channel shape)
+extern int g_kp_small_band;   // kp_config(KP_CFG_SMALL_BAND, v): 1 (default) = LDS-staged band kernel where the rows fit
+static unsigned small_band_plan(int N, int Ho, int Wo, int C, int K, int& R, int& bpi) {
+    if (!small_ch(C) || !small_ch(K) || !g_kp_small_band) return 0;
+    R = small_band_rows(Ho, Wo, C, K);
+    if (!R) return 0;
+    bpi = (Ho + R - 1) / R;
+    const long long bands = (long long)N * bpi;
+    return (unsigned)(bands < 512 ? bands : 512);   // two workgroups per CU; a workgroup walks bands blockIdx, + grid, ...
+}
+
 static unsigned small_wgrad_plan(int N, int Ho, int C, int K, int& rpw) {
     if (!small_ch(C) || !small_ch(K)) return 0;
     const long long rows = (long long)N * Ho;
@@ -252,10 +414,24 @@ static unsigned small_wgrad_plan(int N, int Ho, int C, int K, int& rpw) {
     const long long waves = (rows + rpw - 1) / rpw;
     return (unsigned)((waves + 3) / 4);
 }
-long long kp_conv_small_wgrad_partials(int N, int Ho, int Wo, int C, int K) { int rpw; (void)Wo; return small_wgrad_plan(N, Ho, C, K, rpw); }
+long long kp_conv_small_wgrad_partials(int N, int Ho, int Wo, int C, int K) {
+    int R, bpi, rpw;
+    const unsigned g = small_band_plan(N, Ho, Wo, C, K, R, bpi);
+    return g ? g : small_wgrad_plan(N, Ho, C, K, rpw);
+}
 
 int kp_conv_small_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int dy_pad,
                         hipStream_t st) {
+    int R, bpi;
+    if (const unsigned bgrid = small_band_plan(N, Ho, Wo, C, K, R, bpi)) {
+#define KP_SWB(Kv, Cv) wgrad3x3_small_band_k<Kv, Cv><<<bgrid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, R, bpi, (long long)N * bpi, (long long)Kv * 9 * Cv)
+        if (K == 16 && C == 16) KP_SWB(16, 16);
+        else if (K == 16) KP_SWB(16, 32);
+        else if (C == 16) KP_SWB(32, 16);
+        else KP_SWB(32, 32);
+#undef KP_SWB
+        return kp_check_launch("wgrad3x3_small_band");
+    }
     int rpw;
     const unsigned grid = small_wgrad_plan(N, Ho, C, K, rpw);
     if (!grid) return KP_E_UNSUPPORTED;
