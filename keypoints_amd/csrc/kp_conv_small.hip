@@ -148,6 +148,130 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_k(const h16_t* __restrict__
     }
 }
 
+// ---- forward / data gradient with the input staged through LDS ------------------------------------------------------------
+// The kernel above reads every input pixel nine times (once per tap) through the L1: 0.5-1 GB of L2 -> L1 traffic per layer,
+// which is what sets its pace (2-2.6 TB/s of algorithmic bytes).  Here a workgroup copies a band of R + 2 padded input rows
+// into LDS once (16-byte loads, all in flight before the first LDS store; pixel pitch C * 2 + 16 bytes: the 16 lanes of a
+// ds_read_b128 group land on 16 distinct 4-bank blocks for both channel counts) and its four wavefronts take the (row,
+// 32-pixel segment) items of the band: 9 (18) fragment reads from LDS per item, weights from LDS as above, same epilogue.
+// Statistics: one partial row per wavefront of the grid, accumulated over its items in a fixed order (deterministic).
+constexpr int FB_LDS = 61440;   // band bytes (the weights take 9 / 18 KB more): two workgroups per CU
+constexpr int FSL = 12;         // 16-byte chunks per thread in one band (256 x 12 x 16 B = 48 KB of input)
+template <int CB>
+__global__ __launch_bounds__(TPB) void conv3x3_small_band_k(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
+                                                            const float* __restrict__ bias, h16_t* __restrict__ y,
+                                                            float* __restrict__ partials, int Hi, int Wi, int K, int R,
+                                                            int bands_per_img, long long total_bands) {
+    constexpr int C = CB * 16, PITCH = C * 2 + 16, CPP = C / 8;   // chunks of 16 bytes per pixel
+    __shared__ h16x8 swf[9 * CB][64];
+    __shared__ __attribute__((aligned(16))) unsigned char xl[FB_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int Ho = Hi - 2, Wo = Wi - 2;
+    const int nseg = (Wo + 31) / 32, XPW = nseg * 32 + 2, xrow_l = XPW * PITCH;
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (fr < K) v = *reinterpret_cast<const h16x8*>(w + ((long long)fr * 9 + t) * C + cb * 16 + fh * 8);
+                swf[t * CB + cb][lane] = v;
+            }
+    }
+    float bv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k = 8 * (i >> 2) + 4 * fh + (i & 3);
+        bv[i] = (bias && k < K) ? bias[k] : 0.f;
+    }
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ssum[i] = ssq[i] = 0.f;
+
+    for (long long band = blockIdx.x; band < total_bands; band += gridDim.x) {
+        const long long n = band / bands_per_img;
+        const int p0 = (int)(band % bands_per_img) * R;
+        const int rows = Ho - p0 < R ? Ho - p0 : R;
+        __syncthreads();   // the previous band's fragments have been read (first trip: the weights are in place after the next one)
+        {
+            // chunk id = ((row * XPW) + pixel) * CPP + c; 256 % CPP == 0: a thread keeps its chunk column c and walks pixels.
+            // (Issuing the NEXT band's loads before this band's items and parking them in registers measured slower: 71 -> 77 us.)
+            const int c = tid % CPP, dpx = TPB / CPP;
+            int px = tid / CPP, r = 0;
+            while (px >= XPW) { px -= XPW; ++r; }
+            const unsigned char* xg = (const unsigned char*)x + (((n * Hi + p0) * Wi) * (long long)C) * 2 + c * 16;
+            uint4 sb[FSL];
+            int lo[FSL];
+#pragma unroll
+            for (int u = 0; u < FSL; ++u) {
+                sb[u] = make_uint4(0, 0, 0, 0);
+                lo[u] = -1;
+                if (r < rows + 2) {
+                    lo[u] = r * xrow_l + px * PITCH + c * 16;
+                    if (px < Wi) sb[u] = *reinterpret_cast<const uint4*>(xg + ((long long)r * Wi + px) * (C * 2));
+                }
+                px += dpx;
+                while (px >= XPW) { px -= XPW; ++r; }
+            }
+#pragma unroll
+            for (int u = 0; u < FSL; ++u)
+                if (lo[u] >= 0) *reinterpret_cast<uint4*>(xl + lo[u]) = sb[u];
+        }
+        __syncthreads();
+        for (int item = wave; item < rows * nseg; item += 4) {
+            const int r = item / nseg, sq = item - r * nseg;
+            const int p = p0 + r;
+            const int q = sq * 32 + fr;
+            const bool ok = q < Wo;
+            const unsigned char* xb = xl + r * xrow_l + (sq * 32 + fr) * PITCH + fh * 16;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            h16x8 xf[9 * CB];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+                    xf[t * CB + cb] = *reinterpret_cast<const h16x8*>(xb + (t / 3) * xrow_l + (t % 3) * PITCH + cb * 32);
+#pragma unroll
+            for (int t = 0; t < 9 * CB; ++t) acc = kp_mfma16(swf[t][lane], xf[t], acc, 0, 0, 0);   // (two accumulator chains: no faster, measured)
+            uint32_t pk[8];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[g * 4 + e] + bv[g * 4 + e];
+                    if (ok) { ssum[g * 4 + e] += v[e]; ssq[g * 4 + e] += v[e] * v[e]; }
+                }
+                pk[2 * g] = pack_h16x2(v[0], v[1]);
+                pk[2 * g + 1] = pack_h16x2(v[2], v[3]);
+            }
+            h16_t* yp = y + ((n * Ho + p) * Wo + q) * (long long)K;
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                uint32_t a0 = pk[2 * g], a1 = pk[2 * g + 1], b0 = pk[2 * g + 2], b1 = pk[2 * g + 3];
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a0), "+v"(b0));
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a1), "+v"(b1));
+                const int kc = 8 * (g + fh);
+                if (ok && kc < K) *reinterpret_cast<uint4*>(yp + kc) = make_uint4(a0, a1, b0, b1);
+            }
+        }
+    }
+    if (partials) {
+        const long long gw = (long long)blockIdx.x * 4 + wave;
+        int r1, r2;
+        const float ts = reduce16_over32(ssum, lane, r1);
+        const float tq = reduce16_over32(ssq, lane, r2);
+        const int k = 8 * (r1 >> 2) + 4 * fh + (r1 & 3);
+        if ((lane & 1) == 0 && k < K) {
+            partials[(gw * 2 + 0) * K + k] = ts;
+            partials[(gw * 2 + 1) * K + k] = tq;
+        }
+    }
+}
+
 // scratch[k][tap][c] += sum_pixels dy[pixel][k] * x[pixel + tap][c] on the matrix cores, no LDS staging:
 // D[k][c] (one 32x32 tile per tap, 9 accumulators) += A[k][16 px] B[16 px][c].  Both operands are pixel-major in HBM, so
 // a lane gathers its fragment (8 consecutive pixels of ONE channel) with 2-byte loads at a channel stride -- 64-byte
@@ -374,10 +498,41 @@ static int small_band_rows(int Ho, int Wo, int C, int K) {
 
 }  // namespace
 
+extern int g_kp_small_band;
+// band plan of the LDS-staged forward: rows per band (0: a band does not fit), bands per image
+static int small_fwd_band_rows(int Ho, int Wo, int C) {
+    const int nseg = (Wo + 31) / 32, XPW = nseg * 32 + 2;
+    const long long row_l = (long long)XPW * (C * 2 + 16), row_chunks = (long long)XPW * (C / 8);
+    long long R = FB_LDS / row_l - 2;
+    while (R >= 1 && (R + 2) * row_chunks > (long long)FSL * TPB) --R;
+    if (R > Ho) R = Ho;
+    if (R > 16) R = 16;
+    return R < 1 ? 0 : (int)R;
+}
+
 int kp_conv_small_fwd(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi,
                       int C, int K, hipStream_t st) {
     if (!small_ch(C) || !small_ch(K) || Hi < 3 || Wi < 3) return KP_E_UNSUPPORTED;
     const int Ho = Hi - 2, Wo = Wi - 2;
+    if (g_kp_small_band) {
+        const int R = small_fwd_band_rows(Ho, Wo, C);
+        if (R) {
+            const int bpi = (Ho + R - 1) / R;
+            const long long bands = (long long)N * bpi;
+            long long grid = bands < 512 ? bands : 512;
+            const long long max_rows = ((long long)N * Ho * Wo + 63) / 64;   // the caller's statistics buffer
+            if (stats && grid * 4 > max_rows) grid = max_rows / 4;
+            if (grid >= 1) {
+                if (stats) kp_set_last_rows(grid * 4);
+                KP_QUERY_RETURN();
+                if (C == 16)
+                    conv3x3_small_band_k<1><<<(unsigned)grid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, K, R, bpi, bands);
+                else
+                    conv3x3_small_band_k<2><<<(unsigned)grid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, K, R, bpi, bands);
+                return kp_check_launch("conv3x3_small_band");
+            }
+        }
+    }
     const int spr = (Wo + 31) / 32;
     const long long nseg = (long long)N * Ho * spr;
     // stats rows = waves of the grid; the caller's buffer holds ceil(N*Ho*Wo/64) rows
