@@ -1,5 +1,6 @@
 // MFMA paths of the 1x1 head (out_block = Conv2d(core_out, out, 1) + LeakyReLU, knn.py:123-125) for wide inputs
-// (C >= 128) and up to 64 output channels: the encoder heads (512 -> 64) and the keypoint heads (512 -> K) -- gfx950.
+// (C a multiple of 128) and up to 64 output channels: the encoder heads (512 -> 64) and the keypoint heads (512 -> K); and
+// for the 32-channel heads with more than 4 outputs (Pong-class encoder heads, 32 -> 16) -- gfx950.
 //
 // The head keeps fp32 weights and fp32 NCHW outputs / output gradients.  fp32 operands enter the bf16 matrix cores as
 // a (hi, lo) pair of bf16 values (v = hi + lo up to 2^-17 relative): two or three MFMAs per product instead of one,
@@ -7,7 +8,7 @@
 //   fwd : D[k][px] = sum_c W[k][c] X[px][c]            A = W (hi, lo)   B = X (exact bf16)          2 MFMA / step
 //   dx  : D[c][px] = sum_k W[k][c] dZ[px][k]           A = W^T (hi, lo) B = dZ (hi, lo)             3 MFMA / step
 //   dw  : D[k][c]  = sum_px dZ[px][k] X[px][c]         A = dZ^T (hi, lo) B = X^T (exact bf16)       2 MFMA / step
-// A wavefront owns 32 consecutive pixels of one image (HW % 32 == 0).  The accumulator layout (lane = pixel,
+// A wavefront owns 32 consecutive pixels (image and offset per lane: the group may straddle two images).  The accumulator layout (lane = pixel,
 // register = output channel) is exactly the fp32 NCHW layout of `out`: 128-byte runs per register store; the NCHW
 // gradient gives dZ^T fragments (8 consecutive pixels of one channel) as two 16-byte loads.  No LDS, no barriers.
 #include "kp_mfma_util.h"
@@ -79,7 +80,8 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_k(const h16_t* __restrict__
             acc[kt] = mma(wlo, xb, acc[kt]);
         }
     }
-    const long long n = m0 / HW, hw = m0 - n * HW + px;
+    // (image, offset) per lane: a group of 32 pixels may straddle two images when HW % 32 != 0 (84 x 84 maps)
+    const long long n = (m0 + px) / HW, hw = (m0 + px) - n * HW;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -113,8 +115,8 @@ __global__ __launch_bounds__(256) void head_dx_mfma_k(const float* __restrict__ 
     const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= groups) return;
     const int px = lane & 31, h = lane >> 5;
-    const long long m0 = g * 32, n = m0 / HW;
-    const int hw = (int)(m0 - n * HW) + px;
+    const long long m0 = g * 32, n = (m0 + px) / HW;
+    const int hw = (int)((m0 + px) - n * HW);
     h16x8 zhi[KS], zlo[KS];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
@@ -154,25 +156,26 @@ __global__ __launch_bounds__(256) void head_dx_mfma_k(const float* __restrict__ 
 }
 
 // ---- weight / bias gradient ----------------------------------------------------------------------------------------
-// wavefront = (pixel range, 128 input channels): 4 x KT accumulator tiles; fp32 atomics into dw / db at the end
-template <int KT>
+// wavefront = (pixel range, 32 * CT input channels): CT x KT accumulator tiles (CT = 4: 128-channel ranges of the wide
+// heads; CT = 1: the 32-channel heads of the Pong-class nets); fp32 atomics into dw / db at the end, or per-split partials
+template <int KT, int CT>
 __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ gout, const float* __restrict__ out,
                                                       const h16_t* __restrict__ x, float slope, float* __restrict__ dw,
                                                       float* __restrict__ db, float* __restrict__ ws, long long groups,
                                                       int gpw, int HW, int C, int K) {
     const int lane = threadIdx.x & 63;
-    const int cranges = C / 128;
+    const int cranges = C / (32 * CT);
     const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int cr = (int)(wid % cranges);
     const long long sp = wid / cranges;
     const long long g0 = sp * gpw, g1 = g0 + gpw < groups ? g0 + gpw : groups;
     if (g0 >= g1) return;
     const int r = lane & 31, h = lane >> 5;     // r: output channel row (A) / input channel column (B)
-    f32x16 acc[KT][4];
+    f32x16 acc[KT][CT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[kt][t][i] = 0.f;
     float bsum[KT];
@@ -180,11 +183,12 @@ __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ 
     for (int kt = 0; kt < KT; ++kt) bsum[kt] = 0.f;
 
     for (long long g = g0; g < g1; ++g) {
-        const long long m0 = g * 32, n = m0 / HW;
-        const int hw0 = (int)(m0 - n * HW);
+        const long long m0 = g * 32;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {           // two slices of 16 pixels
-            const int p0 = s * 16 + h * 8;       // this lane's 8 consecutive pixels
+            const int p0 = s * 16 + h * 8;       // this lane's 8 consecutive pixels: inside ONE image (HW % 8 == 0)
+            const long long n = (m0 + p0) / HW;
+            const int hw0 = (int)((m0 + p0) - n * HW) - p0;
             h16x8 zhi[KT], zlo[KT];
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
@@ -205,9 +209,9 @@ __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ 
                 if (cr == 0) bsum[kt] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                 split8(v, zhi[kt], zlo[kt]);
             }
-            const h16_t* xp = x + (m0 + p0) * C + cr * 128 + r;
+            const h16_t* xp = x + (m0 + p0) * C + cr * (32 * CT) + r;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < CT; ++t) {
                 h16x8 xb;      // column = input channel cr*128 + t*32 + r, 8 consecutive pixels (stride C)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) xb[i] = (short)xp[(long long)i * C + t * 32];
@@ -223,12 +227,12 @@ __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ 
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int k = kt * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
                 if (k < K) {
-                    const long long e = (long long)k * C + cr * 128 + t * 32 + r;
+                    const long long e = (long long)k * C + cr * (32 * CT) + t * 32 + r;
                     if (ws) ws[sp * ((long long)K * C + K) + e] = acc[kt][t][i];   // this pixel split's partial (plain store)
                     else unsafeAtomicAdd(dw + e, acc[kt][t][i]);
                 }
@@ -246,7 +250,14 @@ __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ 
     }
 }
 
-bool mfma_shape(long long M, int HW, int C, int K) { return C >= 128 && C % 128 == 0 && K >= 1 && K <= 64 && HW % 32 == 0 && M >= 32; }
+// wide heads (C a multiple of 128), and the 32-channel heads with more than 4 outputs (Pong-class encoder heads: 32 -> 16 over
+// 84 x 84 maps, where the K <= 16 VALU kernels of kp_head_fast.hip run at 1.8 TB/s).  Groups of 32 pixels may straddle images
+// (per-lane image / offset); the weight gradient reads 8-pixel runs of the NCHW gradient: HW % 8 == 0.
+bool mfma_shape(long long M, int HW, int C, int K) {
+    const bool wide = C >= 128 && C % 128 == 0, narrow = C == 32 && K > 4;
+    return (wide || narrow) && K >= 1 && K <= 64 && HW % 8 == 0 && M >= 32 && M % 32 == 0;
+}
+int chan_tiles(int C) { return C % 128 == 0 ? 4 : 1; }
 bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr) { return (((size_t)a | (size_t)b | (size_t)c) & 15) == 0; }
 
 }  // namespace
@@ -280,9 +291,11 @@ int kp_head_dx_mfma(const float* gout, const float* out, const float* w, float s
 static long long dw_mfma_plan(long long M, int HW, int C, int K, bool det, int& gpw) {
     if (!mfma_shape(M, HW, C, K)) return 0;
     const long long groups = M / 32;
-    const int cranges = C / 128;
+    const int cranges = C / (32 * chan_tiles(C));
     long long splits = 2048 / cranges;          // ~2048 wavefronts: pixel splits x channel ranges
-    if (det && splits > KP_HEAD_DET_SPLITS) splits = KP_HEAD_DET_SPLITS;
+    // deterministic mode keeps one partial gradient per split in the workspace: capped at KP_HEAD_DET_SPLITS for the wide
+    // heads (32 K floats each), not for the 32-channel ones (512 floats each: 2048 splits are 4 MB)
+    if (det && splits > KP_HEAD_DET_SPLITS && (long long)K * C > 4096) splits = KP_HEAD_DET_SPLITS;
     if (splits > groups) splits = groups;
     gpw = (int)((groups + splits - 1) / splits);
     return (groups + gpw - 1) / gpw;
@@ -293,11 +306,15 @@ int kp_head_dw_mfma(const float* gout, const float* out, const void* x, float sl
                     long long M, int HW, int C, int K, hipStream_t st) {
     if (!mfma_shape(M, HW, C, K) || !aligned16(gout, out)) return KP_E_UNSUPPORTED;
     const long long groups = M / 32;
-    const int cranges = C / 128;
+    const int ct = chan_tiles(C), cranges = C / (32 * ct);
     int gpw;
     const long long splits = dw_mfma_plan(M, HW, C, K, ws != nullptr, gpw);
     const unsigned grid = (unsigned)((splits * cranges + 3) / 4);
-    if (K <= 32) head_dw_mfma_k<1><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, groups, gpw, HW, C, K);
-    else head_dw_mfma_k<2><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, groups, gpw, HW, C, K);
+#define KP_DW(KTv, CTv) head_dw_mfma_k<KTv, CTv><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, groups, gpw, HW, C, K)
+    if (K <= 32 && ct == 4) KP_DW(1, 4);
+    else if (ct == 4) KP_DW(2, 4);
+    else if (K <= 32) KP_DW(1, 1);
+    else KP_DW(2, 1);
+#undef KP_DW
     return kp_check_launch("head_dw_mfma");
 }

@@ -144,7 +144,10 @@ def test_head_against_golden(golden, precision, tol):
 @pytest.mark.parametrize('N,H,W,C,K', [(2, 16, 16, 64, 3), (1, 8, 8, 512, 10), (3, 5, 7, 16, 1), (2, 32, 32, 128, 16),
                                        # kp_head_mfma.hip: C % 128 == 0, K <= 64, H*W % 32 == 0
                                        (2, 16, 16, 512, 64), (1, 8, 16, 256, 33), (3, 16, 16, 128, 48), (2, 8, 8, 128, 3),
-                                       (64, 16, 16, 512, 64)])
+                                       (64, 16, 16, 512, 64),
+                                       # the 32-channel MFMA heads (Pong-class encoder heads): groups of 32 pixels that straddle
+                                       # images (H*W % 32 != 0, H*W % 8 == 0), K up to 64; and a ragged one that stays on the VALU kernels
+                                       (8, 84, 84, 32, 16), (4, 6, 12, 32, 16), (16, 10, 4, 32, 33), (8, 84, 84, 32, 5), (3, 7, 9, 32, 16)])
 def test_head_small_k_bf16(N, H, W, C, K):
     """kp_head_fast.hip (bf16, K <= 16) and kp_head_mfma.hip (C >= 128, K <= 64) against a torch fp32 computation on
     the same bf16-rounded activation."""
