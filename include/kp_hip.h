@@ -215,6 +215,32 @@ long long kp_head_bwd_ws_floats(int N, int H, int W, int C, int K, int dtype);
 int kp_head_bwd(const float* gout, const float* out, const void* x, const float* w, float slope,
                 void* dx, float* dw, float* db, float* ws, int N, int H, int W, int C, int K, int dtype, void* stream);
 
+/* ---- inference-only Unit forward as one kernel -------- */
+/* `net.keypoint(x)` of the reference's consumers (atari_demo.py:35-36, tests/test_gl_hack.py:454-456): a Unit
+ * (keypoints/models/knn.py:110-130) in eval mode whose core has no pooling / upsampling (the Pong-class tables of
+ * keypoints/models/vgg.py:64-70): L x [ReplicationPad2d(1), Conv2d 3x3, BatchNorm2d(eval), (Leaky)ReLU], then
+ * Conv2d 1x1 + LeakyReLU.  fp32 throughout.
+ * x fp32 NCHW [B][Cin][H][W] -> heat fp32 NCHW [B][K][H][W].
+ * widths (HOST) [L+1]: output channels of the 3x3 layers (multiples of 8), then K.  slopes (HOST) [L+1]: negative slope
+ * of each activation (0 = ReLU).
+ * params (DEVICE fp32, kp_unit_infer_param_floats(...) floats): the folded, kernel-ordered weights, written layer by
+ * layer by kp_unit_infer_pack -- layer = 0..L-1 for the 3x3 layers, L for the head -- from the tensors of the Unit's
+ * state_dict as they are: w = Conv2d.weight [K][C][3][3] ([K][C] for the head), b = Conv2d.bias or NULL, and the
+ * BatchNorm2d weight / bias / running_mean / running_var [K] (var == NULL: the layer has no BatchNorm).  The fold is
+ * w * gamma / sqrt(var + eps), (b - mean) * gamma / sqrt(var + eps) + beta in fp32.  Pack again after the parameters change.
+ * KP_E_UNSUPPORTED: L outside 1..6, a 3x3 width that is not a multiple of 8, a last 3x3 width other than 8 / 16 / 32, or
+ * a chain too wide for one workgroup's LDS. */
+long long kp_unit_infer_param_floats(int Cin, int L, const int* widths);
+int kp_unit_infer_pack(float* params, int layer, int Cin, int L, const int* widths, const float* w, const float* b,
+                       const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                       void* stream);
+int kp_unit_infer_fwd(const float* x, const float* params, float* heat, int B, int Cin, int H, int W, int L,
+                      const int* widths, const float* slopes, void* stream);
+/* The consumer's whole call, `spacial_logsoftmax(net.keypoint(x))` (atari_demo.py:35-36): kp_unit_infer_fwd followed by
+ * kp_spatial_softmax_fwd(log_domain = 1) on the same stream; k [B][K][2] (y, x), p [B][K][H], q [B][K][W]. */
+int kp_unit_infer_keypoints_fwd(const float* x, const float* params, float* heat, float* k, float* p, float* q, int B,
+                                int Cin, int H, int W, int L, const int* widths, const float* slopes, void* stream);
+
 /* ---- keypoint bottleneck (keypoints/models/functional.py) --------------- */
 /* heat fp32 [BK][H][W] -> k [BK][2] (y,x), p [BK][H], q [BK][W].
  * log_domain=1: spacial_logsoftmax (functional.py:37-44); 0: spacial_softmax (:27-34). */

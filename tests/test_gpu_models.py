@@ -391,6 +391,60 @@ def test_inference_keypoint_extractor_matches_oracle():
         assert torch.equal(buf.cpu(), Bf[name]), name
 
 
+@pytest.mark.parametrize('cfg', [('VGG_PONG_LAYERNECK', 1, 16, 4, 84, 84, 1), ('VGG_PONG_LAYERNECK', 1, 16, 4, 84, 84, 3),
+                                 ('VGG_PONG_LAYERNECK', 1, 16, 4, 84, 84, 40),      # 16 x 16 tiles
+                                 ('VGG_PONG_TRIVIAL', 1, 16, 3, 32, 32, 2), ('VGG_PACMAN', 3, 16, 5, 37, 50, 2),
+                                 ('VGG_PACMAN', 3, 16, 5, 96, 80, 24),              # 4 layers, 16 x 16 tiles
+                                 ('VGG_PONG_LAYERNECK', 4, 16, 4, 7, 5, 1)])        # smaller than one tile
+def test_fused_inference_unit_matches_oracle(cfg):
+    """SURVEY 8(f) f3, 'eval-mode BN folded into conv, single fused kernel chain for Pong-size nets': kp_unit_infer_fwd
+    (the whole keypoint Unit as one fp32 kernel, BatchNorm running statistics folded into the weights) against the
+    oracle's eval-mode Unit, then the keypoints; non-trivial running statistics, odd image sizes (tile remainders and the
+    replicate padding of every layer at all four borders), both tile sizes."""
+    from keypoints_amd.inference import FusedUnit, KeypointExtractor
+    from keypoints_amd.models import transporter
+    from oracle import kp_oracle as O
+    typ, cin, z, K, H, W, B = cfg
+    torch.manual_seed(3 + K)
+    net = transporter.make(typ, cin, z, K)
+    g = torch.Generator().manual_seed(9 + H)
+    for name, buf in net.named_buffers():
+        if name.endswith('running_mean'):
+            buf.copy_(torch.randn(buf.shape, generator=g) * 0.1)
+        elif name.endswith('running_var'):
+            buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+    for name, prm in net.named_parameters():    # non-trivial BatchNorm affine parameters and conv biases
+        if prm.dim() == 1:
+            prm.data.copy_(torch.randn(prm.shape, generator=g) * 0.3 + (1.0 if 'weight' in name else 0.0))
+    P = {k: v.detach().clone() for k, v in net.named_parameters()}
+    Bf = {k: v.detach().clone() for k, v in net.named_buffers()}
+    net = net.cuda().eval()
+    x = torch.rand(B, cin, H, W, generator=g) * 2 - 1
+    heat = FusedUnit(net.keypoint)(x.cuda())
+    plans = O.transporter_plans(typ, cin, z, K)
+    oheat = O.unit_forward(plans['keypoint'], P, 'keypoint', x, Bf, training=False)
+    assert heat.shape == oheat.shape and torch.isfinite(heat).all()
+    assert maxerr(heat, oheat) <= 1e-5 * float(oheat.abs().max()) + 1e-5
+    ex = KeypointExtractor(net, graph=False, fused=True)
+    k = ex(x.cuda())
+    ok, _ = O.spatial_logsoftmax(oheat)
+    assert maxerr(k, ok) <= 1e-5
+    assert torch.equal(ex.heatmap, heat)
+    for name, buf in net.named_buffers():
+        assert torch.equal(buf.cpu(), Bf[name]), name
+
+
+def test_fused_inference_unit_refuses_other_forms():
+    from keypoints_amd.inference import FusedUnit, KeypointExtractor
+    from keypoints_amd.models import transporter
+    net = transporter.make('F', 3, 64, 10).cuda().eval()
+    with pytest.raises(NotImplementedError):
+        FusedUnit(net.keypoint)
+    with pytest.raises(NotImplementedError):
+        KeypointExtractor(net, fused=True)
+    assert KeypointExtractor(net, graph=False)._fused_unit is None      # 'auto' keeps the layer chain
+
+
 @pytest.mark.parametrize('cfg', [('VGG_PONG_LAYERNECK', 1, 16, 4, 84, 1), ('VGG_PONG_LAYERNECK', 1, 16, 4, 84, 3),
                                  ('F', 3, 64, 10, 128, 1)])
 def test_keypoint_extractor_graph_replay(cfg):
@@ -420,7 +474,11 @@ def test_keypoint_extractor_graph_replay(cfg):
         assert torch.equal(k, ke), frame
         assert torch.equal(ex.heatmap, eager.heatmap)
         with torch.no_grad():
-            assert torch.equal(ke, MF.spacial_logsoftmax(net.keypoint(x)))
+            kc = MF.spacial_logsoftmax(net.keypoint(x))      # the layer-by-layer chain (training kernels, eval mode)
+        if typ == 'F':
+            assert ex._fused_unit is None and torch.equal(ke, kc)
+        else:                                                # Pong-class: the one-kernel Unit, fp32 like the chain here
+            assert ex._fused_unit is not None and maxerr(ke, kc) <= 2e-5
     assert len(ex._captured) == 1
     for n, b in net.named_buffers():
         assert torch.equal(b, bufs[n]), n

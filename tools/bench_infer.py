@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Latency of the inference-only keypoint extractor (keypoints_amd/inference.py): eager chain of C-ABI launches vs the
-captured HIP graph, per frame, for the Pong-class network (84x84 grey, K=4) and model F (128x128x3, K=10).
+captured HIP graph, and (Pong-class) the one-kernel fused Unit, per frame, for the Pong-class network (84x84 grey, K=4) and model F (128x128x3, K=10).
     python tools/bench_infer.py [--batch 1] [--frames 200]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,8 +19,10 @@ def main():
         net = transporter.make(typ, cin, z, K).cuda().set_precision(prec)
         x = torch.rand(args.batch, cin, S, S, device='cuda')
         line = f'{typ:>18} {S}x{S} batch {args.batch} {prec}:'
-        for graph in (False, True):
-            ex = KeypointExtractor(net, graph=graph)
+        for graph, fused in ((False, False), (True, False), (False, 'auto'), (True, 'auto')):
+            if fused == 'auto' and typ == 'F':
+                continue                      # model F has pooling steps: no one-kernel form
+            ex = KeypointExtractor(net, graph=graph, fused=fused)
             for _ in range(5):
                 ex(x)
             torch.cuda.synchronize()
@@ -29,7 +31,7 @@ def main():
                 k = ex(x)
                 k[0, 0, 0].item()          # the consumer reads the keypoints every frame
             dt = (time.perf_counter() - t0) / args.frames
-            line += f'   {"graph" if graph else "eager"} {dt * 1e6:8.1f} us/frame'
+            line += f'   {"fused " if fused else ""}{"graph" if graph else "eager"} {dt * 1e6:8.1f} us/frame'
         print(line)
 
 
