@@ -228,3 +228,27 @@ def test_row_count_queries_match_the_launches():
         call('kp_bn_act_bwd_reduce', ptr(g), gp, tail, ptr(am), ptr(yv), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]),
              0.01, ptr(partials), N, H, W, C, code, st)
         assert 0 < q == last_rows() <= N * H, (N, H, W, C, tail, gp, prec, q, last_rows())
+
+
+@pytest.mark.parametrize('n,off,masked', [(4096 * 3, 0, False), (1001, 0, True), (4099, 1, False), (7, 0, True),
+                                          (128 * 3 * 128 * 128, 0, False), (2 * 3 * 84 * 84 + 3, 2, True)])
+def test_l2_loss_kernel(n, off, masked):
+    """kp_l2_loss (transporter.py:56-60: mean((x_t - x_)^2 [* loss_mask]) and its gradient): 16-byte lanes with an
+    element-wise remainder; unaligned pointers take the element-wise route throughout."""
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    g = torch.Generator().manual_seed(n + off)
+    x = torch.randn(n + off, generator=g).cuda()[off:]
+    t = torch.randn(n + off, generator=g).cuda()[off:]
+    m = (torch.rand(n + off, generator=g) > 0.3).float().cuda()[off:] if masked else None
+    acc = torch.zeros(1, device='cuda', dtype=torch.float64)
+    grad = torch.full((n + off,), float('nan'), device='cuda')[off:]
+    call('kp_l2_loss', ptr(x), ptr(t), ptr(m), ptr(acc), ptr(grad), 1.0 / n, n, stream_ptr())
+    d = (x.double() - t.double())
+    mk = m.double() if masked else torch.ones_like(d)
+    ref = (d * d * mk).sum()
+    assert abs(acc.item() - ref.item()) <= 1e-6 * ref.item() + 1e-12
+    gref = (2.0 * d * mk / n).float()
+    assert torch.isfinite(grad).all()
+    assert (grad - gref).abs().max().item() <= 1e-6 * gref.abs().max().item() + 1e-12
