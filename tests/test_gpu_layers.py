@@ -252,3 +252,25 @@ def test_l2_loss_kernel(n, off, masked):
     gref = (2.0 * d * mk / n).float()
     assert torch.isfinite(grad).all()
     assert (grad - gref).abs().max().item() <= 1e-6 * gref.abs().max().item() + 1e-12
+
+
+@pytest.mark.parametrize('dt', ['fp32', 'bf16'])
+@pytest.mark.parametrize('N,C,Cp,H,W', [(3, 64, 64, 16, 16), (2, 10, 12, 7, 5), (2, 3, 4, 9, 11), (1, 5, 5, 4, 4)])
+def test_nhwc_grad_to_nchw(N, C, Cp, H, W, dt):
+    """kp_nhwc_grad_to_nchw: the adjoint of (replicate pad by 1, NCHW -> NHWC): border gradients fold onto the edge pixels.
+    Both kernel routes (4 channels per thread when Cp % 4 == 0 and C > 4, else one pixel per thread) against autograd."""
+    import torch.nn.functional as F
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    g = torch.Generator().manual_seed(N + C + H)
+    tdt = torch.float32 if dt == 'fp32' else torch.bfloat16
+    gp = torch.randn(N, H + 2, W + 2, Cp, generator=g).to(tdt)
+    x = torch.zeros(N, C, H, W, dtype=torch.float64, requires_grad=True)
+    xp = F.pad(x, (1, 1, 1, 1), mode='replicate')
+    (xp * gp[..., :C].double().permute(0, 3, 1, 2)).sum().backward()
+    dx = torch.full((N, C, H, W), float('nan'), device='cuda')
+    call('kp_nhwc_grad_to_nchw', ptr(gp.cuda()), ptr(dx), N, C, Cp, H, W, 1, _lib.KP_F32 if dt == 'fp32' else _lib.KP_BF16,
+         stream_ptr())
+    assert torch.isfinite(dx).all()
+    assert (dx.cpu().double() - x.grad).abs().max().item() <= 1e-5
