@@ -107,21 +107,42 @@ struct PackBatch {
     unsigned first_block[PACK_MAX + 1];
     int n;
 };
+// Through an LDS tile of 32 output channels x 32 input channels x 9 taps: the per-element kernel (pack_weights_k) reads the
+// source at a 36-byte stride and scatters the data-gradient pack in 2-byte stores at a stride of 9 K elements (72 us for the
+// 8-9 M weights of a model-F Unit).  Here the source rows come in 1152-byte runs, both packs leave in 64-byte runs; the tile
+// pitch is odd (289 words), so the c-major and the k-major sweeps over it are both conflict-free.
+constexpr int PT = 32, PPITCH = PT * 9 + 1;
 template <typename T>
-__global__ void pack_weights_batch_k(const PackBatch B) {
+__global__ __launch_bounds__(256) void pack_weights_tile_k(const PackBatch B) {
+    __shared__ float tile[PT * PPITCH];
     int l = 0;
     while (l + 1 < B.n && blockIdx.x >= B.first_block[l + 1]) ++l;   // (uniform; n <= 24)
     const int K = B.K[l], C = B.C[l], Cp = B.Cp[l];
-    const long long total = (long long)K * 9 * Cp;
-    const long long t = (long long)(blockIdx.x - B.first_block[l]) * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const int c = (int)(t % Cp);
-    const int s = (int)((t / Cp) % 3);
-    const int r = (int)((t / ((long long)Cp * 3)) % 3);
-    const int k = (int)(t / ((long long)Cp * 9));
-    const float v = c < C ? B.w[l][(((long long)k * C + c) * 3 + r) * 3 + s] : 0.f;
-    st<T>((T*)B.wf[l] + t, v);
-    if (B.wd[l]) st<T>((T*)B.wd[l] + (((long long)c * 3 + (2 - r)) * 3 + (2 - s)) * K + k, v);
+    const int ctiles = (Cp + PT - 1) / PT;
+    const int tb = blockIdx.x - B.first_block[l];
+    const int k0 = (tb / ctiles) * PT, c0 = (tb % ctiles) * PT;
+    const int tid = threadIdx.x;
+    const int cw = (C - c0 < PT ? C - c0 : PT) * 9;          // source floats per k row in this tile (may be <= 0: padding tile)
+    const float* __restrict__ w = B.w[l];
+    for (int e = tid; e < PT * PT * 9; e += 256) {
+        const int kk = e / (PT * 9), j = e - kk * (PT * 9);   // j = cc * 9 + tap
+        float v = 0.f;
+        if (k0 + kk < K && j < cw) v = w[((long long)(k0 + kk) * C + c0) * 9 + j];
+        tile[kk * PPITCH + j] = v;
+    }
+    __syncthreads();
+    T* __restrict__ wf = (T*)B.wf[l];
+    for (int e = tid; e < PT * 9 * PT; e += 256) {            // wf[k][tap][c]: lanes walk c
+        const int cc = e % PT, tap = (e / PT) % 9, kk = e / (PT * 9);
+        if (k0 + kk < K && c0 + cc < Cp) st<T>(wf + ((long long)(k0 + kk) * 9 + tap) * Cp + c0 + cc, tile[kk * PPITCH + cc * 9 + tap]);
+    }
+    if (B.wd[l]) {
+        T* __restrict__ wd = (T*)B.wd[l];
+        for (int e = tid; e < PT * 9 * PT; e += 256) {        // wd[c][8 - tap][k]: lanes walk k
+            const int kk = e % PT, tap = (e / PT) % 9, cc = e / (PT * 9);
+            if (k0 + kk < K && c0 + cc < Cp) st<T>(wd + ((long long)(c0 + cc) * 9 + (8 - tap)) * K + k0 + kk, tile[kk * PPITCH + cc * 9 + tap]);
+        }
+    }
 }
 
 // dw[k][c][r][s] += sum_p scratch[p][k][r][s][c].  A workgroup = 64 element groups (VEC consecutive c of one
@@ -480,10 +501,10 @@ int kp_pack_weights_batch(int n, const float* const* w, void* const* w_fwd, void
         KP_REQUIRE(K[i] > 0 && C[i] > 0 && Cp[i] >= C[i] && w[i] && w_fwd[i], "kp_pack_weights_batch: bad layer %d", i);
         B.w[i] = w[i]; B.wf[i] = w_fwd[i]; B.wd[i] = w_dgrad[i]; B.K[i] = K[i]; B.C[i] = C[i]; B.Cp[i] = Cp[i];
         B.first_block[i] = blocks;
-        blocks += cdiv((size_t)K[i] * 9 * Cp[i], TPB);
+        blocks += cdiv((size_t)K[i], PT) * cdiv((size_t)Cp[i], PT);
     }
     B.first_block[n] = blocks;
-    DISPATCH_T(dtype, pack_weights_batch_k<T><<<blocks, TPB, 0, (hipStream_t)stream>>>(B));
+    DISPATCH_T(dtype, pack_weights_tile_k<T><<<blocks, 256, 0, (hipStream_t)stream>>>(B));
     return kp_check_launch("pack_weights_batch");
 }
 

@@ -274,3 +274,36 @@ def test_nhwc_grad_to_nchw(N, C, Cp, H, W, dt):
          stream_ptr())
     assert torch.isfinite(dx).all()
     assert (dx.cpu().double() - x.grad).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize('dt', ['fp32', 'bf16'])
+def test_pack_weights_batch_equals_per_layer_pack(dt):
+    """kp_pack_weights_batch (all 3x3 layers of a Unit in one launch, LDS-tiled) == kp_pack_weights (one element per
+    thread) layer by layer: forward pack [K][3][3][Cp] with zero padding channels, data-gradient pack [Cp][3][3][K] rotated
+    by 180 degrees; ragged tiles (K, C not multiples of 32), a layer without a data-gradient pack."""
+    import ctypes
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    code, tdt = (_lib.KP_F32, torch.float32) if dt == 'fp32' else (_lib.KP_BF16, torch.bfloat16)
+    shapes = [(64, 3, 4, False), (128, 64, 64, True), (16, 16, 16, True), (32, 16, 16, True), (72, 40, 64, True), (512, 256, 256, True)]
+    g = torch.Generator().manual_seed(5)
+    st = stream_ptr()
+    ws, wfs, wds, refs = [], [], [], []
+    for K, C, Cp, has_d in shapes:
+        w = torch.randn(K, C, 3, 3, generator=g).cuda()
+        wf = torch.full((K, 3, 3, Cp), float('nan'), device='cuda', dtype=tdt)
+        wd = torch.full((Cp, 3, 3, K), float('nan'), device='cuda', dtype=tdt) if has_d else None
+        rf = torch.empty_like(wf); rd = torch.empty_like(wd) if has_d else None
+        call('kp_pack_weights', ptr(w), ptr(rf), ptr(rd), K, C, Cp, 3, code, st)
+        ws.append(w); wfs.append(wf); wds.append(wd); refs.append((rf, rd))
+    n = len(shapes)
+    vp, ia = ctypes.c_void_p * n, ctypes.c_int * n
+    call('kp_pack_weights_batch', n, vp(*[ptr(t) for t in ws]), vp(*[ptr(t) for t in wfs]), vp(*[ptr(t) for t in wds]),
+         ia(*[s[0] for s in shapes]), ia(*[s[1] for s in shapes]), ia(*[s[2] for s in shapes]), code, st)
+    for (K, C, Cp, has_d), w, wf, wd, (rf, rd) in zip(shapes, ws, wfs, wds, refs):
+        assert torch.equal(wf, rf), (K, C, Cp)
+        if has_d:
+            assert torch.equal(wd, rd), (K, C, Cp)
+        assert torch.equal(wf[..., :C].float(), w.permute(0, 2, 3, 1).to(tdt).float())      # and the element kernel itself
+        assert float(wf[..., C:].float().abs().sum()) == 0
