@@ -111,12 +111,17 @@ class KeypointExtractor:
         self._captured = {}
         self._packs = {}
         self._fused_unit = None
+        self._fused_pending = False
         self.heatmap = None
         self._build_fused()
 
     def _build_fused(self):
         self._fused_unit = None
+        self._fused_pending = False
         if self.fused is False:
+            return
+        if next(self.net.keypoint.parameters()).device.type != 'cuda':
+            self._fused_pending = True     # the network is moved to the device later: fold at the first call
             return
         try:
             self._fused_unit = FusedUnit(self.net.keypoint)
@@ -132,6 +137,8 @@ class KeypointExtractor:
 
     @torch.no_grad()
     def _run(self, x):
+        if self._fused_pending:
+            self._build_fused()
         if self._fused_unit is not None:
             return self._fused_unit.keypoints(x)
         else:
