@@ -242,6 +242,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # The network, its plans and the optimizer state are a few hundred thousand long-lived Python objects; a full (generation
+    # 2) collection of the cyclic garbage collector walks all of them: ~40 ms on this host, once every few dozen steps --
+    # nothing for model F (the launch queue is several milliseconds deep) but a quarter of the Pong-class step, whose
+    # 134 launches per 4.2 ms keep the host busy (tools/probes/cfg2_jitter.sh: mean 5.4 ms against a 4.2 ms median per step).
+    # gc.freeze() moves what is alive after the warm-up to the permanent generation; the collector stays on.
+    ka.runtime.freeze_gc()
 
     def barrier():
         torch.cuda.synchronize()
@@ -392,7 +398,7 @@ def main():
             cfg_name = 'custom shape'
         line = dict(metric=f'image-pairs/sec (train step) {what} {args.size}x{args.size} K={args.model_keypoints}', value=value,
                     unit='image-pairs/sec', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_step,
-                    ms_per_step_median_hipevent=median_ms, ms_per_step_min_hipevent=step_ms[0],
+                    ms_per_step_median_hipevent=median_ms, ms_per_step_min_hipevent=step_ms[0], ms_per_step_max_hipevent=step_ms[-1],
                     higher_is_better=True, scaling='weak', vs_baseline=None,
                     dtype={'bf16': 'bf16', 'fp16': 'fp16', 'fp32': 'f32'}[args.precision], data='synthetic',
                     config=dict(workload=f'{what} {args.model_type} {args.size}x{args.size}x'

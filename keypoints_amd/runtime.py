@@ -171,3 +171,13 @@ class _SideBlock:
     def outputs(self, *tensors):
         if self._o._stream is not None:
             _held[self._o._stream] = tensors
+
+
+def freeze_gc():
+    """Call once after the first train steps of a launch-bound network (Pong-class nets: ~130 launches per 4 ms step).
+    The modules, plans, packed weights and optimizer state are long-lived Python objects; every full collection of the
+    cyclic garbage collector walks all of them (~40 ms of host time, during which no kernel is launched).  `gc.freeze()`
+    moves everything alive now to the permanent generation, so later collections look only at what a step creates."""
+    import gc
+    gc.collect()
+    gc.freeze()
