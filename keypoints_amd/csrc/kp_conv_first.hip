@@ -132,6 +132,7 @@ __global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const h16_t* __restri
     float* xw = reinterpret_cast<float*>(smem) + (size_t)wave * 3 * rowf;   // this wave's 3 input rows
     const int KS = 64 / K;                                    // pixel streams per wavefront (K = 16, 32, 64)
     const int k = lane % K, stream = lane / K;
+    const int PP = (CIN == 1 && KS > 1) ? 1 : 4;              // floats per staged pixel
 
     float acc[J];
 #pragma unroll
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const h16_t* __restri
         for (int r = 0; r < 3; ++r)
             for (int i = lane; i < Wi * CIN; i += 64) {
                 const int px = i / CIN, c = i - px * CIN;
-                xw[r * rowf + px * 4 + c] = h2f(xr[r * Wi * CIN + i]);
+                xw[r * rowf + px * PP + c] = h2f(xr[r * Wi * CIN + i]);
             }
         const h16_t* dr = dy + (((n * Hd + p + dy_pad) * Wd) + dy_pad) * (long long)K + k;
         if (KS == 1 && (Wo & 7) == 0) {
@@ -174,6 +175,43 @@ __global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const h16_t* __restri
                             for (int c = 0; c < CIN; ++c)
                                 acc[(r * 3 + s) * CIN + c] = fmaf(d[u], vv[c], acc[(r * 3 + s) * CIN + c]);
                         }
+                }
+            }
+        } else if (KS > 1) {
+            // K = 16 / 32 (Pong-class first layers): a pixel stream walks ONE contiguous quarter / half of the row, so its
+            // 3-wide window slides in registers: one new column = 3 LDS reads per pixel instead of 9 (the interleaved walk
+            // below re-read the whole window for every pixel and was LDS-bound: 102 us where the gradient tensor takes 15).
+            const int seg = (Wo + KS - 1) / KS;
+            const int q0 = stream * seg, q1 = q0 + seg < Wo ? q0 + seg : Wo;
+            float w0[3][CIN], w1[3][CIN];
+            auto column = [&](int r, int q, float (&o)[CIN]) {
+                if (CIN == 1) { o[0] = xw[r * rowf + q]; }
+                else {
+                    const float4 v = *reinterpret_cast<const float4*>(xw + r * rowf + q * 4);
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int c = 0; c < CIN; ++c) o[c] = vv[c];
+                }
+            };
+            if (q0 < q1) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { column(r, q0, w0[r]); column(r, q0 + 1, w1[r]); }
+            }
+#pragma unroll 8
+            for (int q = q0; q < q1; ++q) {
+                const float d = h2f(dr[(long long)q * K]);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    float nw[CIN];
+                    column(r, q + 2, nw);
+#pragma unroll
+                    for (int c = 0; c < CIN; ++c) {
+                        acc[(r * 3 + 0) * CIN + c] = fmaf(d, w0[r][c], acc[(r * 3 + 0) * CIN + c]);
+                        acc[(r * 3 + 1) * CIN + c] = fmaf(d, w1[r][c], acc[(r * 3 + 1) * CIN + c]);
+                        acc[(r * 3 + 2) * CIN + c] = fmaf(d, nw[c], acc[(r * 3 + 2) * CIN + c]);
+                        w0[r][c] = w1[r][c];
+                        w1[r][c] = nw[c];
+                    }
                 }
             }
         } else {
@@ -520,7 +558,8 @@ static bool first_wgrad_plan(int N, int Ho, int Wo, int C, int K, long long& gro
 static unsigned first_wgrad_valu_plan(int N, int Ho, int Wo, int C, int K, int& rpb, size_t& lds) {
     if (C < 1 || C > 4 || !(K == 16 || K == 32 || K == 64)) return 0;
     const long long rows = (long long)N * Ho;
-    rpb = (int)((rows + 511) / 512);            // <= 512 workgroups
+    rpb = (int)((rows + 511) / 512);            // <= 512 workgroups (2048 measured: kernel 58.6 -> 52.6 us, but the sum over 4x the
+                                                // partials in kp_wgrad_unpack 9 -> 22 us)
     if (rpb < 4) rpb = 4;
     rpb = (rpb + 3) / 4 * 4;
     lds = (size_t)4 * 3 * (Wo + 2) * 4 * sizeof(float);

@@ -136,6 +136,8 @@ def test_wgrad_fallback_is_bitwise_repeatable():
 
 FIRST_SHAPES = [  # N, Ho, Wo, C, K
     (2, 32, 32, 3, 64), (1, 16, 16, 1, 16), (2, 128, 128, 3, 64), (3, 16, 48, 3, 32), (1, 8, 8, 4, 64),
+    # K = 16 / 32: sliding-window weight gradient (one contiguous row segment per pixel stream), ragged segments, Wo < streams
+    (4, 84, 84, 1, 16), (64, 20, 37, 1, 32), (64, 9, 5, 3, 16), (32, 33, 50, 4, 32), (32, 6, 3, 1, 16), (4, 84, 84, 1, 32),
     # MFMA first-layer kernels (K = 64, Cin <= 3, Wo % 32 == 0): forward from 4096 pixels, weight gradient from 65536;
     # partially filled and empty wavefronts (150 groups over 20 wavefronts), Cin = 1 and 2
     (16, 64, 64, 3, 64), (1, 50, 96, 3, 64), (7, 96, 160, 3, 64), (8, 128, 128, 1, 64), (6, 128, 96, 2, 64),
