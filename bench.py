@@ -332,7 +332,7 @@ def main():
         # gfx950 correction + WRITE_SIZE), condensed by tools/pmc_summary.py into profiles/ -- not measurable from
         # inside the process, so it is the committed per-launch figure of the last profiled build (or null).
         traffic, pmc, pmc_file = None, None, None
-        for cand in ('r02j_pmc_summary.json', 'r02g_pmc_summary.json', 'r02_pmc_summary.json', 'r01_pmc_summary.json'):
+        for cand in ('r02n_pmc_summary.json', 'r02j_pmc_summary.json', 'r02g_pmc_summary.json', 'r02_pmc_summary.json', 'r01_pmc_summary.json'):
             try:
                 pmc = json.load(open(os.path.join(ROOT, 'profiles', cand)))['conv_patch_bf16_bn128']
                 traffic, pmc_file = pmc['hbm_bytes_per_launch'], cand
