@@ -60,7 +60,11 @@ __global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const h16_t* __restrict
     }
     __syncthreads();
     const long long m_wave = (long long)blockIdx.x * TPB + wave * 64;
-    if (m_wave >= M) return;                   // M % 64 == 0: wavefronts are all-or-nothing
+    const bool active = m_wave < M;            // M % 64 == 0: wavefronts are all-or-nothing (an idle one stays for the barrier below)
+    float* red = reinterpret_cast<float*>(stage + (size_t)4 * 64 * K * 2);   // [4 waves][2][K]: the workgroup's statistics
+    if (partials && !active)
+        for (int i = lane; i < 2 * K; i += 64) red[wave * 2 * K + i] = 0.f;
+    if (active) {
     const long long m = m_wave + lane;
     const int q = (int)(m % Wo);
     const long long t = m / Wo;
@@ -96,9 +100,8 @@ __global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const h16_t* __restrict
             const float ts = reduce8_over64(acc, lane, i1);
             const float tq = reduce8_over64(sq, lane, i2);
             if ((lane & 7) == 0) {
-                const long long row = m_wave >> 6;
-                partials[(row * 2 + 0) * K + k0 + i1] = ts;
-                partials[(row * 2 + 1) * K + k0 + i1] = tq;
+                red[(wave * 2 + 0) * K + k0 + i1] = ts;
+                red[(wave * 2 + 1) * K + k0 + i1] = tq;
             }
         }
         uint4 pk;
@@ -115,6 +118,15 @@ __global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const h16_t* __restrict
         const int px = id / CP, ch = id - px * CP;
         const uint4 v = *reinterpret_cast<const uint4*>(st + (size_t)px * K * 2 + ((ch ^ (px & (CP - 1))) << 4));
         *reinterpret_cast<uint4*>(yw + (size_t)id * 8) = v;
+    }
+    }   // active
+    // ONE statistics row per workgroup (256 pixels), its four wavefronts added in a fixed order: a quarter of the rows of a
+    // row per wavefront -- 7 056 instead of 28 224 at 256 x 84 x 84, which keeps the Pong-class first layer on the one-launch
+    // reduce + finalize (kp_bn.hip: up to 8 192 rows) instead of reduce_rows + finalize (28 + 7 us, four times per step)
+    if (partials) {
+        __syncthreads();
+        for (int i = tid; i < 2 * K; i += TPB)
+            partials[(long long)blockIdx.x * 2 * K + i] = ((red[i] + red[2 * K + i]) + red[4 * K + i]) + red[6 * K + i];
     }
 }
 
@@ -524,9 +536,10 @@ int kp_conv_first_fwd(const void* x, const void* w, const float* bias, void* y, 
 #undef KP_FIRST_FWD_M
         return kp_check_launch("conv3_first_fwd_mfma");
     }
-    KP_QUERY_RETURN();   // (statistics rows of the VALU kernel: the per-64-pixel default set by kp_conv_fwd)
-    const size_t lds = (size_t)9 * C * K * sizeof(float) + (size_t)4 * 64 * K * 2;
     const unsigned grid = (unsigned)((M + TPB - 1) / TPB);
+    if (stats) kp_set_last_rows((long long)grid);   // one statistics row per workgroup of 256 pixels
+    KP_QUERY_RETURN();
+    const size_t lds = (size_t)9 * C * K * sizeof(float) + (size_t)4 * 64 * K * 2 + (size_t)4 * 2 * K * sizeof(float);
 #define KP_FIRST_FWD(CINv)                                                                                          \
     conv3_first_fwd_k<CINv><<<grid, TPB, lds, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, \
                                                     Wi, K, M)
