@@ -18,6 +18,7 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) short h16x8;
 typedef __attribute__((ext_vector_type(4))) short h16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define LDS_AS __attribute__((address_space(3)))
 
 constexpr int TPB = 256;
@@ -444,21 +445,28 @@ __global__ __launch_bounds__(TPB) void wgrad3x3_small_band_k(const h16_t* __rest
                     af[4 * u + 0] = v[0]; af[4 * u + 1] = v[1]; af[4 * u + 2] = v[2]; af[4 * u + 3] = v[3];
                 }
             }
+            // The three column taps of an input row read the SAME pixels shifted by one: pixels 8h .. 8h+9 come in with three
+            // transpose reads (the third serves pixels 8h+8, 8h+9), and the fragments of taps 1 and 2 are formed in registers --
+            // tap 2 is a renaming of the dword pairs, tap 1 four v_alignbit.  9 transpose reads per item for the input side
+            // instead of 18: the multiply phase of this kernel is bound by the rate of ds_read_b64_tr_b16 (~16 cycles per
+            // wavefront instruction; ablations in tools/probes/wgrad_band_abl.sh), the VALU is idle.
 #pragma unroll
             for (int rr = 0; rr < 3; ++rr) {
                 const unsigned char* b = xl + (r + rr) * xrow_b + prow * (C * 2) + chunkb;
-#pragma unroll
-                for (int s_ = 0; s_ < 3; ++s_) {
-                    h16x8 bfv = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (cval) {
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const h16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + (s_ + 4 * u) * (C * 2)));
-                            bfv[4 * u + 0] = v[0]; bfv[4 * u + 1] = v[1]; bfv[4 * u + 2] = v[2]; bfv[4 * u + 3] = v[3];
-                        }
-                    }
-                    acc[rr * 3 + s_] = kp_mfma16(af, bfv, acc[rr * 3 + s_], 0, 0, 0);
+                unsigned R[5] = {0u, 0u, 0u, 0u, 0u};      // (p0,p1) (p2,p3) (p4,p5) (p6,p7) (p8,p9), p = pixel 8h + ..
+                if (cval) {
+                    const uint2 q0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b)));
+                    const uint2 q1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + 4 * (C * 2))));
+                    const uint2 q2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + 8 * (C * 2))));
+                    R[0] = q0.x; R[1] = q0.y; R[2] = q1.x; R[3] = q1.y; R[4] = q2.x;
                 }
+                const u32x4 f0 = {R[0], R[1], R[2], R[3]};
+                const u32x4 f1 = {__builtin_amdgcn_alignbit(R[1], R[0], 16), __builtin_amdgcn_alignbit(R[2], R[1], 16),
+                                  __builtin_amdgcn_alignbit(R[3], R[2], 16), __builtin_amdgcn_alignbit(R[4], R[3], 16)};
+                const u32x4 f2 = {R[1], R[2], R[3], R[4]};
+                acc[rr * 3 + 0] = kp_mfma16(af, __builtin_bit_cast(h16x8, f0), acc[rr * 3 + 0], 0, 0, 0);
+                acc[rr * 3 + 1] = kp_mfma16(af, __builtin_bit_cast(h16x8, f1), acc[rr * 3 + 1], 0, 0, 0);
+                acc[rr * 3 + 2] = kp_mfma16(af, __builtin_bit_cast(h16x8, f2), acc[rr * 3 + 2], 0, 0, 0);
             }
         }
     }
