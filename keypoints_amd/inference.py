@@ -66,9 +66,9 @@ class FusedUnit:
         torch.cuda.current_stream(dev).synchronize()      # `keep` may hold temporaries
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != self.cin:
-            raise RuntimeError(f'FusedUnit: expected a float32 HIP tensor [B, {self.cin}, H, W]')
-        x = x.contiguous()
+        if not x.is_cuda or x.dim() != 4 or x.shape[1] != self.cin:
+            raise RuntimeError(f'FusedUnit: expected a HIP tensor [B, {self.cin}, H, W]')
+        x = x.float().contiguous()     # (no-ops for a contiguous float32 frame; the layer chain converts its input the same way)
         B, _, H, W = x.shape
         heat = torch.empty(B, self.K, H, W, device=x.device, dtype=torch.float32)
         call('kp_unit_infer_fwd', ptr(x), ptr(self.params), ptr(heat), B, self.cin, H, W, self.L, self._widths, self._slopes,
@@ -77,9 +77,9 @@ class FusedUnit:
 
     def keypoints(self, x: torch.Tensor):
         """`spacial_logsoftmax(unit(x))` as one library call: (k [B, K, 2], heat [B, K, H, W])."""
-        if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != self.cin:
-            raise RuntimeError(f'FusedUnit: expected a float32 HIP tensor [B, {self.cin}, H, W]')
-        x = x.contiguous()
+        if not x.is_cuda or x.dim() != 4 or x.shape[1] != self.cin:
+            raise RuntimeError(f'FusedUnit: expected a HIP tensor [B, {self.cin}, H, W]')
+        x = x.float().contiguous()     # (no-ops for a contiguous float32 frame; the layer chain converts its input the same way)
         B, _, H, W = x.shape
         K = self.K
         buf = torch.empty(B * K * (H * W + 2 + H + W), device=x.device, dtype=torch.float32)   # one allocation: heat | k | p | q
