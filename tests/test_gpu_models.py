@@ -434,6 +434,23 @@ def test_fused_inference_unit_matches_oracle(cfg):
         assert torch.equal(buf.cpu(), Bf[name]), name
 
 
+def test_fused_inference_unit_input_forms():
+    """Frames that are not contiguous float32 (bf16, a strided view) are converted like the layer chain converts them."""
+    from keypoints_amd.inference import FusedUnit
+    from keypoints_amd.models import transporter
+    torch.manual_seed(1)
+    net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 4).cuda().eval()
+    fu = FusedUnit(net.keypoint)
+    x = (torch.rand(2, 1, 40, 56, device='cuda') * 2 - 1).bfloat16()
+    ref = fu(x.float())
+    assert torch.equal(fu(x), ref)
+    wide = torch.zeros(2, 1, 40, 112, device='cuda')
+    wide[..., ::2] = x.float()
+    assert torch.equal(fu(wide[..., ::2]), ref)
+    k, heat = fu.keypoints(x)
+    assert torch.equal(heat, ref) and k.shape == (2, 4, 2)
+
+
 def test_fused_inference_unit_refuses_other_forms():
     from keypoints_amd.inference import FusedUnit, KeypointExtractor
     from keypoints_amd.models import transporter

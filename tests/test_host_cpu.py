@@ -212,3 +212,18 @@ def test_overlap_report_on_a_synthetic_trace(tmp_path, capsys):
     lines = {ln.split()[0]: float(ln.split()[-2]) for ln in out.splitlines() if ln.split() and ln.split()[0] in ('mfma', 'hbm', 'mfma+hbm', 'idle')}
     assert lines['mfma+hbm'] == 20.0 and lines['mfma'] == 20.0 and abs(lines['hbm'] - 21.0) < 1e-6 and abs(lines['idle'] - 39.0) < 1e-6
     sys.argv = old
+
+
+def test_freeze_gc_parks_the_live_objects():
+    """runtime.freeze_gc(): everything alive moves to the permanent generation (a later full collection does not walk it),
+    the collector stays enabled."""
+    import gc
+    from keypoints_amd import runtime
+    junk = [[i] for i in range(1000)]
+    before = gc.get_freeze_count()
+    try:
+        runtime.freeze_gc()
+        assert gc.isenabled()
+        assert gc.get_freeze_count() >= before + len(junk)
+    finally:
+        gc.unfreeze()
