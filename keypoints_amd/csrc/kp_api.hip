@@ -16,10 +16,10 @@ void kp_set_last_rows(long long r) { g_last_rows = r; }
 static thread_local int g_query = 0;
 int kp_query_mode() { return g_query; }
 void kp_set_query_mode(int on) { g_query = on; }
-long long* g_kp_trace = nullptr;   // kp_config_ptr(KP_CFG_TRACE, dev_ptr): s_memtime trace buffer (512 x i64) or NULL
-int g_kp_wgrad_patch = 1;   // kp_config(KP_CFG_WGRAD_PATCH, v)
-int g_kp_small_band = 1;    // kp_config(KP_CFG_SMALL_BAND, v)
-int g_kp_bn_fast = 1;       // kp_config(KP_CFG_BN_FAST, v)
+kp_knob_ptr_t g_kp_trace{nullptr};   // kp_config_ptr(KP_CFG_TRACE, dev_ptr): s_memtime trace buffer (512 x i64) or NULL
+kp_knob_t g_kp_wgrad_patch{1};   // kp_config(KP_CFG_WGRAD_PATCH, v)
+kp_knob_t g_kp_small_band{1};    // kp_config(KP_CFG_SMALL_BAND, v)
+kp_knob_t g_kp_bn_fast{1};       // kp_config(KP_CFG_BN_FAST, v)
 // Memory walk order of the passes (kp_common.h: KP_WALK_*; kp_config(KP_CFG_WALK, mask), 0 = every pass front to back):
 // a pass that follows a producer sweeps the producer's output back to front, so that it starts on what is still in the
 // 256 MiB Infinity Cache, and reads what nobody re-reads soon with streaming loads
@@ -27,9 +27,9 @@ static int walk_default() {   // KP_WALK=<mask> in the environment overrides the
     const char* e = getenv("KP_WALK");
     return e ? (int)strtol(e, nullptr, 0) : KP_WALK_DEFAULT;
 }
-int g_kp_walk = walk_default();
-int g_kp_cus = 0;     // kp_config(KP_CFG_CUS, n): CU budget that persistent kernels size their grids to (0 = the whole device)
-int g_kp_debug = 0;   // kp_config(KP_CFG_DEBUG, mask): kernel ablation switches for measurements
+kp_knob_t g_kp_walk{walk_default()};
+kp_knob_t g_kp_cus{0};     // kp_config(KP_CFG_CUS, n): CU budget that persistent kernels size their grids to (0 = the whole device)
+kp_knob_t g_kp_debug{0};   // kp_config(KP_CFG_DEBUG, mask): kernel ablation switches for measurements
 
 void kp_set_error(const char* fmt, ...) {
     va_list ap;
@@ -63,7 +63,7 @@ void kp_prof_event_release(hipEvent_t e) {
     g_event_pool.push_back(e);
 }
 
-int g_kp_conv_patch = -1;   // kp_config(KP_CFG_CONV_PATCH, v); -1 = kp_conv_mfma reads KP_CONV_PATCH from the environment once
+kp_knob_t g_kp_conv_patch{-1};   // kp_config(KP_CFG_CONV_PATCH, v); -1 = kp_conv_mfma reads KP_CONV_PATCH from the environment once
 
 extern "C" {
 

@@ -547,7 +547,7 @@ int kp_bn_act_fwd_fast(const void*, const float*, const float*, const float*, co
 int kp_bn_bwd_fast(int, const void*, int, int, const unsigned char*, const void*, const float*, const float*,
                    const float*, const float*, float, float*, const float*, void*, int, int, int, int, int, hipStream_t);
 int kp_upsample2_bwd_fast(const void*, int, void*, int, int, int, int, hipStream_t);
-extern int g_kp_bn_fast;
+extern kp_knob_t g_kp_bn_fast;
 
 extern "C" {
 

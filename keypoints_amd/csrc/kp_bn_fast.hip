@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void upsample2_bwd_fast_k(const h16_t* __restr
 
 // Channels per thread of a pass (experiment mask, kp_config(KP_CFG_WALK): KP_WALK_V4_* bits select the 4-channel variants)
 static int pick_v(int bit, int C) {
-    extern int g_kp_walk;
+    extern kp_knob_t g_kp_walk;
     return ((g_kp_walk & bit) && fast_shape(C, 4)) ? 4 : 8;
 }
 
@@ -222,7 +222,7 @@ int kp_bn_act_fwd_fast(const void* y, const float* mean, const float* invstd, co
                        hipStream_t st) {
     if (!fast_shape(C)) return KP_E_UNSUPPORTED;
     if (tail == KP_TAIL_MAXPOOL2 && ((H | W) & 1)) return KP_E_UNSUPPORTED;
-    extern int g_kp_walk;
+    extern kp_knob_t g_kp_walk;
     const int walk = ((g_kp_walk & KP_WALK_FWD_REVERSE) ? 1 : 0) | ((g_kp_walk & KP_WALK_STREAM_LOADS) ? 2 : 0);
     BnP bn{mean, invstd, gamma, beta};
     const int Ho = tail == KP_TAIL_MAXPOOL2 ? H / 2 : (tail == KP_TAIL_UPSAMPLE2 ? 2 * H : H);
@@ -266,7 +266,7 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
     if (!(tail == KP_TAIL_NONE || tail == KP_TAIL_MAXPOOL2) || gp < 0 || gp > 1 || !fast_shape(C)) return KP_E_UNSUPPORTED;
     if (tail == KP_TAIL_MAXPOOL2 && ((H | W) & 1)) return KP_E_UNSUPPORTED;
     BnP bn{mean, invstd, gamma, beta};
-    extern int g_kp_walk;
+    extern kp_knob_t g_kp_walk;
     const int walk = ((g_kp_walk & (mode ? KP_WALK_APPLY_REVERSE : KP_WALK_REDUCE_REVERSE)) ? 1 : 0) | ((g_kp_walk & KP_WALK_STREAM_LOADS) ? 2 : 0);
     const int pool = tail == KP_TAIL_MAXPOOL2;
     if (pool) {   // walk pooled rows

@@ -1,5 +1,6 @@
 // Shared device helpers for libkp_hip.so (gfx950 only).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -122,6 +123,12 @@ __device__ __forceinline__ float ruler_at(int i, int n) {
 
 // ---- host side -------------------------------------------------------------
 void kp_set_error(const char* fmt, ...);
+// Process-wide measurement knobs (kp_config / kp_config_ptr, kp_api.hip): atomics, so that a thread that sets one while another
+// launches is a defined program (relaxed cost on the host: a plain load at every read).  They select kernels for A/B
+// measurements; no result depends on them.
+typedef std::atomic<int> kp_knob_t;
+typedef std::atomic<long long*> kp_knob_ptr_t;
+
 int kp_check_launch(const char* what);
 void kp_set_last_rows(long long rows);   // see kp_last_rows() in kp_hip.h
 // Query mode (kp_conv_fwd_stats_rows / kp_bn_bwd_rows): the dispatch runs as usual, every launcher records its row count

@@ -25,7 +25,7 @@ int kp_conv_fwd_f32mfma(const float*, const float*, const float*, float*, float*
 long long kp_conv_wgrad_f32mfma_partials(int, int, int, int, int);
 int kp_conv_wgrad_f32mfma(const float*, const float*, float*, int, int, int, int, int, int, hipStream_t);
 
-extern int g_kp_wgrad_patch;
+extern kp_knob_t g_kp_wgrad_patch;
 
 static int use_mfma() {
     static int v = -1;

@@ -294,7 +294,7 @@ static int launch_linear(const void* x, const void* w, const float* bias, void* 
     return kp_check_launch("conv3x3_mfma");
 }
 
-extern int g_kp_conv_patch;   // kp_api.hip: kp_config(KP_CFG_CONV_PATCH, v); -1 = read KP_CONV_PATCH from the environment once
+extern kp_knob_t g_kp_conv_patch;   // kp_api.hip: kp_config(KP_CFG_CONV_PATCH, v); -1 = read KP_CONV_PATCH from the environment once
 static int patch_mode() {   // 0 forces the linear implicit-GEMM kernel (A/B measurements)
     if (g_kp_conv_patch < 0) {
         const char* e = getenv("KP_CONV_PATCH");

@@ -470,8 +470,8 @@ int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* 
     a.x = (const h16_t*)x; a.w = (const h16_t*)w; a.bias = bias; a.y = (h16_t*)y; a.partials = stats;
     a.Hib = Hib; a.Wib = Wib; a.ioff = ioff; a.Hob = Hob; a.Wob = Wob; a.ooff = ooff; a.H = H; a.W = W;
     a.C = C; a.K = K;
-    { extern int g_kp_debug; extern long long* g_kp_trace; a.dbg = g_kp_debug; a.trace = g_kp_trace; }
-    { extern int g_kp_walk; a.linear = (g_kp_walk & KP_WALK_CONV_LINEAR) ? 1 : 0; }
+    { extern kp_knob_t g_kp_debug; extern kp_knob_ptr_t g_kp_trace; a.dbg = g_kp_debug; a.trace = g_kp_trace; }
+    { extern kp_knob_t g_kp_walk; a.linear = (g_kp_walk & KP_WALK_CONV_LINEAR) ? 1 : 0; }
     const long long ptiles = (long long)N * (H / TS) * (W / TS);
     const int bn = (K % 128 == 0) ? 128 : 64;
     a.ktiles = K / bn;

@@ -506,7 +506,7 @@ static int small_band_rows(int Ho, int Wo, int C, int K) {
 
 }  // namespace
 
-extern int g_kp_small_band;
+extern kp_knob_t g_kp_small_band;
 // band plan of the LDS-staged forward: rows per band (0: a band does not fit), bands per image
 static int small_fwd_band_rows(int Ho, int Wo, int C) {
     const int nseg = (Wo + 31) / 32, XPW = nseg * 32 + 2;
@@ -559,7 +559,7 @@ int kp_conv_small_fwd(const void* x, const void* w, const float* bias, void* y, 
 }
 
 // workgroups of the weight-gradient kernel = partial gradients in its scratch (0: not a small-channel shape)
-extern int g_kp_small_band;   // kp_config(KP_CFG_SMALL_BAND, v): 1 (default) = LDS-staged band kernel where the rows fit
+extern kp_knob_t g_kp_small_band;   // kp_config(KP_CFG_SMALL_BAND, v): 1 (default) = LDS-staged band kernel where the rows fit
 static unsigned small_band_plan(int N, int Ho, int Wo, int C, int K, int& R, int& bpi) {
     if (!small_ch(C) || !small_ch(K) || !g_kp_small_band) return 0;
     R = small_band_rows(Ho, Wo, C, K);

@@ -262,7 +262,7 @@ int kp_conv_wgrad_patch(const void* x, const void* dy, float* scratch, int N, in
     if (rc != KP_OK) return rc;
     a.x = (const h16_t*)x; a.dy = (const h16_t*)dy; a.scratch = scratch;
     a.partial_stride = (long long)K * 9 * C;
-    { extern int g_kp_debug; extern long long* g_kp_trace; a.dbg = g_kp_debug; a.trace = g_kp_trace; }
+    { extern kp_knob_t g_kp_debug; extern kp_knob_ptr_t g_kp_trace; a.dbg = g_kp_debug; a.trace = g_kp_trace; }
     if (k128 && a.trace) wgrad3x3_patch_k<128, 64, true><<<grid, TPB, 0, st>>>(a);
     else if (k128) wgrad3x3_patch_k<128, 64, false><<<grid, TPB, 0, st>>>(a);
     else wgrad3x3_patch_k<64, 128, false><<<grid, TPB, 0, st>>>(a);
