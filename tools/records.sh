@@ -15,7 +15,11 @@ for s in 1 0; do
   cp $(find /tmp/ks$s -name "*kernel_stats.csv" | head -1) $O/${T}_kernel_stats_streams$s.csv
   python $R/tools/overlap_report.py $(find /tmp/ks$s -name "*kernel_trace.csv" | head -1) 0.4 > $O/${T}_overlap_streams$s.txt
 done
+rm -rf /tmp/k2
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k2 -o k -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --profile-steps 0 --streams 0 --model_type VGG_PONG_LAYERNECK --model_in_channels 1 --model_z_channels 16 --model_keypoints 4 --size 84 --batch 256 > /dev/null 2>&1
+cp $(find /tmp/k2 -name "*kernel_stats.csv" | head -1) $O/${T}_cfg2_kernel_stats.csv
 cd $R
+(python tools/bench_infer.py; python tools/bench_infer.py --batch 32; python tools/bench_infer.py --batch 256 --frames 50) 2>&1 | grep -v amdgpu.ids > $O/${T}_infer.txt
 python - <<EOF
 import json
 for n in ('bench', 'bench_streams0', 'bench_fp16', 'cfg2_bench', 'cfg3_bench', 'cfg5_bench', 'fp32_bench'):
