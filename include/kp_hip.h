@@ -354,6 +354,8 @@ int kp_comm_unique_id(void* id128);
 int kp_comm_init(const void* id128, int rank, int world, void** comm);
 int kp_comm_allreduce(void* comm, void* buf, size_t count, int dtype, int average, void* stream);
 int kp_comm_broadcast(void* comm, void* buf, size_t count, int dtype, int root, void* stream);
+/* number of ranks of the communicator (ncclCommCount): what bench.py prints as `dp.nccl_ranks` for --comm native */
+int kp_comm_count(void* comm, int* ranks);
 int kp_comm_destroy(void* comm);
 
 #ifdef __cplusplus

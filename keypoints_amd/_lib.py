@@ -64,6 +64,7 @@ SIGNATURES = {
     'kp_comm_init': [_p, _i, _i, _p],
     'kp_comm_allreduce': [_p, _p, _z, _i, _i, _p],
     'kp_comm_broadcast': [_p, _p, _z, _i, _i, _p],
+    'kp_comm_count': [_p, _p],
     'kp_comm_destroy': [_p],
     'kp_prof_enable': [_i],
     'kp_config': [_i, _i],

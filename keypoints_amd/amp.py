@@ -70,12 +70,23 @@ class _ScaleLoss(torch.autograd.Function):
         return out[0].reshape(()), None
 
 
+def _require_scaling_optimizer(optimizer, who):
+    """A loss scaler only works with an optimizer whose step() un-scales the gradients, skips non-finite steps and adapts the
+    scale (keypoints_amd.FusedAdam).  On any other optimizer -- torch.optim.Adam, which is what transporter.py:47 builds --
+    `.scaler` would be an ignored attribute: the loss multiplied by 2^16 and nothing dividing the gradients again."""
+    from .optim import FusedAdam
+    if not (isinstance(optimizer, FusedAdam) or getattr(optimizer, 'honours_loss_scaler', False)):
+        raise TypeError(f'{who}: {type(optimizer).__name__} does not un-scale gradients; use keypoints_amd.FusedAdam '
+                        '(or an optimizer that sets `honours_loss_scaler = True` and divides by `.scaler` in step())')
+
+
 def initialize(net, optimizer, opt_level='O2', loss_scale='dynamic', **scaler_kwargs):
     """apex.amp.initialize's role: 'O0' -> strict fp32 Units; 'O1' / 'O2' / 'O3' -> fp16 Units with fp32 master
     weights and (loss_scale='dynamic') a device-resident dynamic loss scaler attached to `optimizer`."""
     if opt_level == 'O0':
         net.set_precision('fp32')
         return net, optimizer
+    _require_scaling_optimizer(optimizer, 'amp.initialize')
     net.set_precision('fp16')
     dev = next(net.parameters()).device
     if loss_scale == 'dynamic':

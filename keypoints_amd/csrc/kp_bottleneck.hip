@@ -373,6 +373,9 @@ int kp_transport_fwd(int mode, const float* phi_s, const float* phi_t, const flo
     KP_REQUIRE(B > 0 && C > 0 && K > 0 && H > 0 && W > 0, "kp_transport_fwd: bad dims");
     KP_REQUIRE(mode != KP_COMBINE_PRETRAINED || K == 1, "kp_transport_fwd: 'pretrained_network' takes one-channel masks");
     const unsigned grid = cdiv((long long)B * H * W, TPB);
+    // (the backward keeps per-keypoint arrays in registers: refuse here what could not be differentiated, instead of failing
+    //  inside backward() after the forward succeeded)
+    KP_REQUIRE(mode != KP_COMBINE_LOOP || K <= LOOP_MAXK, "kp_transport_fwd: 'loop' supports up to %d keypoints", LOOP_MAXK);
     hipStream_t st = (hipStream_t)stream;
     if (mode == KP_COMBINE_SUM_AND_CLAMP) transport_mode_fwd_k<1><<<grid, TPB, 0, st>>>(phi_s, phi_t, m_s, m_t, phi, mask_s, mask_t, B, C, K, H * W);
     else if (mode == KP_COMBINE_PRETRAINED) transport_mode_fwd_k<2><<<grid, TPB, 0, st>>>(phi_s, phi_t, m_s, m_t, phi, mask_s, mask_t, B, C, K, H * W);

@@ -19,6 +19,7 @@
 // in LDS, summed in a fixed order), routes that to argmax_k, folds it with the Gaussian's keypoint derivative (one
 // wavefront per keypoint, wave reduction over pixels) and writes the heat-map gradient of the marginal log-softmax.
 // The map gradient itself ([B,K,H,W], zero off the argmax) never exists in memory.
+#include <mutex>
 #include "kp_common.h"
 
 namespace {
@@ -345,6 +346,29 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+// The four kernels take more than the default 64 KiB of dynamic LDS.  The attribute is per DEVICE (a code object is loaded per
+// device) and must be in place whichever entry point a process calls first -- a backward without a forward in this process,
+// or a first forward on another GPU of a multi-GPU process -- so BOTH entry points call this, once per device (call_once per
+// device id; 64 devices is more than a node holds).
+static int set_lds_attributes() {
+    static std::once_flag once[64];
+    static int status[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    std::call_once(once[dev], [dev] {
+        const void* fns[] = {reinterpret_cast<const void*>(bottleneck_fwd_k<4>), reinterpret_cast<const void*>(bottleneck_fwd_k<1>),
+                             reinterpret_cast<const void*>(bottleneck_bwd_k<4>), reinterpret_cast<const void*>(bottleneck_bwd_k<1>)};
+        status[dev] = 0;
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) status[dev] = 1;
+    });
+    if (status[dev]) {
+        kp_set_error("keypoint bottleneck: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed on device %d", dev);
+        return KP_E_LAUNCH;
+    }
+    return KP_OK;
+}
+
 int kp_bottleneck_fused_fwd(const float* heat_s, const float* heat_t, const float* phi_s, const float* phi_t, float* k_t,
                             float* p_t, float* q_t, float* m_t, float* phi, float* mask_s, float* mask_t,
                             unsigned char* arg_t, int B, int C, int K, int H, int W, float sigma, float eps,
@@ -357,14 +381,7 @@ int kp_bottleneck_fused_fwd(const float* heat_s, const float* heat_t, const floa
     const size_t smem = (4 * (size_t)K + (size_t)NW * WAVE_FLOATS) * sizeof(float);
     const bool vec = ((H * W) & 3) == 0 && aligned16(phi_s) && aligned16(phi_t) && aligned16(phi) && aligned16(m_t) &&
                      aligned16(mask_s) && aligned16(mask_t) && ((reinterpret_cast<uintptr_t>(arg_t) & 3) == 0);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_fwd_k<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_fwd_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_bwd_k<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_bwd_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    if (int rc = set_lds_attributes()) return rc;
     if (vec)
         bottleneck_fwd_k<4><<<B, NT, smem, stream>>>(heat_s, heat_t, phi_s, phi_t, k_t, p_t, q_t, m_t, phi, mask_s, mask_t, arg_t, C, K, H, W, inv2s2, eps);
     else
@@ -389,6 +406,7 @@ int kp_bottleneck_fused_bwd(const float* gphi, const float* g_k, const float* g_
     if (G > C) G = C;
     KP_REQUIRE((long long)G * HW <= BWD_LDS_FLOATS, "kp_keypoint_bottleneck_bwd: %d x %d maps do not fit the LDS reduction buffer", H, W);
     const size_t smem = ((size_t)BWD_LDS_FLOATS + 2 * (size_t)K) * sizeof(float);
+    if (int rc = set_lds_attributes()) return rc;
     if (vec)
         bottleneck_bwd_k<4><<<B, NT, smem, stream>>>(gphi, g_k, g_m, phi_s, phi_t, mask_s, mask_t, arg_t, k_t, p_t, q_t, d_phi_t, d_heat, C, K, H, W, G, inv2s2, eps);
     else

@@ -21,6 +21,7 @@ struct Api {
     int (*GetUniqueId)(UniqueId*) = nullptr;
     int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
+    int (*CommCount)(Comm, int*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -40,6 +41,7 @@ Api& api() {
         a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.lib, "ncclGetUniqueId");
         a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.lib, "ncclCommInitRank");
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
+        a.CommCount = (decltype(a.CommCount))dlsym(a.lib, "ncclCommCount");
         a.AllReduce = (decltype(a.AllReduce))dlsym(a.lib, "ncclAllReduce");
         a.Broadcast = (decltype(a.Broadcast))dlsym(a.lib, "ncclBroadcast");
         a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
@@ -100,6 +102,13 @@ int kp_comm_broadcast(void* comm, void* buf, size_t count, int dtype, int root, 
     if (count == 0) return KP_OK;
     const int rc = api().Broadcast(buf, buf, count, t, root, (Comm)comm, (hipStream_t)stream);
     return rc ? fail("ncclBroadcast", rc) : KP_OK;
+}
+
+int kp_comm_count(void* comm, int* ranks) {
+    KP_REQUIRE(comm && ranks, "kp_comm_count: null pointer");
+    KP_REQUIRE(api().ok && api().CommCount, "kp_comm_count: no RCCL library in this process");
+    const int rc = api().CommCount((Comm)comm, ranks);   // what the COMMUNICATOR says, not what the launcher was told
+    return rc ? fail("ncclCommCount", rc) : KP_OK;
 }
 
 int kp_comm_destroy(void* comm) {

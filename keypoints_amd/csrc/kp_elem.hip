@@ -569,7 +569,11 @@ int kp_head_bwd(const float* gout, const float* out, const void* x, const float*
         if (rc == KP_OK) dx = nullptr;
         else if (rc != KP_E_UNSUPPORTED) return rc;
     }
-    const long long parts = (dw && ws) ? head_dw_parts(M, H * W, C, K, dtype) : 0;
+    // rows of the deterministic workspace: sized by kp_head_bwd_ws_floats from the plan of the kernel this SHAPE selects.  A
+    // faster kernel may still decline for a reason that is not the shape (gout / out not 16-byte aligned: sub-allocated
+    // pointers of a foreign caller) and hand over to the generic kernel below, whose own grid would be min(tiles, 512) rows:
+    // that grid is clamped to the rows the workspace holds, and the reduction sums the rows that were actually written.
+    long long parts = (dw && ws) ? head_dw_parts(M, H * W, C, K, dtype) : 0;
     float* const dw_out = dw;
     if (dw && dtype == KP_H16) {
         int rc = kp_head_dw_mfma(gout, out, x, slope, dw, db, ws, M, H * W, C, K, st);
@@ -585,7 +589,11 @@ int kp_head_bwd(const float* gout, const float* out, const void* x, const float*
     }
     if (dw) {
         const long long tiles = (M + HPB - 1) / HPB;
-        const unsigned gx = (unsigned)(tiles < 512 ? tiles : 512);
+        unsigned gx = (unsigned)(tiles < 512 ? tiles : 512);
+        if (parts > 0) {
+            if ((long long)gx > parts) gx = (unsigned)parts;   // the kernel strides over the tiles with its grid: any width is complete
+            parts = gx;
+        }
         const unsigned gy = cdiv((long long)K * C, (long long)TPB * HPAIRS);
         const size_t smem = (size_t)HPB * (K + C) * sizeof(float);
         DISPATCH_T(dtype, head_bwd_dw_k<T><<<dim3(gx, gy), TPB, smem, st>>>(gout, out, (const T*)x, slope, dw, db, ws, M, H * W, C, K));

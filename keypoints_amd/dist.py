@@ -72,6 +72,13 @@ class NativeComm:
         st = torch.cuda.current_stream()
         _lib.call('kp_comm_broadcast', self._h, t.data_ptr(), t.numel(), self._DT[t.dtype], src, st.cuda_stream)
 
+    def count(self) -> int:
+        """Number of ranks of the RCCL communicator itself (ncclCommCount)."""
+        import ctypes
+        n = ctypes.c_int(0)
+        _lib.call('kp_comm_count', self._h, ctypes.byref(n))
+        return int(n.value)
+
     def close(self) -> None:
         if self._h is not None:
             torch.cuda.synchronize()
@@ -111,6 +118,7 @@ class GradReducer:
         self._avg = self.native is not None or dist.get_backend(group) == 'nccl'   # RCCL has ncclAvg; gloo sums then scales
         self._sync = True
         self.pieces_issued = 0   # since the last finish() (tests / diagnostics)
+        self.timing = None       # list of (start, end) HIP event pairs around finish() while `time_finish(True)` (bench.py)
         if broadcast_init:
             for t in list(root.parameters()) + list(root.buffers()):
                 self._bcast(t.data)
@@ -202,10 +210,38 @@ class GradReducer:
             self._reduce(flat)
         self._done.add(id(unit))
 
+    def ranks_seen(self) -> dict:
+        """How many ranks the gradient exchange really spans, asked of the transport itself rather than of the launcher's
+        environment: a SUM all-reduce of a one on the device through the very communicator / process group the gradients
+        use (every participating rank contributes 1), plus ncclCommCount for the native communicator.  bench.py prints this
+        as `dp.nccl_ranks` so that a multi-GPU record proves the collective saw N ranks."""
+        dev = next(self.root.parameters()).device
+        one = torch.ones(1, device=dev, dtype=torch.float32)
+        if self.native is not None:
+            self.native.all_reduce(one, average=False).wait()
+            out = dict(allreduce_of_ones=int(round(float(one.item()))), comm_count=self.native.count(), transport='kp_comm (RCCL via the C ABI)')
+        else:
+            dist.all_reduce(one, op=dist.ReduceOp.SUM, group=self.group)
+            out = dict(allreduce_of_ones=int(round(float(one.item()))), comm_count=dist.get_world_size(self.group),
+                       transport=f'torch.distributed {dist.get_backend(self.group)}')
+        return out
+
+    def time_finish(self, on: bool) -> None:
+        """Record a HIP event pair around every finish() (the EXPOSED part of the exchange: what the step waits for between
+        backward and the optimiser)."""
+        self.timing = [] if on else None
+
+    def exposed_ms(self) -> List[float]:
+        """Milliseconds between the two events of each timed finish() (synchronises)."""
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in (self.timing or [])]
+
     def finish(self) -> None:
         """Join every outstanding gradient all-reduce (call between backward() and optimiser.step()).  Every piece is
         a disjoint arena slice, reduced and scaled exactly once."""
         runtime.join_side_streams()
+        if self.timing is not None:
+            t0 = torch.cuda.Event(enable_timing=True); t0.record()
         if self._early:
             raise RuntimeError('GradReducer.finish(): a Unit sent its arena tail but never finished its backward')
         for t in self._ready:
@@ -220,6 +256,9 @@ class GradReducer:
         self._pending.clear()
         self._done.clear()
         self.pieces_issued = 0
+        if self.timing is not None:
+            t1 = torch.cuda.Event(enable_timing=True); t1.record()
+            self.timing.append((t0, t1))
 
     def broadcast_buffers(self, src: int = 0) -> None:
         """BatchNorm running statistics are per-rank (each rank normalises its own shard); before a checkpoint every

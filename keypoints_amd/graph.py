@@ -35,6 +35,8 @@ class GraphedTrainStep:
         if not example_inputs:
             raise ValueError('GraphedTrainStep needs example inputs (their shapes are frozen into the graph)')
         dev = example_inputs[0].device
+        amp._require_scaling_optimizer(optimizer, 'GraphedTrainStep')
+        self._borrowed_scaler = getattr(optimizer, 'scaler', None) is None
         if optimizer.scaler is None:
             # Adam's step count and bias corrections must advance ON THE DEVICE inside a replayed graph: use the loss-scaler
             # state block with a constant scale of 1 (bf16 / fp32 modes: nothing is scaled, a non-finite gradient skips the
@@ -52,8 +54,20 @@ class GraphedTrainStep:
         cur.wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # capture on the SAME stream the warm-up ran on: runtime.side_stream() keys the side streams by their parent stream, so
+        # the 'chain' / 'wgrad' streams (and their allocator pools) the capture forks into are the warmed ones, not streams
+        # created for the first time inside the capture
+        with torch.cuda.graph(self.graph, stream=s):
             self.loss = self._step()
+
+    def release(self):
+        """Give the optimizer back as it was: the unit loss scaler this object attached (bf16 / fp32 modes) stays on the
+        optimizer for as long as the graph may be replayed -- the replayed Adam kernels read its device state block -- and
+        would make later EAGER steps pay a kp_amp_check per arena and skip non-finite steps silently.  Call when the graph is
+        discarded and training continues eagerly."""
+        if self._borrowed_scaler and getattr(self.opt.scaler, 'unit', False):
+            self.opt.scaler = None
+        self.graph = None
 
     def _step(self):
         self.opt.zero_grad()

@@ -106,6 +106,9 @@ class FusedAdam:
         t = self.step_count
         # hyper-parameters are read from param_groups[0] every step, like torch.optim.Adam: LR schedulers and manual
         # edits of `opt.param_groups[0]['lr']` take effect (one group: the arenas are per Unit, not per group)
+        if len(self.param_groups) != 1:
+            raise RuntimeError(f'FusedAdam: {len(self.param_groups)} param_groups -- one is supported (the flat arenas are per '
+                               'Unit, not per group); parameters of an added group would silently never be updated')
         grp = self.param_groups[0]
         self.lr, self.betas, self.eps = grp['lr'], grp['betas'], grp['eps']
         b1, b2 = self.betas

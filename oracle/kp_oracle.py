@@ -60,8 +60,13 @@ BN_EPS = 1e-5     # nn.BatchNorm2d defaults
 BN_MOMENTUM = 0.1
 
 
-def unit_plan(core_cfg: List, in_channels: int, out_channels: int, core_slope: float) -> List[dict]:
+def unit_plan(core_cfg: List, in_channels: int, out_channels: int, core_slope: float,
+              batch_norm: bool = True) -> List[dict]:
     """Flatten one `knn.Unit` (knn.py:110-130) into a list of steps.
+
+    batch_norm=False restates `Unit(..., batch_norm=False)` over `make_layers(cfg, batch_norm=False)` (knn.py:111,116-117,
+    vgg.py:16,34-35): no BatchNorm2d module anywhere, so a step's `bn` is None and the `nn.Sequential` indices of the
+    core advance by 3 per conv layer instead of 4.
 
     in_block  = Pad(1), Conv3x3(in -> core_in), BN, LeakyReLU      (knn.py:115-119)
     core      = vgg.make_layers(cfg)                               (vgg.py:16-39)
@@ -69,7 +74,7 @@ def unit_plan(core_cfg: List, in_channels: int, out_channels: int, core_slope: f
     `core_slope` is 0.0 for the decoder (ReLU, vgg.py:19) and 0.01 for the
     encoder / keypoint nets (transporter.py:121-122).
     """
-    steps = [dict(op='conv3', key='in_block.1', bn='in_block.2', cin=in_channels,
+    steps = [dict(op='conv3', key='in_block.1', bn='in_block.2' if batch_norm else None, cin=in_channels,
                   cout=core_cfg[0], slope=LEAKY)]
     idx, width = 0, core_cfg[0]
     for v in core_cfg[1:]:
@@ -78,10 +83,10 @@ def unit_plan(core_cfg: List, in_channels: int, out_channels: int, core_slope: f
         elif v == 'U':
             steps.append(dict(op='up')); idx += 1
         else:
-            steps.append(dict(op='conv3', key=f'core.{idx + 1}', bn=f'core.{idx + 2}',
+            steps.append(dict(op='conv3', key=f'core.{idx + 1}', bn=f'core.{idx + 2}' if batch_norm else None,
                               cin=width, cout=v, slope=core_slope))
             width = v
-            idx += 4
+            idx += 4 if batch_norm else 3
     steps.append(dict(op='conv1', key='out_block.0', cin=width, cout=out_channels, slope=LEAKY))
     return steps
 
@@ -111,6 +116,13 @@ def unit_forward(plan: List[dict], P: Params, prefix: str, x: Tensor,
         if st['op'] == 'conv3':
             h = F.pad(h, (1, 1, 1, 1), mode='replicate')                      # vgg.py:30
             h = F.conv2d(h, q(P[f"{prefix}.{st['key']}.weight"]), P[f"{prefix}.{st['key']}.bias"])
+            if st['bn'] is None:                                              # batch_norm=False: conv -> activation (vgg.py:34-36)
+                h = q(h)
+                h = F.leaky_relu(h, st['slope']) if st['slope'] > 0 else F.relu(h)
+                nxt = plan[pos + 1]['op'] if pos + 1 < len(plan) else None
+                if nxt not in ('pool', 'up'):
+                    h = q(h)
+                continue
             bn = f"{prefix}.{st['bn']}"
             rm = buffers[bn + '.running_mean'] if buffers is not None else None
             rv = buffers[bn + '.running_var'] if buffers is not None else None
@@ -281,6 +293,8 @@ def param_shapes(plans) -> Dict[str, Tuple[int, ...]]:
             if st['op'] == 'conv3':
                 shapes[f"{net}.{st['key']}.weight"] = (st['cout'], st['cin'], 3, 3)
                 shapes[f"{net}.{st['key']}.bias"] = (st['cout'],)
+                if st['bn'] is None:
+                    continue
                 shapes[f"{net}.{st['bn']}.weight"] = (st['cout'],)
                 shapes[f"{net}.{st['bn']}.bias"] = (st['cout'],)
             elif st['op'] == 'conv1':
@@ -307,7 +321,7 @@ def init_params(plans, seed: int = 0, dtype=torch.float32) -> Tuple[Params, Para
             P[name] = torch.zeros(shp, dtype=dtype)
     for net, plan in plans.items():
         for st in plan:
-            if st['op'] == 'conv3':
+            if st['op'] == 'conv3' and st['bn'] is not None:
                 B[f"{net}.{st['bn']}.running_mean"] = torch.zeros(st['cout'], dtype=dtype)
                 B[f"{net}.{st['bn']}.running_var"] = torch.ones(st['cout'], dtype=dtype)
                 B[f"{net}.{st['bn']}.num_batches_tracked"] = torch.zeros((), dtype=torch.long)

@@ -108,6 +108,13 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(overlap):
     assert rec['config']['dp_overlap'] is bool(overlap) and rec['scaling'] == 'weak'
     import math
     assert rec['value'] > 0 and rec['config']['loss'] > 0 and math.isfinite(rec['config']['loss']) and 'cpu_baseline' not in rec
+    # the self-check of the multi-GPU record: the collective itself counted two ranks, the exposed exchange was timed, and both
+    # placements of the all-reduces ran back to back
+    dp = rec['dp']
+    assert dp['nccl_ranks']['allreduce_of_ones'] == 2 and dp['nccl_ranks']['comm_count'] == 2
+    assert dp['exposed_allreduce_ms_median'] is not None and dp['exposed_allreduce_ms_median'] >= 0
+    assert set(dp['modes']) == {'dp_overlap_0', 'dp_overlap_1'} and all(m['value'] > 0 for m in dp['modes'].values())
+    assert dp['gradient_bytes_per_step'] == 4 * 24468813      # model F: 97.9 MB of fp32 gradients
 
 
 @pytest.mark.parametrize('typ,size', [('VGG_PONG_LAYERNECK', 32), ('VGG_PACMAN_2', 32)])
@@ -152,6 +159,7 @@ def test_native_comm_world1(nccl_world1):
         comm.broadcast(t, 0)
         torch.cuda.synchronize()
         assert torch.equal(t, ref)
+    assert comm.count() == 1        # ncclCommCount of the library's communicator (kp_comm_count)
     comm.close()
 
     g = torch.Generator().manual_seed(3)
@@ -168,6 +176,7 @@ def test_native_comm_world1(nccl_world1):
         if red is not None:
             assert issued == (2 if mode == 'overlap' else 1) * len(red.units)
             torch.cuda.synchronize()
+            assert red.ranks_seen() == dict(allreduce_of_ones=1, comm_count=1, transport='kp_comm (RCCL via the C ABI)')
             red.detach()
         nets.append(net)
     for other in nets[1:]:

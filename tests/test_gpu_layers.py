@@ -307,3 +307,35 @@ def test_pack_weights_batch_equals_per_layer_pack(dt):
             assert torch.equal(wd, rd), (K, C, Cp)
         assert torch.equal(wf[..., :C].float(), w.permute(0, 2, 3, 1).to(tdt).float())      # and the element kernel itself
         assert float(wf[..., C:].float().abs().sum()) == 0
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('bf16', 3e-2), ('fp16', 4e-3)])
+@pytest.mark.parametrize('tag,cin,cout,typ,enc', [('enc', 3, 5, 'VGG_PONG', True), ('dec', 16, 2, 'VGG_PONG', False),
+                                                   ('pac', 1, 4, 'VGG_PACMAN', True)])
+def test_unit_without_batchnorm_against_golden(golden, tag, cin, cout, typ, enc, precision, tol):
+    """`knn.Unit(in, out, vgg.make_layers(cfg, batch_norm=False), batch_norm=False)` (knn.py:111-125, vgg.py:16-38) through the
+    HIP engine against what the reference computed (tests/golden/nobn.npz): with no BatchNorm the conv bias is live (its
+    gradient is the engine's `dbeta` slot), the activation pass runs with identity statistics, the backward's mean
+    subtraction is off.  Max-pool and bilinear tails, LeakyReLU and ReLU cores, 1- / 3- / 16-channel inputs."""
+    import torch.nn as nn
+    from keypoints_amd.models import knn, vgg
+    z = golden('nobn.npz')
+    leaky = dict(nonlinearity=nn.LeakyReLU, nonlinearity_kwargs={'inplace': True}) if enc else {}
+    cfg = (vgg.vgg_cfg if enc or tag == 'pac' else vgg.decoder_cfg)[typ]
+    unit = knn.Unit(cin, cout, vgg.make_layers(cfg, batch_norm=False, **leaky), batch_norm=False)
+    assert not any(isinstance(m, nn.BatchNorm2d) for m in unit.modules())
+    sd = {}
+    for blk in ('in_block', 'core', 'out_block'):
+        for k in getattr(unit, blk).state_dict():
+            sd[f'{blk}.{k}'] = torch.tensor(z[f'{tag}.p.{blk}.{k}'])
+    unit.load_state_dict(sd, strict=True)          # same nn.Sequential keys as the reference's module
+    unit = unit.cuda()
+    unit.precision = precision
+    x = torch.tensor(z[f'{tag}.x']).cuda().requires_grad_(True)
+    y = unit(x)
+    assert relerr(y, z[f'{tag}.y']) <= tol
+    (y * torch.tensor(z[f'{tag}.w']).cuda()).sum().backward()
+    assert relerr(x.grad, z[f'{tag}.dx']) <= 2 * tol
+    for blk in ('in_block', 'core', 'out_block'):
+        for k, p in getattr(unit, blk).named_parameters():
+            assert relerr(p.grad, z[f'{tag}.g.{blk}.{k}']) <= 2 * tol, (blk, k)

@@ -227,3 +227,19 @@ def test_freeze_gc_parks_the_live_objects():
         assert gc.get_freeze_count() >= before + len(junk)
     finally:
         gc.unfreeze()
+
+
+def test_loss_scaler_refuses_an_optimizer_that_would_ignore_it():
+    """amp.initialize / GraphedTrainStep attach a loss scaler; on torch.optim.Adam (what transporter.py:47 builds) nothing would
+    ever divide the 2^16-scaled gradients again: TypeError instead of silent mis-training.  FusedAdam refuses added groups."""
+    import torch
+    import keypoints_amd as ka
+    from keypoints_amd import amp
+    lin = torch.nn.Linear(2, 2)
+    with pytest.raises(TypeError):
+        amp.initialize(lin, torch.optim.Adam(lin.parameters(), lr=1e-4), opt_level='O2')
+    amp._require_scaling_optimizer(ka.FusedAdam(lin.parameters()), 'test')        # accepted
+    opt = ka.FusedAdam(lin.parameters())
+    opt.param_groups.append(dict(params=[], lr=1e-3, betas=(0.9, 0.999), eps=1e-8))
+    with pytest.raises(RuntimeError, match='param_groups'):
+        opt.step()

@@ -146,3 +146,24 @@ def test_transporter_F_forward(golden):
     close(out[0], z['x_t'], 1e-5); close(out[2], z['k']); close(out[3], z['m'])
     close(O.l2_reconstruction_loss(out[0], xt), z['loss'])
     assert abs(O.conv_flops_per_pair(plans, 128, 128) / 1e9 - 235.23) < 0.01   # BASELINE.md work accounting
+
+
+NOBN = [('enc', 3, 5, 'VGG_PONG', True), ('dec', 16, 2, 'VGG_PONG', False), ('pac', 1, 4, 'VGG_PACMAN', True)]
+
+
+@pytest.mark.parametrize('tag,cin,cout,typ,enc', NOBN)
+def test_unit_without_batchnorm(golden, tag, cin, cout, typ, enc):
+    """`Unit(..., batch_norm=False)` over `make_layers(cfg, batch_norm=False)` (knn.py:111-125, vgg.py:16-38) as the reference
+    computed it (tools/make_golden.py make_nobn): forward, input gradient, every parameter gradient."""
+    z = golden('nobn.npz')
+    cfg = (O.ENCODER_CORES if enc or tag == 'pac' else O.DECODER_CORES)[typ]
+    plan = O.unit_plan(cfg, cin, cout, O.LEAKY if enc else 0.0, batch_norm=False)
+    assert all(s.get('bn') is None for s in plan if s['op'] == 'conv3')
+    P = {n: torch.tensor(z[f'{tag}.p.{n[2:]}'], requires_grad=True) for n in O.param_shapes({'n': plan})}
+    x = torch.tensor(z[f'{tag}.x'], requires_grad=True)
+    y = O.unit_forward(plan, P, 'n', x, None, True)
+    close(y, z[f'{tag}.y'])
+    (y * torch.tensor(z[f'{tag}.w'])).sum().backward()
+    close(x.grad, z[f'{tag}.dx'])
+    for n, p in P.items():
+        close(p.grad, z[f'{tag}.g.{n[2:]}'])
