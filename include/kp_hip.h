@@ -163,6 +163,26 @@ int kp_conv_wgrad_partials(int N, int Ho, int Wo, int C, int K, int R, int dy_pa
 int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R,
                   int dy_pad, int dtype, void* stream);
 
+/* ---- 3x3 layer fed by another 3x3 layer: BatchNorm-apply + activation + replicate pad fused into the consumer -----------
+ * vgg.py:30-38 builds Pad(1) -> Conv3x3 -> BatchNorm2d -> act per layer; between two such layers the reference materialises
+ * act(bn(y_prev)) and its padded copy.  These entry points read the PREVIOUS layer's conv output yprev [N][H][W][C] (no
+ * border) and apply  a[i][j] = act(bn(yprev[clamp(i-1)][clamp(j-1)]))  over the padded domain while staging their input,
+ * so that tensor never exists.  mean/invstd/gamma/beta: the previous layer's BatchNorm (batch statistics in training, running
+ * statistics in eval; all NULL = batch_norm=False, activation only), slope: its LeakyReLU slope (0 = ReLU).
+ *   kp_conv_fwd_bnin  == kp_bn_act_fwd(yprev -> a, KP_TAIL_NONE, out_pad 1) + kp_conv_fwd(a, ..., N, H+2, W+2, C, K, 3)
+ *   kp_conv_wgrad_bnin == the same + kp_conv_wgrad(a, dy, ...)
+ * bit for bit (same expression, same rounding to the storage type, same kernels behind the staging).  Statistics rows /
+ * partial-gradient protocol: kp_conv_fwd_stats_rows(N, H+2, W+2, C, K, 3) / kp_conv_wgrad_partials(N, H, W, C, K, 3, dy_pad).
+ * kp_conv_bnin_supported: 1 if both fused forms exist for the shape (today: C, K in {16, 32}, 16-bit storage: the Pong-class
+ * nets of vgg.py:53,66, whose layers are HBM-bound); otherwise the calls return KP_E_UNSUPPORTED and launch nothing. */
+int kp_conv_bnin_supported(int N, int H, int W, int C, int K, int dtype);
+int kp_conv_fwd_bnin(const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     float slope, const void* w, const float* bias, void* y, float* stats, int N, int H, int W, int C, int K,
+                     int dtype, void* stream);
+int kp_conv_wgrad_bnin(const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                       float slope, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int dy_pad, int dtype,
+                       void* stream);
+
 /* ---- BatchNorm(train) + activation (+ pool / upsample) ----------------- */
 /* fp64 workspace size (in doubles) needed by kp_bn_finalize / kp_bn_bwd_finalize for C channels. */
 int kp_bn_ws_doubles(int C);

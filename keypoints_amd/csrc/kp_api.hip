@@ -191,6 +191,11 @@ KP_DISPATCH(kp_conv_wgrad_partials, (int N, int Ho, int Wo, int C, int K, int R,
             (N, Ho, Wo, C, K, R, dy_pad, dtype))
 KP_DISPATCH(kp_conv_wgrad, (const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R, int dy_pad, int dtype, void* stream),
             (x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, dtype, stream))
+KP_DISPATCH(kp_conv_bnin_supported, (int N, int H, int W, int C, int K, int dtype), (N, H, W, C, K, dtype))
+KP_DISPATCH(kp_conv_fwd_bnin, (const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, const void* w, const float* bias, void* y, float* stats, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (yprev, mean, invstd, gamma, beta, slope, w, bias, y, stats, N, H, W, C, K, dtype, stream))
+KP_DISPATCH(kp_conv_wgrad_bnin, (const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int dy_pad, int dtype, void* stream),
+            (yprev, mean, invstd, gamma, beta, slope, dy, scratch, N, Ho, Wo, C, K, dy_pad, dtype, stream))
 KP_DISPATCH(kp_bn_act_fwd, (const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, int tail, void* out, int out_pad, unsigned char* argmax, int N, int H, int W, int C, int dtype, void* stream),
             (y, mean, invstd, gamma, beta, slope, tail, out, out_pad, argmax, N, H, W, C, dtype, stream))
 KP_DISPATCH(kp_bn_act_bwd_reduce, (const void* gsrc, int gp, int tail, const unsigned char* argmax, const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, float* partials, int N, int H, int W, int C, int dtype, void* stream),

@@ -14,6 +14,12 @@ int kp_conv_wgrad_patch(const void*, const void*, float*, int, int, int, int, in
 long long kp_conv_wgrad_patch_partials(int, int, int, int, int, int);
 int kp_conv_small_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
 int kp_conv_small_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
+int kp_conv_small_fwd_bnin_ok(int, int, int, int, int);
+int kp_conv_small_fwd_bnin(const void*, const float*, const float*, const float*, const float*, float, const void*, const float*,
+                           void*, float*, int, int, int, int, int, hipStream_t);
+int kp_conv_small_wgrad_bnin_ok(int, int, int, int, int);
+int kp_conv_small_wgrad_bnin(const void*, const float*, const float*, const float*, const float*, float, const void*, float*, int,
+                             int, int, int, int, int, hipStream_t);
 int kp_conv_first_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
 int kp_conv_first_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 long long kp_conv_first_wgrad_partials(int, int, int, int, int);
@@ -143,6 +149,44 @@ int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, 
     if (getenv("KP_LOG_GENERIC")) fprintf(stderr, "generic wgrad: N=%d Ho=%d Wo=%d C=%d K=%d R=%d dp=%d dtype=%d\n", N, Ho, Wo, C, K, R, dy_pad, dtype);
     int rc = kp_conv_wgrad_generic(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, dtype, (hipStream_t)stream);
     ps.done(KP_PROF_WGRAD_GENERIC);
+    return rc;
+}
+
+// ---- 3x3 layers fed by another 3x3 layer: the previous layer's BatchNorm-apply + activation + replicate pad fused into the
+// consumer's staging (kp_conv_small.hip, BnIn).  Shapes without a fused kernel answer 0 / KP_E_UNSUPPORTED and the caller
+// runs kp_bn_act_fwd + kp_conv_fwd / kp_conv_wgrad instead: same results, bit for bit.
+int kp_conv_bnin_supported(int N, int H, int W, int C, int K, int dtype) {
+    if (dtype != KP_H16 || !use_mfma() || N <= 0 || H <= 0 || W <= 0) return 0;
+    return kp_conv_small_fwd_bnin_ok(N, H, W, C, K) && kp_conv_small_wgrad_bnin_ok(N, H, W, C, K);
+}
+
+int kp_conv_fwd_bnin(const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     float slope, const void* w, const float* bias, void* y, float* stats, int N, int H, int W, int C, int K,
+                     int dtype, void* stream) {
+    KP_REQUIRE(kp_query_mode() || (yprev && w && y), "kp_conv_fwd_bnin: null pointer");
+    KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "kp_conv_fwd_bnin: bad dims");
+    KP_REQUIRE(!mean == !invstd && !mean == !gamma && !mean == !beta, "kp_conv_fwd_bnin: mean / invstd / gamma / beta must be all set or all NULL");
+    if (!kp_conv_bnin_supported(N, H, W, C, K, dtype)) return KP_E_UNSUPPORTED;
+    const double flops = 2.0 * N * (double)H * W * C * K * 9;
+    const double bytes = 2.0 * ((double)N * H * W * C + (double)N * H * W * K + 9.0 * C * K);
+    ProfScope ps(KP_PROF_CONV_SMALL, flops, (hipStream_t)stream, bytes);
+    const int rc = kp_conv_small_fwd_bnin(yprev, mean, invstd, gamma, beta, slope, w, bias, y, stats, N, H, W, C, K, (hipStream_t)stream);
+    ps.done(KP_PROF_CONV_SMALL);
+    return rc;
+}
+
+int kp_conv_wgrad_bnin(const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                       float slope, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int dy_pad, int dtype,
+                       void* stream) {
+    KP_REQUIRE(yprev && dy && scratch, "kp_conv_wgrad_bnin: null pointer");
+    KP_REQUIRE(N > 0 && Ho > 0 && Wo > 0 && C > 0 && K > 0 && dy_pad >= 0, "kp_conv_wgrad_bnin: bad dims");
+    KP_REQUIRE(!mean == !invstd && !mean == !gamma && !mean == !beta, "kp_conv_wgrad_bnin: mean / invstd / gamma / beta must be all set or all NULL");
+    if (!kp_conv_bnin_supported(N, Ho, Wo, C, K, dtype)) return KP_E_UNSUPPORTED;
+    const double flops = 2.0 * N * (double)Ho * Wo * C * K * 9;
+    const double bytes = 2.0 * ((double)N * Ho * Wo * C + (double)N * Ho * Wo * K) + 4.0 * 9 * C * K;
+    ProfScope ps(KP_PROF_CONV_SMALL, flops, (hipStream_t)stream, bytes);
+    const int rc = kp_conv_small_wgrad_bnin(yprev, mean, invstd, gamma, beta, slope, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
+    ps.done(KP_PROF_CONV_SMALL);
     return rc;
 }
 

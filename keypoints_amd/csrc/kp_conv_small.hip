@@ -149,6 +149,60 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_k(const h16_t* __restrict__
     }
 }
 
+// ---- BatchNorm-apply + activation of the PREVIOUS layer on the staging path (kp_conv_fwd_bnin / kp_conv_wgrad_bnin) --------
+// A 3x3 layer whose input is another 3x3 layer's output reads that layer's conv output y_prev [N][H][W][C] (no border) and
+// applies  a = act(bn(y_prev[clamp(i - 1)][clamp(j - 1)]))  -- BatchNorm2d (train: batch statistics), LeakyReLU / ReLU and
+// ReplicationPad2d(1), vgg.py:30-38 -- between the global load and the LDS store of the band staging: the VALU is idle in these
+// kernels, and the padded activation tensor (write + read of the layer's output, one whole launch) never exists.  The
+// arithmetic is kp_bn_act_fwd's expression for expression ((y - mean) * invstd * gamma + beta, act, RNE to 16 bits), so the
+// fragments the MFMAs see are bit-identical to what the separate pass would have stored.
+struct BnIn {
+    const float *mean, *invstd, *gamma, *beta;   // mean == nullptr: no BatchNorm (batch_norm=False), activation only
+    float slope;
+};
+// per-channel constants of the layer in LDS: [4][32] floats (mean, invstd, gamma, beta).  Without BatchNorm the constants are
+// the EXACT identity of the expression below: (y - (+0)) * 1 * 1 + (-0) == y for every y, signed zeros included.
+__device__ __forceinline__ void bnin_fill(float (*cst)[32], const BnIn& bn, int C, int tid) {
+    if (tid < C) {
+        const bool aff = bn.mean != nullptr;
+        cst[0][tid] = aff ? bn.mean[tid] : 0.f;
+        cst[1][tid] = aff ? bn.invstd[tid] : 1.f;
+        cst[2][tid] = aff ? bn.gamma[tid] : 1.f;
+        cst[3][tid] = aff ? bn.beta[tid] : -0.f;
+    }
+}
+// a thread's 8 channels (c0 .. c0 + 7) of the four constants, LDS -> registers: once per band, issued behind the band's global
+// loads (re-reading them per 16-byte chunk put 16 dependent LDS round trips in front of every chunk: +40 us per launch)
+struct BnReg {
+    float mu[8], is[8], ga[8], be[8];
+    __device__ __forceinline__ void load(const float (*cst)[32], int c0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 a = *reinterpret_cast<const float4*>(&cst[0][c0 + 4 * h]);
+            const float4 b = *reinterpret_cast<const float4*>(&cst[1][c0 + 4 * h]);
+            const float4 c = *reinterpret_cast<const float4*>(&cst[2][c0 + 4 * h]);
+            const float4 d = *reinterpret_cast<const float4*>(&cst[3][c0 + 4 * h]);
+            mu[4 * h] = a.x; mu[4 * h + 1] = a.y; mu[4 * h + 2] = a.z; mu[4 * h + 3] = a.w;
+            is[4 * h] = b.x; is[4 * h + 1] = b.y; is[4 * h + 2] = b.z; is[4 * h + 3] = b.w;
+            ga[4 * h] = c.x; ga[4 * h + 1] = c.y; ga[4 * h + 2] = c.z; ga[4 * h + 3] = c.w;
+            be[4 * h] = d.x; be[4 * h + 1] = d.y; be[4 * h + 2] = d.z; be[4 * h + 3] = d.w;
+        }
+    }
+};
+// one 16-byte chunk = 8 consecutive channels of a pixel.  act(z) = max(z, z * slope) is (z > 0 ? z : z * slope) bit for bit
+// for 0 <= slope <= 1 (the launchers check it), zeros and NaNs included, without the compare + select per element.
+__device__ __forceinline__ uint4 bnin_apply(const uint4 raw, const BnReg& k, float slope) {
+    float v[8];
+    unpack_h16x2(raw.x, v[0], v[1]); unpack_h16x2(raw.y, v[2], v[3]);
+    unpack_h16x2(raw.z, v[4], v[5]); unpack_h16x2(raw.w, v[6], v[7]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float z = (v[e] - k.mu[e]) * k.is[e] * k.ga[e] + k.be[e];
+        v[e] = fmaxf(z, z * slope);
+    }
+    return make_uint4(pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]), pack_h16x2(v[6], v[7]));
+}
+
 // ---- forward / data gradient with the input staged through LDS ------------------------------------------------------------
 // The kernel above reads every input pixel nine times (once per tap) through the L1: 0.5-1 GB of L2 -> L1 traffic per layer,
 // which is what sets its pace (2-2.6 TB/s of algorithmic bytes).  Here a workgroup copies a band of R + 2 padded input rows
@@ -158,14 +212,18 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_k(const h16_t* __restrict__
 // Statistics: one partial row per wavefront of the grid, accumulated over its items in a fixed order (deterministic).
 constexpr int FB_LDS = 61440;   // band bytes (the weights take 9 / 18 KB more): two workgroups per CU
 constexpr int FSL = 12;         // 16-byte chunks per thread in one band (256 x 12 x 16 B = 48 KB of input)
-template <int CB>
+// BNIN: x is the previous layer's conv output [N][Hi - 2][Wi - 2][C] and `bn` its BatchNorm / activation (see BnIn above);
+// otherwise x is the padded activation [N][Hi][Wi][C] as stored.
+template <int CB, bool BNIN>
 __global__ __launch_bounds__(TPB) void conv3x3_small_band_k(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
                                                             const float* __restrict__ bias, h16_t* __restrict__ y,
                                                             float* __restrict__ partials, int Hi, int Wi, int K, int R,
-                                                            int bands_per_img, long long total_bands) {
+                                                            int bands_per_img, long long total_bands, BnIn bn) {
     constexpr int C = CB * 16, PITCH = C * 2 + 16, CPP = C / 8;   // chunks of 16 bytes per pixel
     __shared__ h16x8 swf[9 * CB][64];
     __shared__ __attribute__((aligned(16))) unsigned char xl[FB_LDS];
+    __shared__ __attribute__((aligned(16))) float cst[BNIN ? 4 : 1][32];
+    if (BNIN) bnin_fill(cst, bn, C, threadIdx.x);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
     const int Ho = Hi - 2, Wo = Wi - 2;
@@ -201,19 +259,40 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_band_k(const h16_t* __restr
             const int c = tid % CPP, dpx = TPB / CPP;
             int px = tid / CPP, r = 0;
             while (px >= XPW) { px -= XPW; ++r; }
-            const unsigned char* xg = (const unsigned char*)x + (((n * Hi + p0) * Wi) * (long long)C) * 2 + c * 16;
+            const unsigned char* xg = BNIN ? (const unsigned char*)x + ((n * Ho * Wo) * (long long)C) * 2 + c * 16
+                                           : (const unsigned char*)x + (((n * Hi + p0) * Wi) * (long long)C) * 2 + c * 16;
             uint4 sb[FSL];
             int lo[FSL];
+            unsigned live = 0;   // BNIN: chunks that hold image data (the zero fill beyond Wi stays zero)
 #pragma unroll
             for (int u = 0; u < FSL; ++u) {
                 sb[u] = make_uint4(0, 0, 0, 0);
                 lo[u] = -1;
                 if (r < rows + 2) {
                     lo[u] = r * xrow_l + px * PITCH + c * 16;
-                    if (px < Wi) sb[u] = *reinterpret_cast<const uint4*>(xg + ((long long)r * Wi + px) * (C * 2));
+                    if (px < Wi) {
+                        if (BNIN) {   // ReplicationPad2d(1): padded (p0 + r, px) <- clamp(p0 + r - 1), clamp(px - 1) of the unpadded map
+                            const int sr = p0 + r - 1 < 0 ? 0 : (p0 + r - 1 > Ho - 1 ? Ho - 1 : p0 + r - 1);
+                            const int sc = px - 1 < 0 ? 0 : (px - 1 > Wo - 1 ? Wo - 1 : px - 1);
+                            sb[u] = *reinterpret_cast<const uint4*>(xg + ((long long)sr * Wo + sc) * (C * 2));
+                            live |= 1u << u;
+                        } else {
+                            sb[u] = *reinterpret_cast<const uint4*>(xg + ((long long)r * Wi + px) * (C * 2));
+                        }
+                    }
                 }
                 px += dpx;
                 while (px >= XPW) { px -= XPW; ++r; }
+            }
+            if (BNIN) {
+                BnReg k;
+                k.load(cst, c * 8);
+#pragma unroll
+                for (int u = 0; u < FSL; ++u) {
+                    const uint4 t = bnin_apply(sb[u], k, bn.slope);
+                    const bool on = live & (1u << u);
+                    sb[u] = make_uint4(on ? t.x : 0u, on ? t.y : 0u, on ? t.z : 0u, on ? t.w : 0u);
+                }
             }
 #pragma unroll
             for (int u = 0; u < FSL; ++u)
@@ -361,11 +440,15 @@ __global__ __launch_bounds__(TPB) void wgrad3x3_small_k(const h16_t* __restrict_
 // differ from the kernel above in the last bits, and are bitwise repeatable.
 constexpr int WG_LDS = 77824;
 constexpr int SL = 12;   // 16-byte chunks per thread and tensor in one band (256 threads x 12 x 16 B = 48 KB of each)
-template <int K, int C>
+// BNIN: x is the previous layer's conv output [N][Ho][Wo][C]; its BatchNorm-apply + activation + replicate pad run between the
+// global load and the LDS store (BnIn above), so the weight gradient sees the very fragments the forward multiplied.
+template <int K, int C, bool BNIN>
 __global__ __launch_bounds__(TPB) void wgrad3x3_small_band_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
                                                              float* __restrict__ scratch, int Ho, int Wo, int dy_pad, int R,
-                                                             int bands_per_img, long long total_bands, long long pstride) {
+                                                             int bands_per_img, long long total_bands, long long pstride, BnIn bn) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WG_LDS];
+    __shared__ __attribute__((aligned(16))) float cst[BNIN ? 4 : 1][32];
+    if (BNIN) bnin_fill(cst, bn, C, threadIdx.x);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, h = lane >> 5;
     const int Hi = Ho + 2, Wi = Wo + 2, Hd = Ho + 2 * dy_pad, Wd = Wo + 2 * dy_pad;
@@ -396,20 +479,43 @@ __global__ __launch_bounds__(TPB) void wgrad3x3_small_band_k(const h16_t* __rest
         {
             const int xc = xrow_b / 16, xvalid = Wi * C * 2 / 16, xtot = (rows + 2) * xc;
             const int dc = drow_b / 16, dvalid = Wo * K * 2 / 16, dtot = rows * dc;
-            const unsigned char* xg = (const unsigned char*)x + (((n * Hi + p0) * Wi) * (long long)C) * 2;
+            const unsigned char* xg = BNIN ? (const unsigned char*)x + ((n * Ho * Wo) * (long long)C) * 2
+                                           : (const unsigned char*)x + (((n * Hi + p0) * Wi) * (long long)C) * 2;
             const unsigned char* dg = (const unsigned char*)dy + ((((n * Hd + p0 + dy_pad) * Wd) + dy_pad) * (long long)K) * 2;
             const int xrow_g = Wi * C * 2, drow_g = Wd * K * 2;
             const int xdr = TPB / xc, xdc = TPB % xc, ddr = TPB / dc, ddc = TPB % dc;
             // (two rounds -- input rows, then gradient rows -- of SL registers-quads each: both tensors in flight at once
             //  need 96 staging registers on top of the 144 accumulators and spill)
             uint4 sb[SL];
+            unsigned live = 0;   // BNIN: chunks that hold image data
             int r = tid / xc, c16 = tid % xc;
 #pragma unroll
             for (int u = 0; u < SL; ++u) {
                 sb[u] = make_uint4(0, 0, 0, 0);
-                if (tid + u * TPB < xtot && c16 < xvalid) sb[u] = *reinterpret_cast<const uint4*>(xg + (long long)r * xrow_g + c16 * 16);
+                if (tid + u * TPB < xtot && c16 < xvalid) {
+                    if (BNIN) {   // chunk c16 of padded row p0 + r = (pixel c16 / CPP, channels 8 * (c16 % CPP) ..) <- clamped source
+                        constexpr int CPP = C / 8;
+                        const int px = c16 / CPP, cg = c16 % CPP;
+                        const int sr = p0 + r - 1 < 0 ? 0 : (p0 + r - 1 > Ho - 1 ? Ho - 1 : p0 + r - 1);
+                        const int sc = px - 1 < 0 ? 0 : (px - 1 > Wo - 1 ? Wo - 1 : px - 1);
+                        sb[u] = *reinterpret_cast<const uint4*>(xg + (((long long)sr * Wo + sc) * CPP + cg) * 16);
+                        live |= 1u << u;
+                    } else {
+                        sb[u] = *reinterpret_cast<const uint4*>(xg + (long long)r * xrow_g + c16 * 16);
+                    }
+                }
                 r += xdr; c16 += xdc;
                 if (c16 >= xc) { c16 -= xc; ++r; }
+            }
+            if (BNIN) {
+                BnReg k;
+                k.load(cst, (tid % (C / 8)) * 8);   // TPB and xc are multiples of C / 8: a thread's chunks all hold the same channels
+#pragma unroll
+                for (int u = 0; u < SL; ++u) {
+                    const uint4 t = bnin_apply(sb[u], k, bn.slope);
+                    const bool on = live & (1u << u);
+                    sb[u] = make_uint4(on ? t.x : 0u, on ? t.y : 0u, on ? t.z : 0u, on ? t.w : 0u);
+                }
             }
 #pragma unroll
             for (int u = 0; u < SL; ++u)
@@ -518,27 +624,33 @@ static int small_fwd_band_rows(int Ho, int Wo, int C) {
     return R < 1 ? 0 : (int)R;
 }
 
+// band plan of the LDS-staged forward: rows per band, bands per image, grid (0: no band kernel for this shape)
+static long long small_fwd_band_plan(int N, int Ho, int Wo, int C, bool stats, int& R, int& bpi, long long& bands) {
+    R = small_fwd_band_rows(Ho, Wo, C);
+    if (!R) return 0;
+    bpi = (Ho + R - 1) / R;
+    bands = (long long)N * bpi;
+    long long grid = bands < 512 ? bands : 512;
+    const long long max_rows = ((long long)N * Ho * Wo + 63) / 64;   // the caller's statistics buffer
+    if (stats && grid * 4 > max_rows) grid = max_rows / 4;
+    return grid >= 1 ? grid : 0;
+}
+
 int kp_conv_small_fwd(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi,
                       int C, int K, hipStream_t st) {
     if (!small_ch(C) || !small_ch(K) || Hi < 3 || Wi < 3) return KP_E_UNSUPPORTED;
     const int Ho = Hi - 2, Wo = Wi - 2;
     if (g_kp_small_band) {
-        const int R = small_fwd_band_rows(Ho, Wo, C);
-        if (R) {
-            const int bpi = (Ho + R - 1) / R;
-            const long long bands = (long long)N * bpi;
-            long long grid = bands < 512 ? bands : 512;
-            const long long max_rows = ((long long)N * Ho * Wo + 63) / 64;   // the caller's statistics buffer
-            if (stats && grid * 4 > max_rows) grid = max_rows / 4;
-            if (grid >= 1) {
-                if (stats) kp_set_last_rows(grid * 4);
-                KP_QUERY_RETURN();
-                if (C == 16)
-                    conv3x3_small_band_k<1><<<(unsigned)grid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, K, R, bpi, bands);
-                else
-                    conv3x3_small_band_k<2><<<(unsigned)grid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, K, R, bpi, bands);
-                return kp_check_launch("conv3x3_small_band");
-            }
+        int R, bpi;
+        long long bands;
+        if (const long long grid = small_fwd_band_plan(N, Ho, Wo, C, stats != nullptr, R, bpi, bands)) {
+            if (stats) kp_set_last_rows(grid * 4);
+            KP_QUERY_RETURN();
+            if (C == 16)
+                conv3x3_small_band_k<1, false><<<(unsigned)grid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, K, R, bpi, bands, BnIn{});
+            else
+                conv3x3_small_band_k<2, false><<<(unsigned)grid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, K, R, bpi, bands, BnIn{});
+            return kp_check_launch("conv3x3_small_band");
         }
     }
     const int spr = (Wo + 31) / 32;
@@ -556,6 +668,32 @@ int kp_conv_small_fwd(const void* x, const void* w, const float* bias, void* y, 
     else
         conv3x3_small_k<2><<<(unsigned)blocks, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, N, Hi, Wi, K, nseg, spr);
     return kp_check_launch("conv3x3_small");
+}
+
+// The same forward with the previous layer's BatchNorm-apply + activation + replicate pad on the staging path (BnIn above):
+// yprev [N][Ho][Wo][C].  Only the band kernel has this form; the plan (grid, statistics rows) is kp_conv_small_fwd's for
+// (N, Ho + 2, Wo + 2, C, K), so kp_conv_fwd_stats_rows of that shape tells the rows.
+int kp_conv_small_fwd_bnin_ok(int N, int Ho, int Wo, int C, int K) {
+    int R, bpi;
+    long long bands;
+    return small_ch(C) && small_ch(K) && Ho >= 1 && Wo >= 1 && g_kp_small_band && small_fwd_band_plan(N, Ho, Wo, C, true, R, bpi, bands) > 0;
+}
+int kp_conv_small_fwd_bnin(const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           float slope, const void* w, const float* bias, void* y, float* stats, int N, int Ho, int Wo, int C,
+                           int K, hipStream_t st) {
+    if (!kp_conv_small_fwd_bnin_ok(N, Ho, Wo, C, K) || !(slope >= 0.f && slope <= 1.f)) return KP_E_UNSUPPORTED;
+    int R, bpi;
+    long long bands;
+    const long long grid = small_fwd_band_plan(N, Ho, Wo, C, stats != nullptr, R, bpi, bands);
+    if (!grid) return KP_E_UNSUPPORTED;
+    if (stats) kp_set_last_rows(grid * 4);
+    KP_QUERY_RETURN();
+    const BnIn bn{mean, invstd, gamma, beta, slope};
+    if (C == 16)
+        conv3x3_small_band_k<1, true><<<(unsigned)grid, TPB, 0, st>>>((const h16_t*)yprev, (const h16_t*)w, bias, (h16_t*)y, stats, Ho + 2, Wo + 2, K, R, bpi, bands, bn);
+    else
+        conv3x3_small_band_k<2, true><<<(unsigned)grid, TPB, 0, st>>>((const h16_t*)yprev, (const h16_t*)w, bias, (h16_t*)y, stats, Ho + 2, Wo + 2, K, R, bpi, bands, bn);
+    return kp_check_launch("conv3x3_small_band_bnin");
 }
 
 // workgroups of the weight-gradient kernel = partial gradients in its scratch (0: not a small-channel shape)
@@ -587,7 +725,7 @@ int kp_conv_small_wgrad(const void* x, const void* dy, float* scratch, int N, in
                         hipStream_t st) {
     int R, bpi;
     if (const unsigned bgrid = small_band_plan(N, Ho, Wo, C, K, R, bpi)) {
-#define KP_SWB(Kv, Cv) wgrad3x3_small_band_k<Kv, Cv><<<bgrid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, R, bpi, (long long)N * bpi, (long long)Kv * 9 * Cv)
+#define KP_SWB(Kv, Cv) wgrad3x3_small_band_k<Kv, Cv, false><<<bgrid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, R, bpi, (long long)N * bpi, (long long)Kv * 9 * Cv, BnIn{})
         if (K == 16 && C == 16) KP_SWB(16, 16);
         else if (K == 16) KP_SWB(16, 32);
         else if (C == 16) KP_SWB(32, 16);
@@ -606,4 +744,26 @@ int kp_conv_small_wgrad(const void* x, const void* dy, float* scratch, int N, in
     else KP_SWG(32, 32);
 #undef KP_SWG
     return kp_check_launch("wgrad3x3_small");
+}
+
+// The weight gradient with the input side read from the previous layer's conv output (BnIn): band kernel only; partial
+// protocol = kp_conv_small_wgrad_partials of the same shape.
+int kp_conv_small_wgrad_bnin_ok(int N, int Ho, int Wo, int C, int K) {
+    int R, bpi;
+    return small_band_plan(N, Ho, Wo, C, K, R, bpi) > 0;
+}
+int kp_conv_small_wgrad_bnin(const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             float slope, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int dy_pad,
+                             hipStream_t st) {
+    int R, bpi;
+    const unsigned bgrid = small_band_plan(N, Ho, Wo, C, K, R, bpi);
+    if (!bgrid || !(slope >= 0.f && slope <= 1.f)) return KP_E_UNSUPPORTED;
+    const BnIn bn{mean, invstd, gamma, beta, slope};
+#define KP_SWB(Kv, Cv) wgrad3x3_small_band_k<Kv, Cv, true><<<bgrid, TPB, 0, st>>>((const h16_t*)yprev, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, R, bpi, (long long)N * bpi, (long long)Kv * 9 * Cv, bn)
+    if (K == 16 && C == 16) KP_SWB(16, 16);
+    else if (K == 16) KP_SWB(16, 32);
+    else if (C == 16) KP_SWB(32, 16);
+    else KP_SWB(32, 32);
+#undef KP_SWB
+    return kp_check_launch("wgrad3x3_small_band_bnin");
 }

@@ -181,3 +181,18 @@ def freeze_gc():
     import gc
     gc.collect()
     gc.freeze()
+
+
+_FUSE_BN_INPUT = True
+
+
+def fuse_bn_input() -> bool:
+    """3x3 -> 3x3 layer pairs run the first layer's BatchNorm-apply + activation inside the second convolution's staging
+    (kp_conv_fwd_bnin / kp_conv_wgrad_bnin) where the library has such a kernel for the shape.  Results are bit-identical
+    either way; `set_fuse_bn_input(False)` restores the separate pass for A/B measurements and tests."""
+    return _FUSE_BN_INPUT
+
+
+def set_fuse_bn_input(on: bool) -> None:
+    global _FUSE_BN_INPUT
+    _FUSE_BN_INPUT = bool(on)

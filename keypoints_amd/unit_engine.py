@@ -208,6 +208,7 @@ class UnitFunction(torch.autograd.Function):
         a = torch.empty(N, H + 2 * pad0, W + 2 * pad0, Cp0, device=dev, dtype=tdt)
         call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, Cin, Cp0, H, W, pad0, code, st)
         saved = []
+        fin = None   # pending BatchNorm-apply of the previous layer, fused into the next convolution (None: `a` is materialised)
         packs = _pack_unit(plan, Cin, Cp0, record, dev, tdt, code, st)
         C = Cin
         for idx, stp in enumerate(plan[:-1]):
@@ -221,7 +222,13 @@ class UnitFunction(torch.autograd.Function):
             y = torch.empty(N, H, W, K, device=dev, dtype=tdt)
             training = bn is not None and bn.training
             stats = torch.empty((N * H * W + 63) // 64, 2, K, device=dev, dtype=torch.float32) if training else None
-            call('kp_conv_fwd', ptr(a), ptr(wf), ptr(conv.bias), ptr(y), ptr(stats), N, H + 2, W + 2, C, K, 3, code, st)
+            if fin is not None:
+                # the previous layer's BatchNorm-apply + activation + replicate pad run on this convolution's staging path
+                # (kp_conv_fwd_bnin): its padded activation was never written
+                call('kp_conv_fwd_bnin', ptr(fin['y']), *fin['bn'], fin['slope'], ptr(wf), ptr(conv.bias), ptr(y), ptr(stats),
+                     N, H, W, C, K, code, st)
+            else:
+                call('kp_conv_fwd', ptr(a), ptr(wf), ptr(conv.bias), ptr(y), ptr(stats), N, H + 2, W + 2, C, K, 3, code, st)
             srows = _lib.lib().kp_conv_fwd_stats_rows(N, H + 2, W + 2, C, K, 3, code) if training else 0
             mean = invstd = None
             if bn is not None:
@@ -253,14 +260,26 @@ class UnitFunction(torch.autograd.Function):
             Ho, Wo = _tail_dims(H, W, tail)
             nxt = plan[idx + 1]
             out_pad = 1 if nxt['kind'] == 'conv3' else 0
-            a_next = torch.empty(N, Ho + 2 * out_pad, Wo + 2 * out_pad, K, device=dev, dtype=tdt)
-            argmax = torch.empty(N, Ho, Wo, K, device=dev, dtype=torch.uint8) if (tail == 'M' and record) else None
-            call('kp_bn_act_fwd', ptr(y), ptr(mean), ptr(invstd), ptr(bn.weight) if bn is not None else None,
-                 ptr(bn.bias) if bn is not None else None, stp['slope'], TAILS[tail], ptr(a_next), out_pad, ptr(argmax),
-                 N, H, W, K, code, st)
+            gamma = bn.weight if bn is not None else None
+            beta = bn.bias if bn is not None else None
+            # 3x3 -> 3x3 with no pool / upsample between them (vgg.py:30-38) and a consumer kernel that applies BatchNorm +
+            # activation + replicate pad while it stages its input: this layer's activation pass is skipped altogether
+            fuse_next = (tail is None and nxt['kind'] == 'conv3' and runtime.fuse_bn_input() and 0.0 <= stp['slope'] <= 1.0
+                         and _lib.lib().kp_conv_bnin_supported(N, H, W, K, nxt['conv'].out_channels, code) == 1)
+            argmax = None
+            if fuse_next:
+                a_next = None
+                fin_next = dict(y=y, bn=(ptr(mean), ptr(invstd), ptr(gamma), ptr(beta)), slope=stp['slope'],
+                                keep=(mean, invstd, gamma, beta))
+            else:
+                fin_next = None
+                a_next = torch.empty(N, Ho + 2 * out_pad, Wo + 2 * out_pad, K, device=dev, dtype=tdt)
+                argmax = torch.empty(N, Ho, Wo, K, device=dev, dtype=torch.uint8) if (tail == 'M' and record) else None
+                call('kp_bn_act_fwd', ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), stp['slope'], TAILS[tail],
+                     ptr(a_next), out_pad, ptr(argmax), N, H, W, K, code, st)
             if record:
-                saved.append(dict(a=a, y=y, mean=mean, invstd=invstd, argmax=argmax, wd=wd, H=H, W=W, C=C, Cl=Cl, K=K))
-            a, C, H, W = a_next, K, Ho, Wo
+                saved.append(dict(a=a, fin=fin, y=y, mean=mean, invstd=invstd, argmax=argmax, wd=wd, H=H, W=W, C=C, Cl=Cl, K=K))
+            a, fin, C, H, W = a_next, fin_next, K, Ho, Wo
         head = plan[-1]
         hconv = head['conv']
         Kout = hconv.out_channels
@@ -362,13 +381,17 @@ class UnitFunction(torch.autograd.Function):
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                 wst = stream_ptr()
                 scratch = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device=dev, dtype=torch.float32)
-                call('kp_conv_wgrad', ptr(sv['a']), ptr(dy), ptr(scratch), N, H, W, C, K, 3, dp, code, wst)
+                if sv['fin'] is not None:   # the input side is read from the previous layer's conv output (see forward)
+                    f = sv['fin']
+                    call('kp_conv_wgrad_bnin', ptr(f['y']), *f['bn'], f['slope'], ptr(dy), ptr(scratch), N, H, W, C, K, dp, code, wst)
+                else:
+                    call('kp_conv_wgrad', ptr(sv['a']), ptr(dy), ptr(scratch), N, H, W, C, K, 3, dp, code, wst)
                 call('kp_wgrad_unpack', ptr(scratch), parts, ptr(gv[id(conv.weight)]), K, sv['Cl'], C, 3, wst)
             if side is not None:
                 # dy and the saved input are read on the side stream: they stay referenced until this stream has waited
                 # for it (end of the Unit's backward) -- the caching allocator recycles a block in the order of ITS stream
                 # (tensor.record_stream would do the same bookkeeping per block; measured: steps of 160-220 ms at random)
-                keep.append((dy, sv['a']))
+                keep.append((dy, sv['a'], sv['fin']))
                 if unit.layer_done is not None:   # a gradient reducer reads the arena from this stream
                     cur.wait_stream(side)
             unit._layer_done(idx)   # the arena slots of plan steps >= idx (and of the head) are final from here on

@@ -103,6 +103,16 @@ def fp16_storage(t: Tensor) -> Tensor:
     return t + (t.detach().to(torch.float16).to(t.dtype) - t.detach())
 
 
+def _per_image_chunks(fn, h: Tensor) -> Tensor:
+    """torch's replicate-pad / max-pool / bilinear kernels index with 32 bits: a tensor of 2^31 elements or more (the fp64
+    full-batch checker of BASELINE config 5: 256 x 128 x 258 x 258) goes through them in chunks of whole images.  These ops
+    act per image, so the result is the same tensor."""
+    if h.numel() < 2 ** 31 - 2 ** 24:
+        return fn(h)
+    per = max(1, (2 ** 30) // max(1, h[0].numel()))
+    return torch.cat([fn(h[i:i + per]) for i in range(0, h.shape[0], per)], dim=0)
+
+
 def unit_forward(plan: List[dict], P: Params, prefix: str, x: Tensor,
                  buffers: Optional[Params] = None, training: bool = True, quant=None) -> Tensor:
     """`knn.Unit.forward` (knn.py:127-130) on the CPU.
@@ -114,7 +124,7 @@ def unit_forward(plan: List[dict], P: Params, prefix: str, x: Tensor,
     h = q(x)
     for pos, st in enumerate(plan):
         if st['op'] == 'conv3':
-            h = F.pad(h, (1, 1, 1, 1), mode='replicate')                      # vgg.py:30
+            h = _per_image_chunks(lambda t: F.pad(t, (1, 1, 1, 1), mode='replicate'), h)   # vgg.py:30
             h = F.conv2d(h, q(P[f"{prefix}.{st['key']}.weight"]), P[f"{prefix}.{st['key']}.bias"])
             if st['bn'] is None:                                              # batch_norm=False: conv -> activation (vgg.py:34-36)
                 h = q(h)
@@ -146,9 +156,9 @@ def unit_forward(plan: List[dict], P: Params, prefix: str, x: Tensor,
             if nxt not in ('pool', 'up'):
                 h = q(h)
         elif st['op'] == 'pool':
-            h = q(F.max_pool2d(h, 2, 2))                                       # vgg.py:24
+            h = q(_per_image_chunks(lambda t: F.max_pool2d(t, 2, 2), h))         # vgg.py:24
         elif st['op'] == 'up':
-            h = q(F.interpolate(h, scale_factor=2, mode='bilinear', align_corners=True))  # vgg.py:26
+            h = q(_per_image_chunks(lambda t: F.interpolate(t, scale_factor=2, mode='bilinear', align_corners=True), h))  # vgg.py:26
         else:
             h = F.conv2d(h, P[f"{prefix}.{st['key']}.weight"], P[f"{prefix}.{st['key']}.bias"])
             h = F.leaky_relu(h, st['slope'])

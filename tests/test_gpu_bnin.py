@@ -1,0 +1,122 @@
+"""BatchNorm-apply + activation + replicate pad of a 3x3 layer fused into the NEXT 3x3 layer's kernels (kp_conv_fwd_bnin,
+kp_conv_wgrad_bnin; vgg.py:30-38 layer pairs of the Pong-class nets, vgg.py:53,66) against the separate pass it replaces
+(kp_bn_act_fwd + kp_conv_fwd / kp_conv_wgrad): the same expression and the same rounding to the storage type feed the same
+MFMAs, so every output bit must agree -- on NaN-prefilled outputs, at ragged sizes, with and without BatchNorm, and through a
+whole train step of the Pong transporter."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(3, 84, 84), (2, 37, 50), (4, 5, 7), (1, 1, 3), (2, 32, 32), (5, 16, 33)]
+
+
+def _bn(C, g, on=True):
+    if not on:
+        return (None,) * 4
+    return ((torch.randn(C, generator=g) * 0.3).cuda(), (torch.rand(C, generator=g) + 0.5).cuda(),
+            (torch.randn(C, generator=g) * 0.5 + 1).cuda(), (torch.randn(C, generator=g) * 0.3).cuda())
+
+
+@pytest.mark.parametrize('N,H,W', SHAPES)
+@pytest.mark.parametrize('C,K', [(16, 16), (16, 32), (32, 16), (32, 32)])
+@pytest.mark.parametrize('dt,bn_on,slope', [('bf16', True, 0.01), ('fp16', True, 0.0), ('bf16', False, 0.01)])
+def test_conv_fwd_and_wgrad_bnin_equal_the_separate_pass(N, H, W, C, K, dt, bn_on, slope):
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    tdt, code = (torch.bfloat16, _lib.KP_BF16) if dt == 'bf16' else (torch.float16, _lib.KP_F16)
+    L = _lib.lib()
+    if L.kp_conv_bnin_supported(N, H, W, C, K, code) != 1:
+        pytest.skip('no fused kernel for this shape (the engine then runs the separate pass)')
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + C + K)
+    yprev = torch.randn(N, H, W, C, generator=g).to(tdt).cuda()
+    bn = _bn(C, g, bn_on)
+    w = (torch.randn(K, 3, 3, C, generator=g) * 0.1).to(tdt).cuda()
+    bias = (torch.randn(K, generator=g) * 0.1).cuda()
+    st = stream_ptr()
+    # reference: the separate pass, then the plain kernels
+    a = torch.full((N, H + 2, W + 2, C), float('nan'), device='cuda', dtype=tdt)
+    call('kp_bn_act_fwd', ptr(yprev), *[ptr(t) for t in bn], slope, _lib.TAIL_NONE, ptr(a), 1, None, N, H, W, C, code, st)
+    rows = L.kp_conv_fwd_stats_rows(N, H + 2, W + 2, C, K, 3, code)
+    nrows = (N * H * W + 63) // 64
+    outs = []
+    for fused in (False, True):
+        y = torch.full((N, H, W, K), float('nan'), device='cuda', dtype=tdt)
+        stats = torch.full((nrows, 2, K), float('nan'), device='cuda', dtype=torch.float32)
+        if fused:
+            call('kp_conv_fwd_bnin', ptr(yprev), *[ptr(t) for t in bn], slope, ptr(w), ptr(bias), ptr(y), ptr(stats), N, H, W, C, K, code, st)
+        else:
+            call('kp_conv_fwd', ptr(a), ptr(w), ptr(bias), ptr(y), ptr(stats), N, H + 2, W + 2, C, K, 3, code, st)
+        outs.append((y.float().cpu(), stats[:rows].cpu()))
+    assert torch.isfinite(outs[1][0]).all() and torch.isfinite(outs[1][1]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # sanity of the reference itself against torch (the fused path is then right by the equality above)
+    af = a.float().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(af, w.float().permute(0, 3, 1, 2), bias).permute(0, 2, 3, 1).cpu()
+    assert (outs[1][0] - ref).abs().max() <= 2.0 ** (-7 if dt == 'bf16' else -10) * max(1.0, float(ref.abs().max()))
+    # weight gradient
+    for dp in (0, 2):
+        dy = torch.zeros(N, H + 2 * dp, W + 2 * dp, K, dtype=tdt)
+        dy[:, dp:dp + H, dp:dp + W] = (torch.randn(N, H, W, K, generator=g) * 0.1).to(tdt)
+        dy = dy.cuda()
+        parts = L.kp_conv_wgrad_partials(N, H, W, C, K, 3, dp, code)
+        res = []
+        for fused in (False, True):
+            scratch = (torch.zeros if parts == 1 else lambda *s, **k: torch.full(s, float('nan'), **k))(parts, K, 3, 3, C, device='cuda', dtype=torch.float32)
+            if fused:
+                call('kp_conv_wgrad_bnin', ptr(yprev), *[ptr(t) for t in bn], slope, ptr(dy), ptr(scratch), N, H, W, C, K, dp, code, st)
+            else:
+                call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, W, C, K, 3, dp, code, st)
+            res.append(scratch.cpu())
+        assert torch.isfinite(res[1]).all() and torch.equal(res[0], res[1])
+
+
+def test_unsupported_shapes_launch_nothing():
+    """Shapes without a fused kernel (model F's 64..512-channel layers, fp32 storage) answer 0 / KP_E_UNSUPPORTED."""
+    from keypoints_amd import _lib
+    L = _lib.lib()
+    assert L.kp_conv_bnin_supported(2, 16, 16, 64, 128, _lib.KP_BF16) == 0
+    assert L.kp_conv_bnin_supported(2, 84, 84, 16, 32, _lib.KP_F32) == 0
+    assert L.kp_conv_bnin_supported(2, 84, 84, 16, 32, _lib.KP_BF16) == 1
+    y = torch.zeros(8, device='cuda')
+    with pytest.raises(_lib.KpError):
+        _lib.call('kp_conv_fwd_bnin', _lib.ptr(y), None, None, None, None, 0.0, _lib.ptr(y), None, _lib.ptr(y), None,
+                  2, 16, 16, 64, 128, _lib.KP_BF16, None)
+
+
+@pytest.mark.parametrize('typ,cin,z,K,size', [('VGG_PONG_LAYERNECK', 1, 16, 4, 84), ('VGG_PACMAN', 3, 16, 4, 37),
+                                              ('VGG_PONG_TRIVIAL', 1, 16, 3, 32)])
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_train_steps_are_bitwise_the_same_with_and_without_the_fusion(typ, cin, z, K, size, precision):
+    """Two Adam steps of a Pong-class Transporter: outputs, loss, every parameter and BatchNorm buffer bit-identical with the
+    BatchNorm-apply pass fused into the consumers (default) and run as its own launch (runtime.set_fuse_bn_input(False))."""
+    import keypoints_amd as ka
+    from keypoints_amd import runtime
+    from keypoints_amd.models import transporter
+    g = torch.Generator().manual_seed(5)
+    xs = (torch.rand(6, cin, size, size, generator=g) * 2 - 1).cuda()
+    xt = (torch.rand(6, cin, size, size, generator=g) * 2 - 1).cuda()
+    res = []
+    try:
+        for fuse in (False, True):
+            runtime.set_fuse_bn_input(fuse)
+            torch.manual_seed(9)
+            net = transporter.make(typ, cin, z, K).cuda().set_precision(precision)
+            opt = ka.FusedAdam(net.parameters(), lr=1e-3).bind(net)
+            if precision == 'fp16':
+                opt.scaler = ka.amp.LossScaler('cuda')
+            for _ in range(2):
+                opt.zero_grad()
+                out = net(xs, xt)
+                loss = ka.l2_reconstruction_loss(out[0], xt)
+                with ka.amp.scale_loss(loss, opt) as sl:
+                    sl.backward()
+                opt.step()
+            torch.cuda.synchronize()
+            res.append((out[0].detach().clone(), loss.detach().clone(), {k: v.detach().clone() for k, v in net.state_dict().items()}))
+    finally:
+        runtime.set_fuse_bn_input(True)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k

@@ -35,6 +35,7 @@ def main():
     gt = torch.Generator().manual_seed(7)
     xs_e, xt_e = structured_pairs(128, 128, gt, device='cuda')
     done = 0
+    loss = float('nan')
     for target in steps_list:
         t0 = time.time()
         while done < target:
