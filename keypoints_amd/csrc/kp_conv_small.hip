@@ -18,6 +18,7 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) short h16x8;
 typedef __attribute__((ext_vector_type(4))) short h16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define LDS_AS __attribute__((address_space(3)))
 
@@ -210,12 +211,30 @@ __device__ __forceinline__ uint4 bnin_apply(const uint4 raw, const BnReg& k, flo
 // ds_read_b128 group land on 16 distinct 4-bank blocks for both channel counts) and its four wavefronts take the (row,
 // 32-pixel segment) items of the band: 9 (18) fragment reads from LDS per item, weights from LDS as above, same epilogue.
 // Statistics: one partial row per wavefront of the grid, accumulated over its items in a fixed order (deterministic).
+#ifndef KP_FB_ABL
+#define KP_FB_ABL 0   // measurement builds only (tools/probes/small_abl.sh): 1 no global loads, 2 no items, 4 no stores, 8 no MFMAs, 16 no fragment reads
+#endif
 constexpr int FB_LDS = 61440;   // band bytes (the weights take 9 / 18 KB more): two workgroups per CU
-constexpr int FSL = 12;         // 16-byte chunks per thread in one band (256 x 12 x 16 B = 48 KB of input)
+// Workgroup size of the band kernel (a build-time knob for A/B runs: tools/probes/small_variant.sh).  Eight-wave workgroups
+// (4 waves per SIMD at <= 128 VGPRs instead of 2) run the kernels 5-8 % faster in isolation, but the BatchNorm-input variants
+// then spill, and in the train step -- where these kernels share the chip with side-stream work -- the step was 3 % SLOWER
+// (3.88 vs 4.00 ms, one box, interleaved): four waves it is.
+#ifndef KP_FB_TPB
+#define KP_FB_TPB 256
+#endif
+constexpr int FTPB = KP_FB_TPB, FNW = FTPB / 64;
+constexpr int FSL = 12 * 256 / FTPB;   // 16-byte chunks per thread in one band (FTPB x FSL x 16 B = 48 KB of input)
 // BNIN: x is the previous layer's conv output [N][Hi - 2][Wi - 2][C] and `bn` its BatchNorm / activation (see BnIn above);
 // otherwise x is the padded activation [N][Hi][Wi][C] as stored.
+// The kernel is bound by VALU ISSUE, not by HBM (rocprofv3 SQ counters, tools/probes/small_pmc.sh: 3 200 VALU instructions per
+// wave for 142 MFMAs -- the VALU pipe is busy for > 40 % of the launch and ~70 % of the time waves are resident, HBM moves 3.5
+// of ~5 TB/s).  So the body is written to keep work OFF the vector ALU: everything that is uniform over a wavefront (item ->
+// row / segment, output row base, LDS row base) is computed on the scalar unit (`wave` comes from readfirstlane), the per-lane
+// parts of every address are constants computed once, the staging tables (LDS offset, source offset, row of each of a
+// thread's chunks) are built once per kernel instead of once per band, statistics use packed FMAs and are skipped -- like
+// the lane mask of ragged segments -- where a wave-uniform test says they are not needed.
 template <int CB, bool BNIN>
-__global__ __launch_bounds__(TPB) void conv3x3_small_band_k(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
+__global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
                                                             const float* __restrict__ bias, h16_t* __restrict__ y,
                                                             float* __restrict__ partials, int Hi, int Wi, int K, int R,
                                                             int bands_per_img, long long total_bands, BnIn bn) {
@@ -224,7 +243,8 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_band_k(const h16_t* __restr
     __shared__ __attribute__((aligned(16))) unsigned char xl[FB_LDS];
     __shared__ __attribute__((aligned(16))) float cst[BNIN ? 4 : 1][32];
     if (BNIN) bnin_fill(cst, bn, C, threadIdx.x);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
     const int Ho = Hi - 2, Wo = Wi - 2;
     const int nseg = (Wo + 31) / 32, XPW = nseg * 32 + 2, xrow_l = XPW * PITCH;
@@ -238,15 +258,33 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_band_k(const h16_t* __restr
                 swf[t * CB + cb][lane] = v;
             }
     }
-    float bv[16];
+    // D[k][px]: lane: pixel = fr, k = 8 * (reg >> 2) + 4 * fh + (reg & 3); register PAIRS (2j, 2j + 1) are the packed operands
+    f32x2 bv[8], ssum[8], ssq[8];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int k = 8 * (i >> 2) + 4 * fh + (i & 3);
-        bv[i] = (bias && k < K) ? bias[k] : 0.f;
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * (j >> 1) + 4 * fh + 2 * (j & 1);
+        bv[j] = f32x2{(bias && k < K) ? bias[k] : 0.f, (bias && k + 1 < K) ? bias[k + 1] : 0.f};
+        ssum[j] = ssq[j] = f32x2{0.f, 0.f};
     }
-    float ssum[16], ssq[16];
+    // ---- staging tables of this thread's FSL chunks (band-independent): chunk id = tid + u * FTPB = (row * XPW + pixel) * CPP + c
+    const int c = tid % CPP;
+    int lo[FSL], so[FSL], rw[FSL];   // LDS byte offset; source byte offset (BNIN: of the clamped column only); band row (big: never staged)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ssum[i] = ssq[i] = 0.f;
+    for (int u = 0; u < FSL; ++u) {
+        const int pix = (tid + u * FTPB) / CPP;
+        const int r = pix / XPW, px = pix - r * XPW;
+        lo[u] = r * xrow_l + px * PITCH + c * 16;
+        rw[u] = px < Wi ? r : (r | 0x4000);   // bit 14: zero fill beyond the image row
+        if (BNIN) {
+            const int sc = px - 1 < 0 ? 0 : (px - 1 > Wo - 1 ? Wo - 1 : px - 1);   // ReplicationPad2d(1): column clamp
+            so[u] = (sc * CPP + c) * 16;
+        } else {
+            so[u] = ((r * Wi + px) * CPP + c) * 16;
+        }
+    }
+    const int lane_ld = fr * PITCH + fh * 16;          // fragment read: lane part of the LDS address
+    const int lane_st = (fr * K + 8 * fh) * 2;         // output store: lane part of the byte offset (chunk g adds 32 bytes)
+    const bool want_stats = partials != nullptr;       // forward with BatchNorm statistics; the data gradient has none
 
     for (long long band = blockIdx.x; band < total_bands; band += gridDim.x) {
         const long long n = band / bands_per_img;
@@ -254,35 +292,23 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_band_k(const h16_t* __restr
         const int rows = Ho - p0 < R ? Ho - p0 : R;
         __syncthreads();   // the previous band's fragments have been read (first trip: the weights are in place after the next one)
         {
-            // chunk id = ((row * XPW) + pixel) * CPP + c; 256 % CPP == 0: a thread keeps its chunk column c and walks pixels.
             // (Issuing the NEXT band's loads before this band's items and parking them in registers measured slower: 71 -> 77 us.)
-            const int c = tid % CPP, dpx = TPB / CPP;
-            int px = tid / CPP, r = 0;
-            while (px >= XPW) { px -= XPW; ++r; }
-            const unsigned char* xg = BNIN ? (const unsigned char*)x + ((n * Ho * Wo) * (long long)C) * 2 + c * 16
-                                           : (const unsigned char*)x + (((n * Hi + p0) * Wi) * (long long)C) * 2 + c * 16;
+            const unsigned char* xg = BNIN ? (const unsigned char*)x + ((n * Ho * Wo) * (long long)C) * 2
+                                           : (const unsigned char*)x + (((n * Hi + p0) * Wi) * (long long)C) * 2;
             uint4 sb[FSL];
-            int lo[FSL];
-            unsigned live = 0;   // BNIN: chunks that hold image data (the zero fill beyond Wi stays zero)
+            unsigned live = 0;   // chunks that hold image data (the zero fill beyond Wi stays zero)
 #pragma unroll
             for (int u = 0; u < FSL; ++u) {
                 sb[u] = make_uint4(0, 0, 0, 0);
-                lo[u] = -1;
-                if (r < rows + 2) {
-                    lo[u] = r * xrow_l + px * PITCH + c * 16;
-                    if (px < Wi) {
-                        if (BNIN) {   // ReplicationPad2d(1): padded (p0 + r, px) <- clamp(p0 + r - 1), clamp(px - 1) of the unpadded map
-                            const int sr = p0 + r - 1 < 0 ? 0 : (p0 + r - 1 > Ho - 1 ? Ho - 1 : p0 + r - 1);
-                            const int sc = px - 1 < 0 ? 0 : (px - 1 > Wo - 1 ? Wo - 1 : px - 1);
-                            sb[u] = *reinterpret_cast<const uint4*>(xg + ((long long)sr * Wo + sc) * (C * 2));
-                            live |= 1u << u;
-                        } else {
-                            sb[u] = *reinterpret_cast<const uint4*>(xg + ((long long)r * Wi + px) * (C * 2));
-                        }
+                if (rw[u] < rows + 2 && !(KP_FB_ABL & 1)) {      // (rows beyond the band and the zero fill have a large rw)
+                    int off = so[u];
+                    if (BNIN) {   // row clamp of the replicate pad: padded row p0 + r <- clamp(p0 + r - 1) of the unpadded map
+                        const int pr = p0 + rw[u] - 1;
+                        off += (pr < 0 ? 0 : (pr > Ho - 1 ? Ho - 1 : pr)) * (Wo * C * 2);
                     }
+                    sb[u] = *reinterpret_cast<const uint4*>(xg + off);
+                    live |= 1u << u;
                 }
-                px += dpx;
-                while (px >= XPW) { px -= XPW; ++r; }
             }
             if (BNIN) {
                 BnReg k;
@@ -296,15 +322,16 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_band_k(const h16_t* __restr
             }
 #pragma unroll
             for (int u = 0; u < FSL; ++u)
-                if (lo[u] >= 0) *reinterpret_cast<uint4*>(xl + lo[u]) = sb[u];
+                if ((rw[u] & 0x3fff) < rows + 2) *reinterpret_cast<uint4*>(xl + lo[u]) = sb[u];
         }
         __syncthreads();
-        for (int item = wave; item < rows * nseg; item += 4) {
+        unsigned char* const yband = (unsigned char*)y + ((n * Ho + p0) * Wo) * (long long)K * 2;   // uniform
+        const int nitems = (KP_FB_ABL & 2) ? 0 : rows * nseg;
+        for (int item = wave; item < nitems; item += FNW) {    // all of this is scalar: row, segment, bases
             const int r = item / nseg, sq = item - r * nseg;
-            const int p = p0 + r;
-            const int q = sq * 32 + fr;
-            const bool ok = q < Wo;
-            const unsigned char* xb = xl + r * xrow_l + (sq * 32 + fr) * PITCH + fh * 16;
+            const bool full = sq * 32 + 32 <= Wo;              // whole segment inside the row: no lane mask anywhere
+            const bool ok = (full || sq * 32 + fr < Wo) && !(KP_FB_ABL & 4);
+            const unsigned char* xb = xl + (r * xrow_l + sq * 32 * PITCH) + lane_ld;
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -313,37 +340,49 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_band_k(const h16_t* __restr
             for (int t = 0; t < 9; ++t)
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb)
-                    xf[t * CB + cb] = *reinterpret_cast<const h16x8*>(xb + (t / 3) * xrow_l + (t % 3) * PITCH + cb * 32);
+                    xf[t * CB + cb] = (KP_FB_ABL & 16) ? h16x8{(short)item, 0, 0, 0, 0, 0, 0, 0}
+                                                       : *reinterpret_cast<const h16x8*>(xb + (t / 3) * xrow_l + (t % 3) * PITCH + cb * 32);
 #pragma unroll
-            for (int t = 0; t < 9 * CB; ++t) acc = kp_mfma16(swf[t][lane], xf[t], acc, 0, 0, 0);   // (two accumulator chains: no faster, measured)
-            uint32_t pk[8];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[g * 4 + e] + bv[g * 4 + e];
-                    if (ok) { ssum[g * 4 + e] += v[e]; ssq[g * 4 + e] += v[e] * v[e]; }
-                }
-                pk[2 * g] = pack_h16x2(v[0], v[1]);
-                pk[2 * g + 1] = pack_h16x2(v[2], v[3]);
+            for (int t = 0; t < 9 * CB; ++t) {
+                if (KP_FB_ABL & 8) acc[t & 15] += (float)xf[t][0];
+                else acc = kp_mfma16(swf[t][lane], xf[t], acc, 0, 0, 0);   // (two accumulator chains: no faster, measured)
             }
-            h16_t* yp = y + ((n * Ho + p) * Wo + q) * (long long)K;
+            f32x2 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = f32x2{acc[2 * j], acc[2 * j + 1]} + bv[j];
+            if (want_stats) {
+                if (full) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] = __builtin_elementwise_fma(v[j], v[j], ssq[j]); }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const f32x2 m = ok ? v[j] : f32x2{0.f, 0.f};
+                        ssum[j] += m; ssq[j] = __builtin_elementwise_fma(m, m, ssq[j]);
+                    }
+                }
+            }
+            // pair the half-waves' 8-byte pieces: after the swaps lanes fh = 0 hold channels 8g .. 8g+7 of chunk g (even g),
+            // lanes fh = 1 those of chunk g + 1
+            unsigned char* const yp = yband + (r * Wo + sq * 32) * K * 2;   // uniform; + lane_st per lane
 #pragma unroll
             for (int g = 0; g < 4; g += 2) {
-                uint32_t a0 = pk[2 * g], a1 = pk[2 * g + 1], b0 = pk[2 * g + 2], b1 = pk[2 * g + 3];
+                uint32_t a0 = pack_h16x2(v[2 * g][0], v[2 * g][1]), a1 = pack_h16x2(v[2 * g + 1][0], v[2 * g + 1][1]);
+                uint32_t b0 = pack_h16x2(v[2 * g + 2][0], v[2 * g + 2][1]), b1 = pack_h16x2(v[2 * g + 3][0], v[2 * g + 3][1]);
                 asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a0), "+v"(b0));
                 asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a1), "+v"(b1));
-                const int kc = 8 * (g + fh);
-                if (ok && kc < K) *reinterpret_cast<uint4*>(yp + kc) = make_uint4(a0, a1, b0, b1);
+                if (ok && 8 * (g + fh) < K) *reinterpret_cast<uint4*>(yp + lane_st + g * 16) = make_uint4(a0, a1, b0, b1);
             }
         }
     }
     if (partials) {
-        const long long gw = (long long)blockIdx.x * 4 + wave;
+        const long long gw = (long long)blockIdx.x * FNW + wave;
+        float s1[16], s2[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[2 * j] = ssum[j][0]; s1[2 * j + 1] = ssum[j][1]; s2[2 * j] = ssq[j][0]; s2[2 * j + 1] = ssq[j][1]; }
         int r1, r2;
-        const float ts = reduce16_over32(ssum, lane, r1);
-        const float tq = reduce16_over32(ssq, lane, r2);
+        const float ts = reduce16_over32(s1, lane, r1);
+        const float tq = reduce16_over32(s2, lane, r2);
         const int k = 8 * (r1 >> 2) + 4 * fh + (r1 & 3);
         if ((lane & 1) == 0 && k < K) {
             partials[(gw * 2 + 0) * K + k] = ts;
@@ -618,7 +657,7 @@ static int small_fwd_band_rows(int Ho, int Wo, int C) {
     const int nseg = (Wo + 31) / 32, XPW = nseg * 32 + 2;
     const long long row_l = (long long)XPW * (C * 2 + 16), row_chunks = (long long)XPW * (C / 8);
     long long R = FB_LDS / row_l - 2;
-    while (R >= 1 && (R + 2) * row_chunks > (long long)FSL * TPB) --R;
+    while (R >= 1 && (R + 2) * row_chunks > (long long)FSL * FTPB) --R;
     if (R > Ho) R = Ho;
     if (R > 16) R = 16;
     return R < 1 ? 0 : (int)R;
@@ -632,7 +671,7 @@ static long long small_fwd_band_plan(int N, int Ho, int Wo, int C, bool stats, i
     bands = (long long)N * bpi;
     long long grid = bands < 512 ? bands : 512;
     const long long max_rows = ((long long)N * Ho * Wo + 63) / 64;   // the caller's statistics buffer
-    if (stats && grid * 4 > max_rows) grid = max_rows / 4;
+    if (stats && grid * FNW > max_rows) grid = max_rows / FNW;
     return grid >= 1 ? grid : 0;
 }
 
@@ -644,12 +683,12 @@ int kp_conv_small_fwd(const void* x, const void* w, const float* bias, void* y, 
         int R, bpi;
         long long bands;
         if (const long long grid = small_fwd_band_plan(N, Ho, Wo, C, stats != nullptr, R, bpi, bands)) {
-            if (stats) kp_set_last_rows(grid * 4);
+            if (stats) kp_set_last_rows(grid * FNW);
             KP_QUERY_RETURN();
             if (C == 16)
-                conv3x3_small_band_k<1, false><<<(unsigned)grid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, K, R, bpi, bands, BnIn{});
+                conv3x3_small_band_k<1, false><<<(unsigned)grid, FTPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, K, R, bpi, bands, BnIn{});
             else
-                conv3x3_small_band_k<2, false><<<(unsigned)grid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, K, R, bpi, bands, BnIn{});
+                conv3x3_small_band_k<2, false><<<(unsigned)grid, FTPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, K, R, bpi, bands, BnIn{});
             return kp_check_launch("conv3x3_small_band");
         }
     }
@@ -686,13 +725,13 @@ int kp_conv_small_fwd_bnin(const void* yprev, const float* mean, const float* in
     long long bands;
     const long long grid = small_fwd_band_plan(N, Ho, Wo, C, stats != nullptr, R, bpi, bands);
     if (!grid) return KP_E_UNSUPPORTED;
-    if (stats) kp_set_last_rows(grid * 4);
+    if (stats) kp_set_last_rows(grid * FNW);
     KP_QUERY_RETURN();
     const BnIn bn{mean, invstd, gamma, beta, slope};
     if (C == 16)
-        conv3x3_small_band_k<1, true><<<(unsigned)grid, TPB, 0, st>>>((const h16_t*)yprev, (const h16_t*)w, bias, (h16_t*)y, stats, Ho + 2, Wo + 2, K, R, bpi, bands, bn);
+        conv3x3_small_band_k<1, true><<<(unsigned)grid, FTPB, 0, st>>>((const h16_t*)yprev, (const h16_t*)w, bias, (h16_t*)y, stats, Ho + 2, Wo + 2, K, R, bpi, bands, bn);
     else
-        conv3x3_small_band_k<2, true><<<(unsigned)grid, TPB, 0, st>>>((const h16_t*)yprev, (const h16_t*)w, bias, (h16_t*)y, stats, Ho + 2, Wo + 2, K, R, bpi, bands, bn);
+        conv3x3_small_band_k<2, true><<<(unsigned)grid, FTPB, 0, st>>>((const h16_t*)yprev, (const h16_t*)w, bias, (h16_t*)y, stats, Ho + 2, Wo + 2, K, R, bpi, bands, bn);
     return kp_check_launch("conv3x3_small_band_bnin");
 }
 
