@@ -81,6 +81,7 @@ int kp_config(int key, int value);
 #define KP_WALK_STREAM_LOADS 128  /* the BatchNorm passes read with non-temporal loads (nothing re-reads their inputs soon) */
 #define KP_WALK_V4_ALL 0xfe00
 #define KP_WALK_DEFAULT (KP_WALK_CONV_LINEAR | KP_WALK_FWD_REVERSE | KP_WALK_REDUCE_REVERSE | KP_WALK_STREAM_LOADS | KP_WALK_V4_ALL)
+#define KP_CFG_BN_FLAT 8      /* 1 (default): BatchNorm-backward passes of narrow, few-channel maps keep their loads in flight across image rows (bn_bwd_flat_k); 0: row kernel */
 #define KP_CFG_SMALL_BAND 7   /* 1 (default): LDS-staged weight gradient of the 16/32-channel layers where a band of rows fits; 0: gather kernel */
 #define KP_CFG_CUS 6          /* CU budget the persistent kernels size their grids to (launches on a CU-masked stream); 0 = whole device */
 #define KP_CFG_TRACE 2        /* device buffer of 512 int64: s_memtime stamps of workgroup 0 of the patch conv kernel */

@@ -289,6 +289,28 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
         return kp_check_launch("bn_bwd_pool_fast");
     }
     const int vv = pick_v(mode ? KP_WALK_V4_APPLY : KP_WALK_V4_REDUCE, C);
+    extern kp_knob_t g_kp_bn_flat;
+    // narrow maps with few channels (Pong-class nets): the row kernel's UNB x (TPB / CV) pixel slots are mostly empty -> the
+    // kernel whose slots run over all rows of the workgroup (bn_bwd_flat_k).  Wide layers (model F) keep the row kernel.
+    const int unb = vv == 4 ? UNB4 : UNB;
+    if (g_kp_bn_flat && W < unb * (TPB / (C / vv)) && H >= 2) {
+        const long long frows = (long long)N * H;
+        const int frpb = rows_per_block(frows, W * (C / 8), kp_device_cus());
+        const unsigned fgrid = (unsigned)((frows + frpb - 1) / frpb);
+        if (mode == 0) kp_set_last_rows(fgrid);
+        KP_QUERY_RETURN();
+#define KP_ARGS (const h16_t*)gsrc, (const h16_t*)y, bn, slope, partials, sums, (h16_t*)dy, dp, N, H, W, C, frows, frpb, walk
+#define KP_BWDF(GPv, MODEv)                                                                       \
+    do {                                                                                          \
+        if (vv == 4) v4::bn_bwd_flat_k<GPv, MODEv><<<fgrid, TPB, 0, st>>>(KP_ARGS);               \
+        else v8::bn_bwd_flat_k<GPv, MODEv><<<fgrid, TPB, 0, st>>>(KP_ARGS);                       \
+    } while (0)
+        if (mode == 0) { if (gp) KP_BWDF(1, 0); else KP_BWDF(0, 0); }
+        else { if (gp) KP_BWDF(1, 1); else KP_BWDF(0, 1); }
+#undef KP_BWDF
+#undef KP_ARGS
+        return kp_check_launch("bn_bwd_flat");
+    }
     const long long rows = mode ? (long long)N * (H + 2 * dp) : (long long)N * H;
     const int rpb = rows_per_block(rows, W * (C / 8), kp_device_cus());
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);

@@ -20,15 +20,32 @@ KERNELS = {'conv3x3_patch_k<128': 'conv_patch_bf16_bn128', 'conv3x3_patch_k<128,
            'conv3x3_patch_k<128, false': 'conv_patch_bf16_bn128_dgrad', 'wgrad3x3_patch_k<128, 64': 'wgrad_patch_bf16_128x64'}
 
 
+# BASELINE config 2 (second set of passes, directory suffix 'c2'): the Pong-class band kernels
+KERNELS_C2 = {'conv3x3_small_band_k<': 'conv_small_band_bf16', 'conv3x3_small_band_k<1, false': 'conv_small_band_bf16_c16',
+              'conv3x3_small_band_k<2, false': 'conv_small_band_bf16_c32', 'conv3x3_small_band_k<1, true': 'conv_small_band_bf16_c16_bnin',
+              'conv3x3_small_band_k<2, true': 'conv_small_band_bf16_c32_bnin', 'wgrad3x3_small_band_k<': 'wgrad_small_band_bf16'}
+
+
 def load(name):
-    f = max(glob.glob(f'gpurun_out/pmc_{name}/*/*counter_collection.csv'), key=os.path.getmtime)
-    return list(csv.DictReader(open(f)))
+    fs = glob.glob(f'gpurun_out/pmc_{name}/*/*counter_collection.csv')
+    if not fs:
+        return []
+    return list(csv.DictReader(open(max(fs, key=os.path.getmtime))))
 
 
 def main(tag):
     out = {}
-    rows = {n: load(n) for n in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES')}
-    for key, label in KERNELS.items():
+    for suffix, kernels in (('', KERNELS), ('c2', KERNELS_C2)):
+        summarise(out, suffix, kernels)
+    json.dump(out, open(f'profiles/{tag}_pmc_summary.json', 'w'), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+def summarise(out, suffix, kernels):
+    rows = {n: load(n + suffix) for n in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES')}
+    if not all(rows.values()):
+        return
+    for key, label in kernels.items():
         acc = collections.defaultdict(lambda: [0.0, 0])
         dur = [0.0, 0]
         for n, rs in rows.items():
@@ -51,9 +68,7 @@ def main(tag):
             gpu_active_cycles_per_launch=gui,
             mfma_util=per['SQ_VALU_MFMA_BUSY_CYCLES'] / (gui * 1024.0),
             effective_clock_ghz=gui / (dur[0] / dur[1]),
-            lds_bank_conflict_frac=per['SQ_LDS_BANK_CONFLICT'] / per['SQ_LDS_IDX_ACTIVE'])
-    json.dump(out, open(f'profiles/{tag}_pmc_summary.json', 'w'), indent=1)
-    print(json.dumps(out, indent=1))
+            lds_bank_conflict_frac=per['SQ_LDS_BANK_CONFLICT'] / max(1.0, per['SQ_LDS_IDX_ACTIVE']))
 
 
 if __name__ == '__main__':
