@@ -481,23 +481,33 @@ __global__ __launch_bounds__(TPB) void wgrad3x3_small_k(const h16_t* __restrict_
 #define KP_WGB_MINW 1   // waves per SIMD the register allocation must admit.  The 9 x 16 accumulators + 48 staging registers do not fit 256: with 2 the kernel spills 60-300 registers and is 1.5-2x slower (measured); as it is it takes 320-470 registers = ONE wave per SIMD, i.e. one workgroup per CU whatever the LDS admits
 #endif
 constexpr int WG_LDS = 77824;
-constexpr int SL = 12;   // 16-byte chunks per thread and tensor in one band (256 threads x 12 x 16 B = 48 KB of each)
+constexpr int SL = 12;   // 16-byte chunks per thread and tensor in one band (256 threads x 12 x 16 B = 48 KB of each) ...
+// ... at most: the narrower tensor of a (K, C) pair never gets its half of the LDS, and every chunk is 4 registers that live
+// across the multiply phase (the 32 x 16 variant spilled with 12 + 12)
+constexpr int sl_x(int K, int C) { return C == 32 ? 12 : (K == 32 ? 8 : 10); }
+constexpr int sl_d(int K, int C) { return K == 32 ? 12 : (C == 32 ? 8 : 10); }
 // BNIN: x is the previous layer's conv output [N][Ho][Wo][C]; its BatchNorm-apply + activation + replicate pad run between the
 // global load and the LDS store (BnIn above), so the weight gradient sees the very fragments the forward multiplied.
+// Occupancy and pipeline.  The 9 x 16 accumulators, the fragments and the staging registers take 320-470 registers: ONE wave
+// per SIMD, i.e. one workgroup per CU whatever the LDS admits (capping the allocation at 256 spills 60-300 registers and is
+// 1.5-2x slower, measured).  So nothing else on the CU can cover a workgroup's staging latency -- the kernel has to do it
+// itself: the band is double buffered in LDS (2 x 76 KB), and ALL global loads of band b + 1 (both tensors, 96 registers:
+// there is room, the file is this wave's alone) are issued before the multiply phase of band b and written to the other
+// buffer behind it; one barrier per band.  One workgroup per CU in the grid, each walking bands blockIdx, + grid, ...
 template <int K, int C, bool BNIN>
-__global__ __launch_bounds__(TPB, KP_WGB_MINW) void wgrad3x3_small_band_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
+__global__ __launch_bounds__(TPB, 1) void wgrad3x3_small_band_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
                                                              float* __restrict__ scratch, int Ho, int Wo, int dy_pad, int R,
                                                              int bands_per_img, long long total_bands, long long pstride, BnIn bn) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WG_LDS];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WG_LDS];
     __shared__ __attribute__((aligned(16))) float cst[BNIN ? 4 : 1][32];
     if (BNIN) bnin_fill(cst, bn, C, threadIdx.x);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, h = lane >> 5;
     const int Hi = Ho + 2, Wi = Wo + 2, Hd = Ho + 2 * dy_pad, Wd = Wo + 2 * dy_pad;
     const int Wp = (Wo + 15) & ~15, XP = Wp + 2, nseg = Wp / 16;
     const int xrow_b = XP * C * 2, drow_b = Wp * K * 2;            // LDS bytes per staged row (multiples of 16)
-    unsigned char* xl = smem;                                       // [(R + 2)][XP][C]
-    unsigned char* dl = smem + (size_t)(R + 2) * xrow_b;            // [R][Wp][K]
+    const int dl_off = (R + 2) * xrow_b;                           // a buffer = [(R + 2)][XP][C] input rows, then [R][Wp][K] gradient rows
     // transpose-read lane roles: t = lane & 15 -> (pixel t / 4, chunk t % 4); g = bit 4 -> 16-channel half; lane / 32 -> pixels 8..15
     const int t16 = lane & 15, g16 = (lane >> 4) & 1;
     const int trow = 8 * h + (t16 >> 2);
@@ -509,73 +519,84 @@ __global__ __launch_bounds__(TPB, KP_WGB_MINW) void wgrad3x3_small_band_k(const 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    for (long long band = blockIdx.x; band < total_bands; band += gridDim.x) {
+    // ---- staging: input rows p0 .. p0 + rows + 1 (Wi pixels each, zero-filled to XP), gradient rows (Wo pixels, zero-filled to
+    //      Wp); chunk -> (row, column) by carries, no divisions.  issue(): every 16-byte load of a band in flight at once;
+    //      commit(): (BNIN: BatchNorm + activation of the input chunks,) LDS stores.
+    const int xc = xrow_b / 16, xvalid = Wi * C * 2 / 16, dc = drow_b / 16, dvalid = Wo * K * 2 / 16;
+    const int xrow_g = Wi * C * 2, drow_g = Wd * K * 2;
+    const int xdr = TPB / xc, xdc = TPB % xc, ddr = TPB / dc, ddc = TPB % dc;
+    constexpr int SLX = sl_x(K, C), SLD = sl_d(K, C);
+    uint4 sbx[SLX], sbd[SLD];
+    unsigned livex = 0;      // BNIN: input chunks that hold image data
+    int rows_staged = 0;     // rows of the band the staging registers hold
+    auto issue = [&](long long band) {
         const long long n = band / bands_per_img;
         const int p0 = (int)(band % bands_per_img) * R;
         const int rows = Ho - p0 < R ? Ho - p0 : R;
-        __syncthreads();   // the previous band's fragments have been read
-        // ---- stage: input rows p0 .. p0 + rows + 1 (Wi pixels each, zero-filled to XP), gradient rows (Wo pixels, zero-filled
-        //      to Wp).  ALL of a thread's 16-byte loads are issued before its first LDS store (<= SL chunks per thread and
-        //      tensor: a loop of load -> store pairs serialises the HBM latency, ~20 round trips per band); chunk -> (row,
-        //      column) by carries, no divisions.
-        {
-            const int xc = xrow_b / 16, xvalid = Wi * C * 2 / 16, xtot = (rows + 2) * xc;
-            const int dc = drow_b / 16, dvalid = Wo * K * 2 / 16, dtot = rows * dc;
-            const unsigned char* xg = BNIN ? (const unsigned char*)x + ((n * Ho * Wo) * (long long)C) * 2
-                                           : (const unsigned char*)x + (((n * Hi + p0) * Wi) * (long long)C) * 2;
-            const unsigned char* dg = (const unsigned char*)dy + ((((n * Hd + p0 + dy_pad) * Wd) + dy_pad) * (long long)K) * 2;
-            const int xrow_g = Wi * C * 2, drow_g = Wd * K * 2;
-            const int xdr = TPB / xc, xdc = TPB % xc, ddr = TPB / dc, ddc = TPB % dc;
-            // (two rounds -- input rows, then gradient rows -- of SL registers-quads each: both tensors in flight at once
-            //  need 96 staging registers on top of the 144 accumulators and spill)
-            uint4 sb[SL];
-            unsigned live = 0;   // BNIN: chunks that hold image data
-            int r = tid / xc, c16 = tid % xc;
+        rows_staged = rows;
+        const int xtot = (rows + 2) * xc, dtot = rows * dc;
+        const unsigned char* xg = BNIN ? (const unsigned char*)x + ((n * Ho * Wo) * (long long)C) * 2
+                                       : (const unsigned char*)x + (((n * Hi + p0) * Wi) * (long long)C) * 2;
+        const unsigned char* dg = (const unsigned char*)dy + ((((n * Hd + p0 + dy_pad) * Wd) + dy_pad) * (long long)K) * 2;
+        livex = 0;
+        int r = tid / xc, c16 = tid % xc;
 #pragma unroll
-            for (int u = 0; u < SL; ++u) {
-                sb[u] = make_uint4(0, 0, 0, 0);
-                if (tid + u * TPB < xtot && c16 < xvalid) {
-                    if (BNIN) {   // chunk c16 of padded row p0 + r = (pixel c16 / CPP, channels 8 * (c16 % CPP) ..) <- clamped source
-                        constexpr int CPP = C / 8;
-                        const int px = c16 / CPP, cg = c16 % CPP;
-                        const int sr = p0 + r - 1 < 0 ? 0 : (p0 + r - 1 > Ho - 1 ? Ho - 1 : p0 + r - 1);
-                        const int sc = px - 1 < 0 ? 0 : (px - 1 > Wo - 1 ? Wo - 1 : px - 1);
-                        sb[u] = *reinterpret_cast<const uint4*>(xg + (((long long)sr * Wo + sc) * CPP + cg) * 16);
-                        live |= 1u << u;
-                    } else {
-                        sb[u] = *reinterpret_cast<const uint4*>(xg + (long long)r * xrow_g + c16 * 16);
-                    }
-                }
-                r += xdr; c16 += xdc;
-                if (c16 >= xc) { c16 -= xc; ++r; }
-            }
-            if (BNIN) {
-                BnReg k;
-                k.load(cst, (tid % (C / 8)) * 8);   // TPB and xc are multiples of C / 8: a thread's chunks all hold the same channels
-#pragma unroll
-                for (int u = 0; u < SL; ++u) {
-                    const uint4 t = bnin_apply(sb[u], k, bn.slope);
-                    const bool on = live & (1u << u);
-                    sb[u] = make_uint4(on ? t.x : 0u, on ? t.y : 0u, on ? t.z : 0u, on ? t.w : 0u);
+        for (int u = 0; u < SLX; ++u) {
+            sbx[u] = make_uint4(0, 0, 0, 0);
+            if (tid + u * TPB < xtot && c16 < xvalid) {
+                if (BNIN) {   // chunk c16 of padded row p0 + r = (pixel c16 / CPP, channels 8 * (c16 % CPP) ..) <- clamped source
+                    constexpr int CPP = C / 8;
+                    const int px = c16 / CPP, cg = c16 % CPP;
+                    const int sr = p0 + r - 1 < 0 ? 0 : (p0 + r - 1 > Ho - 1 ? Ho - 1 : p0 + r - 1);
+                    const int sc = px - 1 < 0 ? 0 : (px - 1 > Wo - 1 ? Wo - 1 : px - 1);
+                    sbx[u] = *reinterpret_cast<const uint4*>(xg + (((long long)sr * Wo + sc) * CPP + cg) * 16);
+                    livex |= 1u << u;
+                } else {
+                    sbx[u] = *reinterpret_cast<const uint4*>(xg + (long long)r * xrow_g + c16 * 16);
                 }
             }
-#pragma unroll
-            for (int u = 0; u < SL; ++u)
-                if (tid + u * TPB < xtot) *reinterpret_cast<uint4*>(xl + (tid + u * TPB) * 16) = sb[u];
-            __builtin_amdgcn_sched_barrier(0);
-            int r2 = tid / dc, d16 = tid % dc;
-#pragma unroll
-            for (int u = 0; u < SL; ++u) {
-                sb[u] = make_uint4(0, 0, 0, 0);
-                if (tid + u * TPB < dtot && d16 < dvalid) sb[u] = *reinterpret_cast<const uint4*>(dg + (long long)r2 * drow_g + d16 * 16);
-                r2 += ddr; d16 += ddc;
-                if (d16 >= dc) { d16 -= dc; ++r2; }
-            }
-#pragma unroll
-            for (int u = 0; u < SL; ++u)
-                if (tid + u * TPB < dtot) *reinterpret_cast<uint4*>(dl + (tid + u * TPB) * 16) = sb[u];
+            r += xdr; c16 += xdc;
+            if (c16 >= xc) { c16 -= xc; ++r; }
         }
-        __syncthreads();
+        int r2 = tid / dc, d16 = tid % dc;
+#pragma unroll
+        for (int u = 0; u < SLD; ++u) {
+            sbd[u] = make_uint4(0, 0, 0, 0);
+            if (tid + u * TPB < dtot && d16 < dvalid) sbd[u] = *reinterpret_cast<const uint4*>(dg + (long long)r2 * drow_g + d16 * 16);
+            r2 += ddr; d16 += ddc;
+            if (d16 >= dc) { d16 -= dc; ++r2; }
+        }
+    };
+    auto commit = [&](unsigned char* buf) {
+        const int xtot = (rows_staged + 2) * xc, dtot = rows_staged * dc;
+        if (BNIN) {
+            BnReg k;
+            k.load(cst, (tid % (C / 8)) * 8);   // TPB and xc are multiples of C / 8: a thread's chunks all hold the same channels
+#pragma unroll
+            for (int u = 0; u < SLX; ++u) {
+                const uint4 t = bnin_apply(sbx[u], k, bn.slope);
+                const bool on = livex & (1u << u);
+                sbx[u] = make_uint4(on ? t.x : 0u, on ? t.y : 0u, on ? t.z : 0u, on ? t.w : 0u);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SLX; ++u)
+            if (tid + u * TPB < xtot) *reinterpret_cast<uint4*>(buf + (tid + u * TPB) * 16) = sbx[u];
+#pragma unroll
+        for (int u = 0; u < SLD; ++u)
+            if (tid + u * TPB < dtot) *reinterpret_cast<uint4*>(buf + dl_off + (tid + u * TPB) * 16) = sbd[u];
+    };
+
+    long long band = blockIdx.x;
+    __syncthreads();                     // (BNIN: the constants are in place)
+    if (band < total_bands) { issue(band); commit(smem); }
+    __syncthreads();
+    int cur = 0, rows = rows_staged;
+    for (; band < total_bands; band += gridDim.x) {
+        const bool more = band + gridDim.x < total_bands;
+        if (more) issue(band + gridDim.x);                    // in flight during the multiply phase below
+        const unsigned char* xl = smem + cur * WG_LDS;
+        const unsigned char* dl = xl + dl_off;
         // ---- multiply: items (row, 16-pixel segment) round-robin over the four wavefronts.  A fragment (lane: channel
         //      lane % 32, 8 consecutive pixels 8 * (lane / 32) ..) is two ds_read_b64_tr_b16: per 16-lane group the
         //      instruction hands lane i the 4 rows of column i of a [4 pixels][16 channels] block, lane t supplying the
@@ -601,22 +622,26 @@ __global__ __launch_bounds__(TPB, KP_WGB_MINW) void wgrad3x3_small_band_k(const 
 #pragma unroll
             for (int rr = 0; rr < 3; ++rr) {
                 const unsigned char* b = xl + (r + rr) * xrow_b + prow * (C * 2) + chunkb;
-                unsigned R[5] = {0u, 0u, 0u, 0u, 0u};      // (p0,p1) (p2,p3) (p4,p5) (p6,p7) (p8,p9), p = pixel 8h + ..
+                unsigned Rg[5] = {0u, 0u, 0u, 0u, 0u};      // (p0,p1) (p2,p3) (p4,p5) (p6,p7) (p8,p9), p = pixel 8h + ..
                 if (cval) {
                     const uint2 q0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b)));
                     const uint2 q1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + 4 * (C * 2))));
                     const uint2 q2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + 8 * (C * 2))));
-                    R[0] = q0.x; R[1] = q0.y; R[2] = q1.x; R[3] = q1.y; R[4] = q2.x;
+                    Rg[0] = q0.x; Rg[1] = q0.y; Rg[2] = q1.x; Rg[3] = q1.y; Rg[4] = q2.x;
                 }
-                const u32x4 f0 = {R[0], R[1], R[2], R[3]};
-                const u32x4 f1 = {__builtin_amdgcn_alignbit(R[1], R[0], 16), __builtin_amdgcn_alignbit(R[2], R[1], 16),
-                                  __builtin_amdgcn_alignbit(R[3], R[2], 16), __builtin_amdgcn_alignbit(R[4], R[3], 16)};
-                const u32x4 f2 = {R[1], R[2], R[3], R[4]};
+                const u32x4 f0 = {Rg[0], Rg[1], Rg[2], Rg[3]};
+                const u32x4 f1 = {__builtin_amdgcn_alignbit(Rg[1], Rg[0], 16), __builtin_amdgcn_alignbit(Rg[2], Rg[1], 16),
+                                  __builtin_amdgcn_alignbit(Rg[3], Rg[2], 16), __builtin_amdgcn_alignbit(Rg[4], Rg[3], 16)};
+                const u32x4 f2 = {Rg[1], Rg[2], Rg[3], Rg[4]};
                 acc[rr * 3 + 0] = kp_mfma16(af, __builtin_bit_cast(h16x8, f0), acc[rr * 3 + 0], 0, 0, 0);
                 acc[rr * 3 + 1] = kp_mfma16(af, __builtin_bit_cast(h16x8, f1), acc[rr * 3 + 1], 0, 0, 0);
                 acc[rr * 3 + 2] = kp_mfma16(af, __builtin_bit_cast(h16x8, f2), acc[rr * 3 + 2], 0, 0, 0);
             }
         }
+        if (more) commit(smem + (cur ^ 1) * WG_LDS);          // the other buffer: its readers passed the previous barrier
+        __syncthreads();
+        cur ^= 1;
+        rows = rows_staged;
     }
     // D[k][c]: lane col = c (fr), rows k = (i&3) + 8*(i>>2) + 4*h.  The four wavefronts are summed per tap through LDS (fixed
     // order); the workgroup's sum is ITS partial gradient (kp_wgrad_unpack adds the partials in order).
@@ -648,7 +673,9 @@ static int small_band_rows(int Ho, int Wo, int C, int K) {
     long long R = (WG_LDS - 2 * xrow) / (xrow + drow);
     if (R > Ho) R = Ho;
     if (R > 16) R = 16;
-    while (R >= 1 && ((R + 2) * xrow > (long long)SL * TPB * 16 || R * drow > (long long)SL * TPB * 16)) --R;
+    const long long capx = (long long)(C == 32 ? sl_x(32, 32) : (K == 32 ? sl_x(32, 16) : sl_x(16, 16))) * TPB * 16;
+    const long long capd = (long long)(K == 32 ? sl_d(32, 32) : (C == 32 ? sl_d(16, 32) : sl_d(16, 16))) * TPB * 16;
+    while (R >= 1 && ((R + 2) * xrow > capx || R * drow > capd)) --R;
     return R < 1 ? 0 : (int)R;
 }
 
@@ -746,7 +773,9 @@ static unsigned small_band_plan(int N, int Ho, int Wo, int C, int K, int& R, int
     if (!R) return 0;
     bpi = (Ho + R - 1) / R;
     const long long bands = (long long)N * bpi;
-    return (unsigned)(bands < 512 ? bands : 512);   // two workgroups per CU; a workgroup walks bands blockIdx, + grid, ...
+    int cus = kp_device_cus();
+    if (cus < 1) cus = 256;
+    return (unsigned)(bands < cus ? bands : cus);   // one workgroup per CU (registers, 2 x 76 KB of LDS); it walks bands blockIdx, + grid, ...
 }
 
 static unsigned small_wgrad_plan(int N, int Ho, int C, int K, int& rpw) {
