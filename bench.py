@@ -409,7 +409,7 @@ def _run_leg(args, rank, world, dev):
         # inside the process, so it is the committed per-launch figure of the last profiled build (or null).
         traffic, pmc, pmc_file = None, None, None
         pmc_key = 'conv_small_band_bf16' if dom[0] == 'conv_small_16bit' else 'conv_patch_bf16_bn128'
-        for cand in ('r03_pmc_summary.json', 'r02n_pmc_summary.json', 'r02j_pmc_summary.json', 'r02g_pmc_summary.json', 'r02_pmc_summary.json', 'r01_pmc_summary.json'):
+        for cand in ('r03b_pmc_summary.json', 'r02n_pmc_summary.json', 'r02j_pmc_summary.json', 'r02g_pmc_summary.json', 'r02_pmc_summary.json', 'r01_pmc_summary.json'):
             try:
                 pmc = json.load(open(os.path.join(ROOT, 'profiles', cand)))[pmc_key]
                 traffic, pmc_file = pmc['hbm_bytes_per_launch'], cand
@@ -486,13 +486,14 @@ def _run_leg(args, rank, world, dev):
 
 
 EXTRA_CONFIGS = [
-    # (key, overrides): the other BASELINE.json configurations a single MI355X can hold, in their named precision and per-GPU batch
+    # (key, overrides, steps as a multiple of --extra-steps): the other BASELINE.json configurations a single MI355X can hold, in
+    # their named precision and per-GPU batch (config 2's step is 4 ms: it gets 6x the steps so that its leg is not all ramp)
     ('config2_pong_bf16_b256', dict(net='transporter', model_type='VGG_PONG_LAYERNECK', model_in_channels=1, model_z_channels=16,
-                                    model_keypoints=4, size=84, batch=256, precision='bf16')),
+                                    model_keypoints=4, size=84, batch=256, precision='bf16'), 6),
     ('config3_keynet_tps_bf16_b128', dict(net='keynet', model_type='F', model_in_channels=3, model_z_channels=64, model_keypoints=10,
-                                          size=128, batch=128, precision='bf16')),
+                                          size=128, batch=128, precision='bf16'), 2),
     ('config5_F256_K30_fp16_b256', dict(net='transporter', model_type='F', model_in_channels=3, model_z_channels=64,
-                                        model_keypoints=30, size=256, batch=256, precision='fp16')),
+                                        model_keypoints=30, size=256, batch=256, precision='fp16'), 1),
 ]
 
 
@@ -542,11 +543,11 @@ def main():
                                                ratio_to_headline=o['value'] / line['value'])}
         # (b) the other BASELINE configurations, short legs with their own roofline
         line['extra_configs'] = {}
-        for key, over in EXTRA_CONFIGS:
+        for key, over, mult in EXTRA_CONFIGS:
             leg = copy.copy(args)
             for k, v in over.items():
                 setattr(leg, k, v)
-            leg.steps, leg.warmup, leg.profile_steps, leg.no_augment = args.extra_steps, 3, 1, False
+            leg.steps, leg.warmup, leg.profile_steps, leg.no_augment = args.extra_steps * mult, 2 + mult, 1, False
             try:
                 r = run_leg(leg, rank, world, dev)
                 for k in ('n_gpus', 'higher_is_better', 'scaling', 'vs_baseline', 'data', 'unit'):
