@@ -332,6 +332,9 @@ int kp_warp_tps(const float* x, const float* theta, const float* ctrl, float* ou
                 int reduced, int ctrl_batched, void* stream);
 /* out = F.grid_sample(x, F.affine_grid(mat, x.shape), padding_mode='zeros'); mat [N][2][3]   tps.py:154-166 */
 int kp_warp_affine(const float* x, const float* mat, float* out, int N, int C, int H, int W, void* stream);
+/* the same for per-sample ROTATIONS given as angles [N] (radians) on the device: the matrix [[cos, sin, 0], [-sin, cos, 0]] of
+ * rotate_affine_grid_multi (tps.py:154-166) is formed in the kernel instead of on the host */
+int kp_warp_rotate(const float* x, const float* angle, float* out, int N, int C, int H, int W, void* stream);
 
 /* ---- loss and optimiser -------------------------------------------------- */
 /* l2_reconstruction_loss (transporter.py:56-60): loss_sum[0] += sum (x-t)^2*mask (fp64, zeroed by caller);

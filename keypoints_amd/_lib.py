@@ -52,6 +52,7 @@ SIGNATURES = {
     'kp_keypoint_bottleneck_bwd': [_p] * 13 + [_i] * 5 + [_f, _f, _p],
     'kp_warp_tps': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'kp_warp_affine': [_p, _p, _p, _i, _i, _i, _i, _p],
+    'kp_warp_rotate': [_p, _p, _p, _i, _i, _i, _i, _p],
     'kp_l2_loss': [_p, _p, _p, _p, _p, _f, _z, _p],
     'kp_scale': [_p, _p, _p, _z, _p],
     'kp_adam_step': [_p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _f, _p],

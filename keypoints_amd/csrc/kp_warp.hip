@@ -89,6 +89,24 @@ __global__ __launch_bounds__(TPB) void warp_affine_k(const float* __restrict__ x
     for (int c = 0; c < C; ++c) out[((long long)n * C + c) * hw + o] = sample(x + ((long long)n * C + c) * hw, tp, W);
 }
 
+// the same with the matrix of a pure rotation built per sample on the device: [[cos a, sin a, 0], [-sin a, cos a, 0]]
+// (tps.py:154-166 builds it on the CPU from the drawn angles and ships it)
+__global__ __launch_bounds__(TPB) void warp_rotate_k(const float* __restrict__ x, const float* __restrict__ angle,
+                                                     float* __restrict__ out, int N, int C, int H, int W) {
+    const long long pix = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (pix >= (long long)N * H * W) return;
+    const int j = (int)(pix % W);
+    const int i = (int)((pix / W) % H);
+    const int n = (int)(pix / ((long long)W * H));
+    const float xb = (W > 1 ? (-1.f + 2.f * (float)j / (float)(W - 1)) : 0.f) * ((float)(W - 1) / (float)W);
+    const float yb = (H > 1 ? (-1.f + 2.f * (float)i / (float)(H - 1)) : 0.f) * ((float)(H - 1) / (float)H);
+    const float a = angle[n];
+    const float ca = cosf(a), sa = sinf(a);
+    const Taps tp = make_taps(ca * xb + sa * yb + 0.f, -sa * xb + ca * yb + 0.f, H, W);
+    const long long hw = (long long)H * W, o = (long long)i * W + j;
+    for (int c = 0; c < C; ++c) out[((long long)n * C + c) * hw + o] = sample(x + ((long long)n * C + c) * hw, tp, W);
+}
+
 }  // namespace
 
 extern "C" {
@@ -108,6 +126,14 @@ int kp_warp_affine(const float* x, const float* mat, float* out, int N, int C, i
     const long long pix = (long long)N * H * W;
     warp_affine_k<<<cdiv(pix, TPB), TPB, 0, (hipStream_t)stream>>>(x, mat, out, N, C, H, W);
     return kp_check_launch("warp_affine");
+}
+
+int kp_warp_rotate(const float* x, const float* angle, float* out, int N, int C, int H, int W, void* stream) {
+    KP_REQUIRE(x && angle && out, "kp_warp_rotate: null pointer");
+    KP_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "kp_warp_rotate: bad dims");
+    const long long pix = (long long)N * H * W;
+    warp_rotate_k<<<cdiv(pix, TPB), TPB, 0, (hipStream_t)stream>>>(x, angle, out, N, C, H, W);
+    return kp_check_launch("warp_rotate");
 }
 
 }  // extern "C"

@@ -22,6 +22,23 @@ def peturb(x, tps_theta, cntl_pts, theta_rotate):
     return _tps.rotate_affine_grid_multi(warped, theta_rotate)
 
 
+def _ship_once(params, device):
+    """All tensors of one random draw (TPS weights, control points, angles: a few KB) to `device` in ONE non-blocking copy
+    through a pinned staging buffer, returned as views of the device buffer.  The reference -- and round 2 here -- uploaded every
+    tensor for every warp (image and mask: 6 pageable, i.e. host-blocking, copies per draw)."""
+    if device.type != 'cuda':
+        return params
+    flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+    stage = torch.empty(flat.numel(), dtype=torch.float32, pin_memory=True)
+    stage.copy_(flat)
+    dev = stage.to(device, non_blocking=True)
+    out, off = [], 0
+    for p in params:
+        out.append(dev[off:off + p.numel()].view(p.shape))
+        off += p.numel()
+    return tuple(out)
+
+
 def nop(*data):
     """No augmentation: (x, x_) pass through, no loss mask."""
     return data[0], data[1], None
@@ -43,7 +60,7 @@ class TpsAndRotate(object):
         valid = torch.ones_like(image)
         stages = []
         for _ in range(2):                      # draw, warp the image, warp the mask -- in the reference's order
-            params = self._draw(image.size(0))
+            params = _ship_once(self._draw(image.size(0)), image.device)
             image = peturb(image, *params)
             valid = peturb(valid, *params)
             stages.append(image)

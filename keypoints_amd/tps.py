@@ -35,17 +35,17 @@ def tps_transform(x, theta, cnt_points):
 
 
 def rotate_affine_grid_multi(x, theta):
-    """Per-sample rotation by `theta` radians through affine_grid + grid_sample semantics (tps.py:154-166)."""
+    """Per-sample rotation by `theta` radians through affine_grid + grid_sample semantics (tps.py:154-166).  The rotation
+    matrices are formed on the device from the angles (kp_warp_rotate): nothing is built on the host, and angles that are
+    already on the device (data_augments.TpsAndRotate ships a whole draw in one copy) cost no transfer at all."""
     require_device(x)
     x = f32c(x)
     N, C, H, W = x.shape
-    ang = theta.detach().float().cpu()
-    mat = torch.zeros(N, 2, 3, dtype=torch.float32)
-    mat[:, 0, 0] = torch.cos(ang); mat[:, 0, 1] = torch.sin(ang)
-    mat[:, 1, 0] = -torch.sin(ang); mat[:, 1, 1] = torch.cos(ang)
-    md = mat.to(x.device)
+    ang = f32c(theta.detach().reshape(-1).to(x.device))
+    if ang.numel() != N:
+        raise ValueError(f'{ang.numel()} angles for a batch of {N}')
     out = torch.empty_like(x)
-    call('kp_warp_affine', ptr(x), ptr(md), ptr(out), N, C, H, W, stream_ptr())
+    call('kp_warp_rotate', ptr(x), ptr(ang), ptr(out), N, C, H, W, stream_ptr())
     return out
 
 

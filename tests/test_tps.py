@@ -68,6 +68,36 @@ def test_hip_tps_and_rotate_match_reference_vectors(golden, tag):
 
 
 @pytest.mark.gpu
+def test_rotation_from_device_angles_equals_the_host_built_matrices():
+    """kp_warp_rotate (matrix [[cos, sin, 0], [-sin, cos, 0]] formed in the kernel from angles on the device) against
+    kp_warp_affine fed the matrices tps.py:159-165 builds on the CPU; and TpsAndRotate with its one pinned upload per draw
+    against peturb() called with CPU parameters (the two differ by how the parameters travel, not by a single bit of them)."""
+    from keypoints_amd import _lib, data_augments as DA
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(5, 3, 37, 50, generator=g).cuda()
+    ang = (torch.rand(5, generator=g) * 2 - 1) * 0.3
+    mat = torch.zeros(5, 2, 3)
+    mat[:, 0, 0] = torch.cos(ang); mat[:, 0, 1] = torch.sin(ang)
+    mat[:, 1, 0] = -torch.sin(ang); mat[:, 1, 1] = torch.cos(ang)
+    a, b = torch.empty_like(x), torch.empty_like(x)
+    call('kp_warp_affine', ptr(x), ptr(mat.cuda()), ptr(a), 5, 3, 37, 50, stream_ptr())
+    call('kp_warp_rotate', ptr(x), ptr(ang.cuda()), ptr(b), 5, 3, 37, 50, stream_ptr())
+    assert float((a - b).abs().max()) <= 2e-6      # cosf / sinf on the device vs torch's on the CPU: an ulp of the matrix
+    torch.manual_seed(11)
+    aug = DA.TpsAndRotate(4, 0.05, 0.1)
+    x1, x2, mask = aug(x, x)
+    torch.manual_seed(11)
+    p1 = DA.rand_peturb_params(5, 4, 0.05, 0.1)
+    p2 = DA.rand_peturb_params(5, 4, 0.05, 0.1)
+    r1 = DA.peturb(x, *p1)
+    r2 = DA.peturb(r1, *p2)
+    rm = DA.peturb(DA.peturb(torch.ones_like(x), *p1), *p2)
+    assert torch.equal(x1, r1) and torch.equal(x2, r2) and torch.equal(mask, rm)
+
+
+@pytest.mark.gpu
 def test_hip_tps_full_size_properties():
     """128x128x3 batch of 128 (config 3 shape): identity parameters reproduce the image up to the half-pixel
     resampling of align_corners=False (interior of a constant image stays constant; mask of ones stays <= 1)."""
