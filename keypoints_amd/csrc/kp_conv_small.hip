@@ -233,13 +233,15 @@ constexpr int FSL = 12 * 256 / FTPB;   // 16-byte chunks per thread in one band 
 // parts of every address are constants computed once, the staging tables (LDS offset, source offset, row of each of a
 // thread's chunks) are built once per kernel instead of once per band, statistics use packed FMAs and are skipped -- like
 // the lane mask of ragged segments -- where a wave-uniform test says they are not needed.
-template <int CB, bool BNIN>
+// WREG: the 9 x CB weight fragments live in registers (36 / 72 VGPRs) instead of LDS: occupancy is set by the band's LDS here, not by
+// registers, and an item then issues 9 x CB LDS reads instead of 18 x CB (the 32-channel BatchNorm-input variant has no room).
+template <int CB, bool BNIN, bool WREG = !(BNIN && CB == 2)>
 __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
                                                             const float* __restrict__ bias, h16_t* __restrict__ y,
                                                             float* __restrict__ partials, int Hi, int Wi, int K, int R,
                                                             int bands_per_img, long long total_bands, BnIn bn) {
     constexpr int C = CB * 16, PITCH = C * 2 + 16, CPP = C / 8;   // chunks of 16 bytes per pixel
-    __shared__ h16x8 swf[9 * CB][64];
+    __shared__ h16x8 swf[WREG ? 1 : 9 * CB][64];
     __shared__ __attribute__((aligned(16))) unsigned char xl[FB_LDS];
     __shared__ __attribute__((aligned(16))) float cst[BNIN ? 4 : 1][32];
     if (BNIN) bnin_fill(cst, bn, C, threadIdx.x);
@@ -248,14 +250,16 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
     const int fr = lane & 31, fh = lane >> 5;
     const int Ho = Hi - 2, Wo = Wi - 2;
     const int nseg = (Wo + 31) / 32, XPW = nseg * 32 + 2, xrow_l = XPW * PITCH;
-    if (wave == 0) {
+    h16x8 wreg[WREG ? 9 * CB : 1];
+    if (WREG || wave == 0) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (fr < K) v = *reinterpret_cast<const h16x8*>(w + ((long long)fr * 9 + t) * C + cb * 16 + fh * 8);
-                swf[t * CB + cb][lane] = v;
+                if (WREG) wreg[t * CB + cb] = v;
+                else swf[t * CB + cb][lane] = v;
             }
     }
     // D[k][px]: lane: pixel = fr, k = 8 * (reg >> 2) + 4 * fh + (reg & 3); register PAIRS (2j, 2j + 1) are the packed operands
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
 #pragma unroll
             for (int t = 0; t < 9 * CB; ++t) {
                 if (KP_FB_ABL & 8) acc[t & 15] += (float)xf[t][0];
-                else acc = kp_mfma16(swf[t][lane], xf[t], acc, 0, 0, 0);   // (two accumulator chains: no faster, measured)
+                else acc = kp_mfma16(WREG ? wreg[t] : swf[t][lane], xf[t], acc, 0, 0, 0);   // (two accumulator chains: no faster, measured)
             }
             f32x2 v[8];
 #pragma unroll
