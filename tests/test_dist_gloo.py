@@ -26,6 +26,8 @@ def _worker(rank, world, port, q):
         ref = [torch.empty_like(w0) for _ in range(world)]
         dist.all_gather(ref, w0)
         same_init = all(torch.equal(ref[0], r) for r in ref)
+        seen = red.ranks_seen()      # bench.py's dp.nccl_ranks: a SUM all-reduce of ones through the gradient transport itself
+        same_init = same_init and seen['allreduce_of_ones'] == world and seen['comm_count'] == world and 'gloo' in seen['transport']
         # emulate the end of each Unit's backward: arenas hold rank-dependent gradients
         units = [net.decoder, net.keypoint, net.feature]    # backward order
         pieces = 0
