@@ -131,8 +131,12 @@ __global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const h16_t* __restrict
 }
 
 // scratch[k][tap][c] += sum_pixels dy[pixel][k] * x[pixel + tap][c]
-template <int CIN>
-__global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
+// NW wavefronts per workgroup.  The kernel is a latency chain per image row (stage three input rows, then walk the gradient
+// row): with <= 512 workgroups (= partial gradients) of 4 waves only ~8 waves were resident per CU and the K = 16 / 32 launches
+// of the Pong-class nets took 68 us for a 58 MB tensor (ablations: 15.7 us without the walk, 29 without the gradient loads, 41
+// without the input loads).  Sixteen waves per workgroup keep the partial count and put 4x the rows in flight.
+template <int CIN, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3_first_wgrad_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
                                                            float* __restrict__ scratch, int Ho, int Wo, int K,
                                                            int dy_pad, long long total_rows, int rows_per_block) {
     // every workgroup leaves ITS partial gradient in scratch[blockIdx.x][K][J] (plain stores; kp_wgrad_unpack adds them in order)
@@ -140,18 +144,18 @@ __global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const h16_t* __restri
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Hi = Ho + 2, Wi = Wo + 2, Hd = Ho + 2 * dy_pad, Wd = Wo + 2 * dy_pad;
-    const int rowf = Wi * 4;                                  // floats per staged input row (pixel = 4 floats)
-    float* xw = reinterpret_cast<float*>(smem) + (size_t)wave * 3 * rowf;   // this wave's 3 input rows
     const int KS = 64 / K;                                    // pixel streams per wavefront (K = 16, 32, 64)
     const int k = lane % K, stream = lane / K;
     const int PP = (CIN == 1 && KS > 1) ? 1 : 4;              // floats per staged pixel
+    const int rowf = Wi * PP;                                 // floats per staged input row
+    float* xw = reinterpret_cast<float*>(smem) + (size_t)wave * 3 * rowf;   // this wave's 3 input rows
 
     float acc[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) acc[j] = 0.f;
 
     const long long row0 = (long long)blockIdx.x * rows_per_block;
-    for (int rr = wave; rr < rows_per_block; rr += 4) {
+    for (int rr = wave; rr < rows_per_block; rr += NW) {
         const long long row = row0 + rr;
         if (row >= total_rows) break;
         const int p = (int)(row % Ho);
@@ -247,13 +251,15 @@ __global__ __launch_bounds__(TPB) void conv3_first_wgrad_k(const h16_t* __restri
 #pragma unroll
         for (int j = 0; j < J; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
     __syncthreads();                                          // everyone is done with the staged rows
-    float* red = reinterpret_cast<float*>(smem);              // [4][K][J]
+    float* red = reinterpret_cast<float*>(smem);              // [NW][K][J]
     if (stream == 0)
 #pragma unroll
         for (int j = 0; j < J; ++j) red[(wave * K + k) * J + j] = acc[j];
     __syncthreads();
-    for (int i = tid; i < K * J; i += TPB) {
-        const float s = red[i] + red[K * J + i] + red[2 * K * J + i] + red[3 * K * J + i];
+    for (int i = tid; i < K * J; i += NW * 64) {
+        float s = red[i];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) s += red[w2 * K * J + i];   // fixed order
         scratch[(long long)blockIdx.x * K * J + i] = s;       // a partial is [K][9][CIN] = [K][J]
     }
 }
@@ -568,17 +574,22 @@ static bool first_wgrad_plan(int N, int Ho, int Wo, int C, int K, long long& gro
 }
 
 // VALU kernel: workgroups (= partial gradients), 0 if the shape is not taken
-static unsigned first_wgrad_valu_plan(int N, int Ho, int Wo, int C, int K, int& rpb, size_t& lds) {
+static unsigned first_wgrad_valu_plan(int N, int Ho, int Wo, int C, int K, int& rpb, size_t& lds, int* nw_out = nullptr) {
     if (C < 1 || C > 4 || !(K == 16 || K == 32 || K == 64)) return 0;
     const long long rows = (long long)N * Ho;
+    const int pp = (C == 1 && K < 64) ? 1 : 4;  // floats per staged pixel (the kernel's PP)
+    int nw = K < 64 ? 16 : 4;                   // waves per workgroup (see the kernel): as many as the LDS strips admit
+    while (nw > 4 && ((size_t)nw * 3 * (Wo + 2) * pp * sizeof(float) > 48 * 1024 || (size_t)nw * K * 9 * C * sizeof(float) > 48 * 1024)) nw >>= 1;
+    while (nw > 4 && rows < 4LL * nw) nw >>= 1;   // tiny inputs: keep several workgroups (and the P > 1 partial protocol)
     rpb = (int)((rows + 511) / 512);            // <= 512 workgroups (2048 measured: kernel 58.6 -> 52.6 us, but the sum over 4x the
                                                 // partials in kp_wgrad_unpack 9 -> 22 us)
-    if (rpb < 4) rpb = 4;
-    rpb = (rpb + 3) / 4 * 4;
-    lds = (size_t)4 * 3 * (Wo + 2) * 4 * sizeof(float);
-    const size_t red = (size_t)4 * K * 9 * C * sizeof(float);
+    if (rpb < nw) rpb = nw;
+    rpb = (rpb + nw - 1) / nw * nw;
+    lds = (size_t)nw * 3 * (Wo + 2) * pp * sizeof(float);
+    const size_t red = (size_t)nw * K * 9 * C * sizeof(float);
     if (red > lds) lds = red;
     if (lds > 64 * 1024) return 0;
+    if (nw_out) *nw_out = nw;
     return (unsigned)((rows + rpb - 1) / rpb);
 }
 
@@ -608,12 +619,15 @@ int kp_conv_first_wgrad(const void* x, const void* dy, float* scratch, int N, in
         }
     }
     const long long rows = (long long)N * Ho;
-    int rpb; size_t lds;
-    const unsigned grid = first_wgrad_valu_plan(N, Ho, Wo, C, K, rpb, lds);
+    int rpb, nw = 4; size_t lds;
+    const unsigned grid = first_wgrad_valu_plan(N, Ho, Wo, C, K, rpb, lds, &nw);
     if (!grid) return KP_E_UNSUPPORTED;
 #define KP_FIRST_WG(CINv)                                                                                        \
-    conv3_first_wgrad_k<CINv><<<grid, TPB, lds, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, K,    \
-                                                      dy_pad, rows, rpb)
+    do {                                                                                                         \
+        if (nw == 16) conv3_first_wgrad_k<CINv, 16><<<grid, 1024, lds, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, K, dy_pad, rows, rpb); \
+        else if (nw == 8) conv3_first_wgrad_k<CINv, 8><<<grid, 512, lds, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, K, dy_pad, rows, rpb); \
+        else conv3_first_wgrad_k<CINv, 4><<<grid, 256, lds, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, K, dy_pad, rows, rpb);     \
+    } while (0)
     switch (C) {
         case 1: KP_FIRST_WG(1); break;
         case 2: KP_FIRST_WG(2); break;
