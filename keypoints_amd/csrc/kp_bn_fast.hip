@@ -100,14 +100,23 @@ __device__ __forceinline__ void stv(h16_t* p, const uint4 v) { *reinterpret_cast
 
 bool fast_shape(int C, int v = 8) { return C % v == 0 && (C / v) <= TPB && TPB % (C / v) == 0; }
 
-int rows_per_block(long long total_rows, int vec_per_row, int cus) {
+int rows_per_block(long long total_rows, int vec_per_row, int cus, int max_blocks = 0) {
     // >= 16 vectors per thread, but keep >= ~4 workgroups per CU
     int rpb = (16 * TPB + vec_per_row - 1) / vec_per_row;
     if (rpb < 1) rpb = 1;
     const long long max_rpb = total_rows / ((long long)cus * 4);
     if (rpb > max_rpb) rpb = (int)(max_rpb > 1 ? max_rpb : 1);
+    // reduce passes: every workgroup leaves one partial row for the finalize launch, which is a handful of workgroups streaming
+    // ALL of them (8 192 rows of a 128-channel layer: 35 us for 8 MB) -- cap the grid (KP_BN_REDUCE_BLOCKS rows at most)
+    if (max_blocks > 0 && (total_rows + rpb - 1) / rpb > max_blocks) rpb = (int)((total_rows + max_blocks - 1) / max_blocks);
     return rpb;
 }
+#ifndef KP_BN_REDUCE_BLOCKS
+#define KP_BN_REDUCE_BLOCKS 1024   // (2048 -> 1024: the reduce passes themselves 5-17 % faster at model F shapes, tools/probes/bn_ab3.sh)
+#endif
+#ifndef KP_BN_APPLY_BLOCKS
+#define KP_BN_APPLY_BLOCKS 0   // (apply / forward passes: no finalize behind them; A/B knob)
+#endif
 
 
 // ---- adjoint of the bilinear x2 tail (align_corners=True) with the replicate-pad border folded in ---------------
@@ -272,7 +281,7 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
     if (pool) {   // walk pooled rows
         const int vv = pick_v(mode ? KP_WALK_V4_POOL_APPLY : KP_WALK_V4_POOL_REDUCE, C);
         const long long prows = (long long)N * (H / 2);
-        const int prpb = rows_per_block(prows, (W / 2) * (C / 8) * 4, kp_device_cus());
+        const int prpb = rows_per_block(prows, (W / 2) * (C / 8) * 4, kp_device_cus(), mode == 0 ? KP_BN_REDUCE_BLOCKS : KP_BN_APPLY_BLOCKS);
         const unsigned pgrid = (unsigned)((prows + prpb - 1) / prpb);
         if (mode == 0) kp_set_last_rows(pgrid);
         KP_QUERY_RETURN();
@@ -295,7 +304,7 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
     const int unb = vv == 4 ? UNB4 : UNB;
     if (g_kp_bn_flat && W < unb * (TPB / (C / vv)) && H >= 2) {
         const long long frows = (long long)N * H;
-        const int frpb = rows_per_block(frows, W * (C / 8), kp_device_cus());
+        const int frpb = rows_per_block(frows, W * (C / 8), kp_device_cus(), mode == 0 ? KP_BN_REDUCE_BLOCKS : KP_BN_APPLY_BLOCKS);
         const unsigned fgrid = (unsigned)((frows + frpb - 1) / frpb);
         if (mode == 0) kp_set_last_rows(fgrid);
         KP_QUERY_RETURN();
@@ -312,7 +321,7 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
         return kp_check_launch("bn_bwd_flat");
     }
     const long long rows = mode ? (long long)N * (H + 2 * dp) : (long long)N * H;
-    const int rpb = rows_per_block(rows, W * (C / 8), kp_device_cus());
+    const int rpb = rows_per_block(rows, W * (C / 8), kp_device_cus(), mode == 0 ? KP_BN_REDUCE_BLOCKS : KP_BN_APPLY_BLOCKS);
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
     if (mode == 0) kp_set_last_rows(grid);
     KP_QUERY_RETURN();
