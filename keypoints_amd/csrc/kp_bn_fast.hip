@@ -11,6 +11,7 @@
 //     which also shortens the fp64 column reduction that follows.
 // Arithmetic is expression-for-expression the same as the general kernels (only the summation order of the
 // fold at image edges differs).
+#include <stdlib.h>
 #include "kp_common.h"
 
 namespace {
@@ -114,6 +115,15 @@ int rows_per_block(long long total_rows, int vec_per_row, int cus, int max_block
 #ifndef KP_BN_REDUCE_BLOCKS
 #define KP_BN_REDUCE_BLOCKS 1024   // (2048 -> 1024: the reduce passes themselves 5-17 % faster at model F shapes, tools/probes/bn_ab3.sh)
 #endif
+// measurement: KP_BN_BLOCKS="fwd,reduce,apply" in the environment overrides the three caps (0 = none) for sweeps without a rebuild
+static int bn_blocks_cap(int which, int dflt) {
+    static int v[3] = {-1, -1, -1};
+    if (v[0] == -1) {
+        v[0] = v[1] = v[2] = -2;
+        if (const char* e = getenv("KP_BN_BLOCKS")) sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
+    }
+    return v[which] >= 0 ? v[which] : dflt;
+}
 #ifndef KP_BN_APPLY_BLOCKS
 #define KP_BN_APPLY_BLOCKS 0   // (apply / forward passes: no finalize behind them; A/B knob)
 #endif
@@ -239,7 +249,7 @@ int kp_bn_act_fwd_fast(const void* y, const float* mean, const float* invstd, co
     const long long rows = (long long)N * (Ho + 2 * out_pad);
     const int work = tail == KP_TAIL_NONE ? 1 : 3;   // 4 source vectors per output vector
     const int vv = pick_v(tail == KP_TAIL_NONE ? KP_WALK_V4_FWD_NONE : (tail == KP_TAIL_MAXPOOL2 ? KP_WALK_V4_FWD_POOL : KP_WALK_V4_FWD_UP), C);
-    const int rpb = rows_per_block(rows, (Wo + 2 * out_pad) * (C / 8) * work, kp_device_cus());
+    const int rpb = rows_per_block(rows, (Wo + 2 * out_pad) * (C / 8) * work, kp_device_cus(), bn_blocks_cap(0, 0));
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
     if (tail == KP_TAIL_NONE)
     {
@@ -258,7 +268,7 @@ int kp_bn_act_fwd_fast(const void* y, const float* mean, const float* invstd, co
     else {
         const int HB = (Ho + 2 * out_pad + 1) / 2, WB = (Wo + 2 * out_pad + 1) / 2;
         const long long brows = (long long)N * HB;
-        const int brpb = rows_per_block(brows, WB * (C / 8) * 4, kp_device_cus());
+        const int brpb = rows_per_block(brows, WB * (C / 8) * 4, kp_device_cus(), bn_blocks_cap(0, 0));
         const unsigned bgrid = (unsigned)((brows + brpb - 1) / brpb);
 #define KP_ARGS (const h16_t*)y, bn, slope, (h16_t*)out, out_pad, H, W, C, brows, brpb, walk
         if (vv == 4) v4::bn_act_fwd_up_fast_k<<<bgrid, TPB, 0, st>>>(KP_ARGS);
@@ -281,7 +291,8 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
     if (pool) {   // walk pooled rows
         const int vv = pick_v(mode ? KP_WALK_V4_POOL_APPLY : KP_WALK_V4_POOL_REDUCE, C);
         const long long prows = (long long)N * (H / 2);
-        const int prpb = rows_per_block(prows, (W / 2) * (C / 8) * 4, kp_device_cus(), mode == 0 ? KP_BN_REDUCE_BLOCKS : KP_BN_APPLY_BLOCKS);
+        // (apply over pooled rows: fewer, longer workgroups measured faster at every model F shape -- 277 -> 264, 162 -> 143, 90 -> 77 us)
+        const int prpb = rows_per_block(prows, (W / 2) * (C / 8) * 4, kp_device_cus(), mode == 0 ? bn_blocks_cap(1, KP_BN_REDUCE_BLOCKS) : bn_blocks_cap(2, 512));
         const unsigned pgrid = (unsigned)((prows + prpb - 1) / prpb);
         if (mode == 0) kp_set_last_rows(pgrid);
         KP_QUERY_RETURN();
@@ -304,7 +315,7 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
     const int unb = vv == 4 ? UNB4 : UNB;
     if (g_kp_bn_flat && W < unb * (TPB / (C / vv)) && H >= 2) {
         const long long frows = (long long)N * H;
-        const int frpb = rows_per_block(frows, W * (C / 8), kp_device_cus(), mode == 0 ? KP_BN_REDUCE_BLOCKS : KP_BN_APPLY_BLOCKS);
+        const int frpb = rows_per_block(frows, W * (C / 8), kp_device_cus(), mode == 0 ? bn_blocks_cap(1, KP_BN_REDUCE_BLOCKS) : bn_blocks_cap(2, KP_BN_APPLY_BLOCKS));
         const unsigned fgrid = (unsigned)((frows + frpb - 1) / frpb);
         if (mode == 0) kp_set_last_rows(fgrid);
         KP_QUERY_RETURN();
@@ -321,7 +332,8 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
         return kp_check_launch("bn_bwd_flat");
     }
     const long long rows = mode ? (long long)N * (H + 2 * dp) : (long long)N * H;
-    const int rpb = rows_per_block(rows, W * (C / 8), kp_device_cus(), mode == 0 ? KP_BN_REDUCE_BLOCKS : KP_BN_APPLY_BLOCKS);
+    // (apply: the 512-channel layers like 512 workgroups -- 108 -> 98, 29 -> 26 us --, the wide shallow ones the uncapped grid)
+    const int rpb = rows_per_block(rows, W * (C / 8), kp_device_cus(), mode == 0 ? bn_blocks_cap(1, KP_BN_REDUCE_BLOCKS) : bn_blocks_cap(2, C >= 512 ? 512 : KP_BN_APPLY_BLOCKS));
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
     if (mode == 0) kp_set_last_rows(grid);
     KP_QUERY_RETURN();
