@@ -6,6 +6,7 @@
 // walks the pixels of the row, so the per-channel constants (mean, invstd, gamma, beta) are loaded once
 // per thread and every global access is a full 16-byte lane access on consecutive addresses.
 // All reductions are deterministic (per-row partial sums, then an fp64 tree) -- no atomics.
+#include <stdlib.h>
 #include "kp_common.h"
 
 namespace {
@@ -188,13 +189,18 @@ __global__ __launch_bounds__(TPB) void bn_reduce_finalize_k(const float* __restr
 // two-stage kernel was measured 5x slower: device-scope fences between XCDs cost more than the second launch.)
 // CPW = channels per workgroup (16, 8 or 4): narrow layers get as many workgroups as wide ones (a 64-channel layer with
 // 8192 partial rows on 4 workgroups of 16 channels took 26 us, four times the 512-channel case).
-template <int MODE, int CPW>
-__global__ __launch_bounds__(1024) void bn_reduce_finalize_wide_k(const float* __restrict__ partials, long long rows, int C,
+// NT = threads per workgroup: 1024, or 256 for the 16 / 32-channel layers of the Pong-class nets.  A 16-wave workgroup needs
+// four free wave slots on EVERY SIMD of one CU; beside the small-channel weight gradient (one wave per SIMD holding ~470 of its
+// 512 registers, 152 KB of LDS) it never finds them and the launch -- 6 us of work on the critical path of the backward -- sat
+// out the whole weight gradient: 80-100 us per layer in the config-2 timeline (tools/probes/cfg2_timeline.sh).  Four waves of
+// 16 registers do fit.  (For model F the 256-thread form measured no difference in round 2; its layers keep 1024.)
+template <int MODE, int CPW, int NT = 1024>
+__global__ __launch_bounds__(NT) void bn_reduce_finalize_wide_k(const float* __restrict__ partials, long long rows, int C,
                                                                   float* __restrict__ o0, float* __restrict__ o1,
                                                                   float* __restrict__ r0p, float* __restrict__ r1p,
                                                                   long long* __restrict__ nbt, float momentum, float eps,
                                                                   long long count) {
-    constexpr int RL = 1024 / (2 * CPW);   // row lanes
+    constexpr int RL = NT / (2 * CPW);   // row lanes
     const int cl = threadIdx.x & (CPW - 1), which = (threadIdx.x / CPW) & 1, rl = threadIdx.x / (2 * CPW);
     const int c = blockIdx.x * CPW + cl;
     double s = 0.0;
@@ -548,6 +554,7 @@ int kp_bn_bwd_fast(int, const void*, int, int, const unsigned char*, const void*
                    const float*, const float*, float, float*, const float*, void*, int, int, int, int, int, hipStream_t);
 int kp_upsample2_bwd_fast(const void*, int, void*, int, int, int, int, hipStream_t);
 extern kp_knob_t g_kp_bn_fast;
+static const int g_kp_fin_wide = getenv("KP_FIN_WIDE") ? atoi(getenv("KP_FIN_WIDE")) : 0;   // measurement: 1 = the 1024-thread finalize for every layer
 
 extern "C" {
 
@@ -567,7 +574,10 @@ int kp_bn_finalize(const float* stats, long long rows, double* ws, float* save_m
     if (rows <= WIDE_ROWS) {
 #define KP_WIDE0(CPWv) bn_reduce_finalize_wide_k<0, CPWv><<<cdiv(C, CPWv), 1024, 0, st>>>(stats, rows, C, save_mean, save_invstd, running_mean, \
                                                                                running_var, num_batches_tracked, momentum, eps, count)
-        if (C >= 256) KP_WIDE0(16); else if (C >= 128) KP_WIDE0(8); else KP_WIDE0(4);
+        if (C <= 32 && !g_kp_fin_wide)   // Pong-class layers: a 4-wave workgroup (see the kernel)
+            bn_reduce_finalize_wide_k<0, 4, 256><<<cdiv(C, 4), 256, 0, st>>>(stats, rows, C, save_mean, save_invstd, running_mean,
+                                                                              running_var, num_batches_tracked, momentum, eps, count);
+        else if (C >= 256) KP_WIDE0(16); else if (C >= 128) KP_WIDE0(8); else KP_WIDE0(4);
 #undef KP_WIDE0
         return kp_check_launch("bn_reduce_finalize_wide");
     }
@@ -629,7 +639,10 @@ int kp_bn_bwd_finalize(const float* partials, double* ws, long long rows, int C,
     if (rows <= WIDE_ROWS) {
 #define KP_WIDE1(CPWv) bn_reduce_finalize_wide_k<1, CPWv><<<cdiv(C, CPWv), 1024, 0, st>>>(partials, rows, C, sums, nullptr, dbeta, dgamma, \
                                                                                nullptr, 0.f, 0.f, 1)
-        if (C >= 256) KP_WIDE1(16); else if (C >= 128) KP_WIDE1(8); else KP_WIDE1(4);
+        if (C <= 32 && !g_kp_fin_wide)
+            bn_reduce_finalize_wide_k<1, 4, 256><<<cdiv(C, 4), 256, 0, st>>>(partials, rows, C, sums, nullptr, dbeta, dgamma, nullptr,
+                                                                              0.f, 0.f, 1);
+        else if (C >= 256) KP_WIDE1(16); else if (C >= 128) KP_WIDE1(8); else KP_WIDE1(4);
 #undef KP_WIDE1
         return kp_check_launch("bn_bwd_reduce_finalize_wide");
     }
