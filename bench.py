@@ -29,8 +29,8 @@ PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3     # fp32 vector / f32-MFMA peak
 PEAK_HBM_GBS = 8000.0       # HBM3E spec (MI355X_MICROARCH.md; 6.3 TB/s is what a plain copy reaches)
 FAMILIES = {0: 'conv_valid_generic', 1: 'conv_wgrad_generic', 2: 'conv_mfma_16bit', 3: 'wgrad_mfma_16bit', 4: 'conv_first_16bit',
-            5: 'conv_small_16bit', 6: 'keypoint_bottleneck', 7: 'conv_mfma_f32', 8: 'wgrad_mfma_f32'}
-HBM_BOUND = {'conv_first_16bit', 'conv_small_16bit', 'keypoint_bottleneck'}
+            5: 'conv_small_16bit', 6: 'keypoint_bottleneck', 7: 'conv_mfma_f32', 8: 'wgrad_mfma_f32', 9: 'wgrad_small_16bit'}
+HBM_BOUND = {'conv_first_16bit', 'conv_small_16bit', 'wgrad_small_16bit', 'keypoint_bottleneck'}
 
 
 def parse():

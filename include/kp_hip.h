@@ -93,7 +93,8 @@ int kp_config_ptr(int key, void* value);
 #define KP_PROF_CONV_MFMA 2      /* bf16 MFMA implicit-GEMM conv (fwd + dgrad) */
 #define KP_PROF_WGRAD_MFMA 3
 #define KP_PROF_CONV_FIRST 4     /* Cin <= 4 first-layer VALU kernels (fwd + wgrad), HBM-bound */
-#define KP_PROF_CONV_SMALL 5     /* C, K in {16, 32} small-channel kernels (MFMA fwd/dgrad, VALU wgrad), HBM-bound */
+#define KP_PROF_CONV_SMALL 5     /* C, K in {16, 32} small-channel kernels, forward / data gradient (incl. the BatchNorm-input form) */
+#define KP_PROF_WGRAD_SMALL 9    /* ... their weight gradient (reported apart since round 3: one wave per SIMD, a different bound) */
 #define KP_PROF_CONV_F32MFMA 7   /* strict-fp32 conv on v_mfma_f32_32x32x2_f32 (fwd + dgrad) */
 #define KP_PROF_WGRAD_F32MFMA 8
 #define KP_PROF_BOTTLENECK 6     /* fused keypoint bottleneck (kp_keypoint_bottleneck_fwd / _bwd), HBM-bound; flops = 0 */

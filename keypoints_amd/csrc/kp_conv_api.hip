@@ -139,7 +139,7 @@ int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, 
         }
         if (R == 3) {
             rc = kp_conv_small_wgrad(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
-            if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_SMALL); return rc; }
+            if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_WGRAD_SMALL); return rc; }
         }
     }
     if (dtype == KP_F32 && R == 3 && use_mfma()) {
@@ -184,9 +184,9 @@ int kp_conv_wgrad_bnin(const void* yprev, const float* mean, const float* invstd
     if (!kp_conv_bnin_supported(N, Ho, Wo, C, K, dtype)) return KP_E_UNSUPPORTED;
     const double flops = 2.0 * N * (double)Ho * Wo * C * K * 9;
     const double bytes = 2.0 * ((double)N * Ho * Wo * C + (double)N * Ho * Wo * K) + 4.0 * 9 * C * K;
-    ProfScope ps(KP_PROF_CONV_SMALL, flops, (hipStream_t)stream, bytes);
+    ProfScope ps(KP_PROF_WGRAD_SMALL, flops, (hipStream_t)stream, bytes);
     const int rc = kp_conv_small_wgrad_bnin(yprev, mean, invstd, gamma, beta, slope, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
-    ps.done(KP_PROF_CONV_SMALL);
+    ps.done(KP_PROF_WGRAD_SMALL);
     return rc;
 }
 

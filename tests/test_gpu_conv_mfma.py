@@ -276,7 +276,7 @@ def test_conv_small_channels(N, Ho, Wo, C, K):
         dyd = dy.cuda()
         call('kp_prof_enable', 1)
         call('kp_conv_wgrad', ptr(xd), ptr(dyd), ptr(scratch), N, Ho, Wo, C, K, 3, dp, _lib.KP_BF16, st)
-        call('kp_prof_collect', 5, None, None, ctypes.addressof(n))
+        call('kp_prof_collect', 9, None, None, ctypes.addressof(n))     # KP_PROF_WGRAD_SMALL
         assert n.value == 1, 'the small-channel wgrad kernel did not take this shape'
         gotw = scratch.double().cpu() if parts == 1 else scratch.double().sum(0).cpu()
         assert torch.isfinite(gotw).all()
