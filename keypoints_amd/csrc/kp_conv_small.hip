@@ -606,33 +606,30 @@ __global__ __launch_bounds__(TPB, 1) void wgrad3x3_small_band_k(const h16_t* __r
         //      instruction hands lane i the 4 rows of column i of a [4 pixels][16 channels] block, lane t supplying the
         //      address of (pixel t / 4, 4-channel chunk t % 4).  Pixel rows are C * 2 (K * 2) bytes apart: the four rows of
         //      a block fall on disjoint banks.
-        for (int item = wave; item < rows * nseg; item += 4) {
-            const int r = item / nseg, sg = item - r * nseg;
+        // The multiply phase runs at the rate of ds_read_b64_tr_b16 (~16 LDS cycles per wave-instruction, one LDS per CU): an
+        // item on its own is 2 (gradient) + 3 x 3 (input rows) = 11 reads for 9 MFMAs.  Vertically adjacent items share two of
+        // their three input rows, so a wavefront takes a COLUMN STRIP of items (one 16-pixel segment, half of the band's rows)
+        // and slides a three-row window of raw input dwords down it: 2 + 3 reads per item (+ 6 to fill the window).
+        const int rh = (rows + 1) >> 1;                          // rows per half
+        for (int unit = wave; unit < 2 * nseg; unit += 4) {      // scalar: strip and half
+            const int sg = unit % nseg, half = unit / nseg;
+            const int rbeg = half * rh, rend = rbeg + rh < rows ? rbeg + rh : rows;
+            if (rbeg >= rend) continue;
             const int prow = sg * 16 + trow;
-            h16x8 af = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (kval) {
-                const unsigned char* a = dl + r * drow_b + prow * (K * 2) + chunkb;
+            // raw dwords of an input row at this strip: (p0,p1) (p2,p3) (p4,p5) (p6,p7) (p8,p9), p = pixel 8h + ..
+            auto row_load = [&](int r, unsigned (&Rg)[5]) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const h16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(a + 4 * u * (K * 2)));
-                    af[4 * u + 0] = v[0]; af[4 * u + 1] = v[1]; af[4 * u + 2] = v[2]; af[4 * u + 3] = v[3];
-                }
-            }
-            // The three column taps of an input row read the SAME pixels shifted by one: pixels 8h .. 8h+9 come in with three
-            // transpose reads (the third serves pixels 8h+8, 8h+9), and the fragments of taps 1 and 2 are formed in registers --
-            // tap 2 is a renaming of the dword pairs, tap 1 four v_alignbit.  9 transpose reads per item for the input side
-            // instead of 18: the multiply phase of this kernel is bound by the rate of ds_read_b64_tr_b16 (~16 cycles per
-            // wavefront instruction; ablations in tools/probes/wgrad_band_abl.sh), the VALU is idle.
-#pragma unroll
-            for (int rr = 0; rr < 3; ++rr) {
-                const unsigned char* b = xl + (r + rr) * xrow_b + prow * (C * 2) + chunkb;
-                unsigned Rg[5] = {0u, 0u, 0u, 0u, 0u};      // (p0,p1) (p2,p3) (p4,p5) (p6,p7) (p8,p9), p = pixel 8h + ..
+                for (int i = 0; i < 5; ++i) Rg[i] = 0u;
                 if (cval) {
+                    const unsigned char* b = xl + r * xrow_b + prow * (C * 2) + chunkb;
                     const uint2 q0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b)));
                     const uint2 q1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + 4 * (C * 2))));
                     const uint2 q2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + 8 * (C * 2))));
                     Rg[0] = q0.x; Rg[1] = q0.y; Rg[2] = q1.x; Rg[3] = q1.y; Rg[4] = q2.x;
                 }
+            };
+            // the three column taps of a row from its raw dwords: tap 2 is a renaming of the dword pairs, tap 1 four v_alignbit
+            auto row_mma = [&](const h16x8& af, const unsigned (&Rg)[5], int rr) {
                 const u32x4 f0 = {Rg[0], Rg[1], Rg[2], Rg[3]};
                 const u32x4 f1 = {__builtin_amdgcn_alignbit(Rg[1], Rg[0], 16), __builtin_amdgcn_alignbit(Rg[2], Rg[1], 16),
                                   __builtin_amdgcn_alignbit(Rg[3], Rg[2], 16), __builtin_amdgcn_alignbit(Rg[4], Rg[3], 16)};
@@ -640,6 +637,26 @@ __global__ __launch_bounds__(TPB, 1) void wgrad3x3_small_band_k(const h16_t* __r
                 acc[rr * 3 + 0] = kp_mfma16(af, __builtin_bit_cast(h16x8, f0), acc[rr * 3 + 0], 0, 0, 0);
                 acc[rr * 3 + 1] = kp_mfma16(af, __builtin_bit_cast(h16x8, f1), acc[rr * 3 + 1], 0, 0, 0);
                 acc[rr * 3 + 2] = kp_mfma16(af, __builtin_bit_cast(h16x8, f2), acc[rr * 3 + 2], 0, 0, 0);
+            };
+            unsigned W0[5], W1[5], W2[5];
+            row_load(rbeg, W0);
+            row_load(rbeg + 1, W1);
+            for (int r = rbeg; r < rend; ++r) {
+                h16x8 af = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (kval) {
+                    const unsigned char* a = dl + r * drow_b + prow * (K * 2) + chunkb;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const h16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(a + 4 * u * (K * 2)));
+                        af[4 * u + 0] = v[0]; af[4 * u + 1] = v[1]; af[4 * u + 2] = v[2]; af[4 * u + 3] = v[3];
+                    }
+                }
+                row_load(r + 2, W2);
+                row_mma(af, W0, 0);
+                row_mma(af, W1, 1);
+                row_mma(af, W2, 2);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { W0[i] = W1[i]; W1[i] = W2[i]; }
             }
         }
         if (more) commit(smem + (cur ^ 1) * WG_LDS);          // the other buffer: its readers passed the previous barrier
