@@ -349,3 +349,22 @@ def test_unit_without_batchnorm_against_golden(golden, tag, cin, cout, typ, enc,
             errs[f'{blk}.{k}'] = (gerr(p.grad, z[f'{tag}.g.{blk}.{k}']), gtol)
     print(f'nobn {tag} {precision}:', {k: f'{v[0]:.2e}' for k, v in errs.items()})
     assert all(e <= t for e, t in errs.values()), {k: v for k, v in errs.items() if v[0] > v[1]}
+
+
+@pytest.mark.parametrize('dt', ['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('N,C,Cp,H,W,pad', [(3, 16, 16, 84, 84, 1), (2, 74, 128, 16, 16, 1), (2, 10, 16, 7, 5, 0), (2, 3, 3, 9, 11, 1),
+                                           (1, 64, 64, 16, 16, 1), (2, 5, 8, 4, 6, 1)])
+def test_nchw_to_nhwc(N, C, Cp, H, W, pad, dt):
+    """Unit input layout: fp32 NCHW -> [N][H+2p][W+2p][Cp] in the storage type, replicate border (ReplicationPad2d(1),
+    knn.py:115), zero channel padding -- the 8-channel-per-thread kernel (Cp % 8 == 0) and the per-pixel one, every element."""
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    tdt, code = {'fp32': (torch.float32, _lib.KP_F32), 'bf16': (torch.bfloat16, _lib.KP_BF16), 'fp16': (torch.float16, _lib.KP_F16)}[dt]
+    g = torch.Generator().manual_seed(N + C + H)
+    x = torch.randn(N, C, H, W, generator=g).cuda()
+    out = torch.full((N, H + 2 * pad, W + 2 * pad, Cp), float('nan'), device='cuda', dtype=tdt)
+    call('kp_nchw_to_nhwc', ptr(x), ptr(out), N, C, Cp, H, W, pad, code, stream_ptr())
+    ref = torch.nn.functional.pad(x, (pad,) * 4, mode='replicate') if pad else x
+    ref = torch.nn.functional.pad(ref.permute(0, 2, 3, 1), (0, Cp - C)).to(tdt)
+    assert torch.equal(out, ref)
