@@ -4,6 +4,7 @@ import torch
 import torch.nn as nn
 
 from .. import runtime
+from ..unit_engine import prepack, shared_packs
 from . import knn, vgg
 
 
@@ -19,14 +20,17 @@ class KeyNet(knn.Container):
             self._initialize_weights()
 
     def forward(self, x, x_t):
-        with runtime.fork('chain', x_t) as side:   # two independent encoders: the keypoint one on a side stream
-            with side:
-                heatmap = self.keypoint(x_t)
-                side.outputs(heatmap)
-            z = self.encoder(x)
-        k, p = self.ssm(heatmap, probs=True)
-        m = self.key2map(k, height=z.size(2), width=z.size(3))
-        x_t = self.decoder(torch.cat((z, m), dim=1))
+        with shared_packs():   # the three Units' weight packs in ONE launch, up front (the decoder's off the critical path)
+            prepack([(self.encoder, x.size(1)), (self.keypoint, x_t.size(1)),
+                     (self.decoder, self.encoder.out_block[0].out_channels + self.keypoint.out_block[0].out_channels)])
+            with runtime.fork('chain', x_t) as side:   # two independent encoders: the keypoint one on a side stream
+                with side:
+                    heatmap = self.keypoint(x_t)
+                    side.outputs(heatmap)
+                z = self.encoder(x)
+            k, p = self.ssm(heatmap, probs=True)
+            m = self.key2map(k, height=z.size(2), width=z.size(3))
+            x_t = self.decoder(torch.cat((z, m), dim=1))
         return x_t, z, k, m, p, heatmap
 
     def load(self, directory):

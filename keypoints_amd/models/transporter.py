@@ -5,7 +5,7 @@ import torch.nn as nn
 from . import functional as MF
 from . import knn, vgg
 from .. import runtime
-from ..unit_engine import shared_packs
+from ..unit_engine import prepack, shared_packs
 
 
 class TransporterNet(knn.Container):
@@ -34,17 +34,23 @@ class TransporterNet(knn.Container):
 
     def forward(self, xs, xt):
         with shared_packs():   # both branches run on the same weights: pack them once
-            # the keypoint encoder's two calls are independent of the feature encoder's: they go to a side stream (and,
-            # the autograd engine running a node's backward on the stream of its forward, so does their backward)
-            with runtime.fork('chain', xs, xt) as side:
-                with side:
-                    with torch.no_grad():
-                        heatmap_xs = self.keypoint(xs)
-                    heatmap_xt = self.keypoint(xt)
-                    side.outputs(heatmap_xs, heatmap_xt)
-                with torch.no_grad():   # source branch carries no gradient (transporter.py:36-37)
-                    phi_xs = self.feature(xs)
-                phi_xt = self.feature(xt)
+            return self._forward(xs, xt)
+
+    def _forward(self, xs, xt):
+        # ... and all three Units in ONE launch, up front: the decoder's pack is then off the critical path behind the bottleneck
+        prepack([(self.feature, xs.size(1)), (self.keypoint, xs.size(1)),
+                 (self.decoder, self.feature.out_block[0].out_channels)])
+        # the keypoint encoder's two calls are independent of the feature encoder's: they go to a side stream (and,
+        # the autograd engine running a node's backward on the stream of its forward, so does their backward)
+        with runtime.fork('chain', xs, xt) as side:
+            with side:
+                with torch.no_grad():
+                    heatmap_xs = self.keypoint(xs)
+                heatmap_xt = self.keypoint(xt)
+                side.outputs(heatmap_xs, heatmap_xt)
+            with torch.no_grad():   # source branch carries no gradient (transporter.py:36-37)
+                phi_xs = self.feature(xs)
+            phi_xt = self.feature(xt)
 
         if self._fused_bottleneck_ok(phi_xt):
             # ssm + key2map of both branches and the 'max' blend: one kernel forward, one backward

@@ -66,11 +66,18 @@ def _slope_of(act: nn.Module) -> float:
     raise NotImplementedError(f'activation {type(act).__name__} has no HIP kernel (ReLU / LeakyReLU only)')
 
 
-def _pack_unit(plan, Cin, Cp0, record, dev, tdt, code, st):
-    """Packed copies (compute type, tap-major) of every 3x3 weight of a Unit: `[K][3][3][C]` for the forward and, when a
-    backward may follow (or the packs are shared across calls), `[C][3][3][K]` flipped for the data gradient.  Layers whose
-    packs are not in the shared store yet are packed by ONE kp_pack_weights_batch launch."""
-    import ctypes
+def _first_cp(plan, Cin, precision):
+    """Physical input channels of a Unit's first 3x3 layer: an odd input width (KeyNet decoder: z + K = 74 channels, keynet.py:55)
+    is zero-padded to a multiple of 64 so that the 16-bit MFMA kernels take the layer; its weights are zero-padded to match."""
+    first = plan[0]
+    if (first['kind'] == 'conv3' and precision in ('bf16', 'fp16') and Cin > 4 and Cin % 64 != 0 and Cin not in (16, 32)
+            and first['conv'].out_channels % 64 == 0):   # (16 / 32 channels have their own kernels)
+        return (Cin + 63) // 64 * 64
+    return Cin
+
+
+def _collect_packs(plan, Cin, Cp0, record, dev, tdt, code):
+    """Pack buffers of every 3x3 weight of a Unit (from the shared store where they exist) + the list of layers still to pack."""
     out, todo = [], []
     C = Cin
     for idx, stp in enumerate(plan[:-1]):
@@ -88,6 +95,11 @@ def _pack_unit(plan, Cin, Cp0, record, dev, tdt, code, st):
                 _PACKS[pkey] = ent
         out.append(ent)
         C = K
+    return out, todo
+
+
+def _launch_packs(todo, code, st):
+    import ctypes
     for i in range(0, len(todo), 24):
         part = todo[i:i + 24]
         n = len(part)
@@ -95,7 +107,47 @@ def _pack_unit(plan, Cin, Cp0, record, dev, tdt, code, st):
         call('kp_pack_weights_batch', n, vp(*[ptr(t[0]) for t in part]), vp(*[ptr(t[1]) for t in part]),
              vp(*[ptr(t[2]) for t in part]), ia(*[t[3] for t in part]), ia(*[t[4] for t in part]), ia(*[t[5] for t in part]),
              code, st)
+
+
+def _pack_unit(plan, Cin, Cp0, record, dev, tdt, code, st):
+    """Packed copies (compute type, tap-major) of every 3x3 weight of a Unit: `[K][3][3][C]` for the forward and, when a
+    backward may follow (or the packs are shared across calls), `[C][3][3][K]` flipped for the data gradient.  Layers whose
+    packs are not in the shared store yet are packed by ONE kp_pack_weights_batch launch."""
+    out, todo = _collect_packs(plan, Cin, Cp0, record, dev, tdt, code)
+    _launch_packs(todo, code, st)
     return out
+
+
+import os as _os
+_NO_PREPACK = bool(_os.environ.get('KP_NO_PREPACK'))   # measurement: every Unit packs at its own first call again
+
+
+def prepack(units_cin):
+    """Inside `shared_packs()`: the packs of SEVERAL Units in one launch at the start of a network forward, so that a later Unit
+    (the decoder behind the bottleneck) does not find its pack launch on the critical path in the middle of the step.
+    `units_cin`: [(unit, input channels)].  Units of one storage type share the launch; anything this cannot plan is left to
+    the Unit's own forward."""
+    if _PACKS is None or _NO_PREPACK:
+        return
+    groups = {}
+    for unit, cin in units_cin:
+        try:
+            plan = unit.plan()
+        except NotImplementedError:
+            continue
+        if not any(True for _ in unit.parameters()):
+            continue
+        p0 = next(unit.parameters())
+        if not p0.is_cuda:
+            continue
+        tdt, code = precision_dtype(unit.precision)
+        _, todo = _collect_packs(plan, cin, _first_cp(plan, cin, unit.precision), True, p0.device, tdt, code)
+        groups.setdefault(code, []).extend(todo)
+    if not groups:      # (a CPU network: nothing here; the Unit's own forward raises the loud error)
+        return
+    st = stream_ptr()
+    for code, todo in groups.items():
+        _launch_packs(todo, code, st)
 
 
 def build_plan(blocks: List[nn.Sequential]) -> List[dict]:
@@ -199,12 +251,7 @@ class UnitFunction(torch.autograd.Function):
         N, Cin, H, W = x.shape
         first = plan[0]
         pad0 = 1 if first['kind'] == 'conv3' else 0
-        # An odd input width (KeyNet decoder: z + K = 74 channels, keynet.py:55) is zero-padded to a multiple of 64
-        # so that the bf16 MFMA kernels take the first layer; its weights are zero-padded to match.
-        Cp0 = Cin
-        if (first['kind'] == 'conv3' and unit.precision in ('bf16', 'fp16') and Cin > 4 and Cin % 64 != 0 and Cin not in (16, 32)
-                and first['conv'].out_channels % 64 == 0):   # (16 / 32 channels have their own kernels)
-            Cp0 = (Cin + 63) // 64 * 64
+        Cp0 = _first_cp(plan, Cin, unit.precision)
         a = torch.empty(N, H + 2 * pad0, W + 2 * pad0, Cp0, device=dev, dtype=tdt)
         call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, Cin, Cp0, H, W, pad0, code, st)
         saved = []
