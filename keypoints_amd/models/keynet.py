@@ -21,8 +21,9 @@ class KeyNet(knn.Container):
 
     def forward(self, x, x_t):
         with shared_packs():   # the three Units' weight packs in ONE launch, up front (the decoder's off the critical path)
-            prepack([(self.encoder, x.size(1)), (self.keypoint, x_t.size(1)),
-                     (self.decoder, self.encoder.out_block[0].out_channels + self.keypoint.out_block[0].out_channels)])
+            if torch.is_tensor(x) and all(isinstance(u, knn.Unit) for u in (self.encoder, self.keypoint, self.decoder)):
+                prepack([(self.encoder, x.size(1)), (self.keypoint, x_t.size(1)),
+                         (self.decoder, self.encoder.out_block[0].out_channels + self.keypoint.out_block[0].out_channels)])
             with runtime.fork('chain', x_t) as side:   # two independent encoders: the keypoint one on a side stream
                 with side:
                     heatmap = self.keypoint(x_t)

@@ -38,8 +38,9 @@ class TransporterNet(knn.Container):
 
     def _forward(self, xs, xt):
         # ... and all three Units in ONE launch, up front: the decoder's pack is then off the critical path behind the bottleneck
-        prepack([(self.feature, xs.size(1)), (self.keypoint, xs.size(1)),
-                 (self.decoder, self.feature.out_block[0].out_channels)])
+        if torch.is_tensor(xs) and all(isinstance(u, knn.Unit) for u in (self.feature, self.keypoint, self.decoder)):
+            prepack([(self.feature, xs.size(1)), (self.keypoint, xs.size(1)),
+                     (self.decoder, self.feature.out_block[0].out_channels)])
         # the keypoint encoder's two calls are independent of the feature encoder's: they go to a side stream (and,
         # the autograd engine running a node's backward on the stream of its forward, so does their backward)
         with runtime.fork('chain', xs, xt) as side:
