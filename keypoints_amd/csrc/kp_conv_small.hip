@@ -485,8 +485,7 @@ __global__ __launch_bounds__(TPB) void wgrad3x3_small_k(const h16_t* __restrict_
 #define KP_WGB_MINW 1   // waves per SIMD the register allocation must admit.  The 9 x 16 accumulators + 48 staging registers do not fit 256: with 2 the kernel spills 60-300 registers and is 1.5-2x slower (measured); as it is it takes 320-470 registers = ONE wave per SIMD, i.e. one workgroup per CU whatever the LDS admits
 #endif
 constexpr int WG_LDS = 77824;
-constexpr int SL = 12;   // 16-byte chunks per thread and tensor in one band (256 threads x 12 x 16 B = 48 KB of each) ...
-// ... at most: the narrower tensor of a (K, C) pair never gets its half of the LDS, and every chunk is 4 registers that live
+// 16-byte chunks per thread and tensor in one band: 12 at most (256 threads x 12 x 16 B = 48 KB of each); the narrower tensor of a (K, C) pair never gets its half of the LDS, and every chunk is 4 registers that live
 // across the multiply phase (the 32 x 16 variant spilled with 12 + 12)
 constexpr int sl_x(int K, int C) { return C == 32 ? 12 : (K == 32 ? 8 : 10); }
 constexpr int sl_d(int K, int C) { return K == 32 ? 12 : (C == 32 ? 8 : 10); }
