@@ -481,9 +481,6 @@ __global__ __launch_bounds__(TPB) void wgrad3x3_small_k(const h16_t* __restrict_
 // 9 MFMAs and no packing arithmetic.  <= 76 KB per workgroup: two per CU, one stages while the other multiplies.  Same per-workgroup partial
 // gradients, same order of the reductions inside a workgroup as above is NOT kept (items go round-robin over the waves): results
 // differ from the kernel above in the last bits, and are bitwise repeatable.
-#ifndef KP_WGB_MINW
-#define KP_WGB_MINW 1   // waves per SIMD the register allocation must admit.  The 9 x 16 accumulators + 48 staging registers do not fit 256: with 2 the kernel spills 60-300 registers and is 1.5-2x slower (measured); as it is it takes 320-470 registers = ONE wave per SIMD, i.e. one workgroup per CU whatever the LDS admits
-#endif
 constexpr int WG_LDS = 77824;
 // 16-byte chunks per thread and tensor in one band: 12 at most (256 threads x 12 x 16 B = 48 KB of each); the narrower tensor of a (K, C) pair never gets its half of the LDS, and every chunk is 4 registers that live
 // across the multiply phase (the 32 x 16 variant spilled with 12 + 12)
