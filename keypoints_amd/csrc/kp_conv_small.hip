@@ -235,12 +235,13 @@ constexpr int FSL = 12 * 256 / FTPB;   // 16-byte chunks per thread in one band 
 // the lane mask of ragged segments -- where a wave-uniform test says they are not needed.
 // WREG: the 9 x CB weight fragments live in registers (36 / 72 VGPRs) instead of LDS: occupancy is set by the band's LDS here, not by
 // registers, and an item then issues 9 x CB LDS reads instead of 18 x CB (the 32-channel BatchNorm-input variant has no room).
-template <int CB, bool BNIN, bool WREG = !(BNIN && CB == 2)>
+template <int CB, int KB, bool BNIN, bool STATS, bool WREG = !(BNIN && CB == 2)>
 __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
                                                             const float* __restrict__ bias, h16_t* __restrict__ y,
-                                                            float* __restrict__ partials, int Hi, int Wi, int K, int R,
-                                                            int bands_per_img, long long total_bands, BnIn bn) {
-    constexpr int C = CB * 16, PITCH = C * 2 + 16, CPP = C / 8;   // chunks of 16 bytes per pixel
+                                                            float* __restrict__ partials, int Hi, int Wi, int R,
+                                                            int bands_per_img, int total_bands, BnIn bn) {
+    constexpr int C = CB * 16, K = KB * 16, PITCH = C * 2 + 16, CPP = C / 8;   // chunks of 16 bytes per pixel
+    constexpr int JH = KB * 4;                                                   // register pairs of the accumulator that hold channels < K
     __shared__ h16x8 swf[WREG ? 1 : 9 * CB][64];
     __shared__ __attribute__((aligned(16))) unsigned char xl[FB_LDS];
     __shared__ __attribute__((aligned(16))) float cst[BNIN ? 4 : 1][32];
@@ -263,12 +264,12 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
             }
     }
     // D[k][px]: lane: pixel = fr, k = 8 * (reg >> 2) + 4 * fh + (reg & 3); register PAIRS (2j, 2j + 1) are the packed operands
-    f32x2 bv[8], ssum[8], ssq[8];
+    f32x2 bv[JH], ssum[STATS ? JH : 1], ssq[STATS ? JH : 1];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < JH; ++j) {
         const int k = 8 * (j >> 1) + 4 * fh + 2 * (j & 1);
-        bv[j] = f32x2{(bias && k < K) ? bias[k] : 0.f, (bias && k + 1 < K) ? bias[k + 1] : 0.f};
-        ssum[j] = ssq[j] = f32x2{0.f, 0.f};
+        bv[j] = f32x2{bias ? bias[k] : 0.f, bias ? bias[k + 1] : 0.f};
+        if (STATS) ssum[j] = ssq[j] = f32x2{0.f, 0.f};
     }
     // ---- staging tables of this thread's FSL chunks (band-independent): chunk id = tid + u * FTPB = (row * XPW + pixel) * CPP + c
     const int c = tid % CPP;
@@ -287,18 +288,24 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
         }
     }
     const int lane_ld = fr * PITCH + fh * 16;          // fragment read: lane part of the LDS address
-    const int lane_st = (fr * K + 8 * fh) * 2;         // output store: lane part of the byte offset (chunk g adds 32 bytes)
-    const bool want_stats = partials != nullptr;       // forward with BatchNorm statistics; the data gradient has none
+    // output store, lane part of the byte offset.  16 channels: after the half-wave swaps a lane holds chunk fh (8 channels)
+    // of pixel fr -- the wave's 32 pixels x 32 bytes are one contiguous KB.  32 channels: a second exchange between the
+    // 16-lane rows leaves a lane with chunk 2 * (row & 1) + (row >> 1) of pixel (lane & 15) [first store] and of pixel
+    // 16 + (lane & 15) [second store], so either store writes whole 64-byte pixels, 1 KB contiguous (two stores of 32 bytes
+    // per 64-byte pixel each cost the write path twice the requests: the stores were 17 of the kernel's 53 us)
+    const int lrow = lane >> 4, px16 = lane & 15;
+    const int lane_st = KB == 1 ? fr * 32 + fh * 16 : px16 * 64 + (2 * (lrow & 1) + (lrow >> 1)) * 16;
+    constexpr int OOB = (int)0x80000000;               // beyond every band's bytes: the buffer store drops the lane
 
-    for (long long band = blockIdx.x; band < total_bands; band += gridDim.x) {
-        const long long n = band / bands_per_img;
-        const int p0 = (int)(band % bands_per_img) * R;
+    for (int band = blockIdx.x; band < total_bands; band += gridDim.x) {
+        const int n = band / bands_per_img;
+        const int p0 = (band - n * bands_per_img) * R;
         const int rows = Ho - p0 < R ? Ho - p0 : R;
         __syncthreads();   // the previous band's fragments have been read (first trip: the weights are in place after the next one)
         {
             // (Issuing the NEXT band's loads before this band's items and parking them in registers measured slower: 71 -> 77 us.)
-            const unsigned char* xg = BNIN ? (const unsigned char*)x + ((n * Ho * Wo) * (long long)C) * 2
-                                           : (const unsigned char*)x + (((n * Hi + p0) * Wi) * (long long)C) * 2;
+            const unsigned char* xg = BNIN ? (const unsigned char*)x + (((long long)n * Ho * Wo) * (long long)C) * 2
+                                           : (const unsigned char*)x + ((((long long)n * Hi + p0) * Wi) * (long long)C) * 2;
             uint4 sb[FSL];
             unsigned live = 0;   // chunks that hold image data (the zero fill beyond Wi stays zero)
 #pragma unroll
@@ -329,61 +336,109 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
                 if ((rw[u] & 0x3fff) < rows + 2) *reinterpret_cast<uint4*>(xl + lo[u]) = sb[u];
         }
         __syncthreads();
-        unsigned char* const yband = (unsigned char*)y + ((n * Ho + p0) * Wo) * (long long)K * 2;   // uniform
+        // the band's output rows as one buffer: stores carry a lane-constant offset (or OOB for pixels beyond the row: no
+        // branch around the store) and the item's scalar offset
+        unsigned char* const yband = (unsigned char*)y + (((long long)n * Ho + p0) * Wo) * (long long)K * 2;   // uniform
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)yband, 0, rows * Wo * K * 2, 0x00020000);
         const int nitems = (KP_FB_ABL & 2) ? 0 : rows * nseg;
-        for (int item = wave; item < nitems; item += FNW) {    // all of this is scalar: row, segment, bases
+        // one item = 32 pixels of one row x K channels: 9 x CB fragment reads, 9 x CB MFMAs into one accumulator tile
+        auto mma = [&](int item) {                             // item -> row, segment, LDS base: scalar
             const int r = item / nseg, sq = item - r * nseg;
-            const bool full = sq * 32 + 32 <= Wo;              // whole segment inside the row: no lane mask anywhere
-            const bool ok = (full || sq * 32 + fr < Wo) && !(KP_FB_ABL & 4);
             const unsigned char* xb = xl + (r * xrow_l + sq * 32 * PITCH) + lane_ld;
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            h16x8 xf[9 * CB];
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb)
-                    xf[t * CB + cb] = (KP_FB_ABL & 16) ? h16x8{(short)item, 0, 0, 0, 0, 0, 0, 0}
-                                                       : *reinterpret_cast<const h16x8*>(xb + (t / 3) * xrow_l + (t % 3) * PITCH + cb * 32);
+                for (int cb = 0; cb < CB; ++cb) {
+                    const h16x8 xf = (KP_FB_ABL & 16) ? h16x8{(short)item, 0, 0, 0, 0, 0, 0, 0}
+                                                      : *reinterpret_cast<const h16x8*>(xb + (t / 3) * xrow_l + (t % 3) * PITCH + cb * 32);
+                    if (KP_FB_ABL & 8) acc[(t * CB + cb) & 15] += (float)xf[0];
+                    else acc = kp_mfma16(WREG ? wreg[t * CB + cb] : swf[t * CB + cb][lane], xf, acc, 0, 0, 0);
+                }
+            return acc;
+        };
+        // bias, statistics, 16-bit pack, lane exchange, store: straight-line code (no branch: the scheduler is free to put it
+        // under the MFMAs of the NEXT item, see the loop below)
+        auto epi = [&](int item, const f32x16& acc) {
+            const int r = item / nseg, sq = item - r * nseg;
+            const int valid = Wo - sq * 32;                     // pixels of the segment inside the row (>= 32: all)
+            f32x2 v[JH];
 #pragma unroll
-            for (int t = 0; t < 9 * CB; ++t) {
-                if (KP_FB_ABL & 8) acc[t & 15] += (float)xf[t][0];
-                else acc = kp_mfma16(WREG ? wreg[t] : swf[t][lane], xf[t], acc, 0, 0, 0);   // (two accumulator chains: no faster, measured)
-            }
-            f32x2 v[8];
+            for (int j = 0; j < JH; ++j) v[j] = f32x2{acc[2 * j], acc[2 * j + 1]} + bv[j];
+            if constexpr (STATS) {
+                // lanes beyond the row: x 0 (their fragments are the zero fill and halo, finite); x 1 is exact
+                const float okf = fr < valid ? 1.f : 0.f;
+                f32x2 ok2{okf, okf};
+                asm("" : "+v"(ok2));   // a real register pair: packed multiplies below
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = f32x2{acc[2 * j], acc[2 * j + 1]} + bv[j];
-            if (want_stats) {
-                if (full) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] = __builtin_elementwise_fma(v[j], v[j], ssq[j]); }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const f32x2 m = ok ? v[j] : f32x2{0.f, 0.f};
-                        ssum[j] += m; ssq[j] = __builtin_elementwise_fma(m, m, ssq[j]);
-                    }
+                for (int j = 0; j < JH; ++j) {
+                    const f32x2 m = v[j] * ok2;
+                    ssum[j] += m; ssq[j] = __builtin_elementwise_fma(m, m, ssq[j]);
                 }
             }
-            // pair the half-waves' 8-byte pieces: after the swaps lanes fh = 0 hold channels 8g .. 8g+7 of chunk g (even g),
-            // lanes fh = 1 those of chunk g + 1
-            unsigned char* const yp = yband + (r * Wo + sq * 32) * K * 2;   // uniform; + lane_st per lane
+            uint32_t p[JH];
 #pragma unroll
-            for (int g = 0; g < 4; g += 2) {
-                uint32_t a0 = pack_h16x2(v[2 * g][0], v[2 * g][1]), a1 = pack_h16x2(v[2 * g + 1][0], v[2 * g + 1][1]);
-                uint32_t b0 = pack_h16x2(v[2 * g + 2][0], v[2 * g + 2][1]), b1 = pack_h16x2(v[2 * g + 3][0], v[2 * g + 3][1]);
-                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a0), "+v"(b0));
-                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a1), "+v"(b1));
-                if (ok && 8 * (g + fh) < K) *reinterpret_cast<uint4*>(yp + lane_st + g * 16) = make_uint4(a0, a1, b0, b1);
+            for (int j = 0; j < JH; ++j) p[j] = pack_h16x2(v[j][0], v[j][1]);
+            // pair the half-waves' 8-byte pieces: lanes fh = 0 then hold channels 8g .. 8g + 7 (chunk g, even g), lanes fh = 1 chunk g + 1
+#pragma unroll
+            for (int g = 0; g < JH; g += 4) {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(p[g], p[g + 2], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(p[g + 1], p[g + 3], false, false);
+                p[g] = s0[0]; p[g + 2] = s0[1]; p[g + 1] = s1[0]; p[g + 3] = s1[1];
+            }
+            const int soff = (r * Wo + sq * 32) * K * 2;
+            if constexpr (KB == 1) {
+                const int vo = (fr < valid && !(KP_FB_ABL & 4)) ? lane_st : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{p[0], p[1], p[2], p[3]}, yr, vo, soff, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {                   // 16-lane rows: (p[i], p[4 + i]) -> (pixels 0-15, pixels 16-31)
+                    const auto s = __builtin_amdgcn_permlane16_swap(p[i], p[4 + i], false, false);
+                    p[i] = s[0]; p[4 + i] = s[1];
+                }
+                const int va = (px16 < valid && !(KP_FB_ABL & 4)) ? lane_st : OOB;
+                const int vb = (px16 + 16 < valid && !(KP_FB_ABL & 4)) ? lane_st + 1024 : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{p[0], p[1], p[2], p[3]}, yr, va, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{p[4], p[5], p[6], p[7]}, yr, vb, soff, 0);
+            }
+        };
+        // a wavefront's items wave, wave + FNW, ...: the MFMAs of item i + 1 are issued BEFORE the epilogue of item i, in
+        // one basic block -- a lone wave otherwise runs a 9-deep dependent MFMA chain and then ~60 dependent VALU
+        // instructions back to back (~1 200 cycles per item, with two waves per SIMD to hide it)
+        // (two named accumulators and the loop unrolled by two: no register copies between them -- where the registers
+        // allow: the 32-channel variants with statistics would spill 4-25 and keep the rolled loop and its 8 copies)
+        if (wave < nitems) {
+            int item = wave;
+            f32x16 a0 = mma(item);
+            if constexpr (STATS && KB == 2) {
+                for (; item + FNW < nitems; item += FNW) {
+                    const f32x16 nxt = mma(item + FNW);
+                    epi(item, a0);
+                    a0 = nxt;
+                }
+                epi(item, a0);
+            } else {
+                f32x16 a1;
+                for (;;) {
+                    if (item + FNW >= nitems) { epi(item, a0); break; }
+                    a1 = mma(item + FNW); epi(item, a0); item += FNW;
+                    if (item + FNW >= nitems) { epi(item, a1); break; }
+                    a0 = mma(item + FNW); epi(item, a1); item += FNW;
+                }
             }
         }
     }
-    if (partials) {
+    if constexpr (STATS) {
         const long long gw = (long long)blockIdx.x * FNW + wave;
         float s1[16], s2[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s1[2 * j] = ssum[j][0]; s1[2 * j + 1] = ssum[j][1]; s2[2 * j] = ssq[j][0]; s2[2 * j + 1] = ssq[j][1]; }
+        for (int j = 0; j < 8; ++j) {
+            const bool on = j < JH;
+            s1[2 * j] = on ? ssum[j % JH][0] : 0.f; s1[2 * j + 1] = on ? ssum[j % JH][1] : 0.f;
+            s2[2 * j] = on ? ssq[j % JH][0] : 0.f; s2[2 * j + 1] = on ? ssq[j % JH][1] : 0.f;
+        }
         int r1, r2;
         const float ts = reduce16_over32(s1, lane, r1);
         const float tq = reduce16_over32(s2, lane, r2);
@@ -710,12 +765,31 @@ static int small_fwd_band_rows(int Ho, int Wo, int C) {
     return R < 1 ? 0 : (int)R;
 }
 
+// the 16 instances of the band kernel: input / output channels 16 | 32, BatchNorm input or stored activation, with / without statistics
+template <bool BNIN, int CB, int KB>
+static void small_band_launch_ck(unsigned grid, hipStream_t st, const void* x, const void* w, const float* bias, void* y, float* stats,
+                                 int Hi, int Wi, int R, int bpi, int bands, const BnIn& bn) {
+    if (stats)
+        conv3x3_small_band_k<CB, KB, BNIN, true><<<grid, FTPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, R, bpi, bands, bn);
+    else
+        conv3x3_small_band_k<CB, KB, BNIN, false><<<grid, FTPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, R, bpi, bands, bn);
+}
+template <bool BNIN>
+static void small_band_launch(int C, int K, unsigned grid, hipStream_t st, const void* x, const void* w, const float* bias, void* y,
+                              float* stats, int Hi, int Wi, int R, int bpi, int bands, const BnIn& bn) {
+    if (C == 16 && K == 16) small_band_launch_ck<BNIN, 1, 1>(grid, st, x, w, bias, y, stats, Hi, Wi, R, bpi, bands, bn);
+    else if (C == 16) small_band_launch_ck<BNIN, 1, 2>(grid, st, x, w, bias, y, stats, Hi, Wi, R, bpi, bands, bn);
+    else if (K == 16) small_band_launch_ck<BNIN, 2, 1>(grid, st, x, w, bias, y, stats, Hi, Wi, R, bpi, bands, bn);
+    else small_band_launch_ck<BNIN, 2, 2>(grid, st, x, w, bias, y, stats, Hi, Wi, R, bpi, bands, bn);
+}
+
 // band plan of the LDS-staged forward: rows per band, bands per image, grid (0: no band kernel for this shape)
 static long long small_fwd_band_plan(int N, int Ho, int Wo, int C, bool stats, int& R, int& bpi, long long& bands) {
     R = small_fwd_band_rows(Ho, Wo, C);
     if (!R) return 0;
     bpi = (Ho + R - 1) / R;
     bands = (long long)N * bpi;
+    if (bands > 0x7fffffffLL) return 0;   // the kernel counts bands in 32 bits
     long long grid = bands < 512 ? bands : 512;
     const long long max_rows = ((long long)N * Ho * Wo + 63) / 64;   // the caller's statistics buffer
     if (stats && grid * FNW > max_rows) grid = max_rows / FNW;
@@ -732,10 +806,7 @@ int kp_conv_small_fwd(const void* x, const void* w, const float* bias, void* y, 
         if (const long long grid = small_fwd_band_plan(N, Ho, Wo, C, stats != nullptr, R, bpi, bands)) {
             if (stats) kp_set_last_rows(grid * FNW);
             KP_QUERY_RETURN();
-            if (C == 16)
-                conv3x3_small_band_k<1, false><<<(unsigned)grid, FTPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, K, R, bpi, bands, BnIn{});
-            else
-                conv3x3_small_band_k<2, false><<<(unsigned)grid, FTPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, K, R, bpi, bands, BnIn{});
+            small_band_launch<false>(C, K, (unsigned)grid, st, x, w, bias, y, stats, Hi, Wi, R, bpi, (int)bands, BnIn{});
             return kp_check_launch("conv3x3_small_band");
         }
     }
@@ -775,10 +846,7 @@ int kp_conv_small_fwd_bnin(const void* yprev, const float* mean, const float* in
     if (stats) kp_set_last_rows(grid * FNW);
     KP_QUERY_RETURN();
     const BnIn bn{mean, invstd, gamma, beta, slope};
-    if (C == 16)
-        conv3x3_small_band_k<1, true><<<(unsigned)grid, FTPB, 0, st>>>((const h16_t*)yprev, (const h16_t*)w, bias, (h16_t*)y, stats, Ho + 2, Wo + 2, K, R, bpi, bands, bn);
-    else
-        conv3x3_small_band_k<2, true><<<(unsigned)grid, FTPB, 0, st>>>((const h16_t*)yprev, (const h16_t*)w, bias, (h16_t*)y, stats, Ho + 2, Wo + 2, K, R, bpi, bands, bn);
+    small_band_launch<true>(C, K, (unsigned)grid, st, yprev, w, bias, y, stats, Ho + 2, Wo + 2, R, bpi, (int)bands, bn);
     return kp_check_launch("conv3x3_small_band_bnin");
 }
 
