@@ -11,6 +11,7 @@
 // weight gradient (wgrad3x3_small_k): also MFMA and LDS-free: one 32x32 [k][c] tile per tap (9 accumulators), the
 //   pixel-reduction fragments gathered with 2-byte loads at a channel stride (L1-resident 64-byte runs); the 4
 //   wavefronts of a workgroup are summed through LDS, then fp32 atomics into the zeroed scratch.
+#include <type_traits>
 #include "kp_common.h"
 
 namespace {
@@ -235,7 +236,11 @@ constexpr int FSL = 12 * 256 / FTPB;   // 16-byte chunks per thread in one band 
 // the lane mask of ragged segments -- where a wave-uniform test says they are not needed.
 // WREG: the 9 x CB weight fragments live in registers (36 / 72 VGPRs) instead of LDS: occupancy is set by the band's LDS here, not by
 // registers, and an item then issues 9 x CB LDS reads instead of 18 x CB (the 32-channel BatchNorm-input variant has no room).
-template <int CB, int KB, bool BNIN, bool STATS, bool WREG = !(BNIN && CB == 2)>
+// WIN: a wavefront walks its items DOWN a column of segments (items numbered segment-major) and keeps the fragments of the
+// last two input rows in registers -- 3 x CB fragment reads per item instead of 9 x CB (the ablation build without
+// fragment reads ran 32 -> 21 us: the LDS reads, issue + latency, were the largest single term).  The window is 36 registers
+// per 16 input channels: the 16-channel-input variants have room, and the 32-channel ones without statistics.
+template <int CB, int KB, bool BNIN, bool STATS, bool WREG = !(BNIN && CB == 2), bool WIN = (CB == 1)>
 __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
                                                             const float* __restrict__ bias, h16_t* __restrict__ y,
                                                             float* __restrict__ partials, int Hi, int Wi, int R,
@@ -245,32 +250,15 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
     __shared__ h16x8 swf[WREG ? 1 : 9 * CB][64];
     __shared__ __attribute__((aligned(16))) unsigned char xl[FB_LDS];
     __shared__ __attribute__((aligned(16))) float cst[BNIN ? 4 : 1][32];
+#ifdef KP_FB_TRACE
+    const unsigned long long t_entry = wall_clock64();
+#endif
     if (BNIN) bnin_fill(cst, bn, C, threadIdx.x);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
     const int Ho = Hi - 2, Wo = Wi - 2;
     const int nseg = (Wo + 31) / 32, XPW = nseg * 32 + 2, xrow_l = XPW * PITCH;
-    h16x8 wreg[WREG ? 9 * CB : 1];
-    if (WREG || wave == 0) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) {
-                h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (fr < K) v = *reinterpret_cast<const h16x8*>(w + ((long long)fr * 9 + t) * C + cb * 16 + fh * 8);
-                if (WREG) wreg[t * CB + cb] = v;
-                else swf[t * CB + cb][lane] = v;
-            }
-    }
-    // D[k][px]: lane: pixel = fr, k = 8 * (reg >> 2) + 4 * fh + (reg & 3); register PAIRS (2j, 2j + 1) are the packed operands
-    f32x2 bv[JH], ssum[STATS ? JH : 1], ssq[STATS ? JH : 1];
-#pragma unroll
-    for (int j = 0; j < JH; ++j) {
-        const int k = 8 * (j >> 1) + 4 * fh + 2 * (j & 1);
-        bv[j] = f32x2{bias ? bias[k] : 0.f, bias ? bias[k + 1] : 0.f};
-        if (STATS) ssum[j] = ssq[j] = f32x2{0.f, 0.f};
-    }
     // ---- staging tables of this thread's FSL chunks (band-independent): chunk id = tid + u * FTPB = (row * XPW + pixel) * CPP + c
     const int c = tid % CPP;
     int lo[FSL], so[FSL], rw[FSL];   // LDS byte offset; source byte offset (BNIN: of the clamped column only); band row (big: never staged)
@@ -297,45 +285,96 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
     const int lane_st = KB == 1 ? fr * 32 + fh * 16 : px16 * 64 + (2 * (lrow & 1) + (lrow >> 1)) * 16;
     constexpr int OOB = (int)0x80000000;               // beyond every band's bytes: the buffer store drops the lane
 
+    // ---- staging: the band's R + 2 input rows, global -> registers -> LDS ------------------------------------------------
+    // All of a band's loads are in flight before the first LDS store.  Buffer loads: a chunk outside the band or the image
+    // row carries an out-of-range offset and comes back as zeros -- no branch per chunk.  (Issuing band b + 1's loads
+    // before the items of band b and parking them in registers -- 48 -- was measured twice, with the old and with this
+    // item loop: no faster, 31.3 vs 31.9 us, and the 32-channel variants spill.  The clock stamps of
+    // tools/probes/small_trace.py say why: in steady state a band takes 4.8 us per workgroup = ~6 TB/s over the chip;
+    // what the kernel loses it loses at its ends -- 1.3 us of prologue, 1.5 us until the first band has landed, 4.5 us
+    // between the mean and the last workgroup's end, 4.5 us of launch and teardown around a 22 us body.)
+    uint4 sb[FSL];
+    unsigned live = 0;   // BNIN: chunks that hold image data (the zero fill must stay zero behind the transform)
+    auto issue = [&](int band) {
+        const int n = band / bands_per_img;
+        const int p0 = (band - n * bands_per_img) * R;
+        const int rows = Ho - p0 < R ? Ho - p0 : R;
+        const unsigned char* xg = BNIN ? (const unsigned char*)x + (((long long)n * Ho * Wo) * (long long)C) * 2
+                                       : (const unsigned char*)x + ((((long long)n * Hi + p0) * Wi) * (long long)C) * 2;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, (BNIN ? Ho * Wo : (rows + 2) * Wi) * C * 2, 0x00020000);
+        live = 0;
+#pragma unroll
+        for (int u = 0; u < FSL; ++u) {
+            const bool on = rw[u] < rows + 2 && !(KP_FB_ABL & 1);   // (rows beyond the band and the zero fill have a large rw)
+            int off = so[u];
+            if (BNIN) {   // row clamp of the replicate pad: padded row p0 + r <- clamp(p0 + r - 1) of the unpadded map
+                const int pr = p0 + (rw[u] & 0x3fff) - 1;
+                off += (pr < 0 ? 0 : (pr > Ho - 1 ? Ho - 1 : pr)) * (Wo * C * 2);
+                live |= on ? 1u << u : 0u;
+            }
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(xr, on ? off : OOB, 0, 0);
+            sb[u] = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+    };
+    auto commit = [&]() {
+        if (BNIN) {
+            BnReg k;
+            k.load(cst, c * 8);
+#pragma unroll
+            for (int u = 0; u < FSL; ++u) {
+                const uint4 t = bnin_apply(sb[u], k, bn.slope);
+                const bool on = live & (1u << u);
+                sb[u] = make_uint4(on ? t.x : 0u, on ? t.y : 0u, on ? t.z : 0u, on ? t.w : 0u);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FSL; ++u)
+            if ((rw[u] & 0x3fff) < R + 2) *reinterpret_cast<uint4*>(xl + lo[u]) = sb[u];   // (rows past a short last band: zeros, never read)
+    };
+
+#ifdef KP_FB_TRACE   // probe builds (tools/probes/small_trace.py): clock stamps of wave 0 behind the statistics rows
+    unsigned long long* const trc = STATS ? (unsigned long long*)(partials + 8192 * 2 * K) + (long long)blockIdx.x * 32 : nullptr;
+    int trn = 0;
+    auto stamp = [&]() { if (STATS && tid == 0 && trn < 32) trc[trn++] = wall_clock64(); };
+    if (STATS && tid == 0) trc[trn++] = t_entry;
+    if (STATS && tid == 0) { unsigned id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); trc[trn++] = ((unsigned long long)xcc << 32) | id; }
+    stamp();
+#else
+    auto stamp = [&]() {};
+#endif
+    // (the weights and the bias -- cold loads -- are requested here, behind the address tables, and first used behind the first
+    // band's loads: one round trip for both)
+    h16x8 wreg[WREG ? 9 * CB : 1];
+    if (WREG || wave == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (fr < K) v = *reinterpret_cast<const h16x8*>(w + ((long long)fr * 9 + t) * C + cb * 16 + fh * 8);
+                if (WREG) wreg[t * CB + cb] = v;
+                else swf[t * CB + cb][lane] = v;
+            }
+    }
+    // D[k][px]: lane: pixel = fr, k = 8 * (reg >> 2) + 4 * fh + (reg & 3); register PAIRS (2j, 2j + 1) are the packed operands
+    f32x2 bv[JH], ssum[STATS ? JH : 1], ssq[STATS ? JH : 1];
+#pragma unroll
+    for (int j = 0; j < JH; ++j) {
+        const int k = 8 * (j >> 1) + 4 * fh + 2 * (j & 1);
+        bv[j] = f32x2{bias ? bias[k] : 0.f, bias ? bias[k + 1] : 0.f};
+        if (STATS) ssum[j] = ssq[j] = f32x2{0.f, 0.f};
+    }
     for (int band = blockIdx.x; band < total_bands; band += gridDim.x) {
         const int n = band / bands_per_img;
         const int p0 = (band - n * bands_per_img) * R;
         const int rows = Ho - p0 < R ? Ho - p0 : R;
+        stamp();
         __syncthreads();   // the previous band's fragments have been read (first trip: the weights are in place after the next one)
-        {
-            // (Issuing the NEXT band's loads before this band's items and parking them in registers measured slower: 71 -> 77 us.)
-            const unsigned char* xg = BNIN ? (const unsigned char*)x + (((long long)n * Ho * Wo) * (long long)C) * 2
-                                           : (const unsigned char*)x + ((((long long)n * Hi + p0) * Wi) * (long long)C) * 2;
-            uint4 sb[FSL];
-            unsigned live = 0;   // chunks that hold image data (the zero fill beyond Wi stays zero)
-#pragma unroll
-            for (int u = 0; u < FSL; ++u) {
-                sb[u] = make_uint4(0, 0, 0, 0);
-                if (rw[u] < rows + 2 && !(KP_FB_ABL & 1)) {      // (rows beyond the band and the zero fill have a large rw)
-                    int off = so[u];
-                    if (BNIN) {   // row clamp of the replicate pad: padded row p0 + r <- clamp(p0 + r - 1) of the unpadded map
-                        const int pr = p0 + rw[u] - 1;
-                        off += (pr < 0 ? 0 : (pr > Ho - 1 ? Ho - 1 : pr)) * (Wo * C * 2);
-                    }
-                    sb[u] = *reinterpret_cast<const uint4*>(xg + off);
-                    live |= 1u << u;
-                }
-            }
-            if (BNIN) {
-                BnReg k;
-                k.load(cst, c * 8);
-#pragma unroll
-                for (int u = 0; u < FSL; ++u) {
-                    const uint4 t = bnin_apply(sb[u], k, bn.slope);
-                    const bool on = live & (1u << u);
-                    sb[u] = make_uint4(on ? t.x : 0u, on ? t.y : 0u, on ? t.z : 0u, on ? t.w : 0u);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < FSL; ++u)
-                if ((rw[u] & 0x3fff) < rows + 2) *reinterpret_cast<uint4*>(xl + lo[u]) = sb[u];
-        }
+        stamp();
+        issue(band);
+        commit();
         __syncthreads();
+        stamp();
         // the band's output rows as one buffer: stores carry a lane-constant offset (or OOB for pixels beyond the row: no
         // branch around the store) and the item's scalar offset
         unsigned char* const yband = (unsigned char*)y + (((long long)n * Ho + p0) * Wo) * (long long)K * 2;   // uniform
@@ -361,12 +400,8 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
         };
         // bias, statistics, 16-bit pack, lane exchange, store: straight-line code (no branch: the scheduler is free to put it
         // under the MFMAs of the NEXT item, see the loop below)
-        auto epi = [&](int item, const f32x16& acc) {
-            const int r = item / nseg, sq = item - r * nseg;
+        auto epi_rest = [&](int r, int sq, const f32x2 (&v)[JH]) {
             const int valid = Wo - sq * 32;                     // pixels of the segment inside the row (>= 32: all)
-            f32x2 v[JH];
-#pragma unroll
-            for (int j = 0; j < JH; ++j) v[j] = f32x2{acc[2 * j], acc[2 * j + 1]} + bv[j];
             if constexpr (STATS) {
                 // lanes beyond the row: x 0 (their fragments are the zero fill and halo, finite); x 1 is exact
                 const float okf = fr < valid ? 1.f : 0.f;
@@ -404,12 +439,81 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{p[4], p[5], p[6], p[7]}, yr, vb, soff, 0);
             }
         };
+        auto epi = [&](int item, const f32x16& acc) {
+            const int r = item / nseg, sq = item - r * nseg;
+            f32x2 v[JH];
+#pragma unroll
+            for (int j = 0; j < JH; ++j) v[j] = f32x2{acc[2 * j], acc[2 * j + 1]} + bv[j];
+            epi_rest(r, sq, v);
+        };
         // a wavefront's items wave, wave + FNW, ...: the MFMAs of item i + 1 are issued BEFORE the epilogue of item i, in
         // one basic block -- a lone wave otherwise runs a 9-deep dependent MFMA chain and then ~60 dependent VALU
         // instructions back to back (~1 200 cycles per item, with two waves per SIMD to hide it)
         // (two named accumulators and the loop unrolled by two: no register copies between them -- where the registers
         // allow: the 32-channel variants with statistics would spill 4-25 and keep the rolled loop and its 8 copies)
-        if (wave < nitems) {
+        if constexpr (WIN) {
+            // items segment-major: idx = sq * rows + r; the wavefront's contiguous quarter of them
+            const int beg = nitems * wave / FNW, end = nitems * (wave + 1) / FNW;
+            if (beg < end) {
+                int sq = beg / rows, r = beg - sq * rows, idx = beg;
+                h16x8 w0[3 * CB], w1[3 * CB], w2[3 * CB];       // the window: three input rows x 3 taps x CB
+                auto row_load = [&](h16x8 (&d)[3 * CB], int prow) {
+                    const unsigned char* xb = xl + (prow * xrow_l + sq * 32 * PITCH) + lane_ld;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb)
+                            d[t * CB + cb] = (KP_FB_ABL & 16) ? h16x8{(short)prow, 0, 0, 0, 0, 0, 0, 0}
+                                                              : *reinterpret_cast<const h16x8*>(xb + t * PITCH + cb * 32);
+                };
+                f32x2 vp[JH];                                   // the pending item: accumulators + bias, its row and segment
+                int rp = 0, sqp = 0;
+                // one step: read the new bottom row, multiply (taps in the order of the rolled kernel: bit-identical
+                // outputs), finish the PENDING item under those MFMAs, then take over this item's accumulators
+                auto step = [&](const h16x8 (&a)[3 * CB], const h16x8 (&b)[3 * CB], h16x8 (&cn)[3 * CB], auto first) {
+                    row_load(cn, r + 2);
+                    f32x16 acc;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 9 * CB; ++t) {
+                        const h16x8& xf = t < 3 * CB ? a[t] : (t < 6 * CB ? b[t - 3 * CB] : cn[t - 6 * CB]);
+                        if (KP_FB_ABL & 8) acc[t & 15] += (float)xf[0];
+                        else acc = kp_mfma16(wreg[t], xf, acc, 0, 0, 0);
+                    }
+                    if constexpr (!decltype(first)::value) epi_rest(rp, sqp, vp);
+#pragma unroll
+                    for (int j = 0; j < JH; ++j) vp[j] = f32x2{acc[2 * j], acc[2 * j + 1]} + bv[j];
+                    rp = r; sqp = sq;
+                    ++idx; ++r;
+                };
+                // the three roles of (w0, w1, w2) as straight-line code, each step in a block of its own (a common tail
+                // would take the epilogue out from under the MFMAs); at the bottom of a column: next segment, refill
+                auto wrap = [&]() {
+                    if (r < rows) return false;
+                    r = 0; ++sq;
+                    row_load(w0, 0); row_load(w1, 1);
+                    return true;
+                };
+                row_load(w0, r); row_load(w1, r + 1);
+                step(w0, w1, w2, std::true_type{});
+                while (idx < end) {
+                    if (!wrap()) {
+                        step(w1, w2, w0, std::false_type{});
+                        if (idx >= end) break;
+                        if (!wrap()) {
+                            step(w2, w0, w1, std::false_type{});
+                            if (idx >= end) break;
+                            wrap();
+                        }
+                    }
+                    // here the two newest rows are (w0, w1) -- after a refill, or after three steps
+                    if (idx >= end) break;
+                    step(w0, w1, w2, std::false_type{});
+                }
+                epi_rest(rp, sqp, vp);
+            }
+        } else if (wave < nitems) {
             int item = wave;
             f32x16 a0 = mma(item);
             if constexpr (STATS && KB == 2) {
@@ -430,6 +534,7 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
             }
         }
     }
+    stamp();
     if constexpr (STATS) {
         const long long gw = (long long)blockIdx.x * FNW + wave;
         float s1[16], s2[16];
