@@ -237,6 +237,25 @@ long long kp_head_bwd_ws_floats(int N, int H, int W, int C, int K, int dtype);
 int kp_head_bwd(const float* gout, const float* out, const void* x, const float* w, float slope,
                 void* dx, float* dw, float* db, float* ws, int N, int H, int W, int C, int K, int dtype, void* stream);
 
+/* The head of a Unit fed by its last 3x3 layer's convolution OUTPUT (knn.py:110-130: core ... -> out_block): BatchNorm2d
+ * (train: batch statistics) + (Leaky)ReLU of that layer (vgg.py:30-38) run on the head's load path -- the layer's activation
+ * tensor is never written.  yprev [N][H][W][C] T (no border); mean / invstd / gamma / beta fp32 [C] (all NULL: no BatchNorm);
+ * slope_in: the producing layer's activation slope, 0 <= slope_in <= 1.
+ *   kp_head_fwd_bnin == kp_bn_act_fwd(yprev, ..., slope_in, tail none, a, out_pad 0) + kp_head_fwd(a, ...)
+ *   kp_head_bwd_bnin == the same + kp_head_bwd(gout, out, a, ...)
+ * bit for bit (same expression, same rounding to the storage type).  kp_head_bnin_supported: 1 if both exist for the shape
+ * (16-bit storage, and the kernel kp_head_fwd picks for the shape has the fused form: the 32-channel matrix-core head --
+ * kp_head_mfma.hip -- or the K <= 16 kernels with C a power of two <= 512 -- kp_head_fast.hip; the wide matrix-core heads
+ * do not); otherwise the calls return KP_E_UNSUPPORTED and launch nothing.
+ * Workspace: kp_head_bwd_ws_floats of the same shape. */
+int kp_head_bnin_supported(int N, int H, int W, int C, int K, int dtype);
+int kp_head_fwd_bnin(const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     float slope_in, const float* w, const float* bias, float slope, float* out, int N, int H, int W, int C,
+                     int K, int dtype, void* stream);
+int kp_head_bwd_bnin(const float* gout, const float* out, const void* yprev, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, float slope_in, const float* w, float slope, void* dx, float* dw,
+                     float* db, float* ws, int N, int H, int W, int C, int K, int dtype, void* stream);
+
 /* ---- inference-only Unit forward as one kernel -------- */
 /* `net.keypoint(x)` of the reference's consumers (atari_demo.py:35-36, tests/test_gl_hack.py:454-456): a Unit
  * (keypoints/models/knn.py:110-130) in eval mode whose core has no pooling / upsampling (the Pong-class tables of

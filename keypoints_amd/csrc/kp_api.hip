@@ -210,6 +210,11 @@ KP_DISPATCH(kp_head_fwd, (const void* x, const float* w, const float* bias, floa
             (x, w, bias, slope, out, N, H, W, C, K, dtype, stream))
 KP_DISPATCH(kp_head_bwd, (const float* gout, const float* out, const void* x, const float* w, float slope, void* dx, float* dw, float* db, float* ws, int N, int H, int W, int C, int K, int dtype, void* stream),
             (gout, out, x, w, slope, dx, dw, db, ws, N, H, W, C, K, dtype, stream))
+KP_DISPATCH(kp_head_bnin_supported, (int N, int H, int W, int C, int K, int dtype), (N, H, W, C, K, dtype))
+KP_DISPATCH(kp_head_fwd_bnin, (const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope_in, const float* w, const float* bias, float slope, float* out, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (yprev, mean, invstd, gamma, beta, slope_in, w, bias, slope, out, N, H, W, C, K, dtype, stream))
+KP_DISPATCH(kp_head_bwd_bnin, (const float* gout, const float* out, const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope_in, const float* w, float slope, void* dx, float* dw, float* db, float* ws, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (gout, out, yprev, mean, invstd, gamma, beta, slope_in, w, slope, dx, dw, db, ws, N, H, W, C, K, dtype, stream))
 long long kp_head_bwd_ws_floats__bf16(int, int, int, int, int, int);
 long long kp_head_bwd_ws_floats__f16(int, int, int, int, int, int);
 long long kp_head_bwd_ws_floats(int N, int H, int W, int C, int K, int dtype) {

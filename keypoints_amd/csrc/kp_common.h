@@ -114,6 +114,43 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float act_fwd(float z, float slope) { return z > 0.f ? z : z * slope; }
 __device__ __forceinline__ float act_grad(float z, float slope) { return z > 0.f ? 1.f : slope; }
 
+// ---- BatchNorm-apply + activation of the PRODUCING layer applied by the consumer while it loads its input ------------------
+// (kp_conv_fwd_bnin / kp_conv_wgrad_bnin: kp_conv_small.hip; kp_head_fwd_bnin / kp_head_bwd_bnin: kp_head_fast.hip, kp_head_mfma.hip).
+// The arithmetic is kp_bn_act_fwd's, expression for expression: (y - mean) * invstd * gamma + beta, the activation, RNE to the
+// 16-bit storage type -- what the consumer multiplies is bit for bit what the separate pass would have stored.
+struct KpBnIn {
+    const float *mean, *invstd, *gamma, *beta;   // mean == nullptr: no BatchNorm (batch_norm=False), activation only
+    float slope;                                 // 0 <= slope <= 1 (checked by the launchers)
+};
+// act(z) = max(z, z * slope) is (z > 0 ? z : z * slope) bit for bit for 0 <= slope <= 1, zeros and NaNs included
+__device__ __forceinline__ float kp_bnin1(float y, float mu, float is, float ga, float be, float slope) {
+    const float z = (y - mu) * is * ga + be;
+    return fmaxf(z, z * slope);
+}
+// the four constants of channels c0 .. c0 + 7 (without BatchNorm the EXACT identity (y - (+0)) * 1 * 1 + (-0))
+struct KpBnIn8 {
+    float mu[8], is[8], ga[8], be[8];
+    __device__ __forceinline__ void load(const KpBnIn& bn, int c0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool aff = bn.mean != nullptr;
+            mu[e] = aff ? bn.mean[c0 + e] : 0.f;
+            is[e] = aff ? bn.invstd[c0 + e] : 1.f;
+            ga[e] = aff ? bn.gamma[c0 + e] : 1.f;
+            be[e] = aff ? bn.beta[c0 + e] : -0.f;
+        }
+    }
+    // one 16-byte chunk = 8 consecutive channels of a pixel, raw conv output -> stored activation
+    __device__ __forceinline__ uint4 apply(const uint4 raw, float slope) const {
+        float v[8];
+        unpack_h16x2(raw.x, v[0], v[1]); unpack_h16x2(raw.y, v[2], v[3]);
+        unpack_h16x2(raw.z, v[4], v[5]); unpack_h16x2(raw.w, v[6], v[7]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = kp_bnin1(v[e], mu[e], is[e], ga[e], be[e], slope);
+        return make_uint4(pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]), pack_h16x2(v[6], v[7]));
+    }
+};
+
 // torch.linspace(0, 1, n)[i] in fp32, built the way ATen builds it (symmetric halves).
 __device__ __forceinline__ float ruler_at(int i, int n) {
     if (n <= 1) return 0.f;

@@ -158,10 +158,7 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_k(const h16_t* __restrict__
 // kernels, and the padded activation tensor (write + read of the layer's output, one whole launch) never exists.  The
 // arithmetic is kp_bn_act_fwd's expression for expression ((y - mean) * invstd * gamma + beta, act, RNE to 16 bits), so the
 // fragments the MFMAs see are bit-identical to what the separate pass would have stored.
-struct BnIn {
-    const float *mean, *invstd, *gamma, *beta;   // mean == nullptr: no BatchNorm (batch_norm=False), activation only
-    float slope;
-};
+typedef KpBnIn BnIn;   // kp_common.h: {mean, invstd, gamma, beta, slope}; mean == nullptr: no BatchNorm, activation only
 // per-channel constants of the layer in LDS: [4][32] floats (mean, invstd, gamma, beta).  Without BatchNorm the constants are
 // the EXACT identity of the expression below: (y - (+0)) * 1 * 1 + (-0) == y for every y, signed zeros included.
 __device__ __forceinline__ void bnin_fill(float (*cst)[32], const BnIn& bn, int C, int tid) {
@@ -198,10 +195,7 @@ __device__ __forceinline__ uint4 bnin_apply(const uint4 raw, const BnReg& k, flo
     unpack_h16x2(raw.x, v[0], v[1]); unpack_h16x2(raw.y, v[2], v[3]);
     unpack_h16x2(raw.z, v[4], v[5]); unpack_h16x2(raw.w, v[6], v[7]);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float z = (v[e] - k.mu[e]) * k.is[e] * k.ga[e] + k.be[e];
-        v[e] = fmaxf(z, z * slope);
-    }
+    for (int e = 0; e < 8; ++e) v[e] = kp_bnin1(v[e], k.mu[e], k.is[e], k.ga[e], k.be[e], slope);
     return make_uint4(pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]), pack_h16x2(v[6], v[7]));
 }
 

@@ -477,14 +477,17 @@ __global__ void scale_k(const float* __restrict__ x, const float* __restrict__ s
         else { using T = h16_t; __VA_ARGS__; }        \
     } while (0)
 
-int kp_head_fwd_fast(const void*, const float*, const float*, float, float*, long long, int, int, int, hipStream_t);
-int kp_head_fwd_mfma(const void*, const float*, const float*, float, float*, long long, int, int, int, hipStream_t);
+int kp_head_fwd_fast(const void*, const float*, const float*, float, float*, long long, int, int, int, hipStream_t, const KpBnIn* = nullptr);
+int kp_head_fwd_mfma(const void*, const float*, const float*, float, float*, long long, int, int, int, hipStream_t, const KpBnIn* = nullptr);
 int kp_head_dx_mfma(const float*, const float*, const float*, float, void*, long long, int, int, int, hipStream_t);
-int kp_head_dw_mfma(const float*, const float*, const void*, float, float*, float*, float*, long long, int, int, int, hipStream_t);
+int kp_head_dw_mfma(const float*, const float*, const void*, float, float*, float*, float*, long long, int, int, int, hipStream_t, const KpBnIn* = nullptr);
+bool kp_head_small_shape(long long, int, int);
+bool kp_head_mfma_bnin_shape(long long, int, int, int);
+bool kp_head_mfma_shape(long long, int, int, int);
 long long kp_head_dw_parts_mfma(long long, int, int, int);
 long long kp_head_dw_parts_fast(long long, int, int);
 int kp_head_dx_fast(const float*, const float*, const float*, float, void*, long long, int, int, int, hipStream_t);
-int kp_head_dw_fast(const float*, const float*, const void*, float, float*, float*, float*, long long, int, int, int, hipStream_t);
+int kp_head_dw_fast(const float*, const float*, const void*, float, float*, float*, float*, long long, int, int, int, hipStream_t, const KpBnIn* = nullptr);
 
 extern "C" {
 
@@ -568,6 +571,35 @@ int kp_head_fwd(const void* x, const float* w, const float* bias, float slope, f
     return kp_check_launch("head_fwd");
 }
 
+// ---- the head fed by a convolution OUTPUT: BatchNorm-apply + activation of the producing layer on the head's load path ----
+// (the last 3x3 layer of a Unit: its activation pass -- one launch, write + read of the layer's output -- is not run, the
+// activation tensor never exists).  Only the 16-bit fast paths have this form: kp_head_bnin_supported tells.
+// (the fused form must be the kernel the plain call would pick for the shape -- the matrix-core head where it applies, else the
+//  K <= 16 kernels: two kernels round differently)
+static bool head_bnin_ok(long long M, int HW, int C, int K, int dtype) {
+    if (dtype != KP_H16) return false;
+    return kp_head_mfma_shape(M, HW, C, K) ? kp_head_mfma_bnin_shape(M, HW, C, K) : kp_head_small_shape(M, C, K);
+}
+int kp_head_bnin_supported(int N, int H, int W, int C, int K, int dtype) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 0;
+    return head_bnin_ok((long long)N * H * W, H * W, C, K, dtype) ? 1 : 0;
+}
+
+int kp_head_fwd_bnin(const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     float slope_in, const float* w, const float* bias, float slope, float* out, int N, int H, int W, int C,
+                     int K, int dtype, void* stream) {
+    KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "kp_head_fwd_bnin: bad dims");
+    KP_REQUIRE(slope_in >= 0.f && slope_in <= 1.f, "kp_head_fwd_bnin: activation slope of the producing layer must be in [0, 1]");
+    KP_REQUIRE((mean != nullptr) == (invstd != nullptr) && (mean != nullptr) == (gamma != nullptr) && (mean != nullptr) == (beta != nullptr),
+               "kp_head_fwd_bnin: mean / invstd / gamma / beta: all or none");
+    const long long M = (long long)N * H * W;
+    if (!head_bnin_ok(M, H * W, C, K, dtype)) return KP_E_UNSUPPORTED;
+    const KpBnIn bn{mean, invstd, gamma, beta, slope_in};
+    int rc = kp_head_fwd_mfma(yprev, w, bias, slope, out, M, H * W, C, K, (hipStream_t)stream, &bn);
+    if (rc == KP_E_UNSUPPORTED) rc = kp_head_fwd_fast(yprev, w, bias, slope, out, M, H * W, C, K, (hipStream_t)stream, &bn);
+    return rc;
+}
+
 // partial gradients (workspace rows of K*C + K floats) the weight-gradient kernel of this shape writes in deterministic mode
 static long long head_dw_parts(long long M, int HW, int C, int K, int dtype) {
     if (dtype == KP_H16) {
@@ -584,8 +616,8 @@ long long kp_head_bwd_ws_floats(int N, int H, int W, int C, int K, int dtype) {
     return head_dw_parts((long long)N * H * W, H * W, C, K, dtype) * ((long long)K * C + K);
 }
 
-int kp_head_bwd(const float* gout, const float* out, const void* x, const float* w, float slope, void* dx, float* dw,
-                float* db, float* ws, int N, int H, int W, int C, int K, int dtype, void* stream) {
+static int head_bwd_impl(const float* gout, const float* out, const void* x, const float* w, float slope, void* dx, float* dw,
+                         float* db, float* ws, int N, int H, int W, int C, int K, int dtype, void* stream, const KpBnIn* bn) {
     KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "kp_head_bwd: bad dims");
     KP_REQUIRE(K <= 256 && C <= 2048, "kp_head_bwd: K <= 256, C <= 2048 supported");
     const long long M = (long long)N * H * W;
@@ -603,10 +635,14 @@ int kp_head_bwd(const float* gout, const float* out, const void* x, const float*
     long long parts = (dw && ws) ? head_dw_parts(M, H * W, C, K, dtype) : 0;
     float* const dw_out = dw;
     if (dw && dtype == KP_H16) {
-        int rc = kp_head_dw_mfma(gout, out, x, slope, dw, db, ws, M, H * W, C, K, st);
-        if (rc == KP_E_UNSUPPORTED) rc = kp_head_dw_fast(gout, out, x, slope, dw, db, ws, M, H * W, C, K, st);
+        int rc = kp_head_dw_mfma(gout, out, x, slope, dw, db, ws, M, H * W, C, K, st, bn);
+        if (rc == KP_E_UNSUPPORTED) rc = kp_head_dw_fast(gout, out, x, slope, dw, db, ws, M, H * W, C, K, st, bn);
         if (rc == KP_OK) dw = nullptr;
         else if (rc != KP_E_UNSUPPORTED) return rc;
+    }
+    if (bn && dw) {   // the generic kernels below read a stored activation
+        kp_set_error("kp_head_bwd_bnin: no fast weight-gradient kernel took this call (gout / out must be 16-byte aligned)");
+        return KP_E_UNSUPPORTED;
     }
     if (dx) {
         const size_t smem = (size_t)HPB * (K + 1) * sizeof(float);
@@ -633,6 +669,23 @@ int kp_head_bwd(const float* gout, const float* out, const void* x, const float*
         return kp_check_launch("head_dw_reduce");
     }
     return KP_OK;
+}
+
+int kp_head_bwd(const float* gout, const float* out, const void* x, const float* w, float slope, void* dx, float* dw,
+                float* db, float* ws, int N, int H, int W, int C, int K, int dtype, void* stream) {
+    return head_bwd_impl(gout, out, x, w, slope, dx, dw, db, ws, N, H, W, C, K, dtype, stream, nullptr);
+}
+
+int kp_head_bwd_bnin(const float* gout, const float* out, const void* yprev, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, float slope_in, const float* w, float slope, void* dx, float* dw,
+                     float* db, float* ws, int N, int H, int W, int C, int K, int dtype, void* stream) {
+    KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "kp_head_bwd_bnin: bad dims");
+    KP_REQUIRE(slope_in >= 0.f && slope_in <= 1.f, "kp_head_bwd_bnin: activation slope of the producing layer must be in [0, 1]");
+    KP_REQUIRE((mean != nullptr) == (invstd != nullptr) && (mean != nullptr) == (gamma != nullptr) && (mean != nullptr) == (beta != nullptr),
+               "kp_head_bwd_bnin: mean / invstd / gamma / beta: all or none");
+    if (!head_bnin_ok((long long)N * H * W, H * W, C, K, dtype)) return KP_E_UNSUPPORTED;
+    const KpBnIn bn{mean, invstd, gamma, beta, slope_in};
+    return head_bwd_impl(gout, out, yprev, w, slope, dx, dw, db, ws, N, H, W, C, K, dtype, stream, &bn);
 }
 
 #ifndef KP_F16_BUILD   // no dtype: defined once, by the bf16 build of this source

@@ -44,21 +44,27 @@ __device__ __forceinline__ float group_sum(float v, int CV) {
 constexpr int PIX = 2;   // pixels in flight per thread
 
 // forward: weights in LDS (the register-resident variant measured slower: 173 VGPRs at KB = 16)
-template <int KB>
+// BNIN (all three kernels that read x): x is the producing layer's conv output and `bn` its BatchNorm / activation, applied
+// to each 16-byte chunk as it is loaded (KpBnIn, kp_common.h) -- a thread's 8 channels are fixed, their constants live in registers
+template <int KB, bool BNIN>
 __global__ __launch_bounds__(TPB) void head_fwd_small_k(const h16_t* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float slope,
                                                         float* __restrict__ out, long long M, int HW, int C, int K,
-                                                        int ppb) {
+                                                        int ppb, KpBnIn bn) {
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [K][C]
     for (int i = threadIdx.x; i < K * C; i += TPB) wl[i] = w[i];
     __syncthreads();
     const int CV = C / V, cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
+    KpBnIn8 k8;
+    if (BNIN) k8.load(bn, cv * V);
     const long long m0 = (long long)blockIdx.x * ppb;
     for (int i = pl; i < ppb; i += npl) {
         const long long m = m0 + i;
         if (m >= M) break;   // uniform within a pixel's lane group
         float xv[V];
-        unpack8(*reinterpret_cast<const uint4*>(x + m * C + cv * V), xv);
+        uint4 xraw = *reinterpret_cast<const uint4*>(x + m * C + cv * V);
+        if (BNIN) xraw = k8.apply(xraw, bn.slope);
+        unpack8(xraw, xv);
         float acc[KB];
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
@@ -146,14 +152,16 @@ __global__ __launch_bounds__(TPB) void head_dx_small_k(const float* __restrict__
     }
 }
 
-template <int KB>
+template <int KB, bool BNIN>
 __global__ __launch_bounds__(TPB) void head_dw_small_k(const float* __restrict__ gout, const float* __restrict__ out,
                                                        const h16_t* __restrict__ x, float slope,
                                                        float* __restrict__ dw, float* __restrict__ db,
                                                        float* __restrict__ ws, long long M, int HW, int C, int K,
-                                                       int ppb) {
+                                                       int ppb, KpBnIn bn) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [npl][KC][C] (+ [npl][KC] for db)
     const int CV = C / V, cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
+    KpBnIn8 k8;
+    if (BNIN) k8.load(bn, cv * V);
     float acc[KB][V], dbs[KB];
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
@@ -171,6 +179,10 @@ __global__ __launch_bounds__(TPB) void head_dw_small_k(const float* __restrict__
             if (!(i + u * npl < ppb && m < Mi)) m = -1;
             raw[u] = m >= 0 ? *reinterpret_cast<const uint4*>(x + (long long)m * C + cv * V) : make_uint4(0, 0, 0, 0);
             load_dz<KB>(gout, out, m, HW, K, slope, dz[u]);
+        }
+        if (BNIN) {   // (pixels past the end: dz = 0, whatever the transform makes of the zero chunk)
+#pragma unroll
+            for (int u = 0; u < PIX; ++u) raw[u] = k8.apply(raw[u], bn.slope);
         }
 #pragma unroll
         for (int u = 0; u < PIX; ++u) {
@@ -227,15 +239,18 @@ bool small_shape(int C, int K) {
         else { constexpr int KB = 16; CALL; }        \
     } while (0)
 
+// bn != nullptr: x is the producing layer's conv output, *bn its BatchNorm / activation (kp_head_fwd_bnin)
 int kp_head_fwd_fast(const void* x, const float* w, const float* bias, float slope, float* out, long long M, int HW,
-                     int C, int K, hipStream_t st) {
+                     int C, int K, hipStream_t st, const KpBnIn* bn) {
     if (!small_shape(C, K) || M >= (1LL << 31)) return KP_E_UNSUPPORTED;
     const int npl = TPB / (C / V), ppb = npl * 8;
     const unsigned grid = (unsigned)((M + ppb - 1) / ppb);
     const size_t lds = (size_t)K * C * sizeof(float);
-    KP_HEAD_KB(K, (head_fwd_small_k<KB><<<grid, TPB, lds, st>>>((const h16_t*)x, w, bias, slope, out, M, HW, C, K, ppb)));
+    if (bn) KP_HEAD_KB(K, (head_fwd_small_k<KB, true><<<grid, TPB, lds, st>>>((const h16_t*)x, w, bias, slope, out, M, HW, C, K, ppb, *bn)));
+    else KP_HEAD_KB(K, (head_fwd_small_k<KB, false><<<grid, TPB, lds, st>>>((const h16_t*)x, w, bias, slope, out, M, HW, C, K, ppb, KpBnIn{})));
     return kp_check_launch("head_fwd_fast");
 }
+bool kp_head_small_shape(long long M, int C, int K) { return small_shape(C, K) && M < (1LL << 31); }
 
 int kp_head_dx_fast(const float* gout, const float* out, const float* w, float slope, void* dx, long long M, int HW,
                     int C, int K, hipStream_t st) {
@@ -264,13 +279,14 @@ static long long dw_fast_plan(long long M, int C, int K, long long& ppb) {
 long long kp_head_dw_parts_fast(long long M, int C, int K) { long long ppb; return dw_fast_plan(M, C, K, ppb); }
 
 int kp_head_dw_fast(const float* gout, const float* out, const void* x, float slope, float* dw, float* db, float* ws,
-                    long long M, int HW, int C, int K, hipStream_t st) {
+                    long long M, int HW, int C, int K, hipStream_t st, const KpBnIn* bn) {
     long long ppb;
     const long long parts = dw_fast_plan(M, C, K, ppb);
     if (parts <= 0) return KP_E_UNSUPPORTED;
     const int npl = TPB / (C / V);
     const size_t lds = ((size_t)npl * 4 * C + (size_t)npl * 4) * sizeof(float);
     const unsigned grid = (unsigned)parts;
-    KP_HEAD_KB(K, (head_dw_small_k<KB><<<grid, TPB, lds, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, M, HW, C, K, (int)ppb)));
+    if (bn) KP_HEAD_KB(K, (head_dw_small_k<KB, true><<<grid, TPB, lds, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, M, HW, C, K, (int)ppb, *bn)));
+    else KP_HEAD_KB(K, (head_dw_small_k<KB, false><<<grid, TPB, lds, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, M, HW, C, K, (int)ppb, KpBnIn{})));
     return kp_check_launch("head_dw_fast");
 }

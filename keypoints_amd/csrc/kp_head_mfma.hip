@@ -53,10 +53,13 @@ __device__ __forceinline__ void load_w8(const float* __restrict__ w, int k, int 
 }
 
 // ---- forward -----------------------------------------------------------------------------------------------------
-template <int KT>   // 32-channel tiles of the output (K <= 32 * KT)
+// BNIN (C == 32 only: the Pong-class encoder heads): x is the producing layer's conv output, `bn` its BatchNorm / activation
+// (KpBnIn, kp_common.h), applied to the pixel fragment of either 16-channel step; the constants of a lane's 2 x 8 channels
+// live in registers.
+template <int KT, bool BNIN>   // 32-channel tiles of the output (K <= 32 * KT)
 __global__ __launch_bounds__(256) void head_fwd_mfma_k(const h16_t* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float slope,
-                                                       float* __restrict__ out, long long groups, int HW, int C, int K) {
+                                                       float* __restrict__ out, long long groups, int HW, int C, int K, KpBnIn bn) {
     const int lane = threadIdx.x & 63;
     const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= groups) return;
@@ -68,8 +71,13 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_k(const h16_t* __restrict__
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[kt][i] = 0.f;
-    for (int c0 = 0; c0 < C; c0 += 16) {
-        const h16x8 xb = *reinterpret_cast<const h16x8*>(xp + c0);
+    auto step = [&](int c0, const KpBnIn8* kk) {
+        h16x8 xb = *reinterpret_cast<const h16x8*>(xp + c0);
+        if (BNIN) {
+            const u32x4 r = __builtin_bit_cast(u32x4, xb);
+            const uint4 t = kk->apply(make_uint4(r[0], r[1], r[2], r[3]), bn.slope);
+            xb = __builtin_bit_cast(h16x8, u32x4{t.x, t.y, t.z, t.w});
+        }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             float wv[8];
@@ -79,6 +87,13 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_k(const h16_t* __restrict__
             acc[kt] = mma(whi, xb, acc[kt]);
             acc[kt] = mma(wlo, xb, acc[kt]);
         }
+    };
+    if constexpr (BNIN) {   // C == 32: two steps, either with its own constants in registers
+        KpBnIn8 k0, k1;
+        k0.load(bn, h * 8); k1.load(bn, 16 + h * 8);
+        step(0, &k0); step(16, &k1);
+    } else {
+        for (int c0 = 0; c0 < C; c0 += 16) step(c0, nullptr);
     }
     // (image, offset) per lane: a group of 32 pixels may straddle two images when HW % 32 != 0 (84 x 84 maps)
     const long long n = (m0 + px) / HW, hw = (m0 + px) - n * HW;
@@ -158,11 +173,12 @@ __global__ __launch_bounds__(256) void head_dx_mfma_k(const float* __restrict__ 
 // ---- weight / bias gradient ----------------------------------------------------------------------------------------
 // wavefront = (pixel range, 32 * CT input channels): CT x KT accumulator tiles (CT = 4: 128-channel ranges of the wide
 // heads; CT = 1: the 32-channel heads of the Pong-class nets); fp32 atomics into dw / db at the end, or per-split partials
-template <int KT, int CT>
+// BNIN (CT == 1, C == 32): a lane's input-channel column is fixed (r), its four constants are scalars of the lane
+template <int KT, int CT, bool BNIN>
 __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ gout, const float* __restrict__ out,
                                                       const h16_t* __restrict__ x, float slope, float* __restrict__ dw,
                                                       float* __restrict__ db, float* __restrict__ ws, long long groups,
-                                                      int gpw, int HW, int C, int K) {
+                                                      int gpw, int HW, int C, int K, KpBnIn bn) {
     const int lane = threadIdx.x & 63;
     const int cranges = C / (32 * CT);
     const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -181,6 +197,8 @@ __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ 
     float bsum[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) bsum[kt] = 0.f;
+    float bmu = 0.f, bis = 1.f, bga = 1.f, bbe = -0.f;   // (the exact identity without BatchNorm)
+    if (BNIN && bn.mean) { const int ch = cr * (32 * CT) + r; bmu = bn.mean[ch]; bis = bn.invstd[ch]; bga = bn.gamma[ch]; bbe = bn.beta[ch]; }
 
     for (long long g = g0; g < g1; ++g) {
         const long long m0 = g * 32;
@@ -214,7 +232,11 @@ __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ 
             for (int t = 0; t < CT; ++t) {
                 h16x8 xb;      // column = input channel cr*128 + t*32 + r, 8 consecutive pixels (stride C)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) xb[i] = (short)xp[(long long)i * C + t * 32];
+                for (int i = 0; i < 8; ++i) {
+                    h16_t e = xp[(long long)i * C + t * 32];
+                    if (BNIN) e = f2h(kp_bnin1(h2f(e), bmu, bis, bga, bbe, bn.slope));
+                    xb[i] = (short)e;
+                }
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
                     acc[kt][t] = mma(zhi[kt], xb, acc[kt][t]);
@@ -262,13 +284,19 @@ bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr) 
 
 }  // namespace
 
+// bn != nullptr (kp_head_fwd_bnin / kp_head_bwd_bnin): the 32-channel shapes only
+bool kp_head_mfma_bnin_shape(long long M, int HW, int C, int K) { return mfma_shape(M, HW, C, K) && C == 32 && K <= 32; }
+bool kp_head_mfma_shape(long long M, int HW, int C, int K) { return mfma_shape(M, HW, C, K); }
+
 int kp_head_fwd_mfma(const void* x, const float* w, const float* bias, float slope, float* out, long long M, int HW,
-                     int C, int K, hipStream_t st) {
+                     int C, int K, hipStream_t st, const KpBnIn* bn) {
     if (!mfma_shape(M, HW, C, K) || !aligned16(x, w)) return KP_E_UNSUPPORTED;
+    if (bn && !kp_head_mfma_bnin_shape(M, HW, C, K)) return KP_E_UNSUPPORTED;
     const long long groups = M / 32;
     const unsigned grid = (unsigned)((groups + 3) / 4);
-    if (K <= 32) head_fwd_mfma_k<1><<<grid, 256, 0, st>>>((const h16_t*)x, w, bias, slope, out, groups, HW, C, K);
-    else head_fwd_mfma_k<2><<<grid, 256, 0, st>>>((const h16_t*)x, w, bias, slope, out, groups, HW, C, K);
+    if (bn) head_fwd_mfma_k<1, true><<<grid, 256, 0, st>>>((const h16_t*)x, w, bias, slope, out, groups, HW, C, K, *bn);
+    else if (K <= 32) head_fwd_mfma_k<1, false><<<grid, 256, 0, st>>>((const h16_t*)x, w, bias, slope, out, groups, HW, C, K, KpBnIn{});
+    else head_fwd_mfma_k<2, false><<<grid, 256, 0, st>>>((const h16_t*)x, w, bias, slope, out, groups, HW, C, K, KpBnIn{});
     return kp_check_launch("head_fwd_mfma");
 }
 
@@ -303,15 +331,17 @@ static long long dw_mfma_plan(long long M, int HW, int C, int K, bool det, int& 
 long long kp_head_dw_parts_mfma(long long M, int HW, int C, int K) { int gpw; return dw_mfma_plan(M, HW, C, K, true, gpw); }
 
 int kp_head_dw_mfma(const float* gout, const float* out, const void* x, float slope, float* dw, float* db, float* ws,
-                    long long M, int HW, int C, int K, hipStream_t st) {
+                    long long M, int HW, int C, int K, hipStream_t st, const KpBnIn* bn) {
     if (!mfma_shape(M, HW, C, K) || !aligned16(gout, out)) return KP_E_UNSUPPORTED;
+    if (bn && !kp_head_mfma_bnin_shape(M, HW, C, K)) return KP_E_UNSUPPORTED;
     const long long groups = M / 32;
     const int ct = chan_tiles(C), cranges = C / (32 * ct);
     int gpw;
     const long long splits = dw_mfma_plan(M, HW, C, K, ws != nullptr, gpw);
     const unsigned grid = (unsigned)((splits * cranges + 3) / 4);
-#define KP_DW(KTv, CTv) head_dw_mfma_k<KTv, CTv><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, groups, gpw, HW, C, K)
-    if (K <= 32 && ct == 4) KP_DW(1, 4);
+#define KP_DW(KTv, CTv) head_dw_mfma_k<KTv, CTv, false><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, groups, gpw, HW, C, K, KpBnIn{})
+    if (bn) head_dw_mfma_k<1, 1, true><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, groups, gpw, HW, C, K, *bn);
+    else if (K <= 32 && ct == 4) KP_DW(1, 4);
     else if (ct == 4) KP_DW(2, 4);
     else if (K <= 32) KP_DW(1, 1);
     else KP_DW(2, 1);

@@ -313,6 +313,10 @@ class UnitFunction(torch.autograd.Function):
             # activation + replicate pad while it stages its input: this layer's activation pass is skipped altogether
             fuse_next = (tail is None and nxt['kind'] == 'conv3' and runtime.fuse_bn_input() and 0.0 <= stp['slope'] <= 1.0
                          and _lib.lib().kp_conv_bnin_supported(N, H, W, K, nxt['conv'].out_channels, code) == 1)
+            # ... and the last 3x3 layer in front of the 1x1 head likewise (kp_head_fwd_bnin / kp_head_bwd_bnin)
+            if (not fuse_next and tail is None and nxt is plan[-1] and runtime.fuse_bn_input() and 0.0 <= stp['slope'] <= 1.0
+                    and _lib.lib().kp_head_bnin_supported(N, H, W, K, nxt['conv'].out_channels, code) == 1):
+                fuse_next = True
             argmax = None
             if fuse_next:
                 a_next = None
@@ -331,9 +335,13 @@ class UnitFunction(torch.autograd.Function):
         hconv = head['conv']
         Kout = hconv.out_channels
         out = torch.empty(N, Kout, H, W, device=dev, dtype=torch.float32)
-        call('kp_head_fwd', ptr(a), ptr(hconv.weight), ptr(hconv.bias), head['slope'], ptr(out), N, H, W, C, Kout, code, st)
+        if fin is not None:   # the head reads the last layer's conv output; its BatchNorm-apply + activation run on the load path
+            call('kp_head_fwd_bnin', ptr(fin['y']), *fin['bn'], fin['slope'], ptr(hconv.weight), ptr(hconv.bias), head['slope'],
+                 ptr(out), N, H, W, C, Kout, code, st)
+        else:
+            call('kp_head_fwd', ptr(a), ptr(hconv.weight), ptr(hconv.bias), head['slope'], ptr(out), N, H, W, C, Kout, code, st)
         if record:
-            ctx.unit, ctx.saved, ctx.head_in = unit, saved, a
+            ctx.unit, ctx.saved, ctx.head_in = unit, saved, (a if fin is None else fin)
             ctx.save_for_backward(out)   # an OUTPUT kept as a plain ctx attribute would be a reference cycle
             ctx.dims = (N, Cin, x.shape[2], x.shape[3], H, W, C, Kout, pad0)
             ctx.cp0 = Cp0
@@ -369,9 +377,13 @@ class UnitFunction(torch.autograd.Function):
         g = torch.empty(N, Hh, Wh, Ch, device=dev, dtype=tdt) if (has_body or need_x) else None
         # the workspace makes the head's weight gradient a fixed-order two-stage sum (bitwise reproducible step)
         hws = torch.empty(_lib.lib().kp_head_bwd_ws_floats(N, Hh, Wh, Ch, Kout, code), device=dev, dtype=torch.float32)
-        call('kp_head_bwd', ptr(gout), ptr(out), ptr(a_last), ptr(hconv.weight), head['slope'], ptr(g),
-             ptr(gv[id(hconv.weight)]), ptr(gv[id(hconv.bias)]) if hconv.bias is not None else None, ptr(hws),
-             N, Hh, Wh, Ch, Kout, code, st)
+        hgrads = (ptr(g), ptr(gv[id(hconv.weight)]), ptr(gv[id(hconv.bias)]) if hconv.bias is not None else None, ptr(hws))
+        if isinstance(a_last, dict):   # the forward's fused form: the head's input is recomputed from the conv output
+            call('kp_head_bwd_bnin', ptr(gout), ptr(out), ptr(a_last['y']), *a_last['bn'], a_last['slope'], ptr(hconv.weight),
+                 head['slope'], *hgrads, N, Hh, Wh, Ch, Kout, code, st)
+        else:
+            call('kp_head_bwd', ptr(gout), ptr(out), ptr(a_last), ptr(hconv.weight), head['slope'], *hgrads,
+                 N, Hh, Wh, Ch, Kout, code, st)
         gp = 0   # border width of g (0 = plain, 1 = padded-domain gradient that still needs folding)
         for idx in range(len(saved) - 1, -1, -1):
             stp, sv = plan[idx], saved[idx]

@@ -72,6 +72,51 @@ def test_conv_fwd_and_wgrad_bnin_equal_the_separate_pass(N, H, W, C, K, dt, bn_o
         assert torch.isfinite(res[1]).all() and torch.equal(res[0], res[1])
 
 
+@pytest.mark.parametrize('N,H,W', [(3, 84, 84), (2, 37, 50), (4, 8, 8), (1, 1, 3), (2, 32, 32), (5, 16, 33)])
+@pytest.mark.parametrize('C,K', [(32, 4), (16, 1), (32, 16), (64, 3), (16, 10), (128, 16)])
+@pytest.mark.parametrize('dt,bn_on,slope_in', [('bf16', True, 0.01), ('fp16', True, 0.0), ('bf16', False, 0.01)])
+def test_head_fwd_and_bwd_bnin_equal_the_separate_pass(N, H, W, C, K, dt, bn_on, slope_in):
+    """The 1x1 head fed by the last 3x3 layer's conv output (kp_head_fwd_bnin / kp_head_bwd_bnin; knn.py:110-130) against
+    kp_bn_act_fwd + kp_head_fwd / kp_head_bwd: output, input gradient, weight and bias gradient bit for bit."""
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    tdt, code = (torch.bfloat16, _lib.KP_BF16) if dt == 'bf16' else (torch.float16, _lib.KP_F16)
+    L = _lib.lib()
+    if L.kp_head_bnin_supported(N, H, W, C, K, code) != 1:
+        pytest.skip('no fused head kernel for this shape (the engine then runs the separate pass)')
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + C + K)
+    yprev = torch.randn(N, H, W, C, generator=g).to(tdt).cuda()
+    bn = _bn(C, g, bn_on)
+    w = (torch.randn(K, C, generator=g) * 0.2).cuda()
+    bias = (torch.randn(K, generator=g) * 0.1).cuda()
+    gout = torch.randn(N, K, H, W, generator=g).cuda()
+    st = stream_ptr()
+    a = torch.full((N, H, W, C), float('nan'), device='cuda', dtype=tdt)
+    call('kp_bn_act_fwd', ptr(yprev), *[ptr(t) for t in bn], slope_in, _lib.TAIL_NONE, ptr(a), 0, None, N, H, W, C, code, st)
+    res = []
+    for fused in (False, True):
+        out = torch.full((N, K, H, W), float('nan'), device='cuda')
+        if fused:
+            call('kp_head_fwd_bnin', ptr(yprev), *[ptr(t) for t in bn], slope_in, ptr(w), ptr(bias), 0.2, ptr(out), N, H, W, C, K, code, st)
+        else:
+            call('kp_head_fwd', ptr(a), ptr(w), ptr(bias), 0.2, ptr(out), N, H, W, C, K, code, st)
+        dx = torch.full((N, H, W, C), float('nan'), device='cuda', dtype=tdt)
+        dw, db = torch.zeros(K, C, device='cuda'), torch.zeros(K, device='cuda')
+        ws = torch.full((L.kp_head_bwd_ws_floats(N, H, W, C, K, code),), float('nan'), device='cuda')
+        if fused:
+            call('kp_head_bwd_bnin', ptr(gout), ptr(out), ptr(yprev), *[ptr(t) for t in bn], slope_in, ptr(w), 0.2, ptr(dx), ptr(dw),
+                 ptr(db), ptr(ws), N, H, W, C, K, code, st)
+        else:
+            call('kp_head_bwd', ptr(gout), ptr(out), ptr(a), ptr(w), 0.2, ptr(dx), ptr(dw), ptr(db), ptr(ws), N, H, W, C, K, code, st)
+        res.append([t.float().cpu() for t in (out, dx, dw, db)])
+    for r, f in zip(*res):
+        assert torch.isfinite(f).all() and torch.equal(r, f)
+    # sanity of the reference itself against torch
+    ref = torch.nn.functional.leaky_relu(torch.einsum('nhwc,kc->nkhw', a.float(), w) + bias.view(1, K, 1, 1), 0.2).cpu()
+    assert (res[1][0] - ref).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max()))
+
+
 def test_unsupported_shapes_launch_nothing():
     """Shapes without a fused kernel (model F's 64..512-channel layers, fp32 storage) answer 0 / KP_E_UNSUPPORTED."""
     from keypoints_amd import _lib
@@ -79,6 +124,10 @@ def test_unsupported_shapes_launch_nothing():
     assert L.kp_conv_bnin_supported(2, 16, 16, 64, 128, _lib.KP_BF16) == 0
     assert L.kp_conv_bnin_supported(2, 84, 84, 16, 32, _lib.KP_F32) == 0
     assert L.kp_conv_bnin_supported(2, 84, 84, 16, 32, _lib.KP_BF16) == 1
+    assert L.kp_head_bnin_supported(2, 16, 16, 512, 64, _lib.KP_BF16) == 0      # model F's wide encoder head
+    assert L.kp_head_bnin_supported(2, 84, 84, 32, 16, _lib.KP_F32) == 0
+    assert L.kp_head_bnin_supported(2, 128, 128, 64, 3, _lib.KP_BF16) == 1       # model F's decoder head
+    assert L.kp_head_bnin_supported(256, 84, 84, 32, 16, _lib.KP_F16) == 1       # Pong-class encoder head
     y = torch.zeros(8, device='cuda')
     with pytest.raises(_lib.KpError):
         _lib.call('kp_conv_fwd_bnin', _lib.ptr(y), None, None, None, None, 0.0, _lib.ptr(y), None, _lib.ptr(y), None,
