@@ -191,12 +191,7 @@ struct BnReg {
 // one 16-byte chunk = 8 consecutive channels of a pixel.  act(z) = max(z, z * slope) is (z > 0 ? z : z * slope) bit for bit
 // for 0 <= slope <= 1 (the launchers check it), zeros and NaNs included, without the compare + select per element.
 __device__ __forceinline__ uint4 bnin_apply(const uint4 raw, const BnReg& k, float slope) {
-    float v[8];
-    unpack_h16x2(raw.x, v[0], v[1]); unpack_h16x2(raw.y, v[2], v[3]);
-    unpack_h16x2(raw.z, v[4], v[5]); unpack_h16x2(raw.w, v[6], v[7]);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = kp_bnin1(v[e], k.mu[e], k.is[e], k.ga[e], k.be[e], slope);
-    return make_uint4(pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]), pack_h16x2(v[6], v[7]));
+    return kp_bnin8(raw, k.mu, k.is, k.ga, k.be, slope);
 }
 
 // ---- forward / data gradient with the input staged through LDS ------------------------------------------------------------

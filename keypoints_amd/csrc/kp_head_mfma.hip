@@ -53,13 +53,10 @@ __device__ __forceinline__ void load_w8(const float* __restrict__ w, int k, int 
 }
 
 // ---- forward -----------------------------------------------------------------------------------------------------
-// BNIN (C == 32 only: the Pong-class encoder heads): x is the producing layer's conv output, `bn` its BatchNorm / activation
-// (KpBnIn, kp_common.h), applied to the pixel fragment of either 16-channel step; the constants of a lane's 2 x 8 channels
-// live in registers.
-template <int KT, bool BNIN>   // 32-channel tiles of the output (K <= 32 * KT)
+template <int KT>   // 32-channel tiles of the output (K <= 32 * KT)
 __global__ __launch_bounds__(256) void head_fwd_mfma_k(const h16_t* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float slope,
-                                                       float* __restrict__ out, long long groups, int HW, int C, int K, KpBnIn bn) {
+                                                       float* __restrict__ out, long long groups, int HW, int C, int K) {
     const int lane = threadIdx.x & 63;
     const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= groups) return;
@@ -71,13 +68,8 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_k(const h16_t* __restrict__
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[kt][i] = 0.f;
-    auto step = [&](int c0, const KpBnIn8* kk) {
-        h16x8 xb = *reinterpret_cast<const h16x8*>(xp + c0);
-        if (BNIN) {
-            const u32x4 r = __builtin_bit_cast(u32x4, xb);
-            const uint4 t = kk->apply(make_uint4(r[0], r[1], r[2], r[3]), bn.slope);
-            xb = __builtin_bit_cast(h16x8, u32x4{t.x, t.y, t.z, t.w});
-        }
+    for (int c0 = 0; c0 < C; c0 += 16) {
+        const h16x8 xb = *reinterpret_cast<const h16x8*>(xp + c0);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             float wv[8];
@@ -87,13 +79,6 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_k(const h16_t* __restrict__
             acc[kt] = mma(whi, xb, acc[kt]);
             acc[kt] = mma(wlo, xb, acc[kt]);
         }
-    };
-    if constexpr (BNIN) {   // C == 32: two steps, either with its own constants in registers
-        KpBnIn8 k0, k1;
-        k0.load(bn, h * 8); k1.load(bn, 16 + h * 8);
-        step(0, &k0); step(16, &k1);
-    } else {
-        for (int c0 = 0; c0 < C; c0 += 16) step(c0, nullptr);
     }
     // (image, offset) per lane: a group of 32 pixels may straddle two images when HW % 32 != 0 (84 x 84 maps)
     const long long n = (m0 + px) / HW, hw = (m0 + px) - n * HW;
@@ -104,6 +89,68 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_k(const h16_t* __restrict__
             const int k = kt * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
             if (k < K) out[(n * K + k) * HW + hw] = act_fwd(acc[kt][i] + (bias ? bias[k] : 0.f), slope);
         }
+}
+
+// The 32-channel head (Pong-class encoder heads: 32 -> 16 over 256 x 84 x 84) as a loop: the kernel above takes ONE group of 32
+// pixels per wavefront and loads + splits its weight fragments for it (2 x ~50 VALU, 16 loads per 4 MFMAs); here a wavefront keeps
+// the (hi, lo) fragments of both 16-channel steps in registers and walks groups wave, wave + waves, ..., the next group's
+// pixels requested before the current one is multiplied.  Same operands into the same MFMAs in the same order: bit-identical.
+// BNIN: x is the producing layer's conv output, `bn` its BatchNorm / activation (KpBnIn, kp_common.h), applied to the two
+// 16-byte pixel fragments of a lane -- always the same 2 x 8 channels, constants in registers.
+template <int KT, bool BNIN>
+__global__ __launch_bounds__(256) void head_fwd_mfma32_k(const h16_t* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float slope,
+                                                         float* __restrict__ out, long long groups, int HW, int K, KpBnIn bn) {
+    constexpr int C = 32;
+    const int lane = threadIdx.x & 63;
+    const long long waves = (long long)gridDim.x * 4;
+    long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= groups) return;
+    const int px = lane & 31, h = lane >> 5;
+    h16x8 whi[KT][2], wlo[KT][2];
+    float bk[KT][16];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float wv[8];
+            load_w8(w, kt * 32 + px, K, C, s * 16 + h * 8, wv);
+            split8(wv, whi[kt][s], wlo[kt][s]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = kt * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+            bk[kt][i] = (bias && k < K) ? bias[k] : 0.f;
+        }
+    }
+    KpBnIn8 k0, k1;
+    if (BNIN) { k0.load(bn, h * 8); k1.load(bn, 16 + h * 8); }
+    const h16_t* xp = x + px * C + h * 8;
+    uint4 a0 = *reinterpret_cast<const uint4*>(xp + g * 32 * C), a1 = *reinterpret_cast<const uint4*>(xp + g * 32 * C + 16);
+    for (; g < groups; g += waves) {
+        uint4 c0 = a0, c1 = a1;
+        const long long gn = g + waves < groups ? g + waves : g;   // (the last trip re-reads its own pixels)
+        a0 = *reinterpret_cast<const uint4*>(xp + gn * 32 * C);
+        a1 = *reinterpret_cast<const uint4*>(xp + gn * 32 * C + 16);
+        if (BNIN) { c0 = k0.apply(c0, bn.slope); c1 = k1.apply(c1, bn.slope); }
+        const h16x8 x0 = __builtin_bit_cast(h16x8, u32x4{c0.x, c0.y, c0.z, c0.w}), x1 = __builtin_bit_cast(h16x8, u32x4{c1.x, c1.y, c1.z, c1.w});
+        const long long m = g * 32 + px, n = m / HW, hw = m - n * HW;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            acc = mma(whi[kt][0], x0, acc);
+            acc = mma(wlo[kt][0], x0, acc);
+            acc = mma(whi[kt][1], x1, acc);
+            acc = mma(wlo[kt][1], x1, acc);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = kt * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+                if (k < K) out[(n * K + k) * HW + hw] = act_fwd(acc[i] + bk[kt][i], slope);
+            }
+        }
+    }
 }
 
 // dZ fragment of this lane for reduction slice kk: 8 consecutive output channels of pixel (n, hw)
@@ -173,12 +220,11 @@ __global__ __launch_bounds__(256) void head_dx_mfma_k(const float* __restrict__ 
 // ---- weight / bias gradient ----------------------------------------------------------------------------------------
 // wavefront = (pixel range, 32 * CT input channels): CT x KT accumulator tiles (CT = 4: 128-channel ranges of the wide
 // heads; CT = 1: the 32-channel heads of the Pong-class nets); fp32 atomics into dw / db at the end, or per-split partials
-// BNIN (CT == 1, C == 32): a lane's input-channel column is fixed (r), its four constants are scalars of the lane
-template <int KT, int CT, bool BNIN>
+template <int KT, int CT>
 __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ gout, const float* __restrict__ out,
                                                       const h16_t* __restrict__ x, float slope, float* __restrict__ dw,
                                                       float* __restrict__ db, float* __restrict__ ws, long long groups,
-                                                      int gpw, int HW, int C, int K, KpBnIn bn) {
+                                                      int gpw, int HW, int C, int K) {
     const int lane = threadIdx.x & 63;
     const int cranges = C / (32 * CT);
     const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -197,8 +243,6 @@ __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ 
     float bsum[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) bsum[kt] = 0.f;
-    float bmu = 0.f, bis = 1.f, bga = 1.f, bbe = -0.f;   // (the exact identity without BatchNorm)
-    if (BNIN && bn.mean) { const int ch = cr * (32 * CT) + r; bmu = bn.mean[ch]; bis = bn.invstd[ch]; bga = bn.gamma[ch]; bbe = bn.beta[ch]; }
 
     for (long long g = g0; g < g1; ++g) {
         const long long m0 = g * 32;
@@ -232,11 +276,7 @@ __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ 
             for (int t = 0; t < CT; ++t) {
                 h16x8 xb;      // column = input channel cr*128 + t*32 + r, 8 consecutive pixels (stride C)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    h16_t e = xp[(long long)i * C + t * 32];
-                    if (BNIN) e = f2h(kp_bnin1(h2f(e), bmu, bis, bga, bbe, bn.slope));
-                    xb[i] = (short)e;
-                }
+                for (int i = 0; i < 8; ++i) xb[i] = (short)xp[(long long)i * C + t * 32];
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
                     acc[kt][t] = mma(zhi[kt], xb, acc[kt][t]);
@@ -272,6 +312,110 @@ __global__ __launch_bounds__(256) void head_dw_mfma_k(const float* __restrict__ 
     }
 }
 
+// The 32-channel head's weight gradient (CT = 1 above) with the input tile staged through LDS: a wavefront copies the 32 pixels
+// x 32 channels of a group (2 KB, two 16-byte loads per lane) into its own 2 KB of LDS, pixel-major, and reads the two B
+// fragments (lane: channel lane % 32, 8 consecutive pixels) with hardware transpose reads (2 x ds_read_b64_tr_b16 each) -- the
+// kernel above gathers them with sixteen 2-byte loads at a channel stride.  Same operands into the same MFMAs in the same
+// order: bit-identical results.  BNIN: the producing layer's BatchNorm / activation (KpBnIn) applied to the 16-byte chunks
+// between the load and the LDS store; a lane's chunk is always the same 8 channels (constants in registers) -- on the
+// gathered elements the transform cost 70 us per launch (164 vs 93), here ~10.
+template <int KT, bool BNIN>
+__global__ __launch_bounds__(256) void head_dw_mfma32_k(const float* __restrict__ gout, const float* __restrict__ out,
+                                                        const h16_t* __restrict__ x, float slope, float* __restrict__ dw,
+                                                        float* __restrict__ db, float* __restrict__ ws, long long groups,
+                                                        int gpw, int HW, int K, KpBnIn bn) {
+    constexpr int C = 32;
+    __shared__ __attribute__((aligned(16))) unsigned char tile[4][32 * C * 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long sp = (long long)blockIdx.x * 4 + wave;
+    const long long g0 = sp * gpw, g1 = g0 + gpw < groups ? g0 + gpw : groups;
+    if (g0 >= g1) return;
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[KT];
+    float bsum[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        bsum[kt] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[kt][i] = 0.f;
+    }
+    KpBnIn8 k8;
+    if (BNIN) k8.load(bn, (lane & 3) * 8);
+    unsigned char* const tl = tile[wave];
+    // transpose-read lane roles (as in wgrad3x3_small_band_k): t = lane & 15 -> (pixel t / 4, 4-channel chunk t % 4); bit 4 -> channels 16..31
+    const int t16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int tr_off = (8 * h + (t16 >> 2)) * (C * 2) + (16 * g16 + (t16 & 3) * 4) * 2;
+    for (long long g = g0; g < g1; ++g) {
+        const long long m0 = g * 32;
+        const uint4* xs = reinterpret_cast<const uint4*>(x + m0 * C);
+        uint4 c0 = xs[lane], c1 = xs[lane + 64];             // chunk id = pixel * 4 + (8-channel chunk): lane % 4 is the chunk of both
+        h16x8 zhi[2][KT], zlo[2][KT];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {           // two slices of 16 pixels
+            const int p0 = s * 16 + h * 8;       // this lane's 8 consecutive pixels: inside ONE image (HW % 8 == 0)
+            const long long n = (m0 + p0) / HW;
+            const int hw0 = (int)((m0 + p0) - n * HW);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const int k = kt * 32 + r;
+                float v[8];
+                if (k < K) {
+                    const long long idx = (n * K + k) * HW + hw0;
+                    const float4 ga = *reinterpret_cast<const float4*>(gout + idx), gb = *reinterpret_cast<const float4*>(gout + idx + 4);
+                    const float4 oa = *reinterpret_cast<const float4*>(out + idx), ob = *reinterpret_cast<const float4*>(out + idx + 4);
+                    v[0] = ga.x * act_grad(oa.x, slope); v[1] = ga.y * act_grad(oa.y, slope);
+                    v[2] = ga.z * act_grad(oa.z, slope); v[3] = ga.w * act_grad(oa.w, slope);
+                    v[4] = gb.x * act_grad(ob.x, slope); v[5] = gb.y * act_grad(ob.y, slope);
+                    v[6] = gb.z * act_grad(ob.z, slope); v[7] = gb.w * act_grad(ob.w, slope);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+                }
+                bsum[kt] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                split8(v, zhi[s][kt], zlo[s][kt]);
+            }
+        }
+        if (BNIN) { c0 = k8.apply(c0, bn.slope); c1 = k8.apply(c1, bn.slope); }
+        *reinterpret_cast<uint4*>(tl + lane * 16) = c0;
+        *reinterpret_cast<uint4*>(tl + (lane + 64) * 16) = c1;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const unsigned char* b = tl + s * 16 * (C * 2) + tr_off;
+            const h16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) h16x4*)(b));
+            const h16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) h16x4*)(b + 4 * (C * 2)));
+            const h16x8 xb = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                acc[kt] = mma(zhi[s][kt], xb, acc[kt]);
+                acc[kt] = mma(zlo[s][kt], xb, acc[kt]);
+            }
+        }
+    }
+    // D[k][c]: lane column = c (r), rows k = 8*(i>>2) + 4*h + (i&3)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = kt * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+            if (k < K) {
+                const long long e = (long long)k * C + r;
+                if (ws) ws[sp * ((long long)K * C + K) + e] = acc[kt][i];   // this pixel split's partial (plain store)
+                else unsafeAtomicAdd(dw + e, acc[kt][i]);
+            }
+        }
+    if (db || ws) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const float tot = bsum[kt] + __shfl_xor(bsum[kt], 32, 64);   // the two 8-pixel halves
+            const int k = kt * 32 + r;
+            if (h == 0 && k < K) {
+                if (ws) ws[sp * ((long long)K * C + K) + (long long)K * C + k] = tot;
+                else unsafeAtomicAdd(db + k, tot);
+            }
+        }
+    }
+}
+
 // wide heads (C a multiple of 128), and the 32-channel heads with more than 4 outputs (Pong-class encoder heads: 32 -> 16 over
 // 84 x 84 maps, where the K <= 16 VALU kernels of kp_head_fast.hip run at 1.8 TB/s).  Groups of 32 pixels may straddle images
 // (per-lane image / offset); the weight gradient reads 8-pixel runs of the NCHW gradient: HW % 8 == 0.
@@ -285,7 +429,7 @@ bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr) 
 }  // namespace
 
 // bn != nullptr (kp_head_fwd_bnin / kp_head_bwd_bnin): the 32-channel shapes only
-bool kp_head_mfma_bnin_shape(long long M, int HW, int C, int K) { return mfma_shape(M, HW, C, K) && C == 32 && K <= 32; }
+bool kp_head_mfma_bnin_shape(long long M, int HW, int C, int K) { return mfma_shape(M, HW, C, K) && C == 32; }
 bool kp_head_mfma_shape(long long M, int HW, int C, int K) { return mfma_shape(M, HW, C, K); }
 
 int kp_head_fwd_mfma(const void* x, const float* w, const float* bias, float slope, float* out, long long M, int HW,
@@ -294,9 +438,17 @@ int kp_head_fwd_mfma(const void* x, const float* w, const float* bias, float slo
     if (bn && !kp_head_mfma_bnin_shape(M, HW, C, K)) return KP_E_UNSUPPORTED;
     const long long groups = M / 32;
     const unsigned grid = (unsigned)((groups + 3) / 4);
-    if (bn) head_fwd_mfma_k<1, true><<<grid, 256, 0, st>>>((const h16_t*)x, w, bias, slope, out, groups, HW, C, K, *bn);
-    else if (K <= 32) head_fwd_mfma_k<1, false><<<grid, 256, 0, st>>>((const h16_t*)x, w, bias, slope, out, groups, HW, C, K, KpBnIn{});
-    else head_fwd_mfma_k<2, false><<<grid, 256, 0, st>>>((const h16_t*)x, w, bias, slope, out, groups, HW, C, K, KpBnIn{});
+    if (C == 32) {   // ~8 groups per wavefront
+        long long wg = (groups / 8 + 3) / 4;
+        wg = wg < 1 ? 1 : wg;
+        const KpBnIn b = bn ? *bn : KpBnIn{};
+#define KP_FW(KTv, Bv) head_fwd_mfma32_k<KTv, Bv><<<(unsigned)wg, 256, 0, st>>>((const h16_t*)x, w, bias, slope, out, groups, HW, K, b)
+        if (bn) { if (K <= 32) KP_FW(1, true); else KP_FW(2, true); }
+        else { if (K <= 32) KP_FW(1, false); else KP_FW(2, false); }
+#undef KP_FW
+    }
+    else if (K <= 32) head_fwd_mfma_k<1><<<grid, 256, 0, st>>>((const h16_t*)x, w, bias, slope, out, groups, HW, C, K);
+    else head_fwd_mfma_k<2><<<grid, 256, 0, st>>>((const h16_t*)x, w, bias, slope, out, groups, HW, C, K);
     return kp_check_launch("head_fwd_mfma");
 }
 
@@ -339,8 +491,18 @@ int kp_head_dw_mfma(const float* gout, const float* out, const void* x, float sl
     int gpw;
     const long long splits = dw_mfma_plan(M, HW, C, K, ws != nullptr, gpw);
     const unsigned grid = (unsigned)((splits * cranges + 3) / 4);
-#define KP_DW(KTv, CTv) head_dw_mfma_k<KTv, CTv, false><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, groups, gpw, HW, C, K, KpBnIn{})
-    if (bn) head_dw_mfma_k<1, 1, true><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, groups, gpw, HW, C, K, *bn);
+#define KP_DW(KTv, CTv) head_dw_mfma_k<KTv, CTv><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, groups, gpw, HW, C, K)
+    if (C == 32 && aligned16(x)) {   // (cranges == 1: a wavefront = a pixel split)
+        const KpBnIn b = bn ? *bn : KpBnIn{};
+        if (bn) {
+            if (K <= 32) head_dw_mfma32_k<1, true><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, groups, gpw, HW, K, b);
+            else head_dw_mfma32_k<2, true><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, groups, gpw, HW, K, b);
+        } else {
+            if (K <= 32) head_dw_mfma32_k<1, false><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, groups, gpw, HW, K, b);
+            else head_dw_mfma32_k<2, false><<<grid, 256, 0, st>>>(gout, out, (const h16_t*)x, slope, dw, db, ws, groups, gpw, HW, K, b);
+        }
+    }
+    else if (bn) return KP_E_UNSUPPORTED;   // (x of a foreign caller not 16-byte aligned: the gather kernel has no fused form)
     else if (K <= 32 && ct == 4) KP_DW(1, 4);
     else if (ct == 4) KP_DW(2, 4);
     else if (K <= 32) KP_DW(1, 1);
