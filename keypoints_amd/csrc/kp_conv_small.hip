@@ -622,6 +622,9 @@ __global__ __launch_bounds__(TPB) void wgrad3x3_small_k(const h16_t* __restrict_
     }
 }
 
+#ifdef KP_FB_TRACE   // probe builds (tools/probes/wgrad_trace.py): 100 MHz clock stamps of wave 0 of every workgroup of the LAST weight-gradient launch
+static __device__ unsigned long long g_wg_trace[512 * 64];
+#endif
 // The same weight gradient with the operands staged through LDS.  The kernel above gathers every MFMA fragment with 2-byte
 // GLOBAL loads (38 per 9 MFMAs, ~64 texture-unit cycles each: 169 us per 16 -> 32 layer of the Pong decoder at 256 x 84 x 84,
 // where the data takes 50 us).  Here a workgroup copies a band of R image rows -- R + 2 input rows, R gradient rows, 16-byte
@@ -736,14 +739,30 @@ __global__ __launch_bounds__(TPB, 1) void wgrad3x3_small_band_k(const h16_t* __r
             if (tid + u * TPB < dtot) *reinterpret_cast<uint4*>(buf + dl_off + (tid + u * TPB) * 16) = sbd[u];
     };
 
+#ifdef KP_FB_TRACE
+    int trn = 0;
+    auto stamp = [&]() { if (tid == 0 && trn < 64 && blockIdx.x < 512) g_wg_trace[blockIdx.x * 64 + trn++] = wall_clock64(); };
+    if (tid == 0 && blockIdx.x < 512) for (int i = 0; i < 64; ++i) g_wg_trace[blockIdx.x * 64 + i] = 0;
+#else
+    auto stamp = [&]() {};
+#endif
+    // (Clock stamps of the 16 -> 32 layer at 256 x 84 x 84, 12 bands per workgroup, 67 us: issue 1.0 us per band -- a CU's
+    //  vector-memory path takes a 1 KB wave-load per ~16 cycles and the 20-24 loads x 4 waves arrive in one burst --, multiply
+    //  3.4, commit 0.8.  Spreading the loads over the items of the multiply phase was tried twice: through a switch on a slot
+    //  counter the compiler must assume a register is reloaded while its previous load is in flight and waits vmcnt(0) per slot,
+    //  111 us; reading the next item's fragments ahead of the MFMAs: 73 vs 66 us, the multiply phase is bound by the rate of
+    //  the transpose reads, not by their latency.)
+    stamp();
     long long band = blockIdx.x;
     __syncthreads();                     // (BNIN: the constants are in place)
-    if (band < total_bands) { issue(band); commit(smem); }
+    if (band < total_bands) { issue(band); stamp(); commit(smem); }
     __syncthreads();
+    stamp();
     int cur = 0, rows = rows_staged;
     for (; band < total_bands; band += gridDim.x) {
         const bool more = band + gridDim.x < total_bands;
         if (more) issue(band + gridDim.x);                    // in flight during the multiply phase below
+        stamp();
         const unsigned char* xl = smem + cur * WG_LDS;
         const unsigned char* dl = xl + dl_off;
         // ---- multiply: items (row, 16-pixel segment) round-robin over the four wavefronts.  A fragment (lane: channel
@@ -804,8 +823,11 @@ __global__ __launch_bounds__(TPB, 1) void wgrad3x3_small_band_k(const h16_t* __r
                 for (int i = 0; i < 5; ++i) { W0[i] = W1[i]; W1[i] = W2[i]; }
             }
         }
+        stamp();
         if (more) commit(smem + (cur ^ 1) * WG_LDS);          // the other buffer: its readers passed the previous barrier
+        stamp();
         __syncthreads();
+        stamp();
         cur ^= 1;
         rows = rows_staged;
     }
@@ -1017,3 +1039,9 @@ int kp_conv_small_wgrad_bnin(const void* yprev, const float* mean, const float* 
 #undef KP_SWB
     return kp_check_launch("wgrad3x3_small_band_bnin");
 }
+
+#if defined(KP_FB_TRACE) && !defined(KP_F16_BUILD)
+extern "C" int kp_debug_wgrad_trace(unsigned long long* dst) {   // host buffer of 512 * 64 stamps
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wg_trace), sizeof(unsigned long long) * 512 * 64);
+}
+#endif

@@ -120,6 +120,7 @@ def _pack_unit(plan, Cin, Cp0, record, dev, tdt, code, st):
 
 import os as _os
 _NO_PREPACK = bool(_os.environ.get('KP_NO_PREPACK'))   # measurement: every Unit packs at its own first call again
+_ABL = set(filter(None, _os.environ.get('KP_ABLATE', '').split(',')))   # measurement ONLY (wrong gradients): 'wgrad' skips the 3x3 weight-gradient launches (tools/probes/ablate.sh)
 
 
 def prepack(units_cin):
@@ -440,7 +441,9 @@ class UnitFunction(torch.autograd.Function):
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                 wst = stream_ptr()
                 scratch = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device=dev, dtype=torch.float32)
-                if sv['fin'] is not None:   # the input side is read from the previous layer's conv output (see forward)
+                if 'wgrad' in _ABL:
+                    pass
+                elif sv['fin'] is not None:   # the input side is read from the previous layer's conv output (see forward)
                     f = sv['fin']
                     call('kp_conv_wgrad_bnin', ptr(f['y']), *f['bn'], f['slope'], ptr(dy), ptr(scratch), N, H, W, C, K, dp, code, wst)
                 else:
