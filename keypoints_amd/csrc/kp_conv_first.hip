@@ -59,12 +59,13 @@ __global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const h16_t* __restrict
         wl[j * K + k] = h2f(w[i]);
     }
     __syncthreads();
-    const long long m_wave = (long long)blockIdx.x * TPB + wave * 64;
-    const bool active = m_wave < M;            // M % 64 == 0: wavefronts are all-or-nothing (an idle one stays for the barrier below)
     float* red = reinterpret_cast<float*>(stage + (size_t)4 * 64 * K * 2);   // [4 waves][2][K]: the workgroup's statistics
-    if (partials && !active)
+    if (partials)
         for (int i = lane; i < 2 * K; i += 64) red[wave * 2 * K + i] = 0.f;
-    if (active) {
+    // a wavefront walks 64-pixel groups blockIdx * 4 + wave, + 4 * grid, ... (M % 64 == 0: groups are all-or-nothing); the
+    // weights are staged once per workgroup, and the statistics row of a workgroup covers all its groups (<= 2 048 rows
+    // for the finalize instead of M / 256: 7 056 at 256 x 84 x 84, 15 -> 8 us four times per step)
+    for (long long m_wave = (long long)blockIdx.x * TPB + wave * 64; m_wave < M; m_wave += (long long)gridDim.x * TPB) {
     const long long m = m_wave + lane;
     const int q = (int)(m % Wo);
     const long long t = m / Wo;
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const h16_t* __restrict
             const float ts = reduce8_over64(acc, lane, i1);
             const float tq = reduce8_over64(sq, lane, i2);
             if ((lane & 7) == 0) {
-                red[(wave * 2 + 0) * K + k0 + i1] = ts;
-                red[(wave * 2 + 1) * K + k0 + i1] = tq;
+                red[(wave * 2 + 0) * K + k0 + i1] += ts;
+                red[(wave * 2 + 1) * K + k0 + i1] += tq;
             }
         }
         uint4 pk;
@@ -119,10 +120,8 @@ __global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const h16_t* __restrict
         const uint4 v = *reinterpret_cast<const uint4*>(st + (size_t)px * K * 2 + ((ch ^ (px & (CP - 1))) << 4));
         *reinterpret_cast<uint4*>(yw + (size_t)id * 8) = v;
     }
-    }   // active
-    // ONE statistics row per workgroup (256 pixels), its four wavefronts added in a fixed order: a quarter of the rows of a
-    // row per wavefront -- 7 056 instead of 28 224 at 256 x 84 x 84, which keeps the Pong-class first layer on the one-launch
-    // reduce + finalize (kp_bn.hip: up to 8 192 rows) instead of reduce_rows + finalize (28 + 7 us, four times per step)
+    }   // groups
+    // ONE statistics row per workgroup, its four wavefronts added in a fixed order
     if (partials) {
         __syncthreads();
         for (int i = tid; i < 2 * K; i += TPB)
@@ -542,8 +541,10 @@ int kp_conv_first_fwd(const void* x, const void* w, const float* bias, void* y, 
 #undef KP_FIRST_FWD_M
         return kp_check_launch("conv3_first_fwd_mfma");
     }
-    const unsigned grid = (unsigned)((M + TPB - 1) / TPB);
-    if (stats) kp_set_last_rows((long long)grid);   // one statistics row per workgroup of 256 pixels
+    long long wgs = (M + TPB - 1) / TPB;
+    if (wgs > 2048) wgs = 2048;                     // (the caller's statistics buffer holds M / 64 rows)
+    const unsigned grid = (unsigned)wgs;
+    if (stats) kp_set_last_rows((long long)grid);   // one statistics row per workgroup
     KP_QUERY_RETURN();
     const size_t lds = (size_t)9 * C * K * sizeof(float) + (size_t)4 * 64 * K * 2 + (size_t)4 * 2 * K * sizeof(float);
 #define KP_FIRST_FWD(CINv)                                                                                          \

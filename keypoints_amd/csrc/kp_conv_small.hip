@@ -750,8 +750,10 @@ __global__ __launch_bounds__(TPB, 1) void wgrad3x3_small_band_k(const h16_t* __r
     //  vector-memory path takes a 1 KB wave-load per ~16 cycles and the 20-24 loads x 4 waves arrive in one burst --, multiply
     //  3.4, commit 0.8.  Spreading the loads over the items of the multiply phase was tried twice: through a switch on a slot
     //  counter the compiler must assume a register is reloaded while its previous load is in flight and waits vmcnt(0) per slot,
-    //  111 us; reading the next item's fragments ahead of the MFMAs: 73 vs 66 us, the multiply phase is bound by the rate of
-    //  the transpose reads, not by their latency.)
+    //  111 us; reading the next item's fragments ahead of the MFMAs (a four-row window ring, no copies, unconditional reads
+    //  through a zero pad so that the waits sit at the MFMAs): 16-channel inputs 66 -> 62 us, 32-channel ones 72 -> 81: the
+    //  multiply phase is bound by the rate of the transpose reads, not by their latency.  The weight gradient costs the
+    //  config-2 step its full kernel time, side stream or not: 3.38 -> 2.85 ms with the launches skipped, tools/probes/ablate.sh.)
     stamp();
     long long band = blockIdx.x;
     __syncthreads();                     // (BNIN: the constants are in place)
