@@ -9,6 +9,7 @@ Corrections applied (guide, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on
 bytes of wide coalesced reads -> doubled.  GRBM_GUI_ACTIVE comes back summed over the 8 XCDs -> divided by 8.
 """
 import collections
+import re
 import csv
 import glob
 import json
@@ -21,9 +22,10 @@ KERNELS = {'conv3x3_patch_k<128': 'conv_patch_bf16_bn128', 'conv3x3_patch_k<128,
 
 
 # BASELINE config 2 (second set of passes, directory suffix 'c2'): the Pong-class band kernels
-KERNELS_C2 = {'conv3x3_small_band_k<': 'conv_small_band_bf16', 'conv3x3_small_band_k<1, false': 'conv_small_band_bf16_c16',
-              'conv3x3_small_band_k<2, false': 'conv_small_band_bf16_c32', 'conv3x3_small_band_k<1, true': 'conv_small_band_bf16_c16_bnin',
-              'conv3x3_small_band_k<2, true': 'conv_small_band_bf16_c32_bnin', 'wgrad3x3_small_band_k<': 'wgrad_small_band_bf16'}
+# config 2 (template arguments of the band kernel: input channels / 16, output channels / 16, BatchNorm input, statistics, ...)
+KERNELS_C2 = {'conv3x3_small_band_k<': 'conv_small_band_bf16', 'conv3x3_small_band_k<1, [12], false': 'conv_small_band_bf16_c16',
+              'conv3x3_small_band_k<2, [12], false': 'conv_small_band_bf16_c32', 'conv3x3_small_band_k<1, [12], true': 'conv_small_band_bf16_c16_bnin',
+              'conv3x3_small_band_k<2, [12], true': 'conv_small_band_bf16_c32_bnin', 'wgrad3x3_small_band_k<': 'wgrad_small_band_bf16'}
 
 
 def load(name):
@@ -50,7 +52,7 @@ def summarise(out, suffix, kernels):
         dur = [0.0, 0]
         for n, rs in rows.items():
             for r in rs:
-                if key in r['Kernel_Name']:
+                if re.search(key, r['Kernel_Name']):   # (keys are regular expressions)
                     a = acc[r['Counter_Name']]
                     a[0] += float(r['Counter_Value']); a[1] += 1
                     if n == 'FETCH_SIZE':
