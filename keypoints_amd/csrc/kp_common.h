@@ -65,6 +65,18 @@ template <typename A8, typename C16> __device__ __forceinline__ C16 kp_mfma16(A8
 #endif
 }
 
+// v_mfma_f32_16x16x32_{bf16,f16}: D[16][16] += A[16][32] B[32][16]; a lane holds 8 consecutive reduction elements
+// 8 * (lane >> 4) .. of row / column lane & 15; D: column lane & 15, rows 4 * (lane >> 4) + reg.  C4: 4 x float.
+template <typename A8, typename C4> __device__ __forceinline__ C4 kp_mfma16x16(A8 a, A8 b, C4 c) {
+    typedef kp_h16_native v8 __attribute__((ext_vector_type(8)));
+    static_assert(sizeof(A8) == 16 && sizeof(C4) == 16, "kp_mfma16x16: 8 x 16-bit operands, 4 x fp32 accumulator");
+#ifdef KP_F16_BUILD
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+#endif
+}
+
 template <typename T> __device__ __forceinline__ float ld(const T* p);
 template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld<h16_t>(const h16_t* p) { return h2f(*p); }

@@ -854,7 +854,227 @@ __global__ __launch_bounds__(TPB, 1) void wgrad3x3_small_band_k(const h16_t* __r
     }
 }
 
+// ---- weight gradient of the channel pairs with a 16-channel side, on the 16 x 16 x 32 matrix-core shape --------------------------
+// wgrad3x3_small_band_k above multiplies 32 x 32 x 16 tiles: with 16 channels on either side half of every MFMA and of every
+// transpose read is empty, its 9 x 16 accumulators hold it at ONE wave per SIMD and one workgroup per CU, and nothing covers
+// its staging (clock stamps: 1.0 + 0.8 us of 5.3 us per band) -- the kernel costs the config-2 step its full 0.53 ms.  Here
+// D[k][c] (16 x 16 per tile, 4 registers) += A[k][32 px] B[32 px][c]: an item is 32 pixels of a row, a lane's fragment 8
+// consecutive pixels of one channel (two ds_read_b64_tr_b16 of the pixel-major rows, every lane useful); per item 3 (6) reads
+// for the new bottom row of the input window + 2 per 16 gradient channels: 5-8 where the kernel above needs 10 per 32 pixels.
+// 9 x KT x CT x 4 = 36-72 accumulator registers: three waves per SIMD, TWO workgroups of six wavefronts per CU -- one stages its
+// band (single LDS buffer, loads straight through registers) while the other multiplies.  Six wavefronts: 84-pixel rows are three
+// segments, x two halves of the band's rows = six column strips.  Same LDS image, staging code and partial-gradient protocol.
+constexpr int W16_TPB = 384, W16_NW = W16_TPB / 64, W16_LDS = 77824;
+constexpr int w16_slx(int K, int C) { return C == 32 ? 9 : (K == 32 ? 6 : 7); }
+constexpr int w16_sld(int K, int C) { return C == 32 ? 4 : (K == 32 ? 8 : 6); }
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int K, int C, bool BNIN>
+__global__ __launch_bounds__(W16_TPB, 3) void wgrad3x3_small16_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
+                                                               float* __restrict__ scratch, int Ho, int Wo, int dy_pad, int R,
+                                                               int bands_per_img, long long total_bands, long long pstride, BnIn bn) {
+    constexpr int TPBW = W16_TPB, KT = K / 16, CT = C / 16;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[W16_LDS];
+    __shared__ __attribute__((aligned(16))) float cst[BNIN ? 4 : 1][32];
+    if (BNIN) bnin_fill(cst, bn, C, threadIdx.x);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Hi = Ho + 2, Wi = Wo + 2, Hd = Ho + 2 * dy_pad, Wd = Wo + 2 * dy_pad;
+    const int Wp = (Wo + 31) & ~31, XP = Wp + 2, nseg = Wp / 32;
+    const int xrow_b = XP * C * 2, drow_b = Wp * K * 2;            // LDS bytes per staged row (multiples of 16)
+    const int dl_off = (R + 2) * xrow_b;                           // [(R + 2)][XP][C] input rows, then [R][Wp][K] gradient rows
+    // transpose-read lane roles: t = lane & 15 -> (pixel t / 4, 4-channel chunk t % 4) of the lane group's 8-pixel run 8 * (lane >> 4)
+    const int t16 = lane & 15, grp = lane >> 4;
+    const int xlane = (8 * grp + (t16 >> 2)) * (C * 2) + (t16 & 3) * 8;
+    const int dlane = (8 * grp + (t16 >> 2)) * (K * 2) + (t16 & 3) * 8;
+    // ONE 16 x 16 tile per wavefront and tap (36 accumulator registers): with two tiles (32 channels on one side) the six wavefronts
+    // are three pairs, wavefront w owns tile w % 2 for the whole kernel and takes two of the six column strips of a band -- both
+    // tiles in one wavefront want 183-216 registers, and at the 168 of three waves per SIMD the spills made it slower than the old kernel
+    constexpr int TILES = KT * CT;
+    static_assert(TILES <= 2, "16 x 16 x 32 weight gradient: one side has 16 channels");
+    const int tw = wave % TILES, kt = KT == 2 ? tw : 0, ct = CT == 2 ? tw : 0;
+    f32x4v acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    // ---- staging (as above): chunk -> (row, column) by carries; all loads of a band in flight, then the LDS stores
+    const int xc = xrow_b / 16, xvalid = Wi * C * 2 / 16, dc = drow_b / 16, dvalid = Wo * K * 2 / 16;
+    const int xrow_g = Wi * C * 2, drow_g = Wd * K * 2;
+    const int xdr = TPBW / xc, xdc = TPBW % xc, ddr = TPBW / dc, ddc = TPBW % dc;
+    constexpr int SLX = w16_slx(K, C), SLD = w16_sld(K, C);
+    auto stage = [&](long long band, int& rows_out) {
+        const long long n = band / bands_per_img;
+        const int p0 = (int)(band % bands_per_img) * R;
+        const int rows = Ho - p0 < R ? Ho - p0 : R;
+        rows_out = rows;
+        const int xtot = (rows + 2) * xc, dtot = rows * dc;
+        const unsigned char* xg = BNIN ? (const unsigned char*)x + ((n * Ho * Wo) * (long long)C) * 2
+                                       : (const unsigned char*)x + (((n * Hi + p0) * Wi) * (long long)C) * 2;
+        const unsigned char* dg = (const unsigned char*)dy + ((((n * Hd + p0 + dy_pad) * Wd) + dy_pad) * (long long)K) * 2;
+        // (in batches of 3-8 chunks, the two tensors one after the other: 168 registers per wave)
+        constexpr int XB = BNIN ? 3 : 5, DB = 8;
+        int r = tid / xc, c16 = tid % xc;
+#pragma unroll
+        for (int u0 = 0; u0 < SLX; u0 += XB) {
+            constexpr int dummy = 0; (void)dummy;
+            uint4 sbx[XB];
+            unsigned livex = 0;
+#pragma unroll
+            for (int v = 0; v < XB; ++v) {
+                const int u = u0 + v;
+                sbx[v] = make_uint4(0, 0, 0, 0);
+                if (u < SLX) {
+                    if (tid + u * TPBW < xtot && c16 < xvalid) {
+                        if (BNIN) {   // chunk c16 of padded row p0 + r = (pixel c16 / CPP, channels 8 * (c16 % CPP) ..) <- clamped source
+                            constexpr int CPP = C / 8;
+                            const int px = c16 / CPP, cg = c16 % CPP;
+                            const int sr = p0 + r - 1 < 0 ? 0 : (p0 + r - 1 > Ho - 1 ? Ho - 1 : p0 + r - 1);
+                            const int sc = px - 1 < 0 ? 0 : (px - 1 > Wo - 1 ? Wo - 1 : px - 1);
+                            sbx[v] = *reinterpret_cast<const uint4*>(xg + (((long long)sr * Wo + sc) * CPP + cg) * 16);
+                            livex |= 1u << v;
+                        } else {
+                            sbx[v] = *reinterpret_cast<const uint4*>(xg + (long long)r * xrow_g + c16 * 16);
+                        }
+                    }
+                    r += xdr; c16 += xdc;
+                    if (c16 >= xc) { c16 -= xc; ++r; }
+                }
+            }
+            if (BNIN) {
+                BnReg k;
+                k.load(cst, (tid % (C / 8)) * 8);   // TPBW and xc are multiples of C / 8: a thread's chunks all hold the same channels
+#pragma unroll
+                for (int v = 0; v < XB; ++v) {
+                    const uint4 t = bnin_apply(sbx[v], k, bn.slope);
+                    const bool on = livex & (1u << v);
+                    sbx[v] = make_uint4(on ? t.x : 0u, on ? t.y : 0u, on ? t.z : 0u, on ? t.w : 0u);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < XB; ++v)
+                if (u0 + v < SLX && tid + (u0 + v) * TPBW < xtot) *reinterpret_cast<uint4*>(smem + (tid + (u0 + v) * TPBW) * 16) = sbx[v];
+        }
+        int r2 = tid / dc, d16 = tid % dc;
+#pragma unroll
+        for (int u0 = 0; u0 < SLD; u0 += DB) {
+            uint4 sbd[DB];
+#pragma unroll
+            for (int v = 0; v < DB; ++v) {
+                const int u = u0 + v;
+                sbd[v] = make_uint4(0, 0, 0, 0);
+                if (u < SLD) {
+                    if (tid + u * TPBW < dtot && d16 < dvalid) sbd[v] = *reinterpret_cast<const uint4*>(dg + (long long)r2 * drow_g + d16 * 16);
+                    r2 += ddr; d16 += ddc;
+                    if (d16 >= dc) { d16 -= dc; ++r2; }
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < DB; ++v)
+                if (u0 + v < SLD && tid + (u0 + v) * TPBW < dtot) *reinterpret_cast<uint4*>(smem + dl_off + (tid + (u0 + v) * TPBW) * 16) = sbd[v];
+        }
+    };
+
+    for (long long band = blockIdx.x; band < total_bands; band += gridDim.x) {
+        int rows;
+        __syncthreads();                 // the previous band's fragments have been read (first trip, BNIN: the constants are in place)
+        stage(band, rows);
+        __syncthreads();
+        const unsigned char* xl = smem;
+        const unsigned char* dl = smem + dl_off;
+        // ---- multiply: a wavefront takes column strips (32-pixel segment, half of the band's rows) and slides a three-row window
+        //      of raw input dwords down each: per item the new bottom row (3 reads per 16 channels) + the gradient fragments
+        const int rh = (rows + 1) >> 1;
+        for (int unit = wave / TILES; unit < 2 * nseg; unit += W16_NW / TILES) {
+            const int sg = unit % nseg, half = unit / nseg;
+            const int rbeg = half * rh, rend = rbeg + rh < rows ? rbeg + rh : rows;
+            if (rbeg >= rend) continue;
+            // raw dwords of an input row at this strip: (p0,p1) (p2,p3) (p4,p5) (p6,p7) (p8,p9), p = pixel 8 * grp + ..
+            auto row_load = [&](int r, unsigned (&Rg)[5]) {
+                const unsigned char* b = xl + r * xrow_b + sg * 32 * (C * 2) + xlane + ct * 32;
+                const uint2 q0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b)));
+                const uint2 q1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + 4 * (C * 2))));
+                const uint2 q2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + 8 * (C * 2))));
+                Rg[0] = q0.x; Rg[1] = q0.y; Rg[2] = q1.x; Rg[3] = q1.y; Rg[4] = q2.x;
+            };
+            // the three column taps of a row from its raw dwords: tap 2 is a renaming of the dword pairs, tap 1 four v_alignbit
+            auto row_mma = [&](const h16x8& af, const unsigned (&Rg)[5], int rr) {
+                const u32x4 f0 = {Rg[0], Rg[1], Rg[2], Rg[3]};
+                const u32x4 f1 = {__builtin_amdgcn_alignbit(Rg[1], Rg[0], 16), __builtin_amdgcn_alignbit(Rg[2], Rg[1], 16),
+                                  __builtin_amdgcn_alignbit(Rg[3], Rg[2], 16), __builtin_amdgcn_alignbit(Rg[4], Rg[3], 16)};
+                const u32x4 f2 = {Rg[1], Rg[2], Rg[3], Rg[4]};
+                acc[rr * 3 + 0] = kp_mfma16x16(af, __builtin_bit_cast(h16x8, f0), acc[rr * 3 + 0]);
+                acc[rr * 3 + 1] = kp_mfma16x16(af, __builtin_bit_cast(h16x8, f1), acc[rr * 3 + 1]);
+                acc[rr * 3 + 2] = kp_mfma16x16(af, __builtin_bit_cast(h16x8, f2), acc[rr * 3 + 2]);
+            };
+            unsigned W0[5], W1[5], W2[5];
+            row_load(rbeg, W0);
+            row_load(rbeg + 1, W1);
+            for (int r = rbeg; r < rend; ++r) {
+                const unsigned char* a = dl + r * drow_b + sg * 32 * (K * 2) + dlane + kt * 32;
+                const h16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(a));
+                const h16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(a + 4 * (K * 2)));
+                const h16x8 af = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                row_load(r + 2, W2);
+                row_mma(af, W0, 0);
+                row_mma(af, W1, 1);
+                row_mma(af, W2, 2);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { W0[i] = W1[i]; W1[i] = W2[i]; }
+            }
+        }
+    }
+    // D tile of this wavefront: lane column c = ct * 16 + (lane & 15), rows k = kt * 16 + 4 * (lane >> 4) + i.  The wavefronts that own
+    // the same tile are summed per tap through LDS in a fixed order; the workgroup's sum is ITS partial gradient (kp_wgrad_unpack adds
+    // the partials in order).
+    float (*red)[4][64] = reinterpret_cast<float (*)[4][64]>(smem);
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[t][i];
+        __syncthreads();
+        if (wave < TILES) {   // wave == tw
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = kt * 16 + 4 * grp + i, c = ct * 16 + t16;
+                float s = red[wave][i][lane];
+#pragma unroll
+                for (int wv = TILES; wv < W16_NW; wv += TILES) s += red[wave + wv][i][lane];
+                scratch[(long long)blockIdx.x * pstride + ((long long)k * 9 + t) * C + c] = s;
+            }
+        }
+    }
+}
+
 bool small_ch(int v) { return v == 16 || v == 32; }
+static const int g_kp_wg16 = getenv("KP_WG16") ? atoi(getenv("KP_WG16")) : 1;   // measurement: 0 = the 32 x 32 x 16 kernel for every channel pair
+
+// band plan of the 16 x 16 x 32 weight gradient: rows per band (0: not its shape / the rows do not fit), grid = min(bands, 2 per CU)
+static unsigned small16_plan(int N, int Ho, int Wo, int C, int K, int& R, int& bpi) {
+    if (!g_kp_wg16 || !small_ch(C) || !small_ch(K) || (C == 32 && K == 32)) return 0;
+    const int Wp = (Wo + 31) & ~31;
+    const long long xrow = (long long)(Wp + 2) * C * 2, drow = (long long)Wp * K * 2;
+    long long r = (W16_LDS - 2 * xrow) / (xrow + drow);
+    if (r > Ho) r = Ho;
+    if (r > 16) r = 16;
+    const int slx = C == 32 ? w16_slx(16, 32) : (K == 32 ? w16_slx(32, 16) : w16_slx(16, 16));
+    const int sld = C == 32 ? w16_sld(16, 32) : (K == 32 ? w16_sld(32, 16) : w16_sld(16, 16));
+    while (r >= 1 && ((r + 2) * xrow > (long long)slx * W16_TPB * 16 || r * drow > (long long)sld * W16_TPB * 16)) --r;
+    if (r < 1) return 0;
+    R = (int)r;
+    bpi = (Ho + R - 1) / R;
+    const long long bands = (long long)N * bpi;
+    int cus = kp_device_cus();
+    if (cus < 1) cus = 256;
+    return (unsigned)(bands < 2LL * cus ? bands : 2LL * cus);
+}
+template <bool BNIN>
+static void small16_launch(int C, int K, unsigned grid, hipStream_t st, const void* x, const void* dy, float* scratch, int Ho, int Wo,
+                           int dy_pad, int R, int bpi, long long bands, const BnIn& bn) {
+#define KP_W16(Kv, Cv) wgrad3x3_small16_k<Kv, Cv, BNIN><<<grid, W16_TPB, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, R, bpi, bands, (long long)Kv * 9 * Cv, bn)
+    if (K == 16 && C == 16) KP_W16(16, 16);
+    else if (K == 16) KP_W16(16, 32);
+    else KP_W16(32, 16);
+#undef KP_W16
+}
 
 // band plan of the LDS-staged weight gradient: rows per band (0: the rows do not fit -- use the gather kernel), grid
 static int small_band_rows(int Ho, int Wo, int C, int K) {
@@ -991,6 +1211,8 @@ static unsigned small_wgrad_plan(int N, int Ho, int C, int K, int& rpw) {
 }
 long long kp_conv_small_wgrad_partials(int N, int Ho, int Wo, int C, int K) {
     int R, bpi, rpw;
+    if (g_kp_small_band)
+        if (const unsigned g16 = small16_plan(N, Ho, Wo, C, K, R, bpi)) return g16;
     const unsigned g = small_band_plan(N, Ho, Wo, C, K, R, bpi);
     return g ? g : small_wgrad_plan(N, Ho, C, K, rpw);
 }
@@ -998,6 +1220,11 @@ long long kp_conv_small_wgrad_partials(int N, int Ho, int Wo, int C, int K) {
 int kp_conv_small_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int dy_pad,
                         hipStream_t st) {
     int R, bpi;
+    if (g_kp_small_band)
+        if (const unsigned g16 = small16_plan(N, Ho, Wo, C, K, R, bpi)) {
+            small16_launch<false>(C, K, g16, st, x, dy, scratch, Ho, Wo, dy_pad, R, bpi, (long long)N * bpi, BnIn{});
+            return kp_check_launch("wgrad3x3_small16");
+        }
     if (const unsigned bgrid = small_band_plan(N, Ho, Wo, C, K, R, bpi)) {
 #define KP_SWB(Kv, Cv) wgrad3x3_small_band_k<Kv, Cv, false><<<bgrid, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, R, bpi, (long long)N * bpi, (long long)Kv * 9 * Cv, BnIn{})
         if (K == 16 && C == 16) KP_SWB(16, 16);
@@ -1030,9 +1257,15 @@ int kp_conv_small_wgrad_bnin(const void* yprev, const float* mean, const float* 
                              float slope, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int dy_pad,
                              hipStream_t st) {
     int R, bpi;
-    const unsigned bgrid = small_band_plan(N, Ho, Wo, C, K, R, bpi);
-    if (!bgrid || !(slope >= 0.f && slope <= 1.f)) return KP_E_UNSUPPORTED;
+    if (!(slope >= 0.f && slope <= 1.f)) return KP_E_UNSUPPORTED;
     const BnIn bn{mean, invstd, gamma, beta, slope};
+    if (g_kp_small_band)
+        if (const unsigned g16 = small16_plan(N, Ho, Wo, C, K, R, bpi)) {
+            small16_launch<true>(C, K, g16, st, yprev, dy, scratch, Ho, Wo, dy_pad, R, bpi, (long long)N * bpi, bn);
+            return kp_check_launch("wgrad3x3_small16_bnin");
+        }
+    const unsigned bgrid = small_band_plan(N, Ho, Wo, C, K, R, bpi);
+    if (!bgrid) return KP_E_UNSUPPORTED;
 #define KP_SWB(Kv, Cv) wgrad3x3_small_band_k<Kv, Cv, true><<<bgrid, TPB, 0, st>>>((const h16_t*)yprev, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, R, bpi, (long long)N * bpi, (long long)Kv * 9 * Cv, bn)
     if (K == 16 && C == 16) KP_SWB(16, 16);
     else if (K == 16) KP_SWB(16, 32);

@@ -168,44 +168,46 @@ __global__ __launch_bounds__(256) void pack_weights_tile_k(const PackBatch B) {
     }
 }
 
-// dw[k][c][r][s] += sum_p scratch[p][k][r][s][c].  A workgroup = 64 element groups (VEC consecutive c of one
-// (k, r, s) of the scratch layout: coalesced 16-byte lanes) x 4 partial lanes; lane q sums the partials p = q, q+4, ...
-// (4 loads in flight), the 4 lanes are combined through LDS in a fixed order -> deterministic.
-template <int VEC>
+// dw[k][c][r][s] += sum_p scratch[p][k][r][s][c].  A workgroup = 256 / Q element groups (VEC consecutive c of one
+// (k, r, s) of the scratch layout: coalesced 16-byte lanes) x Q partial lanes; lane q sums the partials p = q, q + Q, ...
+// (4 loads in flight), the Q lanes are combined through LDS in a fixed order -> deterministic.  Q = 4, or 16 for the few-KB
+// gradients of the Pong-class layers with hundreds of partials (18 workgroups walking 128 dependent rounds each took 14 us).
+template <int VEC, int Q>
 __global__ __launch_bounds__(256) void wgrad_unpack_k(const float* __restrict__ scratch, int partials,
                                                       float* __restrict__ dw, int K, int Cd, int C, int R) {
     // C = channels of the scratch layout (possibly padded), Cd <= C = channels of dw
+    constexpr int EG = 256 / Q;
     const long long total = (long long)K * C * R * R;
-    const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const long long t = ((long long)blockIdx.x * 64 + el) * VEC;
+    const int el = threadIdx.x % EG, q = threadIdx.x / EG;
+    const long long t = ((long long)blockIdx.x * EG + el) * VEC;
     float acc[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
     if (t < total) {
         int p = q;
         if (VEC == 4) {
-            for (; p + 12 < partials; p += 16) {
+            for (; p + 3 * Q < partials; p += 4 * Q) {
                 float4 v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(scratch + (long long)(p + 4 * u) * total + t);
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(scratch + (long long)(p + Q * u) * total + t);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { acc[0] += v[u].x; acc[1] += v[u].y; acc[2] += v[u].z; acc[3] += v[u].w; }
             }
         }
         if (VEC == 1) {   // many small partials (first layer: one per workgroup): 8 loads in flight per lane
-            for (; p + 28 < partials; p += 32) {
+            for (; p + 7 * Q < partials; p += 8 * Q) {
                 float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = scratch[(long long)(p + 4 * u) * total + t];
+                for (int u = 0; u < 8; ++u) v[u] = scratch[(long long)(p + Q * u) * total + t];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc[0] += v[u];
             }
         }
-        for (; p < partials; p += 4)
+        for (; p < partials; p += Q)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[e] += scratch[(long long)p * total + t + e];
     }
-    __shared__ float red[4][64][VEC];
+    __shared__ float red[Q][EG][VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) red[q][el][e] = acc[e];
     __syncthreads();
@@ -216,8 +218,12 @@ __global__ __launch_bounds__(256) void wgrad_unpack_k(const float* __restrict__ 
         const int k = (int)(t / ((long long)C * R * R));
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
-            if (c + e < Cd)
-                dw[(((long long)k * Cd + c + e) * R + r) * R + s] += ((red[0][el][e] + red[1][el][e]) + red[2][el][e]) + red[3][el][e];
+            if (c + e < Cd) {
+                float sum = ((red[0][el][e] + red[1][el][e]) + red[2][el][e]) + red[3][el][e];
+#pragma unroll
+                for (int g = 4; g < Q; g += 4) sum += ((red[g][el][e] + red[g + 1][el][e]) + red[g + 2][el][e]) + red[g + 3][el][e];
+                dw[(((long long)k * Cd + c + e) * R + r) * R + s] += sum;
+            }
     }
 }
 
@@ -547,9 +553,12 @@ int kp_wgrad_unpack(const float* scratch, int partials, float* dw, int K, int C,
         return kp_check_launch("wgrad_unpack_tile");
     }
     if (Cp % 4 == 0)
-        wgrad_unpack_k<4><<<cdiv(total / 4, 64), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, Cp, R);
+        if (partials >= 128 && total <= 16384)
+            wgrad_unpack_k<4, 16><<<cdiv(total / 4, 16), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, Cp, R);
+        else
+            wgrad_unpack_k<4, 4><<<cdiv(total / 4, 64), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, Cp, R);
     else
-        wgrad_unpack_k<1><<<cdiv(total, 64), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, Cp, R);
+        wgrad_unpack_k<1, 4><<<cdiv(total, 64), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, Cp, R);
     return kp_check_launch("wgrad_unpack");
 }
 
