@@ -25,7 +25,7 @@ KERNELS = {'conv3x3_patch_k<128': 'conv_patch_bf16_bn128', 'conv3x3_patch_k<128,
 # config 2 (template arguments of the band kernel: input channels / 16, output channels / 16, BatchNorm input, statistics, ...)
 KERNELS_C2 = {'conv3x3_small_band_k<': 'conv_small_band_bf16', 'conv3x3_small_band_k<1, [12], false': 'conv_small_band_bf16_c16',
               'conv3x3_small_band_k<2, [12], false': 'conv_small_band_bf16_c32', 'conv3x3_small_band_k<1, [12], true': 'conv_small_band_bf16_c16_bnin',
-              'conv3x3_small_band_k<2, [12], true': 'conv_small_band_bf16_c32_bnin', 'wgrad3x3_small_band_k<': 'wgrad_small_band_bf16'}
+              'conv3x3_small_band_k<2, [12], true': 'conv_small_band_bf16_c32_bnin', 'wgrad3x3_small_band_k<': 'wgrad_small_band_bf16', 'wgrad3x3_small16_k<': 'wgrad_small16_bf16'}
 
 
 def load(name):
