@@ -490,6 +490,7 @@ int kp_head_dw_mfma(const float*, const float*, const void*, float, float*, floa
 bool kp_head_small_shape(long long, int, int);
 bool kp_head_mfma_bnin_shape(long long, int, int, int);
 bool kp_head_mfma_shape(long long, int, int, int);
+bool kp_head_mfma_fwd_shape(long long, int, int, int);
 long long kp_head_dw_parts_mfma(long long, int, int, int);
 long long kp_head_dw_parts_fast(long long, int, int);
 int kp_head_dx_fast(const float*, const float*, const float*, float, void*, long long, int, int, int, hipStream_t);
@@ -587,7 +588,9 @@ int kp_head_fwd(const void* x, const float* w, const float* bias, float slope, f
 //  K <= 16 kernels: two kernels round differently)
 static bool head_bnin_ok(long long M, int HW, int C, int K, int dtype) {
     if (dtype != KP_H16) return false;
-    return kp_head_mfma_shape(M, HW, C, K) ? kp_head_mfma_bnin_shape(M, HW, C, K) : kp_head_small_shape(M, C, K);
+    const bool fwd = kp_head_mfma_fwd_shape(M, HW, C, K) ? C == 32 : kp_head_small_shape(M, C, K);
+    const bool bwd = kp_head_mfma_shape(M, HW, C, K) ? kp_head_mfma_bnin_shape(M, HW, C, K) : kp_head_small_shape(M, C, K);
+    return fwd && bwd;
 }
 int kp_head_bnin_supported(int N, int H, int W, int C, int K, int dtype) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 0;

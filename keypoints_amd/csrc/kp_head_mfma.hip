@@ -431,11 +431,16 @@ bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr) 
 // bn != nullptr (kp_head_fwd_bnin / kp_head_bwd_bnin): the 32-channel shapes only
 bool kp_head_mfma_bnin_shape(long long M, int HW, int C, int K) { return mfma_shape(M, HW, C, K) && C == 32; }
 bool kp_head_mfma_shape(long long M, int HW, int C, int K) { return mfma_shape(M, HW, C, K); }
+// the FORWARD also takes the 32-channel heads with K <= 4 (Pong-class keypoint heads, 32 -> K): the looped kernel streams their
+// input at the rate of the 16-output head, the K <= 16 VALU kernel (kp_head_fast.hip) is 25 % slower once it applies the BatchNorm input
+bool kp_head_mfma_fwd_shape(long long M, int HW, int C, int K) {
+    return mfma_shape(M, HW, C, K) || (C == 32 && K >= 1 && K <= 4 && HW % 8 == 0 && M >= 32 && M % 32 == 0);
+}
 
 int kp_head_fwd_mfma(const void* x, const float* w, const float* bias, float slope, float* out, long long M, int HW,
                      int C, int K, hipStream_t st, const KpBnIn* bn) {
-    if (!mfma_shape(M, HW, C, K) || !aligned16(x, w)) return KP_E_UNSUPPORTED;
-    if (bn && !kp_head_mfma_bnin_shape(M, HW, C, K)) return KP_E_UNSUPPORTED;
+    if (!kp_head_mfma_fwd_shape(M, HW, C, K) || !aligned16(x, w)) return KP_E_UNSUPPORTED;
+    if (bn && C != 32) return KP_E_UNSUPPORTED;
     const long long groups = M / 32;
     const unsigned grid = (unsigned)((groups + 3) / 4);
     if (C == 32) {   // ~8 groups per wavefront
