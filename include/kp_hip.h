@@ -185,6 +185,21 @@ int kp_conv_wgrad_bnin(const void* yprev, const float* mean, const float* invstd
                        float slope, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int dy_pad, int dtype,
                        void* stream);
 
+/* The data gradient of a 3x3 layer L that also leaves the first pass of layer L - 1's BatchNorm backward (the layer whose padded
+ * activation was L's input; vgg.py:30-38 pairs).  gx: exactly kp_conv_dgrad's output [N][H+2][W+2][C] (padded domain, bit for
+ * bit).  partials: what kp_bn_act_bwd_reduce(gx, gp = 1, tail none, yred, ...) would leave -- rows x [2][C] sums of
+ * gh = fold(gx) * act'(z) and gh * xhat over yred = layer L - 1's conv output [N][H][W][C] with ITS BatchNorm (mean / invstd /
+ * gamma / beta, all NULL without BatchNorm) and activation slope -- computed in the padded domain (folding is the adjoint of
+ * the replicate pad: every element of gx meets the factors of its clamped source pixel), equal up to the order of the fp32
+ * additions; kp_bn_bwd_finalize takes the rows.  Row count: kp_conv_dgrad_bnred_rows (a pure function of the shape), at most
+ * ceil(N * (H + 2) * (W + 2) / 64).  kp_conv_dgrad_bnred_supported: 1 where the fused kernel exists (16-bit storage,
+ * C, K in {16, 32}, a band of rows fits the LDS); otherwise KP_E_UNSUPPORTED, nothing launched. */
+int kp_conv_dgrad_bnred_supported(int N, int H, int W, int K, int C, int dtype);
+long long kp_conv_dgrad_bnred_rows(int N, int H, int W, int K, int C, int dtype);
+int kp_conv_dgrad_bnred(const void* dy, const void* w_dgrad, void* gx, const void* yred, const float* mean, const float* invstd,
+                        const float* gamma, const float* beta, float slope, float* partials, int N, int H, int W, int K, int C,
+                        int dtype, void* stream);
+
 /* ---- BatchNorm(train) + activation (+ pool / upsample) ----------------- */
 /* fp64 workspace size (in doubles) needed by kp_bn_finalize / kp_bn_bwd_finalize for C channels. */
 int kp_bn_ws_doubles(int C);

@@ -198,6 +198,9 @@ KP_DISPATCH(kp_conv_fwd_bnin, (const void* yprev, const float* mean, const float
             (yprev, mean, invstd, gamma, beta, slope, w, bias, y, stats, N, H, W, C, K, dtype, stream))
 KP_DISPATCH(kp_conv_wgrad_bnin, (const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int dy_pad, int dtype, void* stream),
             (yprev, mean, invstd, gamma, beta, slope, dy, scratch, N, Ho, Wo, C, K, dy_pad, dtype, stream))
+KP_DISPATCH(kp_conv_dgrad_bnred_supported, (int N, int H, int W, int K, int C, int dtype), (N, H, W, K, C, dtype))
+KP_DISPATCH(kp_conv_dgrad_bnred, (const void* dy, const void* w_dgrad, void* gx, const void* yred, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, float* partials, int N, int H, int W, int K, int C, int dtype, void* stream),
+            (dy, w_dgrad, gx, yred, mean, invstd, gamma, beta, slope, partials, N, H, W, K, C, dtype, stream))
 KP_DISPATCH(kp_bn_act_fwd, (const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, int tail, void* out, int out_pad, unsigned char* argmax, int N, int H, int W, int C, int dtype, void* stream),
             (y, mean, invstd, gamma, beta, slope, tail, out, out_pad, argmax, N, H, W, C, dtype, stream))
 KP_DISPATCH(kp_bn_act_bwd_reduce, (const void* gsrc, int gp, int tail, const unsigned char* argmax, const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, float* partials, int N, int H, int W, int C, int dtype, void* stream),
@@ -227,6 +230,13 @@ long long kp_conv_fwd_stats_rows(int N, int Hi, int Wi, int C, int K, int R, int
     kp_set_query_mode(1);
     float dummy;   // non-NULL stats: the launchers only look at the pointer's truth value in query mode
     const int rc = kp_conv_fwd(nullptr, nullptr, nullptr, nullptr, &dummy, N, Hi, Wi, C, K, R, dtype, nullptr);
+    kp_set_query_mode(0);
+    return rc == KP_OK ? kp_last_rows() : (long long)rc;
+}
+
+long long kp_conv_dgrad_bnred_rows(int N, int H, int W, int K, int C, int dtype) {
+    kp_set_query_mode(1);
+    const int rc = kp_conv_dgrad_bnred(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, N, H, W, K, C, dtype, nullptr);
     kp_set_query_mode(0);
     return rc == KP_OK ? kp_last_rows() : (long long)rc;
 }

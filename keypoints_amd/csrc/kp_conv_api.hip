@@ -20,6 +20,9 @@ int kp_conv_small_fwd_bnin(const void*, const float*, const float*, const float*
 int kp_conv_small_wgrad_bnin_ok(int, int, int, int, int);
 int kp_conv_small_wgrad_bnin(const void*, const float*, const float*, const float*, const float*, float, const void*, float*, int,
                              int, int, int, int, int, hipStream_t);
+int kp_conv_small_dgrad_bnred_ok(int, int, int, int, int);
+int kp_conv_small_dgrad_bnred(const void*, const void*, void*, const void*, const float*, const float*, const float*, const float*, float,
+                              float*, int, int, int, int, int, hipStream_t);
 int kp_conv_first_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
 int kp_conv_first_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 long long kp_conv_first_wgrad_partials(int, int, int, int, int);
@@ -187,6 +190,30 @@ int kp_conv_wgrad_bnin(const void* yprev, const float* mean, const float* invstd
     ProfScope ps(KP_PROF_WGRAD_SMALL, flops, (hipStream_t)stream, bytes);
     const int rc = kp_conv_small_wgrad_bnin(yprev, mean, invstd, gamma, beta, slope, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
     ps.done(KP_PROF_WGRAD_SMALL);
+    return rc;
+}
+
+// ---- the data gradient of a 3x3 layer that also leaves the first pass of the PRODUCING layer's BatchNorm backward ------------
+// (kp_conv_small.hip, BRED): gx as from kp_conv_dgrad, bit for bit; partials = kp_bn_act_bwd_reduce's sums of the layer below
+// (gp = 1, tail none) up to the order of the fp32 additions -- that pass is then not run.  Rows written: the return value
+// of kp_conv_dgrad_bnred_rows (= kp_last_rows() after the call), at most ceil(N * (H + 2) * (W + 2) / 64) rows of [2][C].
+int kp_conv_dgrad_bnred_supported(int N, int H, int W, int K, int C, int dtype) {
+    if (dtype != KP_H16 || !use_mfma() || N <= 0 || H <= 0 || W <= 0) return 0;
+    return kp_conv_small_dgrad_bnred_ok(N, H, W, K, C);
+}
+
+int kp_conv_dgrad_bnred(const void* dy, const void* w_dgrad, void* gx, const void* yred, const float* mean, const float* invstd,
+                        const float* gamma, const float* beta, float slope, float* partials, int N, int H, int W, int K, int C,
+                        int dtype, void* stream) {
+    KP_REQUIRE(kp_query_mode() || (dy && w_dgrad && gx && yred && partials), "kp_conv_dgrad_bnred: null pointer");
+    KP_REQUIRE(N > 0 && C > 0 && K > 0 && H > 0 && W > 0, "kp_conv_dgrad_bnred: bad dims");
+    KP_REQUIRE(!mean == !invstd && !mean == !gamma && !mean == !beta, "kp_conv_dgrad_bnred: mean / invstd / gamma / beta must be all set or all NULL");
+    if (!kp_conv_dgrad_bnred_supported(N, H, W, K, C, dtype)) return KP_E_UNSUPPORTED;
+    const double flops = 2.0 * N * (double)H * W * C * K * 9;
+    const double bytes = 2.0 * ((double)N * (H + 4) * (W + 4) * K + (double)N * (H + 2) * (W + 2) * C + (double)N * H * W * C + 9.0 * C * K);
+    ProfScope ps(KP_PROF_CONV_SMALL, flops, (hipStream_t)stream, bytes);
+    const int rc = kp_conv_small_dgrad_bnred(dy, w_dgrad, gx, yred, mean, invstd, gamma, beta, slope, partials, N, H, W, K, C, (hipStream_t)stream);
+    ps.done(KP_PROF_CONV_SMALL);
     return rc;
 }
 

@@ -229,11 +229,21 @@ constexpr int FSL = 12 * 256 / FTPB;   // 16-byte chunks per thread in one band 
 // last two input rows in registers -- 3 x CB fragment reads per item instead of 9 x CB (the ablation build without
 // fragment reads ran 32 -> 21 us: the LDS reads, issue + latency, were the largest single term).  The window is 36 registers
 // per 16 input channels: the 16-channel-input variants have room, and the 32-channel ones without statistics.
-template <int CB, int KB, bool BNIN, bool STATS, bool WREG = !(BNIN && CB == 2), bool WIN = (CB == 1)>
+// BRED (the data gradient of layer L as the producer of layer L - 1's BatchNorm backward; plain input, no statistics): the
+// first pass of that backward -- sums over the batch of gh = g * act'(z) and gh * xhat (kp_bn_act_bwd_reduce) -- runs in the
+// epilogue, on the stored (rounded) gradient values.  The output of this kernel is the gradient in the PADDED domain and the
+// separate pass folds it first; folding is the adjoint of the replicate pad, so sum_ij fold(g)_ij f_ij = sum_pq g_pq f[clamp(p - 1)]
+// [clamp(q - 1)]: every padded-domain element is multiplied with the factors of its clamped source pixel, no fold.  `yred` =
+// layer L - 1's conv output [N][Ho - 2][Wo - 2][K], `bn` ITS BatchNorm / activation; a lane's 16-byte chunk of yred is requested
+// together with the MFMAs of its item and used one item later; `partials`: one row [2][K] per wavefront of the grid, as for
+// the forward statistics (kp_bn_bwd_finalize takes them).  Same sums as the separate pass up to the order of the fp32 additions.
+template <int CB, int KB, bool BNIN, bool STATS, bool WREG = !(BNIN && CB == 2), bool WIN = (CB == 1), bool BRED = false>
 __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
                                                             const float* __restrict__ bias, h16_t* __restrict__ y,
                                                             float* __restrict__ partials, int Hi, int Wi, int R,
-                                                            int bands_per_img, int total_bands, BnIn bn) {
+                                                            int bands_per_img, int total_bands, BnIn bn,
+                                                            const h16_t* __restrict__ yred = nullptr) {
+    static_assert(!BRED || (!BNIN && !STATS && !WIN), "BRED: data-gradient form (plain input, no statistics, item-strided loop)");
     constexpr int C = CB * 16, K = KB * 16, PITCH = C * 2 + 16, CPP = C / 8;   // chunks of 16 bytes per pixel
     constexpr int JH = KB * 4;                                                   // register pairs of the accumulator that hold channels < K
     __shared__ h16x8 swf[WREG ? 1 : 9 * CB][64];
@@ -273,6 +283,15 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
     const int lrow = lane >> 4, px16 = lane & 15;
     const int lane_st = KB == 1 ? fr * 32 + fh * 16 : px16 * 64 + (2 * (lrow & 1) + (lrow >> 1)) * 16;
     constexpr int OOB = (int)0x80000000;               // beyond every band's bytes: the buffer store drops the lane
+    // BRED: the lane's stored chunk (8 channels of a pixel) is chunk fh (16 channels) / 2 * (row & 1) + (row >> 1) (32) of either store
+    const int rchunk = KB == 1 ? fh : 2 * (lrow & 1) + (lrow >> 1);
+    KpBnIn8 rk;
+    float rsb[BRED ? 8 : 1], rsg[BRED ? 8 : 1];
+    if constexpr (BRED) {
+        rk.load(bn, rchunk * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rsb[e] = rsg[e] = 0.f;
+    }
 
     // ---- staging: the band's R + 2 input rows, global -> registers -> LDS ------------------------------------------------
     // All of a band's loads are in flight before the first LDS store.  Buffer loads: a chunk outside the band or the image
@@ -369,6 +388,41 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
         unsigned char* const yband = (unsigned char*)y + (((long long)n * Ho + p0) * Wo) * (long long)K * 2;   // uniform
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)yband, 0, rows * Wo * K * 2, 0x00020000);
         const int nitems = (KP_FB_ABL & 2) ? 0 : rows * nseg;
+        // BRED: the clamped source pixels of this band's items in layer L - 1's conv output (image n)
+        const int Hr = Ho - 2, Wr = Wo - 2;
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+            BRED ? (void*)((const unsigned char*)yred + ((long long)n * Hr * Wr) * (long long)K * 2) : (void*)y, 0, BRED ? Hr * Wr * K * 2 : 0, 0x00020000);
+        struct YPair { u32x4 a, b; };
+        auto yload = [&](int item) {
+            YPair q{};
+            if constexpr (BRED) {
+                const int r = item / nseg, sq = item - r * nseg;
+                const int pr = p0 + r - 1;
+                const int rowoff = (pr < 0 ? 0 : (pr > Hr - 1 ? Hr - 1 : pr)) * Wr;      // scalar
+                const int col = sq * 32 + (KB == 1 ? fr : px16);
+                const int ca = col - 1 < 0 ? 0 : (col - 1 > Wr - 1 ? Wr - 1 : col - 1);
+                q.a = __builtin_amdgcn_raw_buffer_load_b128(rr, col < Wo ? ((rowoff + ca) * K + rchunk * 8) * 2 : OOB, 0, 0);
+                if constexpr (KB == 2) {
+                    const int cb2 = col + 15 > Wr - 1 ? Wr - 1 : col + 15;               // (col + 16) - 1 >= 0
+                    q.b = __builtin_amdgcn_raw_buffer_load_b128(rr, col + 16 < Wo ? ((rowoff + cb2) * K + rchunk * 8) * 2 : OOB, 0, 0);
+                }
+            }
+            return q;
+        };
+        // gh = g * act'(z), sums of gh and gh * xhat over the lane's pixels; g = the stored chunk, lanes beyond the row: g = 0
+        auto bred = [&](const u32x4& gw, const u32x4& yw, bool on) {
+            float g[8], yv[8];
+            unpack_h16x2(gw[0], g[0], g[1]); unpack_h16x2(gw[1], g[2], g[3]); unpack_h16x2(gw[2], g[4], g[5]); unpack_h16x2(gw[3], g[6], g[7]);
+            unpack_h16x2(yw[0], yv[0], yv[1]); unpack_h16x2(yw[1], yv[2], yv[3]); unpack_h16x2(yw[2], yv[4], yv[5]); unpack_h16x2(yw[3], yv[6], yv[7]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (yv[e] - rk.mu[e]) * rk.is[e];
+                const float z = xh * rk.ga[e] + rk.be[e];
+                const float gh = (on ? g[e] : 0.f) * act_grad(z, bn.slope);
+                rsb[e] += gh;
+                rsg[e] += gh * xh;
+            }
+        };
         // one item = 32 pixels of one row x K channels: 9 x CB fragment reads, 9 x CB MFMAs into one accumulator tile
         auto mma = [&](int item) {                             // item -> row, segment, LDS base: scalar
             const int r = item / nseg, sq = item - r * nseg;
@@ -389,7 +443,7 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
         };
         // bias, statistics, 16-bit pack, lane exchange, store: straight-line code (no branch: the scheduler is free to put it
         // under the MFMAs of the NEXT item, see the loop below)
-        auto epi_rest = [&](int r, int sq, const f32x2 (&v)[JH]) {
+        auto epi_rest = [&](int r, int sq, const f32x2 (&v)[JH], const YPair& yq = YPair{}) {
             const int valid = Wo - sq * 32;                     // pixels of the segment inside the row (>= 32: all)
             if constexpr (STATS) {
                 // lanes beyond the row: x 0 (their fragments are the zero fill and halo, finite); x 1 is exact
@@ -416,6 +470,7 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
             if constexpr (KB == 1) {
                 const int vo = (fr < valid && !(KP_FB_ABL & 4)) ? lane_st : OOB;
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{p[0], p[1], p[2], p[3]}, yr, vo, soff, 0);
+                if constexpr (BRED) bred(u32x4{p[0], p[1], p[2], p[3]}, yq.a, fr < valid);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {                   // 16-lane rows: (p[i], p[4 + i]) -> (pixels 0-15, pixels 16-31)
@@ -426,14 +481,18 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
                 const int vb = (px16 + 16 < valid && !(KP_FB_ABL & 4)) ? lane_st + 1024 : OOB;
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{p[0], p[1], p[2], p[3]}, yr, va, soff, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{p[4], p[5], p[6], p[7]}, yr, vb, soff, 0);
+                if constexpr (BRED) {
+                    bred(u32x4{p[0], p[1], p[2], p[3]}, yq.a, px16 < valid);
+                    bred(u32x4{p[4], p[5], p[6], p[7]}, yq.b, px16 + 16 < valid);
+                }
             }
         };
-        auto epi = [&](int item, const f32x16& acc) {
+        auto epi = [&](int item, const f32x16& acc, const YPair& yq = YPair{}) {
             const int r = item / nseg, sq = item - r * nseg;
             f32x2 v[JH];
 #pragma unroll
             for (int j = 0; j < JH; ++j) v[j] = f32x2{acc[2 * j], acc[2 * j + 1]} + bv[j];
-            epi_rest(r, sq, v);
+            epi_rest(r, sq, v, yq);
         };
         // a wavefront's items wave, wave + FNW, ...: the MFMAs of item i + 1 are issued BEFORE the epilogue of item i, in
         // one basic block -- a lone wave otherwise runs a 9-deep dependent MFMA chain and then ~60 dependent VALU
@@ -505,25 +564,47 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
         } else if (wave < nitems) {
             int item = wave;
             f32x16 a0 = mma(item);
-            if constexpr (STATS && KB == 2) {
+            if constexpr ((STATS || BRED) && KB == 2) {
+                YPair y0 = yload(item);
                 for (; item + FNW < nitems; item += FNW) {
                     const f32x16 nxt = mma(item + FNW);
-                    epi(item, a0);
-                    a0 = nxt;
+                    const YPair yn = yload(item + FNW);
+                    epi(item, a0, y0);
+                    a0 = nxt; y0 = yn;
                 }
-                epi(item, a0);
+                epi(item, a0, y0);
             } else {
                 f32x16 a1;
+                YPair y0 = yload(item), y1{};
                 for (;;) {
-                    if (item + FNW >= nitems) { epi(item, a0); break; }
-                    a1 = mma(item + FNW); epi(item, a0); item += FNW;
-                    if (item + FNW >= nitems) { epi(item, a1); break; }
-                    a0 = mma(item + FNW); epi(item, a1); item += FNW;
+                    if (item + FNW >= nitems) { epi(item, a0, y0); break; }
+                    a1 = mma(item + FNW); y1 = yload(item + FNW); epi(item, a0, y0); item += FNW;
+                    if (item + FNW >= nitems) { epi(item, a1, y1); break; }
+                    a0 = mma(item + FNW); y0 = yload(item + FNW); epi(item, a1, y1); item += FNW;
                 }
             }
         }
     }
     stamp();
+    if constexpr (BRED) {
+        // lanes that hold the same chunk: the 32 of a half-wave (16 channels) / the 16 of a row (32 channels)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = 1; o < (KB == 1 ? 32 : 16); o <<= 1) {
+                rsb[e] += __shfl_xor(rsb[e], o, 64);
+                rsg[e] += __shfl_xor(rsg[e], o, 64);
+            }
+        }
+        const long long gw = (long long)blockIdx.x * FNW + wave;
+        if ((lane & (KB == 1 ? 31 : 15)) == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                partials[(gw * 2 + 0) * K + rchunk * 8 + e] = rsb[e];
+                partials[(gw * 2 + 1) * K + rchunk * 8 + e] = rsg[e];
+            }
+        }
+    }
     if constexpr (STATS) {
         const long long gw = (long long)blockIdx.x * FNW + wave;
         float s1[16], s2[16];
@@ -1163,6 +1244,36 @@ int kp_conv_small_fwd(const void* x, const void* w, const float* bias, void* y, 
     else
         conv3x3_small_k<2><<<(unsigned)blocks, TPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, N, Hi, Wi, K, nseg, spr);
     return kp_check_launch("conv3x3_small");
+}
+
+// The data gradient of a 3x3 layer (dy with its zero border of 2, weights in the data-gradient layout) that also leaves the first pass
+// of the PRODUCING layer's BatchNorm backward (BRED above): gx [N][H + 2][W + 2][C] as from kp_conv_small_fwd(dy, ..., H + 4, W + 4,
+// K, C), partials = rows x [2][C] sums of gh and gh * xhat over yred [N][H][W][C]; rows = kp_last_rows().
+int kp_conv_small_dgrad_bnred_ok(int N, int H, int W, int K, int C) {
+    int R, bpi;
+    long long bands;
+    return small_ch(C) && small_ch(K) && H >= 1 && W >= 1 && g_kp_small_band && small_fwd_band_plan(N, H + 2, W + 2, K, true, R, bpi, bands) > 0;
+}
+int kp_conv_small_dgrad_bnred(const void* dy, const void* w_dgrad, void* gx, const void* yred, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, float slope, float* partials, int N, int H, int W, int K, int C,
+                              hipStream_t st) {
+    if (!kp_conv_small_dgrad_bnred_ok(N, H, W, K, C)) return KP_E_UNSUPPORTED;
+    int R, bpi;
+    long long bands;
+    const long long grid = small_fwd_band_plan(N, H + 2, W + 2, K, true, R, bpi, bands);   // (statistics-style rows: one per wavefront)
+    if (!grid) return KP_E_UNSUPPORTED;
+    kp_set_last_rows(grid * FNW);
+    KP_QUERY_RETURN();
+    const BnIn bn{mean, invstd, gamma, beta, slope};
+    // kernel roles: input channels = K (the gradient's), output channels = C
+    // (32 output channels: two chunks of constants / sums per lane -- the weight fragments go to LDS to make room)
+#define KP_BRED(CBv, KBv) conv3x3_small_band_k<CBv, KBv, false, false, KBv == 1, false, true><<<(unsigned)grid, FTPB, 0, st>>>((const h16_t*)dy, (const h16_t*)w_dgrad, nullptr, (h16_t*)gx, partials, H + 4, W + 4, R, bpi, (int)bands, bn, (const h16_t*)yred)
+    if (K == 16 && C == 16) KP_BRED(1, 1);
+    else if (K == 16) KP_BRED(1, 2);
+    else if (C == 16) KP_BRED(2, 1);
+    else KP_BRED(2, 2);
+#undef KP_BRED
+    return kp_check_launch("conv3x3_small_band_bnred");
 }
 
 // The same forward with the previous layer's BatchNorm-apply + activation + replicate pad on the staging path (BnIn above):

@@ -196,3 +196,22 @@ def fuse_bn_input() -> bool:
 def set_fuse_bn_input(on: bool) -> None:
     global _FUSE_BN_INPUT
     _FUSE_BN_INPUT = bool(on)
+
+
+_FUSE_BN_REDUCE = bool(_os.environ.get('KP_BN_REDUCE_FUSION'))
+
+
+def fuse_bn_reduce() -> bool:
+    """The data gradient of a 3x3 layer leaves the first pass of the BatchNorm backward of the layer below in its epilogue
+    (kp_conv_dgrad_bnred) where the library has such a kernel: that pass is not launched.  Same sums up to the order of the fp32
+    additions (NOT bit-identical to the separate pass: its own switch, apart from `fuse_bn_input`).
+    OFF by default: measured on config 2 it takes 0.09 ms of kernel time out of the step (five 42 us passes gone, the five data
+    gradients 18-30 us longer: they read the conv output the pass would have read) and the step is 0.02 ms SLOWER -- the
+    HBM-bound pass ran beside the weight gradient of the side stream, the longer data gradient (two workgroups per CU, 60 KB of
+    LDS each) does not.  `set_fuse_bn_reduce(True)` / KP_BN_REDUCE_FUSION=1 switch it on."""
+    return _FUSE_BN_REDUCE
+
+
+def set_fuse_bn_reduce(on: bool) -> None:
+    global _FUSE_BN_REDUCE
+    _FUSE_BN_REDUCE = bool(on)

@@ -386,6 +386,7 @@ class UnitFunction(torch.autograd.Function):
             call('kp_head_bwd', ptr(gout), ptr(out), ptr(a_last), ptr(hconv.weight), head['slope'], *hgrads,
                  N, Hh, Wh, Ch, Kout, code, st)
         gp = 0   # border width of g (0 = plain, 1 = padded-domain gradient that still needs folding)
+        pending_red = None   # (partial rows, count) of the NEXT layer's BatchNorm-backward sums, left by a fused data gradient
         for idx in range(len(saved) - 1, -1, -1):
             stp, sv = plan[idx], saved[idx]
             conv, bn = stp['conv'], stp['bn']
@@ -397,19 +398,23 @@ class UnitFunction(torch.autograd.Function):
                 g, gp, tcode = g2, 0, _lib.TAIL_NONE
             else:
                 tcode = TAILS[tail]
-            partials = torch.empty(N * H, 2, K, device=dev, dtype=torch.float32)
             gamma = bn.weight if bn is not None else None
             beta = bn.bias if bn is not None else None
             bn_args = (ptr(sv['mean']), ptr(sv['invstd']), ptr(gamma), ptr(beta))
-            call('kp_bn_act_bwd_reduce', ptr(g), gp, tcode, ptr(sv['argmax']), ptr(sv['y']), *bn_args, stp['slope'],
-                 ptr(partials), N, H, W, K, code, st)
+            if pending_red is not None:   # the layer above left this layer's sums in its data gradient's epilogue (below)
+                partials, prows = pending_red
+                pending_red = None
+            else:
+                partials = torch.empty(N * H, 2, K, device=dev, dtype=torch.float32)
+                call('kp_bn_act_bwd_reduce', ptr(g), gp, tcode, ptr(sv['argmax']), ptr(sv['y']), *bn_args, stp['slope'],
+                     ptr(partials), N, H, W, K, code, st)
+                prows = _lib.lib().kp_bn_bwd_rows(gp, tcode, N, H, W, K, code)
             if bn is not None:
                 dgam, dbet = ptr(gv[id(bn.weight)]), ptr(gv[id(bn.bias)])
             else:   # no BN: sum of dy is the conv-bias gradient
                 dgam, dbet = None, (ptr(gv[id(conv.bias)]) if conv.bias is not None else None)
             sums = torch.empty(2 * K, device=dev, dtype=torch.float32)
             ws = torch.empty(128 * K, device=dev, dtype=torch.float64)
-            prows = _lib.lib().kp_bn_bwd_rows(gp, tcode, N, H, W, K, code)
             call('kp_bn_bwd_finalize', ptr(partials), ptr(ws), prows, K, ptr(sums), dgam, dbet, st)
             sync = unit.sync_bn if bn is not None else None
             if sync is not None:
@@ -428,7 +433,20 @@ class UnitFunction(torch.autograd.Function):
             parts = _lib.lib().kp_conv_wgrad_partials(N, H, W, C, K, 3, dp, code)
             if need_dx:
                 gx = torch.empty(N, H + 2, W + 2, C, device=dev, dtype=tdt)
-                call('kp_conv_dgrad', ptr(dy), ptr(sv['wd']), ptr(gx), N, H, W, K, C, code, st)
+                # the layer below (3x3, no pool / upsample behind it: this layer read its padded activation): the first pass of ITS
+                # BatchNorm backward -- sums over gx and its conv output -- in this data gradient's epilogue where the kernel exists
+                below = plan[idx - 1] if idx > 0 else None
+                if (below is not None and below['kind'] == 'conv3' and below['tail'] is None and runtime.fuse_bn_reduce() and 0.0 <= below['slope'] <= 1.0
+                        and _lib.lib().kp_conv_dgrad_bnred_supported(N, H, W, K, C, code) == 1):
+                    svb, bnb = saved[idx - 1], below['bn']
+                    rows_b = _lib.lib().kp_conv_dgrad_bnred_rows(N, H, W, K, C, code)
+                    part_b = torch.empty(rows_b, 2, C, device=dev, dtype=torch.float32)
+                    call('kp_conv_dgrad_bnred', ptr(dy), ptr(sv['wd']), ptr(gx), ptr(svb['y']), ptr(svb['mean']), ptr(svb['invstd']),
+                         ptr(bnb.weight if bnb is not None else None), ptr(bnb.bias if bnb is not None else None), below['slope'],
+                         ptr(part_b), N, H, W, K, C, code, st)
+                    pending_red = (part_b, rows_b)
+                else:
+                    call('kp_conv_dgrad', ptr(dy), ptr(sv['wd']), ptr(gx), N, H, W, K, C, code, st)
                 g, gp = gx, 1
             else:
                 g = None

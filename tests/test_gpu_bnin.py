@@ -117,6 +117,50 @@ def test_head_fwd_and_bwd_bnin_equal_the_separate_pass(N, H, W, C, K, dt, bn_on,
     assert (res[1][0] - ref).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize('N,H,W', [(3, 84, 84), (2, 37, 50), (4, 5, 7), (1, 1, 3), (2, 32, 32), (5, 16, 33)])
+@pytest.mark.parametrize('K,C', [(16, 16), (32, 16), (16, 32), (32, 32)])
+@pytest.mark.parametrize('dt,bn_on,slope', [('bf16', True, 0.01), ('fp16', True, 0.0), ('bf16', False, 0.01)])
+def test_dgrad_with_the_batchnorm_backward_sums_in_its_epilogue(N, H, W, K, C, dt, bn_on, slope):
+    """kp_conv_dgrad_bnred against kp_conv_dgrad + kp_bn_act_bwd_reduce(gp = 1): the padded-domain gradient bit for bit, the sums
+    of the layer below (after kp_bn_bwd_finalize) to fp32 summation accuracy -- the fused kernel adds them in another order and in
+    the padded domain (fold = adjoint of the replicate pad)."""
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    tdt, code = (torch.bfloat16, _lib.KP_BF16) if dt == 'bf16' else (torch.float16, _lib.KP_F16)
+    L = _lib.lib()
+    if L.kp_conv_dgrad_bnred_supported(N, H, W, K, C, code) != 1:
+        pytest.skip('no fused kernel for this shape (the engine then runs the separate pass)')
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + C + K)
+    dy = torch.zeros(N, H + 4, W + 4, K, dtype=tdt)
+    dy[:, 2:2 + H, 2:2 + W] = (torch.randn(N, H, W, K, generator=g) * 0.1).to(tdt)
+    dy = dy.cuda()
+    wd = (torch.randn(C, 3, 3, K, generator=g) * 0.1).to(tdt).cuda()
+    yred = torch.randn(N, H, W, C, generator=g).to(tdt).cuda()
+    bn = _bn(C, g, bn_on)
+    st = stream_ptr()
+    nrows = (N * (H + 2) * (W + 2) + 63) // 64
+    # reference: plain data gradient, then the separate reduce pass over the folded gradient
+    gx0 = torch.full((N, H + 2, W + 2, C), float('nan'), device='cuda', dtype=tdt)
+    call('kp_conv_dgrad', ptr(dy), ptr(wd), ptr(gx0), N, H, W, K, C, code, st)
+    p0 = torch.full((N * H, 2, C), float('nan'), device='cuda')
+    call('kp_bn_act_bwd_reduce', ptr(gx0), 1, _lib.TAIL_NONE, None, ptr(yred), *[ptr(t) for t in bn], slope, ptr(p0), N, H, W, C, code, st)
+    r0 = L.kp_bn_bwd_rows(1, _lib.TAIL_NONE, N, H, W, C, code)
+    gx1 = torch.full((N, H + 2, W + 2, C), float('nan'), device='cuda', dtype=tdt)
+    p1 = torch.full((max(nrows, 1), 2, C), float('nan'), device='cuda')
+    call('kp_conv_dgrad_bnred', ptr(dy), ptr(wd), ptr(gx1), ptr(yred), *[ptr(t) for t in bn], slope, ptr(p1), N, H, W, K, C, code, st)
+    r1 = L.kp_conv_dgrad_bnred_rows(N, H, W, K, C, code)
+    assert 1 <= r1 <= nrows
+    assert torch.isfinite(gx1.float()).all() and torch.equal(gx0, gx1)
+    s0 = p0[:r0].double().sum(0).cpu()
+    s1 = p1[:r1].double().sum(0).cpu()
+    assert torch.isfinite(p1[:r1]).all()
+    # scale of the sums: sum of |terms| ~ N*H*W * |gh|; fp32 accumulation in chunks: 1e-4 of that is generous and catches a wrong pixel map
+    ref = yred.float()
+    scale = float(gx0.float().abs().sum() / C) * max(1.0, float(ref.abs().max()))
+    assert (s0 - s1).abs().max() <= 1e-4 * scale + 1e-6, ((s0 - s1).abs().max(), scale)
+
+
 def test_unsupported_shapes_launch_nothing():
     """Shapes without a fused kernel (model F's 64..512-channel layers, fp32 storage) answer 0 / KP_E_UNSUPPORTED."""
     from keypoints_amd import _lib
@@ -169,3 +213,38 @@ def test_train_steps_are_bitwise_the_same_with_and_without_the_fusion(typ, cin, 
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     for k in res[0][2]:
         assert torch.equal(res[0][2][k], res[1][2][k]), k
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_train_step_with_the_reduce_pass_in_the_data_gradient(precision):
+    """runtime.set_fuse_bn_reduce(True) (off by default: DESIGN 3.9): a train step of the Pong transporter with the first pass of the
+    BatchNorm backward in the data gradients' epilogues -- same loss bit for bit (the forward is untouched), parameter gradients to
+    fp32-summation accuracy of the sums that feed them."""
+    import keypoints_amd as ka
+    from keypoints_amd import runtime
+    from keypoints_amd.models import transporter
+    g = torch.Generator().manual_seed(11)
+    xs = (torch.rand(6, 1, 84, 84, generator=g) * 2 - 1).cuda()
+    xt = (torch.rand(6, 1, 84, 84, generator=g) * 2 - 1).cuda()
+    res = []
+    try:
+        for fuse in (False, True):
+            runtime.set_fuse_bn_reduce(fuse)
+            torch.manual_seed(9)
+            net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 4).cuda().set_precision(precision)
+            out = net(xs, xt)
+            loss = ka.l2_reconstruction_loss(out[0], xt)
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((loss.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}))
+    finally:
+        runtime.set_fuse_bn_reduce(False)
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) > 10
+    worst = 0.0
+    for k in res[0][1]:
+        a, b = res[0][1][k].float(), res[1][1][k].float()
+        assert torch.isfinite(b).all()
+        worst = max(worst, float((a - b).norm() / (a.norm() + 1e-12)))
+    # the 16-bit rounding of dy downstream of slightly different sums: a few units of the storage type's epsilon, relative L2
+    assert worst <= (2e-2 if precision == 'bf16' else 3e-3), worst
