@@ -198,17 +198,18 @@ def set_fuse_bn_input(on: bool) -> None:
     _FUSE_BN_INPUT = bool(on)
 
 
-_FUSE_BN_REDUCE = bool(_os.environ.get('KP_BN_REDUCE_FUSION'))
+_FUSE_BN_REDUCE = not bool(_os.environ.get('KP_NO_BN_REDUCE_FUSION'))
 
 
 def fuse_bn_reduce() -> bool:
     """The data gradient of a 3x3 layer leaves the first pass of the BatchNorm backward of the layer below in its epilogue
     (kp_conv_dgrad_bnred) where the library has such a kernel: that pass is not launched.  Same sums up to the order of the fp32
     additions (NOT bit-identical to the separate pass: its own switch, apart from `fuse_bn_input`).
-    OFF by default: measured on config 2 it takes 0.09 ms of kernel time out of the step (five 42 us passes gone, the five data
-    gradients 18-30 us longer: they read the conv output the pass would have read) and the step is 0.02 ms SLOWER -- the
-    HBM-bound pass ran beside the weight gradient of the side stream, the longer data gradient (two workgroups per CU, 60 KB of
-    LDS each) does not.  `set_fuse_bn_reduce(True)` / KP_BN_REDUCE_FUSION=1 switch it on."""
+    Measured on config 2 (tools/probes/bred_roles_ab.sh, one box, three rounds): kernel time per step -0.09 ms (five 42 us passes
+    gone, the five data gradients 18-30 us longer: they read the conv output the pass read); with the small-channel weight
+    gradients on a side stream the step does not move (3.22 -> 3.23 ms: the HBM-bound pass ran beside them, the longer data
+    gradient does not), with them on the current stream (unit_engine, the default for these layers) 3.26 -> 3.19 ms.
+    `set_fuse_bn_reduce(False)` / KP_NO_BN_REDUCE_FUSION=1 restore the separate pass."""
     return _FUSE_BN_REDUCE
 
 

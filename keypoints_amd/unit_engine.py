@@ -387,6 +387,7 @@ class UnitFunction(torch.autograd.Function):
                  N, Hh, Wh, Ch, Kout, code, st)
         gp = 0   # border width of g (0 = plain, 1 = padded-domain gradient that still needs folding)
         pending_red = None   # (partial rows, count) of the NEXT layer's BatchNorm-backward sums, left by a fused data gradient
+        small_inline = not _os.environ.get('KP_SMALL_SIDE')   # (measurement: KP_SMALL_SIDE=1 puts the small-channel weight gradients back on the side stream)
         for idx in range(len(saved) - 1, -1, -1):
             stp, sv = plan[idx], saved[idx]
             conv, bn = stp['conv'], stp['bn']
@@ -454,9 +455,13 @@ class UnitFunction(torch.autograd.Function):
             # the side stream, ordered behind the data gradient (two matrix-core kernels side by side gain nothing), so that
             # it runs beside the HBM-bound BatchNorm passes of the next layer: wgrad_l || reduce / finalize / apply_{l-1}.
             # (Measured: side stream released right after apply_l instead: +0.45 ms per step.)
-            if side is not None:
-                side.wait_stream(cur)
-            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            # (Pong-class layers, 16 / 32 channels: their weight gradient owns a CU's LDS -- two workgroups of 76 KB -- and nothing
+            # of the next layer's passes runs beside it; with the reduce pass folded into the data gradient there is also less to
+            # run: on the current stream the config-2 step measures 3.19 vs 3.22 ms, tools/probes/bred_roles_ab.sh.)
+            lside = None if (small_inline and C <= 32 and K <= 32) else side
+            if lside is not None:
+                lside.wait_stream(cur)
+            with torch.cuda.stream(lside) if lside is not None else contextlib.nullcontext():
                 wst = stream_ptr()
                 scratch = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device=dev, dtype=torch.float32)
                 if 'wgrad' in _ABL:
@@ -467,7 +472,7 @@ class UnitFunction(torch.autograd.Function):
                 else:
                     call('kp_conv_wgrad', ptr(sv['a']), ptr(dy), ptr(scratch), N, H, W, C, K, 3, dp, code, wst)
                 call('kp_wgrad_unpack', ptr(scratch), parts, ptr(gv[id(conv.weight)]), K, sv['Cl'], C, 3, wst)
-            if side is not None:
+            if lside is not None:
                 # dy and the saved input are read on the side stream: they stay referenced until this stream has waited
                 # for it (end of the Unit's backward) -- the caching allocator recycles a block in the order of ITS stream
                 # (tensor.record_stream would do the same bookkeeping per block; measured: steps of 160-220 ms at random)

@@ -217,7 +217,7 @@ def test_train_steps_are_bitwise_the_same_with_and_without_the_fusion(typ, cin, 
 
 @pytest.mark.parametrize('precision', ['bf16', 'fp16'])
 def test_train_step_with_the_reduce_pass_in_the_data_gradient(precision):
-    """runtime.set_fuse_bn_reduce(True) (off by default: DESIGN 3.9): a train step of the Pong transporter with the first pass of the
+    """runtime.set_fuse_bn_reduce (on by default) against the separate pass: a train step of the Pong transporter with the first pass of the
     BatchNorm backward in the data gradients' epilogues -- same loss bit for bit (the forward is untouched), parameter gradients to
     fp32-summation accuracy of the sums that feed them."""
     import keypoints_amd as ka
@@ -238,7 +238,7 @@ def test_train_step_with_the_reduce_pass_in_the_data_gradient(precision):
             torch.cuda.synchronize()
             res.append((loss.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}))
     finally:
-        runtime.set_fuse_bn_reduce(False)
+        runtime.set_fuse_bn_reduce(True)
     assert torch.equal(res[0][0], res[1][0])
     assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) > 10
     worst = 0.0
