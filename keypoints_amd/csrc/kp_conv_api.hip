@@ -26,6 +26,8 @@ int kp_conv_small_dgrad_bnred(const void*, const void*, void*, const void*, cons
 int kp_conv_first_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
 int kp_conv_first_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 long long kp_conv_first_wgrad_partials(int, int, int, int, int);
+int kp_conv_small_first_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
+long long kp_conv_small_first_wgrad_partials(int, int, int, int, int);
 long long kp_conv_small_wgrad_partials(int, int, int, int, int);
 long long kp_conv_wgrad_generic_partials(int, int, int, int, int, int);
 int kp_conv_wgrad_mfma_accepts(int, int, int, int, int, int);
@@ -100,6 +102,10 @@ int kp_conv_wgrad_partials(int N, int Ho, int Wo, int C, int K, int R, int dy_pa
         const long long p = kp_conv_wgrad_patch_partials(N, Ho, Wo, C, K, dy_pad);
         if (p > 0 && p < 0x7fffffffLL) return (int)p;
     }
+    if (dtype == KP_H16 && use_mfma() && R == 3 && C <= 4 && (K == 16 || K == 32)) {   // Pong-class first layers: the 16 x 16 x 32 kernel
+        const long long p = kp_conv_small_first_wgrad_partials(N, Ho, Wo, C, K);
+        if (p > 0) return (int)p;
+    }
     if (dtype == KP_H16 && use_mfma() && R == 3 && C <= 4) {
         const long long p = kp_conv_first_wgrad_partials(N, Ho, Wo, C, K);
         if (p > 0) return (int)p;
@@ -136,6 +142,10 @@ int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, 
         if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_WGRAD_MFMA); return rc; }
         rc = kp_conv_wgrad_mfma(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, (hipStream_t)stream);
         if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_WGRAD_MFMA); return rc; }
+        if (R == 3 && C <= 4 && (K == 16 || K == 32)) {
+            rc = kp_conv_small_first_wgrad(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
+            if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_FIRST); return rc; }
+        }
         if (R == 3 && C <= 4) {
             rc = kp_conv_first_wgrad(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
             if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_FIRST); return rc; }

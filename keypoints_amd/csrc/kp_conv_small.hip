@@ -949,11 +949,16 @@ constexpr int W16_TPB = 384, W16_NW = W16_TPB / 64, W16_LDS = 77824;
 constexpr int w16_slx(int K, int C) { return C == 32 ? 9 : (K == 32 ? 6 : 7); }
 constexpr int w16_sld(int K, int C) { return C == 32 ? 4 : (K == 32 ? 8 : 6); }
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <int K, int C, bool BNIN>
+// CIN > 0 (C = 16, no BNIN): the FIRST layer of a Unit -- x is the padded input [N][Ho + 2][Wo + 2][CIN] with CIN <= 4 channels
+// (grey / RGB frames); its pixels are widened to 16 zero-padded channels on the way into LDS and only the CIN real columns of the
+// tiles are written: scratch [partials][K][9][CIN].  (The VALU kernel of kp_conv_first.hip walks image rows as a latency chain:
+// 58 us for the 58 MB gradient of the Pong-class first layer, 1 TB/s.)
+template <int K, int C, bool BNIN, int CIN = 0>
 __global__ __launch_bounds__(W16_TPB, 3) void wgrad3x3_small16_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
                                                                float* __restrict__ scratch, int Ho, int Wo, int dy_pad, int R,
                                                                int bands_per_img, long long total_bands, long long pstride, BnIn bn) {
     constexpr int TPBW = W16_TPB, KT = K / 16, CT = C / 16;
+    static_assert(CIN == 0 || (C == 16 && !BNIN && CIN <= 4), "CIN: first-layer form");
     __shared__ __attribute__((aligned(16))) unsigned char smem[W16_LDS];
     __shared__ __attribute__((aligned(16))) float cst[BNIN ? 4 : 1][32];
     if (BNIN) bnin_fill(cst, bn, C, threadIdx.x);
@@ -1012,6 +1017,15 @@ __global__ __launch_bounds__(W16_TPB, 3) void wgrad3x3_small16_k(const h16_t* __
                             const int sc = px - 1 < 0 ? 0 : (px - 1 > Wo - 1 ? Wo - 1 : px - 1);
                             sbx[v] = *reinterpret_cast<const uint4*>(xg + (((long long)sr * Wo + sc) * CPP + cg) * 16);
                             livex |= 1u << v;
+                        } else if (CIN > 0) {   // chunk 0 of a pixel: its CIN elements, zeros behind them; chunk 1: zeros
+                            if ((c16 & 1) == 0) {
+                                const h16_t* e = x + (((n * Hi + p0 + r) * Wi) + (c16 >> 1)) * (long long)CIN;
+                                unsigned w0 = e[0], w1 = 0;
+                                if (CIN > 1) w0 |= (unsigned)e[1] << 16;
+                                if (CIN > 2) w1 = e[2];
+                                if (CIN > 3) w1 |= (unsigned)e[3] << 16;
+                                sbx[v] = make_uint4(w0, w1, 0, 0);
+                            }
                         } else {
                             sbx[v] = *reinterpret_cast<const uint4*>(xg + (long long)r * xrow_g + c16 * 16);
                         }
@@ -1119,7 +1133,8 @@ __global__ __launch_bounds__(W16_TPB, 3) void wgrad3x3_small16_k(const h16_t* __
                 float s = red[wave][i][lane];
 #pragma unroll
                 for (int wv = TILES; wv < W16_NW; wv += TILES) s += red[wave + wv][i][lane];
-                scratch[(long long)blockIdx.x * pstride + ((long long)k * 9 + t) * C + c] = s;
+                if (CIN == 0) scratch[(long long)blockIdx.x * pstride + ((long long)k * 9 + t) * C + c] = s;
+                else if (c < CIN) scratch[(long long)blockIdx.x * pstride + ((long long)k * 9 + t) * CIN + c] = s;
             }
         }
     }
@@ -1320,6 +1335,32 @@ static unsigned small_wgrad_plan(int N, int Ho, int C, int K, int& rpw) {
     const long long waves = (rows + rpw - 1) / rpw;
     return (unsigned)((waves + 3) / 4);
 }
+// first layer (CIN <= 4 input channels, K in {16, 32}) on the same kernel: partials / launch
+long long kp_conv_small_first_wgrad_partials(int N, int Ho, int Wo, int Cin, int K) {
+    int R, bpi;
+    if (Cin < 1 || Cin > 4 || !g_kp_small_band) return 0;
+    return small16_plan(N, Ho, Wo, 16, K, R, bpi);
+}
+int kp_conv_small_first_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int Cin, int K, int dy_pad,
+                              hipStream_t st) {
+    int R, bpi;
+    if (Cin < 1 || Cin > 4 || !g_kp_small_band) return KP_E_UNSUPPORTED;
+    const unsigned grid = small16_plan(N, Ho, Wo, 16, K, R, bpi);
+    if (!grid) return KP_E_UNSUPPORTED;
+    const long long bands = (long long)N * bpi;
+#define KP_W16F(Kv, CINv) wgrad3x3_small16_k<Kv, 16, false, CINv><<<grid, W16_TPB, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, R, bpi, bands, (long long)Kv * 9 * CINv, BnIn{})
+#define KP_W16FK(CINv) do { if (K == 16) KP_W16F(16, CINv); else KP_W16F(32, CINv); } while (0)
+    switch (Cin) {
+        case 1: KP_W16FK(1); break;
+        case 2: KP_W16FK(2); break;
+        case 3: KP_W16FK(3); break;
+        default: KP_W16FK(4); break;
+    }
+#undef KP_W16FK
+#undef KP_W16F
+    return kp_check_launch("wgrad3x3_small16_first");
+}
+
 long long kp_conv_small_wgrad_partials(int N, int Ho, int Wo, int C, int K) {
     int R, bpi, rpw;
     if (g_kp_small_band)

@@ -185,7 +185,7 @@ def test_conv_first_layer(N, Ho, Wo, C, K):
             for s_ in range(3):
                 wref[:, r, s_, :] = torch.einsum('npqk,npqc->kc', df, xf[:, r:r + Ho, s_:s_ + Wo])
         parts = _lib.lib().kp_conv_wgrad_partials(N, Ho, Wo, C, K, 3, dp, _lib.KP_BF16)
-        assert parts > 1   # every 16-bit first-layer / small-channel shape: per-workgroup partials, no atomics
+        assert parts >= 1   # per-workgroup partials, no atomics (one workgroup when the whole problem is one band of rows)
         scratch = torch.zeros(K, 3, 3, C, device='cuda') if parts == 1 else \
             torch.full((parts, K, 3, 3, C), float('nan'), device='cuda')
         dyd = dy.cuda()
