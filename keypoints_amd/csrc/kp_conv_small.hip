@@ -1,6 +1,15 @@
-// 3x3 convolution for SMALL channel counts (C, K in {16, 32}: the Pong-class nets, vgg.py:53,66 VGG_PONG_*), bf16.
+// 3x3 convolution for SMALL channel counts (C, K in {16, 32}: the Pong-class nets, vgg.py:53,66 VGG_PONG_*), 16-bit storage.
 // These layers are HBM-bound (16.6 GFLOP against 174 MB per layer at 256 x 84 x 84), and their images (84 x 84) are
 // not 16x16-tileable, so neither MFMA patch kernel applies and the general fp32 kernels sat ~30x off the roofline.
+//
+// Kernels of this file, in the order the dispatch prefers them (DESIGN.md 3.9 has the measurements behind each):
+//   conv3x3_small_band_k   forward / data gradient, a band of image rows staged through LDS, software-pipelined items; forms:
+//                          BNIN (the producing layer's BatchNorm-apply + activation + replicate pad on the staging path),
+//                          STATS (BatchNorm statistics rows), BRED (the layer below's first BatchNorm-backward pass in the epilogue)
+//   wgrad3x3_small16_k     weight gradient on the 16 x 16 x 32 MFMA shape for the channel pairs with a 16-channel side and for
+//                          the 1-4-channel first layer (CIN): six waves, two workgroups per CU
+//   wgrad3x3_small_band_k  weight gradient on the 32 x 32 x 16 shape (the 32 -> 32 layer): one wave per SIMD, LDS double buffer
+//   conv3x3_small_k / wgrad3x3_small_k   the LDS-free kernels of round 2 (shapes whose band does not fit; described next)
 //
 // forward / data-gradient (conv3x3_small_k): one wavefront per 32-pixel row segment, no LDS, no barriers.
 //   With C = 16 one tap IS one MFMA reduction step (v_mfma_f32_32x32x16_bf16): the pixel operand of tap (r,s) is a
