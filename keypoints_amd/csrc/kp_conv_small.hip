@@ -6,9 +6,10 @@
 //   conv3x3_small_band_k   forward / data gradient, a band of image rows staged through LDS, software-pipelined items; forms:
 //                          BNIN (the producing layer's BatchNorm-apply + activation + replicate pad on the staging path),
 //                          STATS (BatchNorm statistics rows), BRED (the layer below's first BatchNorm-backward pass in the epilogue)
-//   wgrad3x3_small16_k     weight gradient on the 16 x 16 x 32 MFMA shape for the channel pairs with a 16-channel side and for
-//                          the 1-4-channel first layer (CIN): six waves, two workgroups per CU
-//   wgrad3x3_small_band_k  weight gradient on the 32 x 32 x 16 shape (the 32 -> 32 layer): one wave per SIMD, LDS double buffer
+//   wgrad3x3_small16_k     weight gradient on the 16 x 16 x 32 MFMA shape: six waves (one 16 x 16 tile each; (32, 32): four waves with
+//                          two tiles each), two workgroups per CU; also the 1-4-channel first layer (CIN)
+//   wgrad3x3_small_band_k  weight gradient on the 32 x 32 x 16 shape: one wave per SIMD, LDS double buffer (shapes whose band does not
+//                          fit the other kernel's 76 KB; KP_WG16=0)
 //   conv3x3_small_k / wgrad3x3_small_k   the LDS-free kernels of round 2 (shapes whose band does not fit; described next)
 //
 // forward / data-gradient (conv3x3_small_k): one wavefront per 32-pixel row segment, no LDS, no barriers.
@@ -954,19 +955,22 @@ __global__ __launch_bounds__(TPB, 1) void wgrad3x3_small_band_k(const h16_t* __r
 // 9 x KT x CT x 4 = 36-72 accumulator registers: three waves per SIMD, TWO workgroups of six wavefronts per CU -- one stages its
 // band (single LDS buffer, loads straight through registers) while the other multiplies.  Six wavefronts: 84-pixel rows are three
 // segments, x two halves of the band's rows = six column strips.  Same LDS image, staging code and partial-gradient protocol.
-constexpr int W16_TPB = 384, W16_NW = W16_TPB / 64, W16_LDS = 77824;
-constexpr int w16_slx(int K, int C) { return C == 32 ? 9 : (K == 32 ? 6 : 7); }
-constexpr int w16_sld(int K, int C) { return C == 32 ? 4 : (K == 32 ? 8 : 6); }
+constexpr int W16_TPB = 384, W16_LDS = 77824;
+// (32, 32): FOUR wavefronts per workgroup (two per SIMD with two workgroups per CU: 256 registers), each owning the two
+// gradient-channel tiles of one input-channel half -- they share the input window: 3 + 4 transpose reads per item and wavefront
+constexpr int w16_waves(int K, int C) { return (K == 32 && C == 32) ? 4 : 6; }
+constexpr int w16_slx(int K, int C) { return (K == 32 && C == 32) ? 11 : (C == 32 ? 9 : (K == 32 ? 6 : 7)); }
+constexpr int w16_sld(int K, int C) { return (K == 32 && C == 32) ? 8 : (C == 32 ? 4 : (K == 32 ? 8 : 6)); }
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 // CIN > 0 (C = 16, no BNIN): the FIRST layer of a Unit -- x is the padded input [N][Ho + 2][Wo + 2][CIN] with CIN <= 4 channels
 // (grey / RGB frames); its pixels are widened to 16 zero-padded channels on the way into LDS and only the CIN real columns of the
 // tiles are written: scratch [partials][K][9][CIN].  (The VALU kernel of kp_conv_first.hip walks image rows as a latency chain:
 // 58 us for the 58 MB gradient of the Pong-class first layer, 1 TB/s.)
 template <int K, int C, bool BNIN, int CIN = 0>
-__global__ __launch_bounds__(W16_TPB, 3) void wgrad3x3_small16_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
+__global__ __launch_bounds__(w16_waves(K, C) * 64, w16_waves(K, C) == 6 ? 3 : 2) void wgrad3x3_small16_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
                                                                float* __restrict__ scratch, int Ho, int Wo, int dy_pad, int R,
                                                                int bands_per_img, long long total_bands, long long pstride, BnIn bn) {
-    constexpr int TPBW = W16_TPB, KT = K / 16, CT = C / 16;
+    constexpr int NWV = w16_waves(K, C), TPBW = NWV * 64, KT = K / 16, CT = C / 16;
     static_assert(CIN == 0 || (C == 16 && !BNIN && CIN <= 4), "CIN: first-layer form");
     __shared__ __attribute__((aligned(16))) unsigned char smem[W16_LDS];
     __shared__ __attribute__((aligned(16))) float cst[BNIN ? 4 : 1][32];
@@ -984,12 +988,15 @@ __global__ __launch_bounds__(W16_TPB, 3) void wgrad3x3_small16_k(const h16_t* __
     // ONE 16 x 16 tile per wavefront and tap (36 accumulator registers): with two tiles (32 channels on one side) the six wavefronts
     // are three pairs, wavefront w owns tile w % 2 for the whole kernel and takes two of the six column strips of a band -- both
     // tiles in one wavefront want 183-216 registers, and at the 168 of three waves per SIMD the spills made it slower than the old kernel
-    constexpr int TILES = KT * CT;
-    static_assert(TILES <= 2, "16 x 16 x 32 weight gradient: one side has 16 channels");
-    const int tw = wave % TILES, kt = KT == 2 ? tw : 0, ct = CT == 2 ? tw : 0;
-    f32x4v acc[9];
+    constexpr int KW = KT * CT == 4 ? 2 : 1;    // gradient-channel tiles per wavefront (2: the (32, 32) pair, both share the input window)
+    constexpr int TILES = KT * CT / KW;         // tile owners among the wavefronts
+    static_assert(TILES <= 2 && NWV % TILES == 0, "16 x 16 x 32 weight gradient: wavefronts pair up over at most two tile groups");
+    const int tw = wave % TILES, kt = (KT == 2 && KW == 1) ? tw : 0, ct = CT == 2 ? tw : 0;
+    f32x4v acc[9][KW];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < KW; ++j) acc[t][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     // ---- staging (as above): chunk -> (row, column) by carries; all loads of a band in flight, then the LDS stores
     const int xc = xrow_b / 16, xvalid = Wi * C * 2 / 16, dc = drow_b / 16, dvalid = Wo * K * 2 / 16;
@@ -1006,7 +1013,7 @@ __global__ __launch_bounds__(W16_TPB, 3) void wgrad3x3_small16_k(const h16_t* __
                                        : (const unsigned char*)x + (((n * Hi + p0) * Wi) * (long long)C) * 2;
         const unsigned char* dg = (const unsigned char*)dy + ((((n * Hd + p0 + dy_pad) * Wd) + dy_pad) * (long long)K) * 2;
         // (in batches of 3-8 chunks, the two tensors one after the other: 168 registers per wave)
-        constexpr int XB = BNIN ? 3 : 5, DB = 8;
+        constexpr int XB = NWV == 4 ? 6 : (BNIN ? 3 : 5), DB = 8;
         int r = tid / xc, c16 = tid % xc;
 #pragma unroll
         for (int u0 = 0; u0 < SLX; u0 += XB) {
@@ -1087,7 +1094,7 @@ __global__ __launch_bounds__(W16_TPB, 3) void wgrad3x3_small16_k(const h16_t* __
         // ---- multiply: a wavefront takes column strips (32-pixel segment, half of the band's rows) and slides a three-row window
         //      of raw input dwords down each: per item the new bottom row (3 reads per 16 channels) + the gradient fragments
         const int rh = (rows + 1) >> 1;
-        for (int unit = wave / TILES; unit < 2 * nseg; unit += W16_NW / TILES) {
+        for (int unit = wave / TILES; unit < 2 * nseg; unit += NWV / TILES) {
             const int sg = unit % nseg, half = unit / nseg;
             const int rbeg = half * rh, rend = rbeg + rh < rows ? rbeg + rh : rows;
             if (rbeg >= rend) continue;
@@ -1100,23 +1107,30 @@ __global__ __launch_bounds__(W16_TPB, 3) void wgrad3x3_small16_k(const h16_t* __
                 Rg[0] = q0.x; Rg[1] = q0.y; Rg[2] = q1.x; Rg[3] = q1.y; Rg[4] = q2.x;
             };
             // the three column taps of a row from its raw dwords: tap 2 is a renaming of the dword pairs, tap 1 four v_alignbit
-            auto row_mma = [&](const h16x8& af, const unsigned (&Rg)[5], int rr) {
+            auto row_mma = [&](const h16x8 (&af)[KW], const unsigned (&Rg)[5], int rr) {
                 const u32x4 f0 = {Rg[0], Rg[1], Rg[2], Rg[3]};
                 const u32x4 f1 = {__builtin_amdgcn_alignbit(Rg[1], Rg[0], 16), __builtin_amdgcn_alignbit(Rg[2], Rg[1], 16),
                                   __builtin_amdgcn_alignbit(Rg[3], Rg[2], 16), __builtin_amdgcn_alignbit(Rg[4], Rg[3], 16)};
                 const u32x4 f2 = {Rg[1], Rg[2], Rg[3], Rg[4]};
-                acc[rr * 3 + 0] = kp_mfma16x16(af, __builtin_bit_cast(h16x8, f0), acc[rr * 3 + 0]);
-                acc[rr * 3 + 1] = kp_mfma16x16(af, __builtin_bit_cast(h16x8, f1), acc[rr * 3 + 1]);
-                acc[rr * 3 + 2] = kp_mfma16x16(af, __builtin_bit_cast(h16x8, f2), acc[rr * 3 + 2]);
+#pragma unroll
+                for (int j = 0; j < KW; ++j) {
+                    acc[rr * 3 + 0][j] = kp_mfma16x16(af[j], __builtin_bit_cast(h16x8, f0), acc[rr * 3 + 0][j]);
+                    acc[rr * 3 + 1][j] = kp_mfma16x16(af[j], __builtin_bit_cast(h16x8, f1), acc[rr * 3 + 1][j]);
+                    acc[rr * 3 + 2][j] = kp_mfma16x16(af[j], __builtin_bit_cast(h16x8, f2), acc[rr * 3 + 2][j]);
+                }
             };
             unsigned W0[5], W1[5], W2[5];
             row_load(rbeg, W0);
             row_load(rbeg + 1, W1);
             for (int r = rbeg; r < rend; ++r) {
                 const unsigned char* a = dl + r * drow_b + sg * 32 * (K * 2) + dlane + kt * 32;
-                const h16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(a));
-                const h16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(a + 4 * (K * 2)));
-                const h16x8 af = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                h16x8 af[KW];
+#pragma unroll
+                for (int j = 0; j < KW; ++j) {
+                    const h16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(a + j * 32));
+                    const h16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(a + j * 32 + 4 * (K * 2)));
+                    af[j] = h16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                }
                 row_load(r + 2, W2);
                 row_mma(af, W0, 0);
                 row_mma(af, W1, 1);
@@ -1129,40 +1143,46 @@ __global__ __launch_bounds__(W16_TPB, 3) void wgrad3x3_small16_k(const h16_t* __
     // D tile of this wavefront: lane column c = ct * 16 + (lane & 15), rows k = kt * 16 + 4 * (lane >> 4) + i.  The wavefronts that own
     // the same tile are summed per tap through LDS in a fixed order; the workgroup's sum is ITS partial gradient (kp_wgrad_unpack adds
     // the partials in order).
-    float (*red)[4][64] = reinterpret_cast<float (*)[4][64]>(smem);
+    float (*red)[4 * KW][64] = reinterpret_cast<float (*)[4 * KW][64]>(smem);
     for (int t = 0; t < 9; ++t) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[t][i];
+        for (int j = 0; j < KW; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wave][j * 4 + i][lane] = acc[t][j][i];
         __syncthreads();
         if (wave < TILES) {   // wave == tw
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = kt * 16 + 4 * grp + i, c = ct * 16 + t16;
-                float s = red[wave][i][lane];
+            for (int j = 0; j < KW; ++j)
 #pragma unroll
-                for (int wv = TILES; wv < W16_NW; wv += TILES) s += red[wave + wv][i][lane];
-                if (CIN == 0) scratch[(long long)blockIdx.x * pstride + ((long long)k * 9 + t) * C + c] = s;
-                else if (c < CIN) scratch[(long long)blockIdx.x * pstride + ((long long)k * 9 + t) * CIN + c] = s;
-            }
+                for (int i = 0; i < 4; ++i) {
+                    const int k = (kt + j) * 16 + 4 * grp + i, c = ct * 16 + t16;
+                    float s = red[wave][j * 4 + i][lane];
+#pragma unroll
+                    for (int wv = TILES; wv < NWV; wv += TILES) s += red[wave + wv][j * 4 + i][lane];
+                    if (CIN == 0) scratch[(long long)blockIdx.x * pstride + ((long long)k * 9 + t) * C + c] = s;
+                    else if (c < CIN) scratch[(long long)blockIdx.x * pstride + ((long long)k * 9 + t) * CIN + c] = s;
+                }
         }
     }
 }
 
 bool small_ch(int v) { return v == 16 || v == 32; }
-static const int g_kp_wg16 = getenv("KP_WG16") ? atoi(getenv("KP_WG16")) : 1;   // measurement: 0 = the 32 x 32 x 16 kernel for every channel pair
+static const int g_kp_wg16 = getenv("KP_WG16") ? atoi(getenv("KP_WG16")) : 3;   // measurement: 0 = the 32 x 32 x 16 kernel for every channel pair; 1 = ... for the (32, 32) pair only
 
 // band plan of the 16 x 16 x 32 weight gradient: rows per band (0: not its shape / the rows do not fit), grid = min(bands, 2 per CU)
 static unsigned small16_plan(int N, int Ho, int Wo, int C, int K, int& R, int& bpi) {
-    if (!g_kp_wg16 || !small_ch(C) || !small_ch(K) || (C == 32 && K == 32)) return 0;
+    if (!g_kp_wg16 || !small_ch(C) || !small_ch(K) || (C == 32 && K == 32 && !(g_kp_wg16 & 2))) return 0;
     const int Wp = (Wo + 31) & ~31;
     const long long xrow = (long long)(Wp + 2) * C * 2, drow = (long long)Wp * K * 2;
     long long r = (W16_LDS - 2 * xrow) / (xrow + drow);
     if (r > Ho) r = Ho;
     if (r > 16) r = 16;
-    const int slx = C == 32 ? w16_slx(16, 32) : (K == 32 ? w16_slx(32, 16) : w16_slx(16, 16));
-    const int sld = C == 32 ? w16_sld(16, 32) : (K == 32 ? w16_sld(32, 16) : w16_sld(16, 16));
-    while (r >= 1 && ((r + 2) * xrow > (long long)slx * W16_TPB * 16 || r * drow > (long long)sld * W16_TPB * 16)) --r;
+    const bool both = C == 32 && K == 32;
+    const int slx = both ? w16_slx(32, 32) : (C == 32 ? w16_slx(16, 32) : (K == 32 ? w16_slx(32, 16) : w16_slx(16, 16)));
+    const int sld = both ? w16_sld(32, 32) : (C == 32 ? w16_sld(16, 32) : (K == 32 ? w16_sld(32, 16) : w16_sld(16, 16)));
+    const long long tpb = both ? w16_waves(32, 32) * 64 : W16_TPB;
+    while (r >= 1 && ((r + 2) * xrow > (long long)slx * tpb * 16 || r * drow > (long long)sld * tpb * 16)) --r;
     if (r < 1) return 0;
     R = (int)r;
     bpi = (Ho + R - 1) / R;
@@ -1174,10 +1194,11 @@ static unsigned small16_plan(int N, int Ho, int Wo, int C, int K, int& R, int& b
 template <bool BNIN>
 static void small16_launch(int C, int K, unsigned grid, hipStream_t st, const void* x, const void* dy, float* scratch, int Ho, int Wo,
                            int dy_pad, int R, int bpi, long long bands, const BnIn& bn) {
-#define KP_W16(Kv, Cv) wgrad3x3_small16_k<Kv, Cv, BNIN><<<grid, W16_TPB, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, R, bpi, bands, (long long)Kv * 9 * Cv, bn)
+#define KP_W16(Kv, Cv) wgrad3x3_small16_k<Kv, Cv, BNIN><<<grid, w16_waves(Kv, Cv) * 64, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, R, bpi, bands, (long long)Kv * 9 * Cv, bn)
     if (K == 16 && C == 16) KP_W16(16, 16);
     else if (K == 16) KP_W16(16, 32);
-    else KP_W16(32, 16);
+    else if (C == 16) KP_W16(32, 16);
+    else KP_W16(32, 32);
 #undef KP_W16
 }
 
