@@ -6,8 +6,9 @@
 //   conv3x3_small_band_k   forward / data gradient, a band of image rows staged through LDS, software-pipelined items; forms:
 //                          BNIN (the producing layer's BatchNorm-apply + activation + replicate pad on the staging path),
 //                          STATS (BatchNorm statistics rows), BRED (the layer below's first BatchNorm-backward pass in the epilogue)
-//   wgrad3x3_small16_k     weight gradient on the 16 x 16 x 32 MFMA shape: six waves (one 16 x 16 tile each; (32, 32): four waves with
-//                          two tiles each), two workgroups per CU; also the 1-4-channel first layer (CIN)
+//   wgrad3x3_small16_k     weight gradient on the 16 x 16 x 32 MFMA shape: (16, 16) six waves with one 16 x 16 tile each, one 32-channel
+//                          side three waves with two tiles each, (32, 32) four waves with two tiles each; two workgroups per CU; also
+//                          the 1-4-channel first layer (CIN)
 //   wgrad3x3_small_band_k  weight gradient on the 32 x 32 x 16 shape: one wave per SIMD, LDS double buffer (shapes whose band does not
 //                          fit the other kernel's 76 KB; KP_WG16=0)
 //   conv3x3_small_k / wgrad3x3_small_k   the LDS-free kernels of round 2 (shapes whose band does not fit; described next)
@@ -958,19 +959,22 @@ __global__ __launch_bounds__(TPB, 1) void wgrad3x3_small_band_k(const h16_t* __r
 constexpr int W16_TPB = 384, W16_LDS = 77824;
 // (32, 32): FOUR wavefronts per workgroup (two per SIMD with two workgroups per CU: 256 registers), each owning the two
 // gradient-channel tiles of one input-channel half -- they share the input window: 3 + 4 transpose reads per item and wavefront
-constexpr int w16_waves(int K, int C) { return (K == 32 && C == 32) ? 4 : 6; }
-constexpr int w16_slx(int K, int C) { return (K == 32 && C == 32) ? 11 : (C == 32 ? 9 : (K == 32 ? 6 : 7)); }
-constexpr int w16_sld(int K, int C) { return (K == 32 && C == 32) ? 8 : (C == 32 ? 4 : (K == 32 ? 8 : 6)); }
+// W3 (the pairs with ONE 32-channel side): THREE wavefronts per workgroup (256 registers each), every one owning both tiles -- which share
+// the input window (K = 32) or the gradient fragment (C = 32): 7 / 8 transpose reads per item instead of 10 -- and two of the six strips
+constexpr int w16_waves(int K, int C, bool W3 = false) { return (K == 32 && C == 32) ? 4 : (W3 ? 3 : 6); }
+constexpr int w16_slx(int K, int C, bool W3 = false) { return (K == 32 && C == 32) ? 11 : (W3 ? (C == 32 ? 17 : 10) : (C == 32 ? 9 : (K == 32 ? 6 : 7))); }
+constexpr int w16_sld(int K, int C, bool W3 = false) { return (K == 32 && C == 32) ? 8 : (W3 ? (C == 32 ? 6 : 14) : (C == 32 ? 4 : (K == 32 ? 8 : 6))); }
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 // CIN > 0 (C = 16, no BNIN): the FIRST layer of a Unit -- x is the padded input [N][Ho + 2][Wo + 2][CIN] with CIN <= 4 channels
 // (grey / RGB frames); its pixels are widened to 16 zero-padded channels on the way into LDS and only the CIN real columns of the
 // tiles are written: scratch [partials][K][9][CIN].  (The VALU kernel of kp_conv_first.hip walks image rows as a latency chain:
 // 58 us for the 58 MB gradient of the Pong-class first layer, 1 TB/s.)
-template <int K, int C, bool BNIN, int CIN = 0>
-__global__ __launch_bounds__(w16_waves(K, C) * 64, w16_waves(K, C) == 6 ? 3 : 2) void wgrad3x3_small16_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
+template <int K, int C, bool BNIN, int CIN = 0, bool W3 = false>
+__global__ __launch_bounds__(w16_waves(K, C, W3) * 64, w16_waves(K, C, W3) == 6 ? 3 : 2) void wgrad3x3_small16_k(const h16_t* __restrict__ x, const h16_t* __restrict__ dy,
                                                                float* __restrict__ scratch, int Ho, int Wo, int dy_pad, int R,
                                                                int bands_per_img, long long total_bands, long long pstride, BnIn bn) {
-    constexpr int NWV = w16_waves(K, C), TPBW = NWV * 64, KT = K / 16, CT = C / 16;
+    constexpr int NWV = w16_waves(K, C, W3), TPBW = NWV * 64, KT = K / 16, CT = C / 16;
+    static_assert(!W3 || KT * CT == 2, "W3: exactly one 32-channel side");
     static_assert(CIN == 0 || (C == 16 && !BNIN && CIN <= 4), "CIN: first-layer form");
     __shared__ __attribute__((aligned(16))) unsigned char smem[W16_LDS];
     __shared__ __attribute__((aligned(16))) float cst[BNIN ? 4 : 1][32];
@@ -988,21 +992,22 @@ __global__ __launch_bounds__(w16_waves(K, C) * 64, w16_waves(K, C) == 6 ? 3 : 2)
     // ONE 16 x 16 tile per wavefront and tap (36 accumulator registers): with two tiles (32 channels on one side) the six wavefronts
     // are three pairs, wavefront w owns tile w % 2 for the whole kernel and takes two of the six column strips of a band -- both
     // tiles in one wavefront want 183-216 registers, and at the 168 of three waves per SIMD the spills made it slower than the old kernel
-    constexpr int KW = KT * CT == 4 ? 2 : 1;    // gradient-channel tiles per wavefront (2: the (32, 32) pair, both share the input window)
-    constexpr int TILES = KT * CT / KW;         // tile owners among the wavefronts
+    constexpr int KW = (KT * CT == 4 || (W3 && KT == 2)) ? 2 : 1;   // gradient-channel tiles per wavefront (they share the input window)
+    constexpr int CW = (W3 && CT == 2) ? 2 : 1;                      // input-channel tiles per wavefront (they share the gradient fragment)
+    constexpr int TILES = KT * CT / (KW * CW);                       // tile owners among the wavefronts
     static_assert(TILES <= 2 && NWV % TILES == 0, "16 x 16 x 32 weight gradient: wavefronts pair up over at most two tile groups");
-    const int tw = wave % TILES, kt = (KT == 2 && KW == 1) ? tw : 0, ct = CT == 2 ? tw : 0;
-    f32x4v acc[9][KW];
+    const int tw = wave % TILES, kt = (KT == 2 && KW == 1) ? tw : 0, ct = (CT == 2 && CW == 1) ? tw : 0;
+    f32x4v acc[9][KW * CW];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int j = 0; j < KW; ++j) acc[t][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < KW * CW; ++j) acc[t][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     // ---- staging (as above): chunk -> (row, column) by carries; all loads of a band in flight, then the LDS stores
     const int xc = xrow_b / 16, xvalid = Wi * C * 2 / 16, dc = drow_b / 16, dvalid = Wo * K * 2 / 16;
     const int xrow_g = Wi * C * 2, drow_g = Wd * K * 2;
     const int xdr = TPBW / xc, xdc = TPBW % xc, ddr = TPBW / dc, ddc = TPBW % dc;
-    constexpr int SLX = w16_slx(K, C), SLD = w16_sld(K, C);
+    constexpr int SLX = w16_slx(K, C, W3), SLD = w16_sld(K, C, W3);
     auto stage = [&](long long band, int& rows_out) {
         const long long n = band / bands_per_img;
         const int p0 = (int)(band % bands_per_img) * R;
@@ -1013,7 +1018,7 @@ __global__ __launch_bounds__(w16_waves(K, C) * 64, w16_waves(K, C) == 6 ? 3 : 2)
                                        : (const unsigned char*)x + (((n * Hi + p0) * Wi) * (long long)C) * 2;
         const unsigned char* dg = (const unsigned char*)dy + ((((n * Hd + p0 + dy_pad) * Wd) + dy_pad) * (long long)K) * 2;
         // (in batches of 3-8 chunks, the two tensors one after the other: 168 registers per wave)
-        constexpr int XB = NWV == 4 ? 6 : (BNIN ? 3 : 5), DB = 8;
+        constexpr int XB = (W3 && BNIN) ? 3 : (NWV != 6 ? 6 : (BNIN ? 3 : 5)), DB = (W3 && BNIN) ? 6 : 8;
         int r = tid / xc, c16 = tid % xc;
 #pragma unroll
         for (int u0 = 0; u0 < SLX; u0 += XB) {
@@ -1099,27 +1104,33 @@ __global__ __launch_bounds__(w16_waves(K, C) * 64, w16_waves(K, C) == 6 ? 3 : 2)
             const int rbeg = half * rh, rend = rbeg + rh < rows ? rbeg + rh : rows;
             if (rbeg >= rend) continue;
             // raw dwords of an input row at this strip: (p0,p1) (p2,p3) (p4,p5) (p6,p7) (p8,p9), p = pixel 8 * grp + ..
-            auto row_load = [&](int r, unsigned (&Rg)[5]) {
-                const unsigned char* b = xl + r * xrow_b + sg * 32 * (C * 2) + xlane + ct * 32;
-                const uint2 q0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b)));
-                const uint2 q1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + 4 * (C * 2))));
-                const uint2 q2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + 8 * (C * 2))));
-                Rg[0] = q0.x; Rg[1] = q0.y; Rg[2] = q1.x; Rg[3] = q1.y; Rg[4] = q2.x;
-            };
-            // the three column taps of a row from its raw dwords: tap 2 is a renaming of the dword pairs, tap 1 four v_alignbit
-            auto row_mma = [&](const h16x8 (&af)[KW], const unsigned (&Rg)[5], int rr) {
-                const u32x4 f0 = {Rg[0], Rg[1], Rg[2], Rg[3]};
-                const u32x4 f1 = {__builtin_amdgcn_alignbit(Rg[1], Rg[0], 16), __builtin_amdgcn_alignbit(Rg[2], Rg[1], 16),
-                                  __builtin_amdgcn_alignbit(Rg[3], Rg[2], 16), __builtin_amdgcn_alignbit(Rg[4], Rg[3], 16)};
-                const u32x4 f2 = {Rg[1], Rg[2], Rg[3], Rg[4]};
+            auto row_load = [&](int r, unsigned (&Rg)[CW][5]) {
 #pragma unroll
-                for (int j = 0; j < KW; ++j) {
-                    acc[rr * 3 + 0][j] = kp_mfma16x16(af[j], __builtin_bit_cast(h16x8, f0), acc[rr * 3 + 0][j]);
-                    acc[rr * 3 + 1][j] = kp_mfma16x16(af[j], __builtin_bit_cast(h16x8, f1), acc[rr * 3 + 1][j]);
-                    acc[rr * 3 + 2][j] = kp_mfma16x16(af[j], __builtin_bit_cast(h16x8, f2), acc[rr * 3 + 2][j]);
+                for (int jc = 0; jc < CW; ++jc) {
+                    const unsigned char* b = xl + r * xrow_b + sg * 32 * (C * 2) + xlane + (ct + jc) * 32;
+                    const uint2 q0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b)));
+                    const uint2 q1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + 4 * (C * 2))));
+                    const uint2 q2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + 8 * (C * 2))));
+                    Rg[jc][0] = q0.x; Rg[jc][1] = q0.y; Rg[jc][2] = q1.x; Rg[jc][3] = q1.y; Rg[jc][4] = q2.x;
                 }
             };
-            unsigned W0[5], W1[5], W2[5];
+            // the three column taps of a row from its raw dwords: tap 2 is a renaming of the dword pairs, tap 1 four v_alignbit
+            auto row_mma = [&](const h16x8 (&af)[KW], const unsigned (&Rg)[CW][5], int rr) {
+#pragma unroll
+                for (int jc = 0; jc < CW; ++jc) {
+                    const u32x4 f0 = {Rg[jc][0], Rg[jc][1], Rg[jc][2], Rg[jc][3]};
+                    const u32x4 f1 = {__builtin_amdgcn_alignbit(Rg[jc][1], Rg[jc][0], 16), __builtin_amdgcn_alignbit(Rg[jc][2], Rg[jc][1], 16),
+                                      __builtin_amdgcn_alignbit(Rg[jc][3], Rg[jc][2], 16), __builtin_amdgcn_alignbit(Rg[jc][4], Rg[jc][3], 16)};
+                    const u32x4 f2 = {Rg[jc][1], Rg[jc][2], Rg[jc][3], Rg[jc][4]};
+#pragma unroll
+                    for (int j = 0; j < KW; ++j) {
+                        acc[rr * 3 + 0][j * CW + jc] = kp_mfma16x16(af[j], __builtin_bit_cast(h16x8, f0), acc[rr * 3 + 0][j * CW + jc]);
+                        acc[rr * 3 + 1][j * CW + jc] = kp_mfma16x16(af[j], __builtin_bit_cast(h16x8, f1), acc[rr * 3 + 1][j * CW + jc]);
+                        acc[rr * 3 + 2][j * CW + jc] = kp_mfma16x16(af[j], __builtin_bit_cast(h16x8, f2), acc[rr * 3 + 2][j * CW + jc]);
+                    }
+                }
+            };
+            unsigned W0[CW][5], W1[CW][5], W2[CW][5];
             row_load(rbeg, W0);
             row_load(rbeg + 1, W1);
             for (int r = rbeg; r < rend; ++r) {
@@ -1136,27 +1147,30 @@ __global__ __launch_bounds__(w16_waves(K, C) * 64, w16_waves(K, C) == 6 ? 3 : 2)
                 row_mma(af, W1, 1);
                 row_mma(af, W2, 2);
 #pragma unroll
-                for (int i = 0; i < 5; ++i) { W0[i] = W1[i]; W1[i] = W2[i]; }
+                for (int jc = 0; jc < CW; ++jc)
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) { W0[jc][i] = W1[jc][i]; W1[jc][i] = W2[jc][i]; }
             }
         }
     }
     // D tile of this wavefront: lane column c = ct * 16 + (lane & 15), rows k = kt * 16 + 4 * (lane >> 4) + i.  The wavefronts that own
     // the same tile are summed per tap through LDS in a fixed order; the workgroup's sum is ITS partial gradient (kp_wgrad_unpack adds
     // the partials in order).
-    float (*red)[4 * KW][64] = reinterpret_cast<float (*)[4 * KW][64]>(smem);
+    constexpr int TW = KW * CW;
+    float (*red)[4 * TW][64] = reinterpret_cast<float (*)[4 * TW][64]>(smem);
     for (int t = 0; t < 9; ++t) {
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < KW; ++j)
+        for (int j = 0; j < TW; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) red[wave][j * 4 + i][lane] = acc[t][j][i];
         __syncthreads();
         if (wave < TILES) {   // wave == tw
 #pragma unroll
-            for (int j = 0; j < KW; ++j)
+            for (int j = 0; j < TW; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int k = (kt + j) * 16 + 4 * grp + i, c = ct * 16 + t16;
+                    const int k = (kt + j / CW) * 16 + 4 * grp + i, c = (ct + j % CW) * 16 + t16;
                     float s = red[wave][j * 4 + i][lane];
 #pragma unroll
                     for (int wv = TILES; wv < NWV; wv += TILES) s += red[wave + wv][j * 4 + i][lane];
@@ -1168,7 +1182,9 @@ __global__ __launch_bounds__(w16_waves(K, C) * 64, w16_waves(K, C) == 6 ? 3 : 2)
 }
 
 bool small_ch(int v) { return v == 16 || v == 32; }
-static const int g_kp_wg16 = getenv("KP_WG16") ? atoi(getenv("KP_WG16")) : 3;   // measurement: 0 = the 32 x 32 x 16 kernel for every channel pair; 1 = ... for the (32, 32) pair only
+// measurement: KP_WG16 bits -- 1: the 16 x 16 x 32 kernel at all (0: the 32 x 32 x 16 kernel for every channel pair), 2: for the (32, 32) pair too,
+// 4: three wavefronts with both tiles each for the pairs with one 32-channel side (else six wavefronts with one tile each)
+static const int g_kp_wg16 = getenv("KP_WG16") ? atoi(getenv("KP_WG16")) : 7;
 
 // band plan of the 16 x 16 x 32 weight gradient: rows per band (0: not its shape / the rows do not fit), grid = min(bands, 2 per CU)
 static unsigned small16_plan(int N, int Ho, int Wo, int C, int K, int& R, int& bpi) {
@@ -1178,10 +1194,10 @@ static unsigned small16_plan(int N, int Ho, int Wo, int C, int K, int& R, int& b
     long long r = (W16_LDS - 2 * xrow) / (xrow + drow);
     if (r > Ho) r = Ho;
     if (r > 16) r = 16;
-    const bool both = C == 32 && K == 32;
-    const int slx = both ? w16_slx(32, 32) : (C == 32 ? w16_slx(16, 32) : (K == 32 ? w16_slx(32, 16) : w16_slx(16, 16)));
-    const int sld = both ? w16_sld(32, 32) : (C == 32 ? w16_sld(16, 32) : (K == 32 ? w16_sld(32, 16) : w16_sld(16, 16)));
-    const long long tpb = both ? w16_waves(32, 32) * 64 : W16_TPB;
+    const bool both = C == 32 && K == 32, w3 = (g_kp_wg16 & 4) && (C == 32) != (K == 32);
+    const int slx = both ? w16_slx(32, 32) : (C == 32 ? w16_slx(16, 32, w3) : (K == 32 ? w16_slx(32, 16, w3) : w16_slx(16, 16)));
+    const int sld = both ? w16_sld(32, 32) : (C == 32 ? w16_sld(16, 32, w3) : (K == 32 ? w16_sld(32, 16, w3) : w16_sld(16, 16)));
+    const long long tpb = both ? w16_waves(32, 32) * 64 : (w3 ? 192 : W16_TPB);
     while (r >= 1 && ((r + 2) * xrow > (long long)slx * tpb * 16 || r * drow > (long long)sld * tpb * 16)) --r;
     if (r < 1) return 0;
     R = (int)r;
@@ -1195,10 +1211,13 @@ template <bool BNIN>
 static void small16_launch(int C, int K, unsigned grid, hipStream_t st, const void* x, const void* dy, float* scratch, int Ho, int Wo,
                            int dy_pad, int R, int bpi, long long bands, const BnIn& bn) {
 #define KP_W16(Kv, Cv) wgrad3x3_small16_k<Kv, Cv, BNIN><<<grid, w16_waves(Kv, Cv) * 64, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, R, bpi, bands, (long long)Kv * 9 * Cv, bn)
+#define KP_W16_3(Kv, Cv) wgrad3x3_small16_k<Kv, Cv, BNIN, 0, true><<<grid, 192, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, R, bpi, bands, (long long)Kv * 9 * Cv, bn)
+    const bool w3 = (g_kp_wg16 & 4) != 0;
     if (K == 16 && C == 16) KP_W16(16, 16);
-    else if (K == 16) KP_W16(16, 32);
-    else if (C == 16) KP_W16(32, 16);
+    else if (K == 16) { if (w3) KP_W16_3(16, 32); else KP_W16(16, 32); }
+    else if (C == 16) { if (w3) KP_W16_3(32, 16); else KP_W16(32, 16); }
     else KP_W16(32, 32);
+#undef KP_W16_3
 #undef KP_W16
 }
 
