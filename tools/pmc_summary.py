@@ -57,6 +57,8 @@ def summarise(out, suffix, kernels):
                     a[0] += float(r['Counter_Value']); a[1] += 1
                     if n == 'FETCH_SIZE':
                         dur[0] += int(r['End_Timestamp']) - int(r['Start_Timestamp']); dur[1] += 1
+        if 'FETCH_SIZE' not in acc or not dur[1]:   # no launch of this kernel in the profiled run
+            continue
         per = {c: v / n for c, (v, n) in acc.items()}
         fetch_b = 2.0 * per['FETCH_SIZE'] * 1024.0
         write_b = per['WRITE_SIZE'] * 1024.0
