@@ -13,7 +13,7 @@ namespace {
 
 constexpr int TPB = 256;
 constexpr int RED_R = 64;   // row groups of the two-stage column reduction
-constexpr long long WIDE_ROWS = 8192;   // up to here the one-launch wide reduction is used
+[[maybe_unused]] constexpr long long WIDE_ROWS = 8192;   // up to here the one-launch wide reduction is used
 
 __device__ __forceinline__ void fold_range(int h, int H, int p, int& lo, int& hi) {
     lo = (h == 0) ? 0 : h + p;
