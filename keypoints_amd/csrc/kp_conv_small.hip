@@ -1022,7 +1022,6 @@ __global__ __launch_bounds__(w16_waves(K, C, W3) * 64, w16_waves(K, C, W3) == 6 
         int r = tid / xc, c16 = tid % xc;
 #pragma unroll
         for (int u0 = 0; u0 < SLX; u0 += XB) {
-            constexpr int dummy = 0; (void)dummy;
             uint4 sbx[XB];
             unsigned livex = 0;
 #pragma unroll
