@@ -86,6 +86,10 @@ def parse():
     ap.add_argument('--fuse-bn', type=int, default=1,
                     help='1 (default): BatchNorm-apply + activation of a 3x3 layer run inside the next 3x3 layer (kp_conv_fwd_bnin; Pong-class '
                          'nets); 0: as a launch of its own (A/B; results are bit-identical)')
+    ap.add_argument('--detail', default=os.path.join(ROOT, 'gpurun_out', 'bench_detail.json'),
+                    help='file for the FULL record (per-kernel tables of every leg, the concurrent tables, long provenance strings); '
+                         "the printed line is the compact record.  '' = do not write it (--out, if given, takes precedence)")
+    ap.add_argument('--full-line', action='store_true', help='print the full record on stdout (round-3 behaviour, ~22 KB)')
     ap.add_argument('--lib', default='', help='development: time another build of libkp_hip.so (A/B on one box)')
     return ap.parse_args()
 
@@ -427,7 +431,9 @@ def _run_leg(args, rank, world, dev):
                             launches_per_step=dom[1]['launches_per_step'])
         else:
             roofline = dict(bound='mfma', kernel=dom[0], achieved=dom[1]['tflops'], peak=peak, unit='TFLOP/s',
-                            frac=dom[1]['tflops'] / peak, traffic=traffic if dom[0] == 'conv_mfma_16bit' else None,
+                            frac=dom[1]['tflops'] / peak,
+                            # (the PMC passes were taken on the headline workload: other shapes get no traffic figure)
+                            traffic=traffic if (dom[0] == 'conv_mfma_16bit' and config_name(args) == 'BASELINE config 4 shape') else None,
                             traffic_unit=f'HBM bytes per launch (rocprofv3 PMC of a committed profile run of this command, profiles/{pmc_file}; '
                                          'not a measurement of this run)' if pmc_file else None,
                             algorithmic_bytes=dom[1]['algorithmic_bytes_per_launch'],
@@ -483,6 +489,72 @@ def _run_leg(args, rank, world, dev):
     if reducer is not None:
         reducer.detach()
     return line
+
+
+def _round(v, nd=4):
+    if isinstance(v, float):
+        return float(f'{v:.{nd + 2}g}') if abs(v) < 1 else round(v, nd)
+    return v
+
+
+def compact_roofline(r):
+    """The `roofline` object without its per-kernel tables and provenance prose (those stay in the --detail file)."""
+    if not r:
+        return r
+    keep = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes', 'avg_launch_us', 'launches_per_step',
+            'step_tflops', 'step_frac', 'frac_at_measured_clock', 'pmc_mfma_util', 'pmc_effective_clock_ghz')
+    out = {k: _round(r[k]) for k in keep if k in r and r[k] is not None}
+    if 'traffic' not in out:
+        out['traffic'] = None
+    if r.get('traffic_unit'):
+        out['traffic_from'] = r['traffic_unit'].split('profiles/')[-1].split(')')[0].split(';')[0] if 'profiles/' in r['traffic_unit'] else 'pmc'
+    if r.get('power'):
+        p = r['power']
+        out['power'] = {k: _round(p[k], 1) for k in ('avg_socket_w', 'cap_w', 'avg_sclk_mhz', 'joules_per_step') if p.get(k) is not None}
+    if r.get('concurrent'):
+        out['concurrent'] = {k: _round(r['concurrent'][k]) for k in ('achieved', 'frac', 'avg_launch_us')}
+    if r.get('bottleneck'):
+        out['bottleneck'] = {k: _round(v) for k, v in r['bottleneck'].items()}
+    if r.get('kernels'):   # one number per kernel family: ms per step with the chip to itself
+        out['family_ms_per_step'] = {k: _round(v['ms_per_step']) for k, v in r['kernels'].items()}
+    if r.get('device'):
+        out['device'] = r['device'].get('name'), r['device'].get('cus')
+    out['measured'] = 'HIP events per launch on the launch stream, one-stream profile steps after the timed region'
+    return out
+
+
+def compact_line(line, detail_path):
+    """The record the driver reads: BASELINE's metric fields, `roofline`, `cpu_baseline`, and -- LAST, so that an 8 KB tail of
+    stdout always holds it -- `summary` with one entry per other BASELINE configuration and for the other 16-bit type."""
+    out = {k: (_round(v) if isinstance(v, float) else v) for k, v in line.items() if k not in ('roofline', 'extra', 'extra_configs', 'cpu_baseline', 'dp')}
+    if 'config' in out:
+        out['config'] = {k: (_round(v) if isinstance(v, float) else v) for k, v in line['config'].items()}
+    out['roofline'] = compact_roofline(line.get('roofline'))
+    if line.get('dp') is not None:
+        dp = dict(line['dp'])
+        dp.pop('exposed_is', None)
+        out['dp'] = dp
+    if line.get('cpu_baseline'):
+        c = line['cpu_baseline']
+        out['cpu_baseline'] = dict(value=_round(c['value']), unit=c['unit'], cores=c['cores'], kind=c['kind'], cpu_model=c.get('cpu_model'),
+                                   s_per_step_median=_round(c.get('s_per_step_median')), sample=c['sample'])
+    summary = {}
+    for prec, o in (line.get('extra') or {}).items():
+        summary[f'config4_{prec}'] = dict(value=_round(o['value'], 1), ms_per_step=_round(o['ms_per_step']), dtype=o['dtype'],
+                                          ratio_to_headline=_round(o['ratio_to_headline']))
+    for key, r in (line.get('extra_configs') or {}).items():
+        if 'error' in r:
+            summary[key] = dict(error=r['error'][:200])
+            continue
+        rf = r.get('roofline') or {}
+        summary[key] = dict(value=_round(r['value'], 1), ms_per_step=_round(r['ms_per_step']), steps=r['steps'], dtype=r['dtype'],
+                            workload=r['config']['workload'], bound=rf.get('bound'), kernel=rf.get('kernel'),
+                            achieved=_round(rf.get('achieved')), unit=rf.get('unit'), frac=_round(rf.get('frac')),
+                            step_frac=_round(rf.get('step_frac')), traffic=rf.get('traffic'), algorithmic_bytes=rf.get('algorithmic_bytes'))
+    if detail_path:
+        out['detail_file'] = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT) else detail_path
+    out['summary'] = summary
+    return out
 
 
 EXTRA_CONFIGS = [
@@ -559,10 +631,17 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.net == 'transporter':
             line['cpu_baseline'] = cpu_baseline(args)
-        print(json.dumps(line), flush=True)
-        if args.out:
-            with open(args.out, 'w') as f:
-                f.write(json.dumps(line, indent=1) + '\n')
+        # The printed line is the COMPACT record (a few KB: the driver keeps an 8 KB tail of stdout and round 3's 22 KB line
+        # lost the config-2 leg and `extra.bf16` to it); the per-kernel tables of every leg go to --out / --detail.
+        detail = args.detail or args.out
+        if detail:
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(detail)), exist_ok=True)
+                with open(detail, 'w') as f:
+                    f.write(json.dumps(line, indent=1) + '\n')
+            except OSError as e:
+                print(f'bench.py: could not write {detail}: {e}', file=sys.stderr)
+        print(json.dumps(line if args.full_line else compact_line(line, detail)), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
