@@ -57,7 +57,7 @@ long long kp_last_rows(void);
 int kp_device_cus(void);
 
 /* Tuning switches for A/B measurements (not needed in normal use). */
-#define KP_CFG_CONV_PATCH 0   /* 1 (default): LDS-patch 3x3 kernel where eligible; 0: linear implicit-GEMM kernel */
+#define KP_CFG_CONV_PATCH 0   /* 2 (default): LDS-patch 3x3 kernels, pair-tile generation where eligible; 1: first-generation patch kernel only; 0: linear implicit-GEMM kernel */
 #define KP_CFG_DEBUG 1        /* ablation mask for kernel measurements (0 = normal operation) */
 int kp_config(int key, int value);
 #define KP_CFG_WGRAD_PATCH 3  /* 1 (default): tap-reuse weight-gradient kernel where eligible; 0: per-tap kernel */

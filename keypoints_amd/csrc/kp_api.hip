@@ -84,7 +84,7 @@ int kp_device_cus(void) {
 }
 
 int kp_config(int key, int value) {
-    if (key == KP_CFG_CONV_PATCH) { g_kp_conv_patch = value ? 1 : 0; return KP_OK; }
+    if (key == KP_CFG_CONV_PATCH) { g_kp_conv_patch = value < 0 ? 0 : (value > 2 ? 2 : value); return KP_OK; }
     if (key == KP_CFG_DEBUG) { g_kp_debug = value; return KP_OK; }
     if (key == KP_CFG_WALK) { g_kp_walk = value; return KP_OK; }
     if (key == KP_CFG_CUS) { g_kp_cus = value > 0 ? value : 0; return KP_OK; }

@@ -264,6 +264,8 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const h16_t* __restrict
 
 int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hib,
                          int Wib, int ioff, int Hob, int Wob, int ooff, int H, int W, int C, int K, hipStream_t st);
+int kp_conv_pair_launch(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hib,
+                        int Wib, int ioff, int Hob, int Wob, int ooff, int H, int W, int C, int K, hipStream_t st);
 
 template <int MODE>
 static int launch_linear(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi,
@@ -295,12 +297,23 @@ static int launch_linear(const void* x, const void* w, const float* bias, void* 
 }
 
 extern kp_knob_t g_kp_conv_patch;   // kp_api.hip: kp_config(KP_CFG_CONV_PATCH, v); -1 = read KP_CONV_PATCH from the environment once
-static int patch_mode() {   // 0 forces the linear implicit-GEMM kernel (A/B measurements)
+static int patch_mode() {   // 0 forces the linear implicit-GEMM kernel, 1 the first-generation patch kernel (A/B measurements)
     if (g_kp_conv_patch < 0) {
         const char* e = getenv("KP_CONV_PATCH");
-        g_kp_conv_patch = (e && e[0] == '0') ? 0 : 1;
+        g_kp_conv_patch = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
     }
     return g_kp_conv_patch;
+}
+
+// LDS-patch kernels over a 16x16-tileable window: the pair kernel (kp_conv_pair.hip: two pixel tiles per workgroup, 128 x 64 wave
+// tile) where its tile pairing and statistics layout apply, else the first-generation kernel (kp_conv_patch.hip)
+static int patch_launch(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hib, int Wib, int ioff,
+                        int Hob, int Wob, int ooff, int H, int W, int C, int K, hipStream_t st) {
+    if (patch_mode() >= 2) {
+        const int rc = kp_conv_pair_launch(x, w, bias, y, stats, N, Hib, Wib, ioff, Hob, Wob, ooff, H, W, C, K, st);
+        if (rc != KP_E_UNSUPPORTED) return rc;
+    }
+    return kp_conv_patch_launch(x, w, bias, y, stats, N, Hib, Wib, ioff, Hob, Wob, ooff, H, W, C, K, st);
 }
 
 // Dispatch: (a) output a multiple of 16x16 -> LDS-patch kernel; (b) output = 16x16 multiple + a 1-pixel ring
@@ -312,10 +325,10 @@ int kp_conv_fwd_mfma(const void* x, const void* w, const float* bias, void* y, f
     const int Ho = Hi - 2, Wo = Wi - 2;
     if (patch_mode()) {
         if (Ho % 16 == 0 && Wo % 16 == 0) {
-            int rc = kp_conv_patch_launch(x, w, bias, y, stats, N, Hi, Wi, 0, Ho, Wo, 0, Ho, Wo, C, K, st);
+            int rc = patch_launch(x, w, bias, y, stats, N, Hi, Wi, 0, Ho, Wo, 0, Ho, Wo, C, K, st);
             if (rc != KP_E_UNSUPPORTED) return rc;
         } else if (!stats && Ho > 2 && Wo > 2 && (Ho - 2) % 16 == 0 && (Wo - 2) % 16 == 0) {
-            int rc = kp_conv_patch_launch(x, w, bias, y, nullptr, N, Hi, Wi, 1, Ho, Wo, 1, Ho - 2, Wo - 2, C, K, st);
+            int rc = patch_launch(x, w, bias, y, nullptr, N, Hi, Wi, 1, Ho, Wo, 1, Ho - 2, Wo - 2, C, K, st);
             if (rc == KP_OK) return launch_linear<1>(x, w, bias, y, nullptr, N, Hi, Wi, C, K, st);
             if (rc != KP_E_UNSUPPORTED) return rc;
         }
@@ -328,7 +341,7 @@ int kp_conv_fwd_mfma(const void* x, const void* w, const float* bias, void* y, f
 // kernel, border ring with 3 taps per pixel.  KP_E_UNSUPPORTED -> the caller falls back to kp_conv_fwd semantics.
 int kp_conv_dgrad_mfma(const void* dy, const void* w, void* gx, int N, int H, int W, int K, int C, hipStream_t st) {
     if (K % BK != 0 || C % 64 != 0 || H % 16 != 0 || W % 16 != 0 || H < 16 || W < 16 || !patch_mode()) return KP_E_UNSUPPORTED;
-    int rc = kp_conv_patch_launch(dy, w, nullptr, gx, nullptr, N, H + 4, W + 4, 1, H + 2, W + 2, 1, H, W, K, C, st);
+    int rc = patch_launch(dy, w, nullptr, gx, nullptr, N, H + 4, W + 4, 1, H + 2, W + 2, 1, H, W, K, C, st);
     if (rc != KP_OK) return rc;
     return launch_linear<2>(dy, w, nullptr, gx, nullptr, N, H + 4, W + 4, K, C, st);
 }

@@ -49,15 +49,18 @@ def main():
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--ab', action='store_true')
     ap.add_argument('--only', default='')
+    ap.add_argument('--modes', default='', help='comma list of KP_CFG_CONV_PATCH values to time side by side (2 = pair kernel, 1 = first-generation patch kernel, 0 = linear)')
+    ap.add_argument('--f16', action='store_true', help='fp16 storage instead of bf16')
     ap.add_argument('--lib', default='', help='another build of libkp_hip.so to time (A/B between builds)')
     args = ap.parse_args()
     if args.lib:
         _lib.LIB_PATH = os.path.abspath(args.lib)
     N = args.batch
     st = torch.cuda.current_stream().cuda_stream
-    bf = torch.bfloat16
+    bf = torch.float16 if args.f16 else torch.bfloat16
+    DT = _lib.KP_F16 if args.f16 else _lib.KP_BF16
     tot = {}
-    modes = [1, 0] if args.ab else [1]
+    modes = [int(m) for m in args.modes.split(',')] if args.modes else ([1, 0] if args.ab else [2])
     print(f'{"layer":<20}' + ''.join(f'{"fwd":>9}{"dgrad":>9}' for _ in modes) + f'{"wgrad":>9}   (TFLOP/s)')
     for name, C, K, H, nf, nd, nw in LAYERS:
         if args.only and args.only not in name:
@@ -73,26 +76,26 @@ def main():
         dy = torch.zeros(N, H + 4, W + 4, K, device='cuda', dtype=bf)
         dy[:, 2:-2, 2:-2] = (torch.randn(N, H, W, K, device='cuda') * 0.5).to(bf)
         gx = torch.empty(N, H + 2, W + 2, C, device='cuda', dtype=bf)
-        scratch = torch.zeros(_lib.lib().kp_conv_wgrad_partials(N, H, W, C, K, 3, 2, _lib.KP_BF16), K, 3, 3, C, device='cuda')
+        scratch = torch.zeros(_lib.lib().kp_conv_wgrad_partials(N, H, W, C, K, 3, 2, DT), K, 3, 3, C, device='cuda')
         cols = []
         for mode in modes:
             call('kp_config', 0, mode)
             tf = timed(lambda: call('kp_conv_fwd', ptr(a), ptr(wf), ptr(bias), ptr(y), ptr(stats), N, H + 2, W + 2, C, K,
-                                    3, _lib.KP_BF16, st), args.reps)
-            td = timed(lambda: call('kp_conv_dgrad', ptr(dy), ptr(wd), ptr(gx), N, H, W, K, C, _lib.KP_BF16, st), args.reps)
+                                    3, DT, st), args.reps)
+            td = timed(lambda: call('kp_conv_dgrad', ptr(dy), ptr(wd), ptr(gx), N, H, W, K, C, DT, st), args.reps)
             cols += [flops / tf / 1e12, flops / td / 1e12]   # dgrad priced at its algorithmic (interior) FLOPs
             key = f'patch={mode}'
             t = tot.setdefault(key, [0.0, 0.0])
             t[0] += nf * flops + nd * flops   # algorithmic (interior) flops
             t[1] += nf * tf + nd * td
-        call('kp_config', 0, 1)
+        call('kp_config', 0, 2)
         if args.ab:
             call('kp_config', 3, 0)
-            tw0 = timed(lambda: call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, W, C, K, 3, 2, _lib.KP_BF16, st),
+            tw0 = timed(lambda: call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, W, C, K, 3, 2, DT, st),
                         args.reps)
             cols.append(flops / tw0 / 1e12)
             call('kp_config', 3, 1)
-        tw = timed(lambda: call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, W, C, K, 3, 2, _lib.KP_BF16, st),
+        tw = timed(lambda: call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, W, C, K, 3, 2, DT, st),
                    args.reps)
         t = tot.setdefault('wgrad', [0.0, 0.0])
         t[0] += nw * flops
@@ -107,10 +110,10 @@ def main():
         y = torch.empty(N, H, H, K, device='cuda', dtype=bf)
         stats = torch.empty(N * H * H // 64, 2, K, device='cuda')
         dy = (torch.randn(N, H, H, K, device='cuda') * 0.5).to(bf)
-        scratch = torch.zeros(_lib.lib().kp_conv_wgrad_partials(N, H, H, C, K, 3, 0, _lib.KP_BF16), K, 3, 3, C, device='cuda')
+        scratch = torch.zeros(_lib.lib().kp_conv_wgrad_partials(N, H, H, C, K, 3, 0, DT), K, 3, 3, C, device='cuda')
         tf = timed(lambda: call('kp_conv_fwd', ptr(a), ptr(wf), ptr(bias), ptr(y), ptr(stats), N, H + 2, H + 2, C, K, 3,
-                                _lib.KP_BF16, st), args.reps)
-        tw = timed(lambda: call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, H, C, K, 3, 0, _lib.KP_BF16, st),
+                                DT, st), args.reps)
+        tw = timed(lambda: call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, H, C, K, 3, 0, DT, st),
                    args.reps)
         gb = N * H * H * K * 2 / 1e9
         print(f'first 3>64 @128: fwd {tf * 1e6:7.0f} us ({gb / tf:6.0f} GB/s written)   wgrad {tw * 1e6:7.0f} us '

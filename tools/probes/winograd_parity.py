@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Go / no-go on Winograd for the 3x3 layers of model F under fp16 storage: PARITY first (round-3 verdict item 2).
+
+What a Winograd kernel would compute is emulated in torch on the GPU inside the oracle's fp16-storage emulation of the HIP
+path (oracle.unit_forward(quant=fp16_storage): rounding at the HIP engine's storage points), on the CONDITIONED model F of
+tests/test_gpu_fullsize.py::test_conditioned_model_F_16bit_against_the_stated_tolerance (200 Adam steps of the strict-fp32
+HIP path on structured pairs), 128 pairs, against the fp64 oracle:
+
+    direct   : F.conv2d on the fp16-rounded operands, fp32 accumulate           = what kp_conv_patch.hip computes
+    wino2d   : F(2x2, 3x3): V = B^T d B and U = G g G^T ROUNDED TO fp16 (they are the MFMA operands), 16 products per 2x2
+               outputs accumulated in fp32, Y = A^T M A in fp32                    (2.25x fewer MACs)
+    wino1d   : F(2, 3) along x only: 4 products per 2 outputs and filter row       (1.5x fewer MACs)
+
+for (a) every 3x3 layer with C, K >= 64, (b) only the two heaviest layer classes the verdict names (256 -> 256 @ 64^2 and
+512 -> 512 @ 32^2 / 16^2).  The stated 16-bit tolerance: keypoints 5e-3, loss 1e-2, x_t rel-L2 5e-3.
+Reference semantics: keypoints/models/vgg.py:30-38 (ReplicationPad2d(1) + Conv2d(3x3))."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch
+import torch.nn.functional as F
+
+import keypoints_amd as ka
+from keypoints_amd.models import transporter
+from oracle import kp_oracle as O
+from structured import structured_pairs
+
+h16 = lambda t: t.to(torch.float16).to(t.dtype)
+
+
+def wino2d(x, w, bias):
+    """x [N, C, H+2, W+2] (padded, already fp16-rounded), w [K, C, 3, 3] (fp16-rounded) -> [N, K, H, W]; fp32 accumulate."""
+    N, C, Hp, Wp = x.shape
+    K = w.shape[0]
+    H, W = Hp - 2, Wp - 2
+    dt = x.dtype
+    Bt = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=dt, device=x.device)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=dt, device=x.device)
+    At = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=dt, device=x.device)
+    U = h16(torch.einsum('ai,kcij,bj->kcab', G, w, G))                          # [K, C, 4, 4], rounded: an MFMA operand
+    out = torch.empty(N, K, H, W, dtype=dt, device=x.device)
+    per = max(1, (1 << 27) // (C * Hp * Wp))
+    for i in range(0, N, per):
+        d = x[i:i + per].unfold(2, 4, 2).unfold(3, 4, 2)                        # [n, C, H/2, W/2, 4, 4]
+        V = h16(torch.einsum('ai,nchwij,bj->nchwab', Bt, d, Bt))                # rounded: the other MFMA operand
+        M = torch.einsum('kcab,nchwab->nkhwab', U, V)                           # fp32 accumulation over C
+        Y = torch.einsum('ia,nkhwab,jb->nkhwij', At, M, At)                     # [n, K, H/2, W/2, 2, 2]
+        out[i:i + per] = Y.permute(0, 1, 2, 4, 3, 5).reshape(-1, K, H, W)
+    return out + bias[None, :, None, None]
+
+
+def wino1d(x, w, bias):
+    """F(2, 3) along the image row: per filter row r, 4 products per 2 outputs."""
+    N, C, Hp, Wp = x.shape
+    K = w.shape[0]
+    H, W = Hp - 2, Wp - 2
+    dt = x.dtype
+    Bt = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=dt, device=x.device)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=dt, device=x.device)
+    At = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=dt, device=x.device)
+    U = h16(torch.einsum('bj,kcrj->kcrb', G, w))                                # [K, C, 3, 4]
+    out = torch.empty(N, K, H, W, dtype=dt, device=x.device)
+    per = max(1, (1 << 27) // (C * Hp * Wp))
+    for i in range(0, N, per):
+        d = x[i:i + per].unfold(3, 4, 2)                                        # [n, C, H+2, W/2, 4]
+        V = h16(torch.einsum('bj,nchwj->nchwb', Bt, d))                         # [n, C, H+2, W/2, 4]
+        M = sum(torch.einsum('kcb,nchwb->nkhwb', U[:, :, r], V[:, :, r:r + H]) for r in range(3))
+        Y = torch.einsum('jb,nkhwb->nkhwj', At, M)                              # [n, K, H, W/2, 2]
+        out[i:i + per] = Y.reshape(-1, K, H, W)
+    return out + bias[None, :, None, None]
+
+
+class Swap:
+    """F.conv2d inside oracle.unit_forward replaced for the chosen 3x3 layers."""
+
+    def __init__(self, fn, pick):
+        self.fn, self.pick, self.orig, self.hits = fn, pick, F.conv2d, 0
+
+    def __call__(self, x, w, b=None, *a, **kw):
+        if w.shape[2:] == (3, 3) and self.pick(w.shape[1], w.shape[0], x.shape[2] - 2):
+            self.hits += 1
+            return self.fn(x, w, b)
+        return self.orig(x, w, b, *a, **kw)
+
+    def __enter__(self):
+        O.F.conv2d = self
+        return self
+
+    def __exit__(self, *exc):
+        O.F.conv2d = self.orig
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def main():
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    steps = int(os.environ.get('WINO_STEPS', '200'))
+    plans = O.transporter_plans('F', 3, 64, 10)
+    P, Bf = O.init_params(plans, seed=3)
+    net = transporter.make('F', 3, 64, 10)
+    net.load_state_dict({**P, **Bf}, strict=True)
+    net = net.cuda().set_precision('fp32')
+    opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
+    g = torch.Generator().manual_seed(99)
+    t0 = time.time()
+    for it in range(steps):
+        a, b = structured_pairs(32, 128, g, device='cuda')
+        opt.zero_grad()
+        loss = ka.l2_reconstruction_loss(net(a, b)[0], b)
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    print(f'conditioned: {steps} steps, train loss {float(loss):.4f} ({time.time() - t0:.0f} s)')
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    del net, opt
+    xs, xt = structured_pairs(128, 128, torch.Generator().manual_seed(7), device='cuda')
+
+    def fwd(dtype, quant):
+        oP = {k: sd[k].to(dtype).clone() for k in P}
+        oB = {k: (sd[k].to(dtype) if sd[k].dtype.is_floating_point else sd[k]).clone() for k in Bf}
+        with torch.no_grad(), torch.backends.cudnn.flags(enabled=False):
+            out = O.transporter_forward(plans, oP, xs.to(dtype), xt.to(dtype), oB, True, 'max', quant=quant)
+            loss = ((out[0] - xt.to(dtype)) ** 2).mean()
+        return out, float(loss)
+
+    o64, l64 = fwd(torch.float64, None)
+    xmax = float(o64[0].abs().max())
+    heavy = lambda C, K, H: (C, K, H) in ((256, 256, 64), (512, 512, 32), (512, 512, 16))
+    allmf = lambda C, K, H: C >= 64 and K >= 64
+    cases = [('direct (the HIP fp16 path as emulated)', None, None),
+             ('wino2d F(2x2,3x3), every C,K>=64 layer', wino2d, allmf), ('wino2d, heaviest layer classes only', wino2d, heavy),
+             ('wino1d F(2,3) along x, every C,K>=64 layer', wino1d, allmf), ('wino1d, heaviest layer classes only', wino1d, heavy)]
+    print(f'{"variant":<46}{"layers":>7}{"keypoints":>11}{"loss rel":>10}{"x_t relL2":>11}{"x_t max/|x|":>12}{"phi relL2":>11}   (fp16 storage vs fp64 oracle; stated: 5e-3 / 1e-2 / 5e-3)')
+    for name, fn, pick in cases:
+        if fn is None:
+            out, l = fwd(torch.float32, O.fp16_storage)
+            hits = 0
+        else:
+            with Swap(fn, pick) as sw:
+                out, l = fwd(torch.float32, O.fp16_storage)
+                hits = sw.hits
+        k = float((out[2].double() - o64[2]).abs().max())
+        print(f'{name:<46}{hits:>7}{k:>11.2e}{abs(l - l64) / l64:>10.1e}{rel(out[0], o64[0]):>11.2e}'
+              f'{float((out[0].double() - o64[0]).abs().max()) / xmax:>12.2e}{rel(out[1], o64[1]):>11.2e}')
+    # self-check of the emulations: in fp64 without operand rounding they ARE the convolution
+    x = torch.randn(2, 64, 18, 34, dtype=torch.float64, device='cuda')
+    w = torch.randn(64, 64, 3, 3, dtype=torch.float64, device='cuda')
+    bz = torch.zeros(64, dtype=torch.float64, device='cuda')
+    global h16
+    keep, h16 = h16, (lambda t: t)
+    with torch.backends.cudnn.flags(enabled=False):
+        ref = F.conv2d(x, w)
+    print('self-check (fp64, no rounding): wino2d', float((wino2d(x, w, bz) - ref).abs().max()), ' wino1d', float((wino1d(x, w, bz) - ref).abs().max()))
+    h16 = keep
+
+
+if __name__ == '__main__':
+    main()
