@@ -185,6 +185,26 @@ int kp_conv_wgrad_bnin(const void* yprev, const float* mean, const float* invstd
                        float slope, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int dy_pad, int dtype,
                        void* stream);
 
+/* Winograd F(2, 3) form of the 3x3 layers (kp_conv_wino.hip; replaces the same reference statement as kp_conv_fwd / kp_conv_dgrad:
+ * nn.Conv2d(3x3) after ReplicationPad2d(1), keypoints/models/vgg.py:30-33, and its autograd data gradient).  fp16 storage only.
+ * Output rows are computed in pairs from four input rows with 4 instead of 6 products per filter column: 1.5x fewer MACs on the
+ * matrix cores.  The transformed operands (row differences / sums of the activation, filter-row combinations of the weights) are
+ * re-rounded to fp16; accumulation and the output transform are fp32.
+ *   kp_conv_wino_supported: 1 where the kernel takes the shape (C % 32 == 0, C >= 64, K % 64 == 0, H and W multiples of 16, an even
+ *     number of 16x16 pixel tiles; with_stats: the BatchNorm partial rows also fit its per-workgroup layout).
+ *   kp_conv_wino_pack: u[K][4][3][C] from a packed 16-bit weight w_packed[K][3][3][C] (kp_pack_weights' w_fwd; for the data gradient
+ *     the flipped pack w_dgrad[C][3][3][K], read as "K" = C, "C" = K).
+ *   kp_conv_fwd_wino: kp_conv_fwd (R = 3) with u in place of w; statistics rows: kp_conv_fwd_wino_rows.
+ *   kp_conv_dgrad_wino: kp_conv_dgrad; the interior through u_dgrad, the 3-tap border ring through w_dgrad (direct).
+ * KP_E_UNSUPPORTED where the shape / dtype has no kernel: the caller runs kp_conv_fwd / kp_conv_dgrad. */
+int kp_conv_wino_supported(int N, int H, int W, int C, int K, int with_stats, int dtype);
+int kp_conv_wino_pack(const void* w_packed, void* u, int K, int C, int dtype, void* stream);
+int kp_conv_fwd_wino(const void* x, const void* u, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C, int K,
+                     int dtype, void* stream);
+long long kp_conv_fwd_wino_rows(int N, int Hi, int Wi, int C, int K, int dtype);
+int kp_conv_dgrad_wino(const void* dy, const void* u_dgrad, const void* w_dgrad, void* gx, int N, int H, int W, int K, int C, int dtype,
+                       void* stream);
+
 /* The data gradient of a 3x3 layer L that also leaves the first pass of layer L - 1's BatchNorm backward (the layer whose padded
  * activation was L's input; vgg.py:30-38 pairs).  gx: exactly kp_conv_dgrad's output [N][H+2][W+2][C] (padded domain, bit for
  * bit).  partials: what kp_bn_act_bwd_reduce(gx, gp = 1, tail none, yred, ...) would leave -- rows x [2][C] sums of

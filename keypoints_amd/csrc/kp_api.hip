@@ -201,6 +201,12 @@ KP_DISPATCH(kp_conv_wgrad_bnin, (const void* yprev, const float* mean, const flo
 KP_DISPATCH(kp_conv_dgrad_bnred_supported, (int N, int H, int W, int K, int C, int dtype), (N, H, W, K, C, dtype))
 KP_DISPATCH(kp_conv_dgrad_bnred, (const void* dy, const void* w_dgrad, void* gx, const void* yred, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, float* partials, int N, int H, int W, int K, int C, int dtype, void* stream),
             (dy, w_dgrad, gx, yred, mean, invstd, gamma, beta, slope, partials, N, H, W, K, C, dtype, stream))
+KP_DISPATCH(kp_conv_wino_supported, (int N, int H, int W, int C, int K, int with_stats, int dtype), (N, H, W, C, K, with_stats, dtype))
+KP_DISPATCH(kp_conv_wino_pack, (const void* w_packed, void* u, int K, int C, int dtype, void* stream), (w_packed, u, K, C, dtype, stream))
+KP_DISPATCH(kp_conv_fwd_wino, (const void* x, const void* u, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C, int K, int dtype, void* stream),
+            (x, u, bias, y, stats, N, Hi, Wi, C, K, dtype, stream))
+KP_DISPATCH(kp_conv_dgrad_wino, (const void* dy, const void* u_dgrad, const void* w_dgrad, void* gx, int N, int H, int W, int K, int C, int dtype, void* stream),
+            (dy, u_dgrad, w_dgrad, gx, N, H, W, K, C, dtype, stream))
 KP_DISPATCH(kp_bn_act_fwd, (const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, int tail, void* out, int out_pad, unsigned char* argmax, int N, int H, int W, int C, int dtype, void* stream),
             (y, mean, invstd, gamma, beta, slope, tail, out, out_pad, argmax, N, H, W, C, dtype, stream))
 KP_DISPATCH(kp_bn_act_bwd_reduce, (const void* gsrc, int gp, int tail, const unsigned char* argmax, const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, float* partials, int N, int H, int W, int C, int dtype, void* stream),
@@ -230,6 +236,14 @@ long long kp_conv_fwd_stats_rows(int N, int Hi, int Wi, int C, int K, int R, int
     kp_set_query_mode(1);
     float dummy;   // non-NULL stats: the launchers only look at the pointer's truth value in query mode
     const int rc = kp_conv_fwd(nullptr, nullptr, nullptr, nullptr, &dummy, N, Hi, Wi, C, K, R, dtype, nullptr);
+    kp_set_query_mode(0);
+    return rc == KP_OK ? kp_last_rows() : (long long)rc;
+}
+
+long long kp_conv_fwd_wino_rows(int N, int Hi, int Wi, int C, int K, int dtype) {
+    kp_set_query_mode(1);
+    float dummy;
+    const int rc = kp_conv_fwd_wino(nullptr, nullptr, nullptr, nullptr, &dummy, N, Hi, Wi, C, K, dtype, nullptr);
     kp_set_query_mode(0);
     return rc == KP_OK ? kp_last_rows() : (long long)rc;
 }

@@ -345,3 +345,9 @@ int kp_conv_dgrad_mfma(const void* dy, const void* w, void* gx, int N, int H, in
     if (rc != KP_OK) return rc;
     return launch_linear<2>(dy, w, nullptr, gx, nullptr, N, H + 4, W + 4, K, C, st);
 }
+
+// The 3-tap border ring of a data gradient on its own (the interior comes from another kernel: kp_conv_dgrad_wino)
+int kp_conv_ring_dgrad(const void* dy, const void* w, void* gx, int N, int H, int W, int K, int C, hipStream_t st) {
+    if (K % BK != 0 || C % 64 != 0) return KP_E_UNSUPPORTED;
+    return launch_linear<2>(dy, w, nullptr, gx, nullptr, N, H + 4, W + 4, K, C, st);
+}
