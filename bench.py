@@ -90,6 +90,9 @@ def parse():
                     help='file for the FULL record (per-kernel tables of every leg, the concurrent tables, long provenance strings); '
                          "the printed line is the compact record.  '' = do not write it (--out, if given, takes precedence)")
     ap.add_argument('--full-line', action='store_true', help='print the full record on stdout (round-3 behaviour, ~22 KB)')
+    ap.add_argument('--fuse-bn-reduce', type=int, default=1,
+                    help='1 (default): the first pass of a BatchNorm backward (its two sums) runs in the epilogue of the data gradient that '
+                         'produces its incoming gradient (kp_conv_dgrad_bnred); 0: as a pass of its own (A/B)')
     ap.add_argument('--lib', default='', help='development: time another build of libkp_hip.so (A/B on one box)')
     return ap.parse_args()
 
@@ -234,6 +237,7 @@ def _run_leg(args, rank, world, dev):
 
     ka.set_multi_stream(bool(args.streams))
     ka.set_fuse_bn_input(bool(args.fuse_bn))
+    ka.runtime.set_fuse_bn_reduce(bool(args.fuse_bn_reduce))
     torch.manual_seed(0)
     if args.net == 'keynet':
         from keypoints_amd.models import keynet

@@ -57,7 +57,7 @@ long long kp_last_rows(void);
 int kp_device_cus(void);
 
 /* Tuning switches for A/B measurements (not needed in normal use). */
-#define KP_CFG_CONV_PATCH 0   /* 2 (default): LDS-patch 3x3 kernels, pair-tile generation where eligible; 1: first-generation patch kernel only; 0: linear implicit-GEMM kernel */
+#define KP_CFG_CONV_PATCH 0   /* 1 (default): LDS-patch 3x3 kernel where eligible; 2: its pair-tile generation first (kp_conv_pair.hip: measured equal, opt-in); 0: linear implicit-GEMM kernel */
 #define KP_CFG_DEBUG 1        /* ablation mask for kernel measurements (0 = normal operation) */
 int kp_config(int key, int value);
 #define KP_CFG_WGRAD_PATCH 3  /* 1 (default): tap-reuse weight-gradient kernel where eligible; 0: per-tap kernel */
@@ -82,6 +82,9 @@ int kp_config(int key, int value);
 #define KP_WALK_V4_ALL 0xfe00
 #define KP_WALK_DEFAULT (KP_WALK_CONV_LINEAR | KP_WALK_FWD_REVERSE | KP_WALK_REDUCE_REVERSE | KP_WALK_STREAM_LOADS | KP_WALK_V4_ALL)
 #define KP_CFG_BN_FLAT 8      /* 1 (default): BatchNorm-backward passes of narrow, few-channel maps keep their loads in flight across image rows (bn_bwd_flat_k); 0: row kernel */
+#define KP_CFG_BRED_PATCH 9   /* kp_conv_dgrad_bnred for the matrix-core layers (C, K multiples of 64, 16x16-tileable maps): 1 (default) where the data
+                                 gradient has 64 output channels per tile (C % 128 != 0: a gain); 2: for 128-channel tiles too (measured slower: register
+                                 spills); 0: only for the 16/32-channel layers */
 #define KP_CFG_SMALL_BAND 7   /* 1 (default): LDS-staged weight gradient of the 16/32-channel layers where a band of rows fits; 0: gather kernel */
 #define KP_CFG_CUS 6          /* CU budget the persistent kernels size their grids to (launches on a CU-masked stream); 0 = whole device */
 #define KP_CFG_TRACE 2        /* device buffer of 512 int64: s_memtime stamps of workgroup 0 of the patch conv kernel */
@@ -211,9 +214,11 @@ int kp_conv_dgrad_wino(const void* dy, const void* u_dgrad, const void* w_dgrad,
  * gh = fold(gx) * act'(z) and gh * xhat over yred = layer L - 1's conv output [N][H][W][C] with ITS BatchNorm (mean / invstd /
  * gamma / beta, all NULL without BatchNorm) and activation slope -- computed in the padded domain (folding is the adjoint of
  * the replicate pad: every element of gx meets the factors of its clamped source pixel), equal up to the order of the fp32
- * additions; kp_bn_bwd_finalize takes the rows.  Row count: kp_conv_dgrad_bnred_rows (a pure function of the shape), at most
- * ceil(N * (H + 2) * (W + 2) / 64).  kp_conv_dgrad_bnred_supported: 1 where the fused kernel exists (16-bit storage,
- * C, K in {16, 32}, a band of rows fits the LDS); otherwise KP_E_UNSUPPORTED, nothing launched. */
+ * additions; kp_bn_bwd_finalize takes the rows.  Row count: kp_conv_dgrad_bnred_rows (a pure function of the shape and the
+ * device; the caller sizes `partials` with it).  kp_conv_dgrad_bnred_supported: 1 where the fused kernel exists (16-bit storage;
+ * C, K in {16, 32} and a band of rows fits the LDS: kp_conv_small.hip; or C, K multiples of 64 on 16x16-tileable maps: the
+ * persistent LDS-patch kernel's epilogue + the 3-tap ring kernel's, kp_conv_patch.hip / kp_conv_mfma.hip, where every workgroup
+ * keeps one output-channel tile); otherwise KP_E_UNSUPPORTED, nothing launched. */
 int kp_conv_dgrad_bnred_supported(int N, int H, int W, int K, int C, int dtype);
 long long kp_conv_dgrad_bnred_rows(int N, int H, int W, int K, int C, int dtype);
 int kp_conv_dgrad_bnred(const void* dy, const void* w_dgrad, void* gx, const void* yred, const float* mean, const float* invstd,

@@ -87,7 +87,7 @@ _lib = None
 
 
 class KpError(RuntimeError):
-    pass
+    rc = None   # the KP_E_* code of a failed call (None: raised by the loader itself)
 
 
 def lib():
@@ -111,7 +111,25 @@ def call(name: str, *args):
     """Invoke a kp_* entry point; non-zero return -> KpError with the library's message."""
     rc = getattr(lib(), name)(*args)
     if rc != 0:
-        raise KpError(f'{name} failed ({rc}): {lib().kp_last_error().decode()}')
+        e = KpError(f'{name} failed ({rc}): {lib().kp_last_error().decode()}')
+        e.rc = rc
+        raise e
+
+
+KP_E_UNSUPPORTED = -3
+
+
+def try_call(name: str, *args) -> bool:
+    """`call`, but a KP_E_UNSUPPORTED answer (the library declined the shape / alignment / configuration and launched nothing)
+    is returned as False instead of raised: the caller then runs the equivalent unfused sequence."""
+    rc = getattr(lib(), name)(*args)
+    if rc == KP_E_UNSUPPORTED:
+        return False
+    if rc != 0:
+        e = KpError(f'{name} failed ({rc}): {lib().kp_last_error().decode()}')
+        e.rc = rc
+        raise e
+    return True
 
 
 def last_rows() -> int:

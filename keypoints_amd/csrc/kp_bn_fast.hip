@@ -313,9 +313,11 @@ int kp_bn_bwd_fast(int mode, const void* gsrc, int gp, int tail, const unsigned 
     // narrow maps with few channels (Pong-class nets): the row kernel's UNB x (TPB / CV) pixel slots are mostly empty -> the
     // kernel whose slots run over all rows of the workgroup (bn_bwd_flat_k).  Wide layers (model F) keep the row kernel.
     const int unb = vv == 4 ? UNB4 : UNB;
-    if (g_kp_bn_flat && W < unb * (TPB / (C / vv)) && H >= 2) {
-        const long long frows = (long long)N * H;
-        const int frpb = rows_per_block(frows, W * (C / 8), kp_device_cus(), mode == 0 ? bn_blocks_cap(1, KP_BN_REDUCE_BLOCKS) : bn_blocks_cap(2, KP_BN_APPLY_BLOCKS));
+    const long long frows = (long long)N * H;
+    const int frpb = rows_per_block(frows, W * (C / 8), kp_device_cus(), mode == 0 ? bn_blocks_cap(1, KP_BN_REDUCE_BLOCKS) : bn_blocks_cap(2, KP_BN_APPLY_BLOCKS));
+    // (the flat kernel splits a pixel slot into row / column with a float multiply that is exact for slot indices below 2^20:
+    //  a workgroup with more pixels than that -- a capped grid over a very large batch -- takes the row kernel)
+    if (g_kp_bn_flat && W < unb * (TPB / (C / vv)) && H >= 2 && (long long)frpb * W < (1LL << 20)) {
         const unsigned fgrid = (unsigned)((frows + frpb - 1) / frpb);
         if (mode == 0) kp_set_last_rows(fgrid);
         KP_QUERY_RETURN();

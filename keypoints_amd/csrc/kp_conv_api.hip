@@ -40,6 +40,13 @@ int kp_conv_wino_launch(const void*, const void*, const float*, void*, float*, i
 int kp_conv_wino_pack_impl(const void*, void*, int, int, hipStream_t);
 int kp_conv_ring_dgrad(const void*, const void*, void*, int, int, int, int, int, hipStream_t);
 
+long long kp_conv_patch_bred_rows(int, int, int, int, int);
+long long kp_conv_ring_bred_rows(int, int, int);
+int kp_conv_patch_launch_bred(const void*, const void*, void*, const void*, const float*, const float*, const float*, const float*, float, float*,
+                              int, int, int, int, int, hipStream_t);
+int kp_conv_ring_dgrad_bred(const void*, const void*, void*, const void*, const float*, const float*, const float*, const float*, float, float*,
+                            int, int, int, int, int, hipStream_t);
+extern kp_knob_t g_kp_bred_patch;   // kp_config(KP_CFG_BRED_PATCH, v): 1 (default) the matrix-core layers' data gradient offers the fused form
 extern kp_knob_t g_kp_wgrad_patch;
 
 static int use_mfma() {
@@ -213,7 +220,8 @@ int kp_conv_wgrad_bnin(const void* yprev, const float* mean, const float* invstd
 // of kp_conv_dgrad_bnred_rows (= kp_last_rows() after the call), at most ceil(N * (H + 2) * (W + 2) / 64) rows of [2][C].
 int kp_conv_dgrad_bnred_supported(int N, int H, int W, int K, int C, int dtype) {
     if (dtype != KP_H16 || !use_mfma() || N <= 0 || H <= 0 || W <= 0) return 0;
-    return kp_conv_small_dgrad_bnred_ok(N, H, W, K, C);
+    if (kp_conv_small_dgrad_bnred_ok(N, H, W, K, C)) return 1;
+    return g_kp_bred_patch && H >= 16 && W >= 16 && kp_conv_patch_bred_rows(N, H, W, K, C) > 0 ? 1 : 0;
 }
 
 int kp_conv_dgrad_bnred(const void* dy, const void* w_dgrad, void* gx, const void* yred, const float* mean, const float* invstd,
@@ -225,9 +233,21 @@ int kp_conv_dgrad_bnred(const void* dy, const void* w_dgrad, void* gx, const voi
     if (!kp_conv_dgrad_bnred_supported(N, H, W, K, C, dtype)) return KP_E_UNSUPPORTED;
     const double flops = 2.0 * N * (double)H * W * C * K * 9;
     const double bytes = 2.0 * ((double)N * (H + 4) * (W + 4) * K + (double)N * (H + 2) * (W + 2) * C + (double)N * H * W * C + 9.0 * C * K);
-    ProfScope ps(KP_PROF_CONV_SMALL, flops, (hipStream_t)stream, bytes);
-    const int rc = kp_conv_small_dgrad_bnred(dy, w_dgrad, gx, yred, mean, invstd, gamma, beta, slope, partials, N, H, W, K, C, (hipStream_t)stream);
-    ps.done(KP_PROF_CONV_SMALL);
+    if (kp_conv_small_dgrad_bnred_ok(N, H, W, K, C)) {
+        ProfScope ps(KP_PROF_CONV_SMALL, flops, (hipStream_t)stream, bytes);
+        const int rc = kp_conv_small_dgrad_bnred(dy, w_dgrad, gx, yred, mean, invstd, gamma, beta, slope, partials, N, H, W, K, C, (hipStream_t)stream);
+        ps.done(KP_PROF_CONV_SMALL);
+        return rc;
+    }
+    // matrix-core layers: interior (LDS-patch kernel, rows first) + border ring (its rows behind them)
+    const long long prows = kp_conv_patch_bred_rows(N, H, W, K, C);
+    kp_set_last_rows(prows + kp_conv_ring_bred_rows(N, H, W));
+    KP_QUERY_RETURN();
+    ProfScope ps(KP_PROF_CONV_MFMA, flops, (hipStream_t)stream, bytes);
+    int rc = kp_conv_patch_launch_bred(dy, w_dgrad, gx, yred, mean, invstd, gamma, beta, slope, partials, N, H, W, K, C, (hipStream_t)stream);
+    if (rc == KP_OK)
+        rc = kp_conv_ring_dgrad_bred(dy, w_dgrad, gx, yred, mean, invstd, gamma, beta, slope, partials + prows * 2 * C, N, H, W, K, C, (hipStream_t)stream);
+    ps.done(KP_PROF_CONV_MFMA);
     return rc;
 }
 

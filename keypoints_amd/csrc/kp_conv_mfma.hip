@@ -90,11 +90,18 @@ __device__ __forceinline__ void pix_decode(long long m, int Ho, int Wo, int grp,
     }
 }
 
-template <int BN, int MODE>
+// BRED (MODE 2 only): the ring's share of the first pass of the PRODUCING layer's BatchNorm backward (see kp_conv_patch.hip):
+// every ring pixel (p, q) of the padded domain meets the factors of its clamped source pixel (clamp(p-1), clamp(q-1)) of
+// `yred` [N][Ho-2][Wo-2][K]; rows [2][K] per 64 ring pixels (tile-global numbering; rows of a group's empty tail stay as the
+// launcher zeroed them).
+struct RingBred { const h16_t* yred; const float *mean, *invstd, *gamma, *beta; float slope; };
+
+template <int BN, int MODE, bool BRED = false>
 __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
                                                          const float* __restrict__ bias, h16_t* __restrict__ y,
                                                          float* __restrict__ partials, int N, int Hi, int Wi, int C,
-                                                         int K, int mtiles, int ktiles) {
+                                                         int K, int mtiles, int ktiles, const RingBred rb = RingBred{}) {
+    static_assert(!BRED || MODE == 2, "BRED: the data gradient's ring");
     constexpr int WN = BN / 2;            // channels per wave
     constexpr int TN = WN / 32;           // 32-channel MFMA tiles per wave (2 or 1)
     constexpr int XBYTES = BM * ROWB, WBYTES = BN * ROWB, STAGE = XBYTES + WBYTES;
@@ -115,6 +122,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const h16_t* __restrict
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
     }
     int mt = tile / ktiles;
+    const int mt_global = mt;
     const int kt = tile % ktiles;
     int grp = 0;
     if (MODE == 2) {   // m-tiles are laid out group after group; every group is padded to whole tiles
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const h16_t* __restrict
     }
 
     // ---- epilogue: D[k_out][pixel]; lane: pixel = fr, k_out = 8*(reg>>2) + 4*fh + (reg&3)
-    const long long prow = m0 / 64 + wm;   // statistics row of this wave (64 pixels)
+    const long long prow = BRED ? (long long)mt_global * 2 + wm : m0 / 64 + wm;   // statistics row of this wave (64 pixels)
 #pragma unroll
     for (int a = 0; a < TN; ++a) {
         const int kb = k0 + wn * WN + a * 32;
@@ -224,11 +232,15 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const h16_t* __restrict
         for (int b = 0; b < 2; ++b) {
             const long long m = m0 + wm * 64 + b * 32 + fr;
             const bool ok = m < M;
-            long long opix = m;
+            long long opix = m, rpix = 0;
             if (MODE != 0 && ok) {
                 long long n; int p, q;
                 pix_decode<MODE>(m, Ho, Wo, grp, n, p, q);
                 opix = (n * Ho + p) * Wo + q;
+                if constexpr (BRED) {   // clamped source pixel in the unpadded map [Ho - 2][Wo - 2]
+                    const int sp = p < 1 ? 0 : (p > Ho - 2 ? Ho - 3 : p - 1), sqx = q < 1 ? 0 : (q > Wo - 2 ? Wo - 3 : q - 1);
+                    rpix = (n * (Ho - 2) + sp) * (Wo - 2) + sqx;
+                }
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -237,13 +249,30 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const h16_t* __restrict
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[e] = acc[a][b][g * 4 + e] + (bias ? bias[kq + e] : 0.f);
-                    if (ok) { s[g * 4 + e] += v[e]; sq[g * 4 + e] += v[e] * v[e]; }
+                    if (!BRED && ok) { s[g * 4 + e] += v[e]; sq[g * 4 + e] += v[e] * v[e]; }
                 }
                 if (ok) {
                     uint2 pk;
                     pk.x = pack_h16x2(v[0], v[1]);
                     pk.y = pack_h16x2(v[2], v[3]);
                     *reinterpret_cast<uint2*>(y + opix * K + kq) = pk;
+                    if constexpr (BRED) {   // on the stored (rounded) values, the expressions of kp_bn_act_bwd_reduce
+                        float gr[4], yv[4];
+                        unpack_h16x2(pk.x, gr[0], gr[1]); unpack_h16x2(pk.y, gr[2], gr[3]);
+                        const uint2 yw = *reinterpret_cast<const uint2*>(rb.yred + rpix * K + kq);
+                        unpack_h16x2(yw.x, yv[0], yv[1]); unpack_h16x2(yw.y, yv[2], yv[3]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const bool aff = rb.mean != nullptr;
+                            const float mu = aff ? rb.mean[kq + e] : 0.f, is = aff ? rb.invstd[kq + e] : 1.f;
+                            const float ga = aff ? rb.gamma[kq + e] : 1.f, be = aff ? rb.beta[kq + e] : -0.f;
+                            const float xh = (yv[e] - mu) * is;
+                            const float z = xh * ga + be;
+                            const float gh = gr[e] * act_grad(z, rb.slope);
+                            s[g * 4 + e] += gh;
+                            sq[g * 4 + e] += gh * xh;
+                        }
+                    }
                 }
             }
         }
@@ -300,7 +329,7 @@ extern kp_knob_t g_kp_conv_patch;   // kp_api.hip: kp_config(KP_CFG_CONV_PATCH, 
 static int patch_mode() {   // 0 forces the linear implicit-GEMM kernel, 1 the first-generation patch kernel (A/B measurements)
     if (g_kp_conv_patch < 0) {
         const char* e = getenv("KP_CONV_PATCH");
-        g_kp_conv_patch = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
+        g_kp_conv_patch = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;   // (the pair kernel measured no faster: opt-in)
     }
     return g_kp_conv_patch;
 }
@@ -350,4 +379,29 @@ int kp_conv_dgrad_mfma(const void* dy, const void* w, void* gx, int N, int H, in
 int kp_conv_ring_dgrad(const void* dy, const void* w, void* gx, int N, int H, int W, int K, int C, hipStream_t st) {
     if (K % BK != 0 || C % 64 != 0) return KP_E_UNSUPPORTED;
     return launch_linear<2>(dy, w, nullptr, gx, nullptr, N, H + 4, W + 4, K, C, st);
+}
+
+// The ring with the BatchNorm-backward sums of the layer below (BRED): rows = kp_conv_ring_bred_rows, written into `rpart`
+// (zeroed here first: a group's last tile may leave its second row untouched).
+long long kp_conv_ring_bred_rows(int N, int H, int W) {
+    const long long s01 = (long long)N * (W + 2), s23 = (long long)N * H;
+    return 2 * (2 * ((s01 + BM - 1) / BM) + 2 * ((s23 + BM - 1) / BM));
+}
+int kp_conv_ring_dgrad_bred(const void* dy, const void* w, void* gx, const void* yred, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, float slope, float* rpart, int N, int H, int W, int K, int C,
+                            hipStream_t st) {
+    if (K % BK != 0 || C % 64 != 0) return KP_E_UNSUPPORTED;
+    const int Hi = H + 4, Wi = W + 4;
+    const long long mtiles = kp_conv_ring_bred_rows(N, H, W) / 2;
+    const int bn = (C % 128 == 0) ? 128 : 64;
+    const int ktiles = C / bn;
+    if (mtiles * ktiles > 0x7fffffffLL) return KP_E_UNSUPPORTED;
+    if (hipMemsetAsync(rpart, 0, (size_t)mtiles * 2 * 2 * C * sizeof(float), st) != hipSuccess) return KP_E_LAUNCH;
+    const unsigned grid = (unsigned)(mtiles * ktiles);
+    const RingBred rb{(const h16_t*)yred, mean, invstd, gamma, beta, slope};
+    if (bn == 128)
+        conv3x3_mfma_k<128, 2, true><<<grid, TPB, 0, st>>>((const h16_t*)dy, (const h16_t*)w, nullptr, (h16_t*)gx, rpart, N, Hi, Wi, K, C, (int)mtiles, ktiles, rb);
+    else
+        conv3x3_mfma_k<64, 2, true><<<grid, TPB, 0, st>>>((const h16_t*)dy, (const h16_t*)w, nullptr, (h16_t*)gx, rpart, N, Hi, Wi, K, C, (int)mtiles, ktiles, rb);
+    return kp_check_launch("conv3x3_ring_bred");
 }

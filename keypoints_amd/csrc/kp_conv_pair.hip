@@ -403,6 +403,8 @@ static bool pair_plan(const float* stats, int N, int Hib, int Wib, int H, int W,
     // statistics: one set of 4 rows per workgroup, which must then keep ONE k-tile over all of its tiles
     // (more than one tile per workgroup: its stride through the ids must be a multiple of the k-tile count)
     if (stats && ntiles > grid && !(((grid / 8) % ktiles) == 0 && (grid % ktiles) == 0)) return false;
+    // the caller's statistics buffer holds ceil(N H W / 64) rows (include/kp_hip.h): 4 rows per workgroup must fit
+    if (stats && (long long)grid * 4 > ((long long)N * H * W + 63) / 64) return false;
     return true;
 }
 

@@ -20,6 +20,7 @@
 // MFMA operands are swapped ("A" = weights, "B" = pixels): a lane's accumulator registers hold 4 consecutive
 // output channels of one pixel -> packed 8-byte bf16 stores into the NHWC output.
 // BatchNorm batch statistics (vgg.py:35) fall out of the epilogue as per-64-pixel partial rows (no atomics).
+#include <stdlib.h>
 #include "kp_mfma_util.h"
 
 namespace {
@@ -43,6 +44,8 @@ struct PatchArgs {
     int linear;           // 1: tile ids in time order (step i of the grid covers ids [i*grid, (i+1)*grid)); 0: 8 XCD ranges
     int compact;          // 1: BN partial sums are accumulated per workgroup (rows = 4 * grid); 0: 4 rows per pixel tile
     long long* trace;     // optional: s_memtime stamps of workgroup 0 / wave 0 (512 entries), measurement only
+    // BRED (data gradient of layer L that also leaves the first pass of layer L - 1's BatchNorm backward, see below)
+    const h16_t* yred; const float *mean, *invstd, *gamma, *beta; float slope; float* rpart;
 };
 
 // Persistent workgroups: the (tile, 64-channel chunk, tap) steps of all tiles of a workgroup form ONE software
@@ -56,8 +59,18 @@ struct PatchArgs {
 //     MFMA kk=2,3                                    ||  ds_read fragments kk=0,1 of step t+1
 // STATS: the epilogue also accumulates the BatchNorm partial sums (forward); the data-gradient launches leave them out.
 // TRACE: s_memtime stamps for tools/probes/trace.py (measurement build of the same kernel).
-template <int BN, bool STATS, bool TRACE>
+// BRED: this launch is the data gradient of layer L (interior of the padded domain, offset (1, 1)) and its output gx is the incoming
+//       gradient of layer L - 1's BatchNorm + activation: the FIRST pass of that backward (kp_bn_act_bwd_reduce: sums over the batch
+//       of gh = g act'(z) and gh xhat, with z / xhat from layer L - 1's conv output `yred` [N][H][W][K]) runs in the epilogue, on the
+//       stored (rounded) gradient values, at the point where a lane holds 16 bytes = 8 consecutive channels of a pixel for its
+//       coalesced store: the lane's channels are the same for every store of the launch, so their constants and the two sums
+//       per channel live in registers; the matching 16 bytes of yred are requested at the start of the epilogue.  Folding (the
+//       adjoint of the replicate pad) is not needed: sum_ij fold(g)_ij f_ij = sum_pq g_pq f[clamp(p-1)][clamp(q-1)], and an
+//       interior pixel (p, q) of the padded domain IS source pixel (p - 1, q - 1); the border ring adds its share in its own
+//       kernel (kp_conv_mfma.hip).  Rows: 4 per workgroup (one per pixel-row group), zero outside the workgroup's k-tile.
+template <int BN, bool STATS, bool TRACE, bool BRED = false>
 __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
+    static_assert(!BRED || (!STATS && !TRACE), "BRED: data-gradient form");
     constexpr int WBYTES = BN * ROWB;
     constexpr int NWI = BN / 64;          // weight DMA instructions per wave per step
     constexpr int WN = BN / 2;            // channels per wave
@@ -65,7 +78,8 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     constexpr int OFF_W = 2 * PBYTES, OFF_DUMMY = OFF_W + NWBUF * WBYTES;
     constexpr int OFF_BIAS = OFF_DUMMY + 1024;            // [8 waves][64] fp32: each wave's own output-channel biases
     constexpr int OFF_TRACE = OFF_BIAS + NWAVE * 64 * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_TRACE + (TRACE ? 4096 : 16)];
+    constexpr int OFF_RK = OFF_TRACE + 16;                 // BRED: [2 channel halves][8 chunks][mean, invstd, gamma, beta][8] fp32 (2 KB)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_TRACE + (TRACE ? 4096 : (BRED ? 16 + 2048 : 16))];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,6 +96,10 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     int tile = A.linear ? xcd * per_xcd + jb : xcd * Q + jb;
     if (STATS && A.compact) {   // this workgroup's 4 rows: zero everywhere, its own k-tile columns are set at the end
         float* rowp = A.partials + (long long)blockIdx.x * 4 * 2 * K;
+        for (int i = tid; i < 4 * 2 * K; i += TPB) rowp[i] = 0.f;
+    }
+    if (BRED) {   // this workgroup's 4 rows of the BatchNorm-backward sums: zero everywhere, its own k-tile columns are set at the end
+        float* rowp = A.rpart + (long long)blockIdx.x * 4 * 2 * K;
         for (int i = tid; i < 4 * 2 * K; i += TPB) rowp[i] = 0.f;
     }
     if (tile >= tile_hi) return;
@@ -216,6 +234,39 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     }
     constexpr int PPI = 64 / CPP;          // pixels per store instruction
     const int st_voff = ((lane / CPP) * K + (lane % CPP) * 8) * 2;   // lane part of the output address (bytes)
+    constexpr int NST = 32 * CPP / 64;     // store instructions per 32-pixel block
+    // BRED: the lane's 8 channels (k-tile of the workgroup + wn * WN + (lane % CPP) * 8): their running sums in registers, their
+    // constants in LDS (32 more persistent registers beside the 64 accumulators do not fit; read back once per tile)
+    float rsb[BRED ? 8 : 1], rsg[BRED ? 8 : 1];
+    auto bred8 = [&](const KpBnIn8& rk, const u32x4& gw, const u32x4& yw) {
+        float g[8], yv[8];
+        unpack_h16x2(gw[0], g[0], g[1]); unpack_h16x2(gw[1], g[2], g[3]); unpack_h16x2(gw[2], g[4], g[5]); unpack_h16x2(gw[3], g[6], g[7]);
+        unpack_h16x2(yw[0], yv[0], yv[1]); unpack_h16x2(yw[1], yv[2], yv[3]); unpack_h16x2(yw[2], yv[4], yv[5]); unpack_h16x2(yw[3], yv[6], yv[7]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {   // the expressions of kp_bn_act_bwd_reduce (and of kp_conv_small.hip's BRED)
+            const float xh = (yv[e] - rk.mu[e]) * rk.is[e];
+            const float z = xh * rk.ga[e] + rk.be[e];
+            const float gh = g[e] * act_grad(z, A.slope);
+            rsb[e] += gh;
+            rsg[e] += gh * xh;
+        }
+    };
+    // BRED: the tile's window of layer L - 1's conv output (unpadded [H][W]) in the store's lane layout, requested during the tile's
+    // LAST chunk (two steps before they could stall a barrier) so that the epilogue finds them in registers: requested in the
+    // epilogue itself, all workgroups ask for them at once and the chip waits ~3 us per tile round for 17 MB
+    u32x4 yq[BRED ? 2 : 1][BRED ? NST : 1];
+    constexpr int YTAP = 2;   // the tap of the last chunk behind whose DMA issue the requests go
+    auto issue_y = [&](const TileRef& t) {
+        if constexpr (BRED) {
+            const h16_t* rbase = A.yred + ((((long long)t.n * A.H + t.oy0 + wm * 4) * A.W) + t.ox0) * (long long)K + t.k0 + wn * WN;
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)rbase, 0, 0x7ffffffe, 0x00020000);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < NST; ++i)
+                    yq[b][i] = __builtin_amdgcn_raw_buffer_load_b128(rr, st_voff, ((b * 2 + ((i * PPI) >> 4)) * A.W + ((i * PPI) & 15)) * K * 2, 0);
+        }
+    };
     auto epilogue = [&](const TileRef& t, int free_pb) {
         unsigned char* stg = smem + free_pb * PBYTES + wave * (32 * WN * 2);
         const long long prow = (long long)t.pt * 4 + wm;   // statistics row of this wave (64 pixels)
@@ -224,6 +275,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         h16_t* ybase = A.y + ((((long long)t.n * A.Hob + t.oy0 + wm * 4 + A.ooff) * A.Wob) + t.ox0 + A.ooff) * (long long)K +
                         t.k0 + wn * WN;
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, 0x7ffffffe, 0x00020000);
+        u32x4 gq[BRED ? 2 : 1][BRED ? NST : 1];
         if constexpr (STATS) if (!A.compact) {   // per-tile rows: start from zero
 #pragma unroll
             for (int a = 0; a < TN; ++a)
@@ -259,8 +311,23 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                     const u32x4 vv = *reinterpret_cast<const u32x4*>(stg + px * (WN * 2) + ((c16 ^ (px & (CPP - 1))) << 4));
                     const int soff = ((b * 2 + ((i * PPI) >> 4)) * A.Wob + ((i * PPI) & 15)) * K * 2;
                     __builtin_amdgcn_raw_buffer_store_b128(vv, yr, st_voff, soff, 0);
+                    if constexpr (BRED) gq[b][i] = vv;
                 }
             }
+        }
+        if constexpr (BRED) {   // behind all stores of the tile (the accumulator registers are free, the requests are ~1000 cycles old)
+            __builtin_amdgcn_sched_barrier(0);
+            KpBnIn8 rk;
+            const float* tab = reinterpret_cast<const float*>(smem + OFF_RK) + (wn * 8 + (lane % CPP)) * 32;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { rk.mu[e] = tab[e]; rk.is[e] = tab[8 + e]; rk.ga[e] = tab[16 + e]; rk.be[e] = tab[24 + e]; }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < NST; ++i) {
+                    bred8(rk, gq[b][i], yq[b][i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         }
         if constexpr (STATS) if (!A.compact && !(dbg & 2)) {
 #pragma unroll
@@ -311,6 +378,18 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         }
     };
     load_bias(cur);
+    if constexpr (BRED) {   // (one k-tile per workgroup: the launcher checks it; the prologue's barrier publishes the table)
+        if (wm == 0 && lane < CPP) {
+            KpBnIn8 rk;
+            const KpBnIn bnr{A.mean, A.invstd, A.gamma, A.beta, A.slope};
+            rk.load(bnr, cur.k0 + wn * WN + lane * 8);
+            float* tab = reinterpret_cast<float*>(smem + OFF_RK) + (wn * 8 + lane) * 32;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { tab[e] = rk.mu[e]; tab[8 + e] = rk.is[e]; tab[16 + e] = rk.ga[e]; tab[24 + e] = rk.be[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rsb[e] = rsg[e] = 0.f;
+    }
 
     // ---- prologue: patch of chunk 0, weight tiles of steps 0..2 of the first tile -------------------------
 #pragma unroll
@@ -369,7 +448,12 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                 // slices): the DMA count after a barrier is a compile-time constant per tap (dummy targets keep it
                 // so).  Right after an epilogue everything older was already drained and its stores must not be
                 // waited for here.
-                if (!(tap == 0 && after_epi) && !(dbg & 16)) wait_vm<NWI + (((tap + 8) % 9) < PSLICES ? 1 : 0)>();
+                if (!(tap == 0 && after_epi) && !(dbg & 16)) {
+                    constexpr int ND = NWI + (((tap + 8) % 9) < PSLICES ? 1 : 0);
+                    // BRED: the 2 NST requests for layer L - 1's conv output sit in the queue between the DMAs of tap YTAP and YTAP + 1
+                    if (BRED && last_ch && (tap == YTAP + 1 || tap == YTAP + 2)) wait_vm<ND + (BRED ? 2 * NST : 0)>();
+                    else wait_vm<ND>();
+                }
                 stamp();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -409,6 +493,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                     unsigned char* dst = (more_p && ii < PINSTR) ? smem + (pbi ^ 1) * PBYTES + ii * 1024 : smem + OFF_DUMMY;
                     if (!(TRACE && (dbg & 128))) dma16(last_ch ? xrn : xr, dst, pvoff[tap], last_ch ? 0 : (ch + 1) * 128);
                 }
+                if constexpr (BRED && tap == YTAP) if (last_ch) issue_y(cur);
                 __builtin_amdgcn_sched_barrier(0);
                 load_frag(f0, nxb, nwb, ns, 0);
                 mma(f3);
@@ -449,6 +534,25 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
             }
         }
     }
+    if constexpr (BRED) {   // lanes l, l + CPP, l + 2 CPP, ... hold the same 8 channels: fold them, lanes 0 .. CPP-1 write
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = CPP; o < 64; o <<= 1) {
+                rsb[e] += __shfl_xor(rsb[e], o, 64);
+                rsg[e] += __shfl_xor(rsg[e], o, 64);
+            }
+        }
+        if (lane < CPP) {
+            const long long prow = (long long)blockIdx.x * 4 + wm;
+            const int kc = cur.k0 + wn * WN + lane * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                A.rpart[(prow * 2 + 0) * K + kc + e] = rsb[e];
+                A.rpart[(prow * 2 + 1) * K + kc + e] = rsg[e];
+            }
+        }
+    }
     if constexpr (TRACE) if ((dbg & 0x700) && dummy[0] + dummy[1] + dummy[2] + dummy[3] + dummy[4] + dummy[5] + dummy[6] + dummy[7] == 12345.678f)
         A.partials[0] = dummy[0];   // keeps the measurement FMAs alive
     if constexpr (TRACE) if (tracing && lane == 0)
@@ -456,6 +560,55 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
 }
 
 }  // namespace
+
+// The data gradient's interior with the BatchNorm-backward sums of the layer below in its epilogue (BRED above).  gx window as in
+// kp_conv_patch_launch(ioff = ooff = 1); `yred` [N][H][W][C]; rows written into `rpart`: 4 per workgroup = the return value of
+// kp_conv_patch_bred_rows.  KP_E_UNSUPPORTED where a workgroup would change its k-tile between tiles (its constants and sums are
+// per k-tile) or the shape has no patch tiling.
+static bool patch_bred_plan(int N, int H, int W, int K, int C, int& grid, int& ktiles, int& ntiles) {
+    if (K % 64 != 0 || C % 64 != 0 || H % TS != 0 || W % TS != 0 || H <= 0 || W <= 0) return false;
+    if ((long long)(PW + 1) * (W + 4) * K * 2 >= 0x7fffffffLL || 128LL * 9 * K * 2 + 9LL * K * 2 >= 0x7fffffffLL) return false;
+    const long long ptiles = (long long)N * (H / TS) * (W / TS);
+    const int bn = (C % 128 == 0) ? 128 : 64;
+    // 128-channel output tiles: the kernel stands at 179 registers; 16 running sums + 32 registers of prefetched yred + the epilogue's
+    // temporaries push it over the 256 of two waves per SIMD, and ONE spill reload inside the (tap, chunk) loop -- a VMEM
+    // instruction in front of the counted vmcnt waits -- costs 35 % (tools/probes/bred_layers.py: 545 + 117 us separate, 863 us
+    // fused at 256 -> 256 @ 64 x 64; with the requests issued in the epilogue instead: no spill in the loop, 698 us: the chip waits
+    // for 17 MB per tile round).  Only the 64-channel tile (131 registers) takes the fused form: 380 + 118 -> 446 us at
+    // 64 -> 128 @ 128 x 128.  kp_config(KP_CFG_BRED_PATCH, 2) offers the 128-channel form too (tests, measurements).
+    { extern kp_knob_t g_kp_bred_patch; if (bn == 128 && g_kp_bred_patch < 2) return false; }
+    ktiles = C / bn;
+    if (ptiles * ktiles > 0x7fffffffLL) return false;
+    ntiles = (int)(ptiles * ktiles);
+    int cus = kp_device_cus();
+    if (cus <= 0) cus = 256;
+    grid = (cus / 8) * 8;
+    if (grid < 8) grid = 8;
+    const int need = ((ntiles + 7) / 8) * 8;
+    if (grid > need) grid = need;
+    return ntiles <= grid || (((grid / 8) % ktiles) == 0 && (grid % ktiles) == 0);
+}
+long long kp_conv_patch_bred_rows(int N, int H, int W, int K, int C) {
+    int grid, ktiles, ntiles;
+    return patch_bred_plan(N, H, W, K, C, grid, ktiles, ntiles) ? (long long)grid * 4 : 0;
+}
+int kp_conv_patch_launch_bred(const void* dy, const void* w, void* gx, const void* yred, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, float slope, float* rpart, int N, int H, int W, int K, int C,
+                              hipStream_t st) {
+    int grid, ktiles, ntiles;
+    if (!patch_bred_plan(N, H, W, K, C, grid, ktiles, ntiles)) return KP_E_UNSUPPORTED;
+    PatchArgs a;
+    a.x = (const h16_t*)dy; a.w = (const h16_t*)w; a.bias = nullptr; a.y = (h16_t*)gx; a.partials = nullptr;
+    a.Hib = H + 4; a.Wib = W + 4; a.ioff = 1; a.Hob = H + 2; a.Wob = W + 2; a.ooff = 1; a.H = H; a.W = W;
+    a.C = K; a.K = C;   // kernel roles: input channels = the gradient's K, output channels = C
+    a.dbg = 0; a.trace = nullptr;
+    { extern kp_knob_t g_kp_walk; a.linear = (g_kp_walk & KP_WALK_CONV_LINEAR) ? 1 : 0; }
+    a.ktiles = ktiles; a.ntiles = ntiles; a.compact = 0;
+    a.yred = (const h16_t*)yred; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.slope = slope; a.rpart = rpart;
+    if (C % 128 == 0) conv3x3_patch_k<128, false, false, true><<<grid, TPB, 0, st>>>(a);
+    else conv3x3_patch_k<64, false, false, true><<<grid, TPB, 0, st>>>(a);
+    return kp_check_launch("conv3x3_patch_bred");
+}
 
 // Valid 3x3 correlation restricted to a (H x W) window of the output whose top-left output pixel is
 // (ooff, ooff) of y[N][Hob][Wob][K]; it reads x[N][Hib][Wib][C] starting at (ioff, ioff).
@@ -470,6 +623,7 @@ int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* 
     a.x = (const h16_t*)x; a.w = (const h16_t*)w; a.bias = bias; a.y = (h16_t*)y; a.partials = stats;
     a.Hib = Hib; a.Wib = Wib; a.ioff = ioff; a.Hob = Hob; a.Wob = Wob; a.ooff = ooff; a.H = H; a.W = W;
     a.C = C; a.K = K;
+    a.yred = nullptr; a.mean = a.invstd = a.gamma = a.beta = nullptr; a.slope = 0.f; a.rpart = nullptr;
     { extern kp_knob_t g_kp_debug; extern kp_knob_ptr_t g_kp_trace; a.dbg = g_kp_debug; a.trace = g_kp_trace; }
     { extern kp_knob_t g_kp_walk; a.linear = (g_kp_walk & KP_WALK_CONV_LINEAR) ? 1 : 0; }
     const long long ptiles = (long long)N * (H / TS) * (W / TS);

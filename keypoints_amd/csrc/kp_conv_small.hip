@@ -1186,14 +1186,16 @@ bool small_ch(int v) { return v == 16 || v == 32; }
 static const int g_kp_wg16 = getenv("KP_WG16") ? atoi(getenv("KP_WG16")) : 7;
 
 // band plan of the 16 x 16 x 32 weight gradient: rows per band (0: not its shape / the rows do not fit), grid = min(bands, 2 per CU)
-static unsigned small16_plan(int N, int Ho, int Wo, int C, int K, int& R, int& bpi) {
+// `allow_w3`: the three-wave variant's staging capacities may be planned for (the launch site must then launch that variant);
+// the first-layer launcher always runs the plain six-wave kernel and plans with its capacities
+static unsigned small16_plan(int N, int Ho, int Wo, int C, int K, int& R, int& bpi, bool allow_w3 = true) {
     if (!g_kp_wg16 || !small_ch(C) || !small_ch(K) || (C == 32 && K == 32 && !(g_kp_wg16 & 2))) return 0;
     const int Wp = (Wo + 31) & ~31;
     const long long xrow = (long long)(Wp + 2) * C * 2, drow = (long long)Wp * K * 2;
     long long r = (W16_LDS - 2 * xrow) / (xrow + drow);
     if (r > Ho) r = Ho;
     if (r > 16) r = 16;
-    const bool both = C == 32 && K == 32, w3 = (g_kp_wg16 & 4) && (C == 32) != (K == 32);
+    const bool both = C == 32 && K == 32, w3 = allow_w3 && (g_kp_wg16 & 4) && (C == 32) != (K == 32);
     const int slx = both ? w16_slx(32, 32) : (C == 32 ? w16_slx(16, 32, w3) : (K == 32 ? w16_slx(32, 16, w3) : w16_slx(16, 16)));
     const int sld = both ? w16_sld(32, 32) : (C == 32 ? w16_sld(16, 32, w3) : (K == 32 ? w16_sld(32, 16, w3) : w16_sld(16, 16)));
     const long long tpb = both ? w16_waves(32, 32) * 64 : (w3 ? 192 : W16_TPB);
@@ -1387,13 +1389,13 @@ static unsigned small_wgrad_plan(int N, int Ho, int C, int K, int& rpw) {
 long long kp_conv_small_first_wgrad_partials(int N, int Ho, int Wo, int Cin, int K) {
     int R, bpi;
     if (Cin < 1 || Cin > 4 || !g_kp_small_band) return 0;
-    return small16_plan(N, Ho, Wo, 16, K, R, bpi);
+    return small16_plan(N, Ho, Wo, 16, K, R, bpi, false);
 }
 int kp_conv_small_first_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int Cin, int K, int dy_pad,
                               hipStream_t st) {
     int R, bpi;
     if (Cin < 1 || Cin > 4 || !g_kp_small_band) return KP_E_UNSUPPORTED;
-    const unsigned grid = small16_plan(N, Ho, Wo, 16, K, R, bpi);
+    const unsigned grid = small16_plan(N, Ho, Wo, 16, K, R, bpi, false);   // (W16_TPB threads, the plain variant's staging: same as launched below)
     if (!grid) return KP_E_UNSUPPORTED;
     const long long bands = (long long)N * bpi;
 #define KP_W16F(Kv, CINv) wgrad3x3_small16_k<Kv, 16, false, CINv><<<grid, W16_TPB, 0, st>>>((const h16_t*)x, (const h16_t*)dy, scratch, Ho, Wo, dy_pad, R, bpi, bands, (long long)Kv * 9 * CINv, BnIn{})

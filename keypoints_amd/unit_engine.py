@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import call, ptr
+from ._lib import call, ptr, try_call
 from . import runtime
 from .runtime import f32c, precision_dtype, require_device, stream_ptr
 
@@ -121,6 +121,10 @@ def _pack_unit(plan, Cin, Cp0, record, dev, tdt, code, st):
 import os as _os
 _NO_PREPACK = bool(_os.environ.get('KP_NO_PREPACK'))   # measurement: every Unit packs at its own first call again
 _ABL = set(filter(None, _os.environ.get('KP_ABLATE', '').split(',')))   # measurement ONLY (wrong gradients): 'wgrad' skips the 3x3 weight-gradient launches (tools/probes/ablate.sh)
+if _ABL:
+    import warnings as _warnings
+    _warnings.warn(f'KP_ABLATE={",".join(sorted(_ABL))}: measurement mode -- the 3x3 weight gradients are NOT computed (their arena slots '
+                   'stay zero); do not train with this set', RuntimeWarning)
 
 
 def prepack(units_cin):
@@ -235,6 +239,14 @@ def _tail_dims(H, W, tail):
     if tail == 'U':
         return 2 * H, 2 * W
     return H, W
+
+
+def _materialise(fin, N, H, W, C, pad, tdt, code, st):
+    """The activation a fused consumer would have formed on its load path, written out: kp_bn_act_fwd of the saved conv output
+    (`fin`: see UnitFunction.forward) with a replicate border of `pad`."""
+    a = torch.empty(N, H + 2 * pad, W + 2 * pad, C, device=fin['y'].device, dtype=tdt)
+    call('kp_bn_act_fwd', ptr(fin['y']), *fin['bn'], fin['slope'], TAILS[None], ptr(a), pad, None, N, H, W, C, code, st)
+    return a
 
 
 class UnitFunction(torch.autograd.Function):
@@ -380,9 +392,15 @@ class UnitFunction(torch.autograd.Function):
         hws = torch.empty(_lib.lib().kp_head_bwd_ws_floats(N, Hh, Wh, Ch, Kout, code), device=dev, dtype=torch.float32)
         hgrads = (ptr(g), ptr(gv[id(hconv.weight)]), ptr(gv[id(hconv.bias)]) if hconv.bias is not None else None, ptr(hws))
         if isinstance(a_last, dict):   # the forward's fused form: the head's input is recomputed from the conv output
-            call('kp_head_bwd_bnin', ptr(gout), ptr(out), ptr(a_last['y']), *a_last['bn'], a_last['slope'], ptr(hconv.weight),
-                 head['slope'], *hgrads, N, Hh, Wh, Ch, Kout, code, st)
-        else:
+            if not try_call('kp_head_bwd_bnin', ptr(gout), ptr(out), ptr(a_last['y']), *a_last['bn'], a_last['slope'], ptr(hconv.weight),
+                            head['slope'], *hgrads, N, Hh, Wh, Ch, Kout, code, st):
+                # declined in the backward although the forward's shape query accepted (unaligned gradient tensors, a knob that
+                # changed in between): rebuild the activation the forward never wrote and run the plain kernel
+                a_last = _materialise(a_last, N, Hh, Wh, Ch, 0, tdt, code, st)
+        if not isinstance(a_last, dict):
+            if isinstance(ctx.head_in, dict):
+                hws = torch.empty(_lib.lib().kp_head_bwd_ws_floats(N, Hh, Wh, Ch, Kout, code), device=dev, dtype=torch.float32)
+                hgrads = hgrads[:3] + (ptr(hws),)
             call('kp_head_bwd', ptr(gout), ptr(out), ptr(a_last), ptr(hconv.weight), head['slope'], *hgrads,
                  N, Hh, Wh, Ch, Kout, code, st)
         gp = 0   # border width of g (0 = plain, 1 = padded-domain gradient that still needs folding)
@@ -463,15 +481,23 @@ class UnitFunction(torch.autograd.Function):
                 lside.wait_stream(cur)
             with torch.cuda.stream(lside) if lside is not None else contextlib.nullcontext():
                 wst = stream_ptr()
-                scratch = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device=dev, dtype=torch.float32)
-                if 'wgrad' in _ABL:
-                    pass
-                elif sv['fin'] is not None:   # the input side is read from the previous layer's conv output (see forward)
-                    f = sv['fin']
-                    call('kp_conv_wgrad_bnin', ptr(f['y']), *f['bn'], f['slope'], ptr(dy), ptr(scratch), N, H, W, C, K, dp, code, wst)
-                else:
-                    call('kp_conv_wgrad', ptr(sv['a']), ptr(dy), ptr(scratch), N, H, W, C, K, 3, dp, code, wst)
-                call('kp_wgrad_unpack', ptr(scratch), parts, ptr(gv[id(conv.weight)]), K, sv['Cl'], C, 3, wst)
+                if 'wgrad' not in _ABL:   # (measurement mode: neither the kernel nor the unpack of its -- then uninitialised -- scratch)
+                    scratch = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device=dev, dtype=torch.float32)
+                    fused = False
+                    if sv['fin'] is not None:   # the input side is read from the previous layer's conv output (see forward)
+                        f = sv['fin']
+                        fused = try_call('kp_conv_wgrad_bnin', ptr(f['y']), *f['bn'], f['slope'], ptr(dy), ptr(scratch), N, H, W, C, K, dp, code, wst)
+                        if not fused:
+                            # the library declined the fused form NOW (a measurement knob changed since the forward): materialise the
+                            # activation the forward skipped and take the plain kernel -- same values bit for bit
+                            sv['a'] = _materialise(f, N, H, W, C, 1, tdt, code, wst)
+                            parts2 = _lib.lib().kp_conv_wgrad_partials(N, H, W, C, K, 3, dp, code)
+                            if parts2 != parts:
+                                parts = parts2
+                                scratch = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device=dev, dtype=torch.float32)
+                    if not fused:
+                        call('kp_conv_wgrad', ptr(sv['a']), ptr(dy), ptr(scratch), N, H, W, C, K, 3, dp, code, wst)
+                    call('kp_wgrad_unpack', ptr(scratch), parts, ptr(gv[id(conv.weight)]), K, sv['Cl'], C, 3, wst)
             if lside is not None:
                 # dy and the saved input are read on the side stream: they stay referenced until this stream has waited
                 # for it (end of the Unit's backward) -- the caching allocator recycles a block in the order of ITS stream

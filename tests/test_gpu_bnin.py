@@ -54,7 +54,9 @@ def test_conv_fwd_and_wgrad_bnin_equal_the_separate_pass(N, H, W, C, K, dt, bn_o
     # sanity of the reference itself against torch (the fused path is then right by the equality above)
     af = a.float().permute(0, 3, 1, 2)
     ref = torch.nn.functional.conv2d(af, w.float().permute(0, 3, 1, 2), bias).permute(0, 2, 3, 1).cpu()
-    assert (outs[1][0] - ref).abs().max() <= 2.0 ** (-7 if dt == 'bf16' else -10) * max(1.0, float(ref.abs().max()))
+    # every element within ONE ulp of the storage type of the fp32 convolution of the same stored activation (+ fp32 accumulation-order noise)
+    ulp = 2.0 ** (-7 if dt == 'bf16' else -10)
+    assert ((outs[1][0] - ref).abs() <= ulp * ref.abs() + 2e-5 * max(1.0, float(ref.abs().max()))).all()
     # weight gradient
     for dp in (0, 2):
         dy = torch.zeros(N, H + 2 * dp, W + 2 * dp, K, dtype=tdt)
@@ -114,7 +116,8 @@ def test_head_fwd_and_bwd_bnin_equal_the_separate_pass(N, H, W, C, K, dt, bn_on,
         assert torch.isfinite(f).all() and torch.equal(r, f)
     # sanity of the reference itself against torch
     ref = torch.nn.functional.leaky_relu(torch.einsum('nhwc,kc->nkhw', a.float(), w) + bias.view(1, K, 1, 1), 0.2).cpu()
-    assert (res[1][0] - ref).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max()))
+    # fp32 output of fp32 weights x the stored activation (carried as a hi + lo pair of 16-bit values: 2^-17 relative)
+    assert (res[1][0] - ref).abs().max() <= 3e-5 * max(1.0, float(ref.abs().max()))
 
 
 @pytest.mark.parametrize('N,H,W', [(3, 84, 84), (2, 37, 50), (4, 5, 7), (1, 1, 3), (2, 32, 32), (5, 16, 33)])
@@ -124,6 +127,27 @@ def test_dgrad_with_the_batchnorm_backward_sums_in_its_epilogue(N, H, W, K, C, d
     """kp_conv_dgrad_bnred against kp_conv_dgrad + kp_bn_act_bwd_reduce(gp = 1): the padded-domain gradient bit for bit, the sums
     of the layer below (after kp_bn_bwd_finalize) to fp32 summation accuracy -- the fused kernel adds them in another order and in
     the padded domain (fold = adjoint of the replicate pad)."""
+    _check_dgrad_bnred(N, H, W, K, C, dt, bn_on, slope)
+
+
+@pytest.mark.parametrize('N,H,W,K,C,cus', [(4, 32, 32, 128, 256, 8), (6, 16, 16, 512, 64, 8), (2, 48, 48, 64, 128, 8), (8, 16, 32, 256, 128, 16),
+                                           (3, 16, 16, 64, 64, 256), (4, 64, 64, 128, 64, 256), (8, 32, 32, 256, 512, 32)])
+@pytest.mark.parametrize('dt,bn_on,slope', [('fp16', True, 0.01), ('bf16', True, 0.0), ('fp16', False, 0.01)])
+def test_dgrad_bnred_of_the_matrix_core_layers(N, H, W, K, C, cus, dt, bn_on, slope):
+    """The same contract for model F's layers (C, K multiples of 64, 16x16-tileable maps): the sums come from the epilogue of the
+    persistent LDS-patch kernel (interior) and of the 3-tap ring kernel.  The CU budget shrinks the grid so that workgroups walk
+    several tiles."""
+    from keypoints_amd._lib import call
+    call('kp_config', 6, cus)
+    call('kp_config', 9, 2)      # KP_CFG_BRED_PATCH: the 128-channel tile form too (off by default: slower than the separate pass)
+    try:
+        _check_dgrad_bnred(N, H, W, K, C, dt, bn_on, slope)
+    finally:
+        call('kp_config', 6, 0)
+        call('kp_config', 9, 1)
+
+
+def _check_dgrad_bnred(N, H, W, K, C, dt, bn_on, slope):
     from keypoints_amd import _lib
     from keypoints_amd._lib import call, ptr
     from keypoints_amd.runtime import stream_ptr
@@ -147,18 +171,19 @@ def test_dgrad_with_the_batchnorm_backward_sums_in_its_epilogue(N, H, W, K, C, d
     call('kp_bn_act_bwd_reduce', ptr(gx0), 1, _lib.TAIL_NONE, None, ptr(yred), *[ptr(t) for t in bn], slope, ptr(p0), N, H, W, C, code, st)
     r0 = L.kp_bn_bwd_rows(1, _lib.TAIL_NONE, N, H, W, C, code)
     gx1 = torch.full((N, H + 2, W + 2, C), float('nan'), device='cuda', dtype=tdt)
-    p1 = torch.full((max(nrows, 1), 2, C), float('nan'), device='cuda')
-    call('kp_conv_dgrad_bnred', ptr(dy), ptr(wd), ptr(gx1), ptr(yred), *[ptr(t) for t in bn], slope, ptr(p1), N, H, W, K, C, code, st)
     r1 = L.kp_conv_dgrad_bnred_rows(N, H, W, K, C, code)
-    assert 1 <= r1 <= nrows
+    p1 = torch.full((max(nrows, r1, 1), 2, C), float('nan'), device='cuda')
+    call('kp_conv_dgrad_bnred', ptr(dy), ptr(wd), ptr(gx1), ptr(yred), *[ptr(t) for t in bn], slope, ptr(p1), N, H, W, K, C, code, st)
+    assert r1 >= 1
     assert torch.isfinite(gx1.float()).all() and torch.equal(gx0, gx1)
     s0 = p0[:r0].double().sum(0).cpu()
     s1 = p1[:r1].double().sum(0).cpu()
     assert torch.isfinite(p1[:r1]).all()
-    # scale of the sums: sum of |terms| ~ N*H*W * |gh|; fp32 accumulation in chunks: 1e-4 of that is generous and catches a wrong pixel map
+    # scale of the sums: sum of |terms| ~ N*H*W * |gh| (x |xhat| for the second sum); two orders of the same fp32 additions:
+    # 2e-5 of that (the bound the BatchNorm statistics are held to elsewhere); one misplaced pixel is ~1 / (N H W) >= 1e-4 here
     ref = yred.float()
     scale = float(gx0.float().abs().sum() / C) * max(1.0, float(ref.abs().max()))
-    assert (s0 - s1).abs().max() <= 1e-4 * scale + 1e-6, ((s0 - s1).abs().max(), scale)
+    assert (s0 - s1).abs().max() <= 2e-5 * scale + 1e-6, ((s0 - s1).abs().max(), scale)
 
 
 def test_unsupported_shapes_launch_nothing():
@@ -248,3 +273,48 @@ def test_train_step_with_the_reduce_pass_in_the_data_gradient(precision):
         worst = max(worst, float((a - b).norm() / (a.norm() + 1e-12)))
     # the 16-bit rounding of dy downstream of slightly different sums: a few units of the storage type's epsilon, relative L2
     assert worst <= (2e-2 if precision == 'bf16' else 3e-3), worst
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_backward_falls_back_when_the_library_declines_the_fused_form(precision, monkeypatch):
+    """The forward skips an activation pass where the shape queries offer the fused consumers; a backward kernel may still answer
+    KP_E_UNSUPPORTED (unaligned gradient tensors, a measurement knob that changed in between).  unit_engine then writes the
+    activation out (kp_bn_act_fwd of the saved conv output) and runs the plain kernels: same gradients, bit for bit."""
+    import keypoints_amd as ka
+    from keypoints_amd import unit_engine
+    from keypoints_amd.models import transporter
+    g = torch.Generator().manual_seed(13)
+    xs = (torch.rand(5, 1, 84, 84, generator=g) * 2 - 1).cuda()
+    xt = (torch.rand(5, 1, 84, 84, generator=g) * 2 - 1).cuda()
+    real = unit_engine.try_call
+    declined = []
+
+    def declining(name, *args):
+        declined.append(name)
+        return False      # as if the library had returned KP_E_UNSUPPORTED (nothing launched)
+
+    res = []
+    for decline in (False, True):
+        monkeypatch.setattr(unit_engine, 'try_call', declining if decline else real)
+        torch.manual_seed(9)
+        net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 4).cuda().set_precision(precision)
+        loss = ka.l2_reconstruction_loss(net(xs, xt)[0], xt)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((loss.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}))
+    assert {'kp_head_bwd_bnin', 'kp_conv_wgrad_bnin'} <= set(declined)
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+@pytest.mark.parametrize('N,H,W,K,C', [(128, 128, 128, 128, 64), (128, 64, 64, 256, 256), (128, 32, 32, 512, 512), (128, 16, 16, 512, 512),
+                                       (128, 16, 16, 512, 64), (128, 64, 64, 256, 128), (128, 128, 128, 64, 128)])
+def test_dgrad_bnred_at_the_bench_shapes(N, H, W, K, C):
+    """Model F's data gradients at the bench batch (128 images), whole device: the fused sums against the separate pass."""
+    from keypoints_amd._lib import call
+    call('kp_config', 9, 2)
+    try:
+        _check_dgrad_bnred(N, H, W, K, C, 'fp16', True, 0.01)
+    finally:
+        call('kp_config', 9, 1)

@@ -21,7 +21,7 @@ def _knobs():
     from keypoints_amd._lib import call, lib
     walk = 1 | 2 | 4 | 128 | 0xfe00   # KP_WALK_DEFAULT
     yield
-    call('kp_config', KP_CFG_CONV_PATCH, 2)
+    call('kp_config', KP_CFG_CONV_PATCH, 1)
     call('kp_config', KP_CFG_CUS, 0)
     call('kp_config', KP_CFG_WALK, walk)
 

@@ -60,7 +60,7 @@ def main():
     bf = torch.float16 if args.f16 else torch.bfloat16
     DT = _lib.KP_F16 if args.f16 else _lib.KP_BF16
     tot = {}
-    modes = [int(m) for m in args.modes.split(',')] if args.modes else ([1, 0] if args.ab else [2])
+    modes = [int(m) for m in args.modes.split(',')] if args.modes else ([1, 0] if args.ab else [1])
     print(f'{"layer":<20}' + ''.join(f'{"fwd":>9}{"dgrad":>9}' for _ in modes) + f'{"wgrad":>9}   (TFLOP/s)')
     for name, C, K, H, nf, nd, nw in LAYERS:
         if args.only and args.only not in name:
@@ -100,7 +100,7 @@ def main():
             t = tot.setdefault(key, [0.0, 0.0])
             t[0] += nf * flops + nd * flops   # algorithmic (interior) flops
             t[1] += nf * tf + nd * td
-        call('kp_config', 0, 2)
+        call('kp_config', 0, 1)
         if args.ab:
             call('kp_config', 3, 0)
             tw0 = timed(lambda: call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, W, C, K, 3, 2, DT, st),
