@@ -35,14 +35,14 @@ def _pair_grid(N, H, W, K, cus):
 
 FWD = [  # N, H, W, C, K, CU budget, linear walk
     (2, 32, 32, 128, 256, 8, 1),     # 8 tiles on 8 workgroups: one tile each, two k-tiles
-    (6, 16, 16, 64, 256, 8, 1),      # one tile per image: the pair spans two images
+    (8, 16, 16, 64, 256, 8, 1),      # one tile per image: the pair spans two images
     (16, 16, 16, 128, 128, 8, 1),
     (8, 48, 48, 64, 128, 8, 1),      # 3 tiles per row: pairs wrap rows and images; 36 tiles on 8 workgroups (ragged)
     (8, 48, 48, 64, 128, 8, 0),      # ... in 8 per-XCD ranges
     (8, 32, 64, 256, 256, 16, 1),    # 64 tiles on 16 workgroups, k-tile fastest
     (8, 32, 64, 256, 256, 16, 0),
     (4, 32, 32, 128, 64, 8, 1),      # 64-channel k-tile
-    (4, 16, 16, 512, 512, 256, 1),   # the bottleneck-side shape, whole device
+    (8, 16, 16, 512, 256, 256, 1),   # the bottleneck-side maps, whole device (statistics: 4 rows per workgroup must fit the N H W / 64 rows of the caller's buffer)
 ]
 
 
