@@ -417,7 +417,7 @@ def _run_leg(args, rank, world, dev):
         # inside the process, so it is the committed per-launch figure of the last profiled build (or null).
         traffic, pmc, pmc_file = None, None, None
         pmc_key = 'conv_small_band_bf16' if dom[0] == 'conv_small_16bit' else 'conv_patch_bf16_bn128'
-        for cand in ('r03m_pmc_summary.json', 'r03k_pmc_summary.json', 'r03j_pmc_summary.json', 'r03i_pmc_summary.json', 'r03h_pmc_summary.json', 'r03b_pmc_summary.json', 'r02n_pmc_summary.json', 'r02j_pmc_summary.json', 'r02g_pmc_summary.json', 'r02_pmc_summary.json', 'r01_pmc_summary.json'):
+        for cand in ('r04b_pmc_summary.json', 'r03m_pmc_summary.json', 'r03k_pmc_summary.json', 'r03j_pmc_summary.json', 'r03i_pmc_summary.json', 'r03h_pmc_summary.json', 'r03b_pmc_summary.json', 'r02n_pmc_summary.json', 'r02j_pmc_summary.json', 'r02g_pmc_summary.json', 'r02_pmc_summary.json', 'r01_pmc_summary.json'):
             try:
                 pmc = json.load(open(os.path.join(ROOT, 'profiles', cand)))[pmc_key]
                 traffic, pmc_file = pmc['hbm_bytes_per_launch'], cand
@@ -637,7 +637,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline(args)
         # The printed line is the COMPACT record (a few KB: the driver keeps an 8 KB tail of stdout and round 3's 22 KB line
         # lost the config-2 leg and `extra.bf16` to it); the per-kernel tables of every leg go to --out / --detail.
-        detail = args.detail or args.out
+        detail = args.out or args.detail
         if detail:
             try:
                 os.makedirs(os.path.dirname(os.path.abspath(detail)), exist_ok=True)
