@@ -384,6 +384,42 @@ int kp_keypoint_bottleneck_bwd(const float* gphi, const float* g_k, const float*
                                const float* k_t, const float* p_t, const float* q_t, float* d_phi_t, float* d_heat_t,
                                int B, int C, int K, int H, int W, float sigma, float eps, void* stream);
 
+/* ---- 16-bit NHWC ("T") interchange between an encoder head, the keypoint bottleneck and the decoder -----------------------
+ * The reference's Units exchange fp32 NCHW tensors (knn.py:127-130; TransporterNet.forward, transporter.py:34-64: feature
+ * encoder -> 'max' blend -> decoder).  Inside this library a Unit computes in T NHWC; at 16 feature channels over 84 x 84 maps
+ * (the Pong-class nets, vgg.py:53,66) the fp32 planes at the Unit boundaries and the two layout kernels around the decoder are a
+ * measurable share of the step.  These entry points keep the same arithmetic and move the boundary tensors in T NHWC instead:
+ *   kp_head_fwd_t        == kp_head_fwd / kp_head_fwd_bnin with the output rounded once to T: out_t [N][H][W][K]
+ *   kp_head_bwd_t        == kp_head_bwd / kp_head_bwd_bnin reading the output gradient and the saved output as T [N][H][W][K]
+ *                           (bnin != 0: x is the producing 3x3 layer's conv output and mean .. slope_in its BatchNorm / activation,
+ *                           as in kp_head_fwd_bnin; bnin == 0: x is the stored activation, the five arguments are ignored)
+ *   kp_keypoint_bottleneck_fwd_t == kp_keypoint_bottleneck_fwd with phi_s / phi_t T [B][H][W][C] and the blend written as the
+ *                           decoder's first-layer input a [B][H+2][W+2][C] T, replicate border included (knn.py:115: ReplicationPad2d(1));
+ *                           keypoints, marginals, masks, argmax and m_t are bit-identical to kp_keypoint_bottleneck_fwd on the same
+ *                           values, the blend is its value rounded once to T
+ *   kp_keypoint_bottleneck_bwd_t == kp_nhwc_grad_to_nchw (the fold of the replicate border) + kp_keypoint_bottleneck_bwd, with
+ *                           ga [B][H+2][W+2][C] T = the decoder's data gradient over the padded domain and d_phi_t [B][H][W][C] T
+ *   kp_nhwc_to_nchw      interior of a padded T image -> fp32 NCHW (TransporterNet.forward also RETURNS the blend, transporter.py:64)
+ * *_supported: 1 where the form exists (16-bit storage; head: C == 32, K == 16, H*W % 8 == 0, N*H*W % 32 == 0; bottleneck:
+ * C in {8, 16, 32}, H, W <= 256, H*W <= 16384); otherwise the calls return KP_E_UNSUPPORTED and launch nothing, and the caller
+ * runs the fp32 NCHW entry points.  Head workspace: kp_head_bwd_ws_floats of the same shape. */
+int kp_head_t_supported(int N, int H, int W, int C, int K, int dtype);
+int kp_head_fwd_t(const void* x, int bnin, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                  float slope_in, const float* w, const float* bias, float slope, void* out_t, int N, int H, int W, int C, int K,
+                  int dtype, void* stream);
+int kp_head_bwd_t(const void* gout_t, const void* out_t, const void* x, int bnin, const float* mean, const float* invstd,
+                  const float* gamma, const float* beta, float slope_in, const float* w, float slope, void* dx, float* dw, float* db,
+                  float* ws, int N, int H, int W, int C, int K, int dtype, void* stream);
+int kp_keypoint_bottleneck_t_supported(int B, int C, int K, int H, int W, int dtype);
+int kp_keypoint_bottleneck_fwd_t(const float* heat_s, const float* heat_t, const void* phi_s, const void* phi_t, float* k_t,
+                                 float* p_t, float* q_t, float* m_t, void* a, float* mask_s, float* mask_t, unsigned char* arg_t,
+                                 int B, int C, int K, int H, int W, float sigma, float eps, int dtype, void* stream);
+int kp_keypoint_bottleneck_bwd_t(const void* ga, const float* g_k, const float* g_m, const void* phi_s, const void* phi_t,
+                                 const float* mask_s, const float* mask_t, const unsigned char* arg_t, const float* k_t,
+                                 const float* p_t, const float* q_t, void* d_phi_t, float* d_heat_t, int B, int C, int K, int H,
+                                 int W, float sigma, float eps, int dtype, void* stream);
+int kp_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int pad, int dtype, void* stream);
+
 /* ---- input-side augmentation (keypoints/tps.py, keypoints/data_augments.py) ----------------------- */
 /* out = F.grid_sample(x, tps_grid(theta, ctrl, x.shape), padding_mode='zeros')   tps.py:60-87,128-131.
  * x/out fp32 NCHW; theta [N][T+3][2] (reduced != 0: [N][T+2][2], tps.py:48-50); ctrl [N][T][2] or, with

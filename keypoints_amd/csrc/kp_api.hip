@@ -226,6 +226,51 @@ KP_DISPATCH(kp_head_fwd_bnin, (const void* yprev, const float* mean, const float
             (yprev, mean, invstd, gamma, beta, slope_in, w, bias, slope, out, N, H, W, C, K, dtype, stream))
 KP_DISPATCH(kp_head_bwd_bnin, (const float* gout, const float* out, const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope_in, const float* w, float slope, void* dx, float* dw, float* db, float* ws, int N, int H, int W, int C, int K, int dtype, void* stream),
             (gout, out, yprev, mean, invstd, gamma, beta, slope_in, w, slope, dx, dw, db, ws, N, H, W, C, K, dtype, stream))
+KP_DISPATCH(kp_nhwc_to_nchw, (const void* src, float* dst, int N, int C, int H, int W, int pad, int dtype, void* stream), (src, dst, N, C, H, W, pad, dtype, stream))
+KP_DISPATCH(kp_head_t_supported, (int N, int H, int W, int C, int K, int dtype), (N, H, W, C, K, dtype))
+KP_DISPATCH(kp_head_fwd_t, (const void* x, int bnin, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope_in, const float* w, const float* bias, float slope, void* out_t, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (x, bnin, mean, invstd, gamma, beta, slope_in, w, bias, slope, out_t, N, H, W, C, K, dtype, stream))
+KP_DISPATCH(kp_head_bwd_t, (const void* gout_t, const void* out_t, const void* x, int bnin, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope_in, const float* w, float slope, void* dx, float* dw, float* db, float* ws, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (gout_t, out_t, x, bnin, mean, invstd, gamma, beta, slope_in, w, slope, dx, dw, db, ws, N, H, W, C, K, dtype, stream))
+KP_DISPATCH(kp_keypoint_bottleneck_t_supported, (int B, int C, int K, int H, int W, int dtype), (B, C, K, H, W, dtype))
+
+// the T form of the fused bottleneck (kp_bottleneck_t.hip): dtype dispatch + the roofline leg's byte count
+int kp_keypoint_bottleneck_fwd_t__bf16(const float*, const float*, const void*, const void*, float*, float*, float*, float*, void*, float*, float*, unsigned char*, int, int, int, int, int, float, float, int, void*);
+int kp_keypoint_bottleneck_fwd_t__f16(const float*, const float*, const void*, const void*, float*, float*, float*, float*, void*, float*, float*, unsigned char*, int, int, int, int, int, float, float, int, void*);
+int kp_keypoint_bottleneck_bwd_t__bf16(const void*, const float*, const float*, const void*, const void*, const float*, const float*, const unsigned char*, const float*, const float*, const float*, void*, float*, int, int, int, int, int, float, float, int, void*);
+int kp_keypoint_bottleneck_bwd_t__f16(const void*, const float*, const float*, const void*, const void*, const float*, const float*, const unsigned char*, const float*, const float*, const float*, void*, float*, int, int, int, int, int, float, float, int, void*);
+
+int kp_keypoint_bottleneck_fwd_t(const float* heat_s, const float* heat_t, const void* phi_s, const void* phi_t, float* k_t,
+                                 float* p_t, float* q_t, float* m_t, void* a, float* mask_s, float* mask_t, unsigned char* arg_t,
+                                 int B, int C, int K, int H, int W, float sigma, float eps, int dtype, void* stream) {
+    if (dtype != KP_BF16 && dtype != KP_F16) return KP_E_UNSUPPORTED;
+    // 2 heat stacks (fp32) + 2 feature stacks (T) in; padded blend (T), target maps, 2 masks (fp32), argmax, keypoints, marginals out
+    const double hw = (double)H * W;
+    const double bytes = (double)B * (4.0 * (2.0 * K * hw + K * hw + 2.0 * hw) + 2.0 * (2.0 * C * hw + C * (H + 2.0) * (W + 2.0)) + hw + 4.0 * K * (2 + H + W));
+    ProfScope ps(KP_PROF_BOTTLENECK, 0.0, (hipStream_t)stream, bytes);
+    const int rc = dtype == KP_F16
+        ? kp_keypoint_bottleneck_fwd_t__f16(heat_s, heat_t, phi_s, phi_t, k_t, p_t, q_t, m_t, a, mask_s, mask_t, arg_t, B, C, K, H, W, sigma, eps, dtype, stream)
+        : kp_keypoint_bottleneck_fwd_t__bf16(heat_s, heat_t, phi_s, phi_t, k_t, p_t, q_t, m_t, a, mask_s, mask_t, arg_t, B, C, K, H, W, sigma, eps, dtype, stream);
+    ps.done(KP_PROF_BOTTLENECK);
+    return rc;
+}
+
+int kp_keypoint_bottleneck_bwd_t(const void* ga, const float* g_k, const float* g_m, const void* phi_s, const void* phi_t,
+                                 const float* mask_s, const float* mask_t, const unsigned char* arg_t, const float* k_t,
+                                 const float* p_t, const float* q_t, void* d_phi_t, float* d_heat_t, int B, int C, int K, int H,
+                                 int W, float sigma, float eps, int dtype, void* stream) {
+    if (dtype != KP_BF16 && dtype != KP_F16) return KP_E_UNSUPPORTED;
+    // in: padded gradient, phi_s, phi_t (T), masks, argmax, keypoints, marginals; out: d_phi_t (T), d_heat_t (fp32)
+    const double hw = (double)H * W;
+    const double bytes = (double)B * (2.0 * (C * (H + 2.0) * (W + 2.0) + 3.0 * C * hw) + 4.0 * (2.0 * hw + K * hw) + hw + 4.0 * K * (2 + H + W));
+    ProfScope ps(KP_PROF_BOTTLENECK, 0.0, (hipStream_t)stream, bytes);
+    const int rc = dtype == KP_F16
+        ? kp_keypoint_bottleneck_bwd_t__f16(ga, g_k, g_m, phi_s, phi_t, mask_s, mask_t, arg_t, k_t, p_t, q_t, d_phi_t, d_heat_t, B, C, K, H, W, sigma, eps, dtype, stream)
+        : kp_keypoint_bottleneck_bwd_t__bf16(ga, g_k, g_m, phi_s, phi_t, mask_s, mask_t, arg_t, k_t, p_t, q_t, d_phi_t, d_heat_t, B, C, K, H, W, sigma, eps, dtype, stream);
+    ps.done(KP_PROF_BOTTLENECK);
+    return rc;
+}
+
 long long kp_head_bwd_ws_floats__bf16(int, int, int, int, int, int);
 long long kp_head_bwd_ws_floats__f16(int, int, int, int, int, int);
 long long kp_head_bwd_ws_floats(int N, int H, int W, int C, int K, int dtype) {

@@ -106,6 +106,24 @@ __global__ void nhwc_grad_to_nchw_v4_k(const T* __restrict__ g, float* __restric
         if (c0 + e < C) dst[(((long long)n * C + c0 + e) * H + h) * W + w] = a[e];
 }
 
+// interior of a padded T image -> fp32 planes (no fold: the image is a VALUE, e.g. the blended feature map the T form of the keypoint
+// bottleneck wrote as the decoder's padded input, which TransporterNet.forward also returns as fp32 NCHW, transporter.py:64)
+template <typename T>
+__global__ void nhwc_to_nchw_v4_k(const T* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W, int p) {
+    const int Wp = W + 2 * p, Hp = H + 2 * p;
+    const long long total = (long long)N * H * W;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c0 = blockIdx.y * 4;
+    if (t >= total) return;
+    const int w = (int)(t % W);
+    const int h = (int)((t / W) % H);
+    const int n = (int)(t / ((long long)W * H));
+    float v[4];
+    ld4<T>(src + (((long long)n * Hp + h + p) * Wp + w + p) * C + c0, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst[(((long long)n * C + c0 + e) * H + h) * W + w] = v[e];
+}
+
 // ---------------------------------------------------------------- weights
 template <typename T>
 __global__ void pack_weights_k(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int K, int C,
@@ -495,6 +513,10 @@ long long kp_head_dw_parts_mfma(long long, int, int, int);
 long long kp_head_dw_parts_fast(long long, int, int);
 int kp_head_dx_fast(const float*, const float*, const float*, float, void*, long long, int, int, int, hipStream_t);
 int kp_head_dw_fast(const float*, const float*, const void*, float, float*, float*, float*, long long, int, int, int, hipStream_t, const KpBnIn* = nullptr);
+bool kp_head_t_shape(long long, int, int, int);
+int kp_head_fwd_mfma_t(const void*, const float*, const float*, float, void*, long long, int, int, int, hipStream_t, const KpBnIn*);
+int kp_head_dx_mfma_t(const void*, const void*, const float*, float, void*, long long, int, int, int, hipStream_t);
+int kp_head_dw_mfma_t(const void*, const void*, const void*, float, float*, float*, float*, long long, int, int, int, hipStream_t, const KpBnIn*);
 
 extern "C" {
 
@@ -698,6 +720,59 @@ int kp_head_bwd_bnin(const float* gout, const float* out, const void* yprev, con
     if (!head_bnin_ok((long long)N * H * W, H * W, C, K, dtype)) return KP_E_UNSUPPORTED;
     const KpBnIn bn{mean, invstd, gamma, beta, slope_in};
     return head_bwd_impl(gout, out, yprev, w, slope, dx, dw, db, ws, N, H, W, C, K, dtype, stream, &bn);
+}
+
+int kp_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int pad, int dtype, void* stream) {
+    KP_REQUIRE(src && dst && N > 0 && C > 0 && C % 4 == 0 && C / 4 <= 65535 && H > 0 && W > 0 && pad >= 0, "kp_nhwc_to_nchw: bad dims (C a multiple of 4)");
+    const long long total = (long long)N * H * W;
+    DISPATCH_T(dtype, nhwc_to_nchw_v4_k<T><<<dim3(cdiv(total, TPB), C / 4), TPB, 0, (hipStream_t)stream>>>((const T*)src, dst, N, C, H, W, pad));
+    return kp_check_launch("nhwc_to_nchw");
+}
+
+// ---- the head between T tensors (16-bit NHWC in, 16-bit NHWC out): kp_head_mfma.hip ------------------------------------
+int kp_head_t_supported(int N, int H, int W, int C, int K, int dtype) {
+    if (dtype != KP_H16 || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 0;
+    return kp_head_t_shape((long long)N * H * W, H * W, C, K) ? 1 : 0;
+}
+
+static int head_t_bn(const char* who, int bnin, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope_in) {
+    if (!bnin) return KP_OK;
+    KP_REQUIRE(slope_in >= 0.f && slope_in <= 1.f, "%s: activation slope of the producing layer must be in [0, 1]", who);
+    KP_REQUIRE((mean != nullptr) == (invstd != nullptr) && (mean != nullptr) == (gamma != nullptr) && (mean != nullptr) == (beta != nullptr),
+               "%s: mean / invstd / gamma / beta: all or none", who);
+    return KP_OK;
+}
+
+int kp_head_fwd_t(const void* x, int bnin, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                  float slope_in, const float* w, const float* bias, float slope, void* out_t, int N, int H, int W, int C, int K,
+                  int dtype, void* stream) {
+    KP_REQUIRE(x && w && out_t && N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "kp_head_fwd_t: bad args");
+    if (int rc = head_t_bn("kp_head_fwd_t", bnin, mean, invstd, gamma, beta, slope_in)) return rc;
+    if (!kp_head_t_supported(N, H, W, C, K, dtype)) return KP_E_UNSUPPORTED;
+    const KpBnIn bn{mean, invstd, gamma, beta, slope_in};
+    return kp_head_fwd_mfma_t(x, w, bias, slope, out_t, (long long)N * H * W, H * W, C, K, (hipStream_t)stream, bnin ? &bn : nullptr);
+}
+
+int kp_head_bwd_t(const void* gout_t, const void* out_t, const void* x, int bnin, const float* mean, const float* invstd,
+                  const float* gamma, const float* beta, float slope_in, const float* w, float slope, void* dx, float* dw, float* db,
+                  float* ws, int N, int H, int W, int C, int K, int dtype, void* stream) {
+    KP_REQUIRE(gout_t && out_t && x && w && N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "kp_head_bwd_t: bad args");
+    if (int rc = head_t_bn("kp_head_bwd_t", bnin, mean, invstd, gamma, beta, slope_in)) return rc;
+    if (!kp_head_t_supported(N, H, W, C, K, dtype)) return KP_E_UNSUPPORTED;
+    const long long M = (long long)N * H * W;
+    hipStream_t st = (hipStream_t)stream;
+    const KpBnIn bn{mean, invstd, gamma, beta, slope_in};
+    if (dx)
+        if (int rc = kp_head_dx_mfma_t(gout_t, out_t, w, slope, dx, M, H * W, C, K, st)) return rc;
+    if (dw) {
+        if (int rc = kp_head_dw_mfma_t(gout_t, out_t, x, slope, dw, db, ws, M, H * W, C, K, st, bnin ? &bn : nullptr)) return rc;
+        if (ws) {   // deterministic mode: sum the partial gradients in a fixed order
+            const long long n = (long long)K * C + K, parts = kp_head_dw_parts_mfma(M, H * W, C, K);
+            head_dw_reduce_k<<<cdiv(n, 16), TPB, 0, st>>>(ws, (int)parts, n, (long long)K * C, dw, db);
+            return kp_check_launch("head_dw_reduce");
+        }
+    }
+    return KP_OK;
 }
 
 #ifndef KP_F16_BUILD   // no dtype: defined once, by the bf16 build of this source

@@ -97,11 +97,15 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_k(const h16_t* __restrict__
 // pixels requested before the current one is multiplied.  Same operands into the same MFMAs in the same order: bit-identical.
 // BNIN: x is the producing layer's conv output, `bn` its BatchNorm / activation (KpBnIn, kp_common.h), applied to the two
 // 16-byte pixel fragments of a lane -- always the same 2 x 8 channels, constants in registers.
-template <int KT, bool BNIN>
+// TOUT (kp_head_fwd_t, K == 16): `out` is T [M][16] -- the pixel-major 16-bit tensor the keypoint bottleneck's T form and the
+// decoder read (kp_bottleneck_t.hip) -- instead of fp32 planes: the two half-waves' 8-byte pieces of a pixel (channels 4h .. 4h + 3
+// and 8 + 4h ..) are paired with v_permlane32_swap into one 16-byte store per lane, a wavefront writes 1 KB contiguous.
+template <int KT, bool BNIN, bool TOUT = false>
 __global__ __launch_bounds__(256) void head_fwd_mfma32_k(const h16_t* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float slope,
                                                          float* __restrict__ out, long long groups, int HW, int K, KpBnIn bn) {
     constexpr int C = 32;
+    static_assert(!TOUT || KT == 1, "T output: K == 16");
     const int lane = threadIdx.x & 63;
     const long long waves = (long long)gridDim.x * 4;
     long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -144,10 +148,21 @@ __global__ __launch_bounds__(256) void head_fwd_mfma32_k(const h16_t* __restrict
             acc = mma(wlo[kt][0], x0, acc);
             acc = mma(whi[kt][1], x1, acc);
             acc = mma(wlo[kt][1], x1, acc);
+            if constexpr (TOUT) {
+                uint32_t p[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int k = kt * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
-                if (k < K) out[(n * K + k) * HW + hw] = act_fwd(acc[i] + bk[kt][i], slope);
+                for (int q = 0; q < 4; ++q)
+                    p[q] = pack_h16x2(act_fwd(acc[2 * q] + bk[0][2 * q], slope), act_fwd(acc[2 * q + 1] + bk[0][2 * q + 1], slope));
+                // lanes h = 0: (p0, p1) = channels 0-3, (p2, p3) = 8-11; h = 1: 4-7, 12-15 -> h = 0: 0-7, h = 1: 8-15
+                const auto s0 = __builtin_amdgcn_permlane32_swap(p[0], p[2], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(p[1], p[3], false, false);
+                *reinterpret_cast<uint4*>(reinterpret_cast<h16_t*>(out) + m * 16 + h * 8) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int k = kt * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+                    if (k < K) out[(n * K + k) * HW + hw] = act_fwd(acc[i] + bk[kt][i], slope);
+                }
             }
         }
     }
@@ -168,8 +183,28 @@ __device__ __forceinline__ void load_dz_px(const float* __restrict__ gout, const
     }
 }
 
+// the same from T [M][K] gradient / output tensors (kp_head_bwd_t; K a multiple of 8): one 16-byte load each
+__device__ __forceinline__ void load_dz_px_t(const h16_t* __restrict__ gout, const h16_t* __restrict__ out, long long m, int K,
+                                             int k0, float slope, float (&v)[8]) {
+    if (k0 < K) {
+        const uint4 gq = *reinterpret_cast<const uint4*>(gout + m * K + k0), oq = *reinterpret_cast<const uint4*>(out + m * K + k0);
+        const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w}, ow[4] = {oq.x, oq.y, oq.z, oq.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float g0, g1, o0, o1;
+            unpack_h16x2(gw[i], g0, g1);
+            unpack_h16x2(ow[i], o0, o1);
+            v[2 * i] = g0 * act_grad(o0, slope);
+            v[2 * i + 1] = g1 * act_grad(o1, slope);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+}
+
 // ---- input gradient ------------------------------------------------------------------------------------------------
-template <int KS>   // 16-channel reduction slices (K <= 16 * KS)
+template <int KS, bool TIN = false>   // 16-channel reduction slices (K <= 16 * KS); TIN: gout / out are T [M][K]
 __global__ __launch_bounds__(256) void head_dx_mfma_k(const float* __restrict__ gout, const float* __restrict__ out,
                                                       const float* __restrict__ w, float slope, h16_t* __restrict__ dx,
                                                       long long groups, int HW, int C, int K) {
@@ -183,7 +218,8 @@ __global__ __launch_bounds__(256) void head_dx_mfma_k(const float* __restrict__ 
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
         float v[8];
-        load_dz_px(gout, out, n, hw, HW, K, kk * 16 + h * 8, slope, v);
+        if constexpr (TIN) load_dz_px_t(reinterpret_cast<const h16_t*>(gout), reinterpret_cast<const h16_t*>(out), m0 + px, K, kk * 16 + h * 8, slope, v);
+        else load_dz_px(gout, out, n, hw, HW, K, kk * 16 + h * 8, slope, v);
         split8(v, zhi[kk], zlo[kk]);
     }
     h16_t* dp = dx + (m0 + px) * C + 4 * h;
@@ -416,6 +452,111 @@ __global__ __launch_bounds__(256) void head_dw_mfma32_k(const float* __restrict_
     }
 }
 
+// The 32 -> 16 head's weight / bias gradient from T [M][16] gradient / output tensors (kp_head_bwd_t).  The group's 32 x 16
+// elements of dZ = gout * act'(out) are exactly one 16-byte chunk per lane (pixel lane / 2, channels 8 (lane % 2) ..): formed in
+// fp32, split into the (hi, lo) pair and staged pixel-major through 2 x 1 KB of wave-private LDS beside the input tile; the A
+// fragments (row = output channel, 8 consecutive pixels) come back through the same transpose reads as the B fragments
+// (rows 16-31 of the 32 x 32 tile are zero).  The bias gradient is summed in the chunk layout (8 running sums per lane) and
+// folded over the 32 lanes of a channel half at the end.
+template <bool BNIN>
+__global__ __launch_bounds__(256) void head_dw_mfma32_t_k(const h16_t* __restrict__ gout, const h16_t* __restrict__ out,
+                                                          const h16_t* __restrict__ x, float slope, float* __restrict__ dw,
+                                                          float* __restrict__ db, float* __restrict__ ws, long long groups,
+                                                          int gpw, KpBnIn bn) {
+    constexpr int C = 32, K = 16;
+    __shared__ __attribute__((aligned(16))) unsigned char tile[4][32 * C * 2];
+    __shared__ __attribute__((aligned(16))) unsigned char ztile[4][2][32 * K * 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long sp = (long long)blockIdx.x * 4 + wave;
+    const long long g0 = sp * gpw, g1 = g0 + gpw < groups ? g0 + gpw : groups;
+    if (g0 >= g1) return;
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float bz[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bz[e] = 0.f;
+    KpBnIn8 k8;
+    if (BNIN) k8.load(bn, (lane & 3) * 8);
+    unsigned char* const tl = tile[wave];
+    unsigned char* const zh = ztile[wave][0];
+    unsigned char* const zl = ztile[wave][1];
+    const int t16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int tr_off = (8 * h + (t16 >> 2)) * (C * 2) + (16 * g16 + (t16 & 3) * 4) * 2;
+    const int tz_off = (8 * h + (t16 >> 2)) * (K * 2) + ((t16 & 3) * 4) * 2;
+    for (long long g = g0; g < g1; ++g) {
+        const long long m0 = g * 32;
+        const uint4* xs = reinterpret_cast<const uint4*>(x + m0 * C);
+        uint4 c0 = xs[lane], c1 = xs[lane + 64];
+        const uint4 gq = reinterpret_cast<const uint4*>(gout + m0 * K)[lane], oq = reinterpret_cast<const uint4*>(out + m0 * K)[lane];
+        {
+            const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w}, ow[4] = {oq.x, oq.y, oq.z, oq.w};
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float a0, a1, o0, o1;
+                unpack_h16x2(gw[i], a0, a1);
+                unpack_h16x2(ow[i], o0, o1);
+                v[2 * i] = a0 * act_grad(o0, slope);
+                v[2 * i + 1] = a1 * act_grad(o1, slope);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bz[e] += v[e];
+            h16x8 vhi, vlo;
+            split8(v, vhi, vlo);
+            *reinterpret_cast<h16x8*>(zh + lane * 16) = vhi;
+            *reinterpret_cast<h16x8*>(zl + lane * 16) = vlo;
+        }
+        if (BNIN) { c0 = k8.apply(c0, bn.slope); c1 = k8.apply(c1, bn.slope); }
+        *reinterpret_cast<uint4*>(tl + lane * 16) = c0;
+        *reinterpret_cast<uint4*>(tl + (lane + 64) * 16) = c1;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const unsigned char* b = tl + s * 16 * (C * 2) + tr_off;
+            const h16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) h16x4*)(b));
+            const h16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) h16x4*)(b + 4 * (C * 2)));
+            const h16x8 xb = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+            const unsigned char* za = zh + s * 16 * (K * 2) + tz_off;
+            const unsigned char* zb = zl + s * 16 * (K * 2) + tz_off;
+            const h16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) h16x4*)(za));
+            const h16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) h16x4*)(za + 4 * (K * 2)));
+            const h16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) h16x4*)(zb));
+            const h16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) h16x4*)(zb + 4 * (K * 2)));
+            h16x8 fhi = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            h16x8 flo = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            if (g16) {   // rows 16..31 of the A tile: no such output channel
+                fhi = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                flo = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+            acc = mma(fhi, xb, acc);
+            acc = mma(flo, xb, acc);
+        }
+    }
+    // D[k][c]: lane column = c (r), rows k = 8*(i>>2) + 4*h + (i&3): i < 8 are the 16 output channels
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = 8 * (i >> 2) + 4 * h + (i & 3);
+        const long long e = (long long)k * C + r;
+        if (ws) ws[sp * ((long long)K * C + K) + e] = acc[i];
+        else unsafeAtomicAdd(dw + e, acc[i]);
+    }
+    if (db || ws) {
+#pragma unroll
+        for (int o = 2; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bz[e] += __shfl_xor(bz[e], o, 64);
+        if (lane < 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (ws) ws[sp * ((long long)K * C + K) + (long long)K * C + lane * 8 + e] = bz[e];
+                else unsafeAtomicAdd(db + lane * 8 + e, bz[e]);
+            }
+        }
+    }
+}
+
+
 // wide heads (C a multiple of 128), and the 32-channel heads with more than 4 outputs (Pong-class encoder heads: 32 -> 16 over
 // 84 x 84 maps, where the K <= 16 VALU kernels of kp_head_fast.hip run at 1.8 TB/s).  Groups of 32 pixels may straddle images
 // (per-lane image / offset); the weight gradient reads 8-pixel runs of the NCHW gradient: HW % 8 == 0.
@@ -514,4 +655,42 @@ int kp_head_dw_mfma(const float* gout, const float* out, const void* x, float sl
     else KP_DW(2, 1);
 #undef KP_DW
     return kp_check_launch("head_dw_mfma");
+}
+
+// ---- T-layout forms (kp_head_fwd_t / kp_head_bwd_t): the 32 -> 16 encoder head of the Pong-class nets between 16-bit NHWC tensors ----
+bool kp_head_t_shape(long long M, int HW, int C, int K) { return C == 32 && K == 16 && mfma_shape(M, HW, C, K); }
+
+int kp_head_fwd_mfma_t(const void* x, const float* w, const float* bias, float slope, void* out_t, long long M, int HW, int C, int K,
+                       hipStream_t st, const KpBnIn* bn) {
+    if (!kp_head_t_shape(M, HW, C, K) || !aligned16(x, w, out_t)) return KP_E_UNSUPPORTED;
+    const long long groups = M / 32;
+    long long wg = (groups / 8 + 3) / 4;   // ~8 groups per wavefront, as the fp32-output form
+    wg = wg < 1 ? 1 : wg;
+    const KpBnIn b = bn ? *bn : KpBnIn{};
+    if (bn) head_fwd_mfma32_k<1, true, true><<<(unsigned)wg, 256, 0, st>>>((const h16_t*)x, w, bias, slope, (float*)out_t, groups, HW, K, b);
+    else head_fwd_mfma32_k<1, false, true><<<(unsigned)wg, 256, 0, st>>>((const h16_t*)x, w, bias, slope, (float*)out_t, groups, HW, K, b);
+    return kp_check_launch("head_fwd_mfma_t");
+}
+
+int kp_head_dx_mfma_t(const void* gout_t, const void* out_t, const float* w, float slope, void* dx, long long M, int HW, int C, int K,
+                      hipStream_t st) {
+    if (!kp_head_t_shape(M, HW, C, K) || !aligned16(gout_t, out_t, dx)) return KP_E_UNSUPPORTED;
+    const long long groups = M / 32;
+    const unsigned grid = (unsigned)((groups + 3) / 4);
+    head_dx_mfma_k<1, true><<<grid, 256, 0, st>>>((const float*)gout_t, (const float*)out_t, w, slope, (h16_t*)dx, groups, HW, C, K);
+    return kp_check_launch("head_dx_mfma_t");
+}
+
+// (pixel splits / workspace rows: kp_head_dw_parts_mfma of the shape, the plan of the fp32-gradient form)
+int kp_head_dw_mfma_t(const void* gout_t, const void* out_t, const void* x, float slope, float* dw, float* db, float* ws, long long M,
+                      int HW, int C, int K, hipStream_t st, const KpBnIn* bn) {
+    if (!kp_head_t_shape(M, HW, C, K) || !aligned16(gout_t, out_t, x)) return KP_E_UNSUPPORTED;
+    const long long groups = M / 32;
+    int gpw;
+    const long long splits = dw_mfma_plan(M, HW, C, K, ws != nullptr, gpw);
+    const unsigned grid = (unsigned)((splits + 3) / 4);
+    const KpBnIn b = bn ? *bn : KpBnIn{};
+    if (bn) head_dw_mfma32_t_k<true><<<grid, 256, 0, st>>>((const h16_t*)gout_t, (const h16_t*)out_t, (const h16_t*)x, slope, dw, db, ws, groups, gpw, b);
+    else head_dw_mfma32_t_k<false><<<grid, 256, 0, st>>>((const h16_t*)gout_t, (const h16_t*)out_t, (const h16_t*)x, slope, dw, db, ws, groups, gpw, b);
+    return kp_check_launch("head_dw_mfma_t");
 }

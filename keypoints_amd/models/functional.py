@@ -231,6 +231,90 @@ def keypoint_bottleneck(heat_s, heat_t, phi_s, phi_t, sigma=0.1, eps=1e-6):
     return phi, k, (p, q), m, mask_s, mask_t
 
 
+class _KeypointBottleneckT(torch.autograd.Function):
+    """kp_keypoint_bottleneck_fwd_t / _bwd_t: _KeypointBottleneck on the 16-bit NHWC ("T") feature maps of its neighbours.
+    phi_s / phi_t: the encoder head's output [B][H][W][C] in the Units' storage type (Unit.forward_t(out_t=True)); the blend leaves
+    as the decoder's first-layer input [B][H+2][W+2][C] with its replicate border (Unit.forward_t(in_t=True)), whose gradient
+    -- the decoder's data gradient over the padded domain -- is folded inside the backward kernel."""
+
+    @staticmethod
+    def forward(ctx, heat_s, heat_t, phi_s, phi_t, sigma, eps, code):
+        require_device(heat_s, heat_t, phi_s, phi_t)
+        heat_s, heat_t = f32c(heat_s), f32c(heat_t)
+        phi_s, phi_t = phi_s.contiguous(), phi_t.contiguous()
+        B, H, W, C = phi_t.shape
+        K = heat_t.shape[1]
+        if heat_t.shape != (B, K, H, W) or heat_s.shape != heat_t.shape or phi_s.shape != phi_t.shape or phi_s.dtype != phi_t.dtype:
+            raise RuntimeError('keypoint_bottleneck_t: heat-maps and feature maps must share batch and spatial size')
+        dev = phi_t.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        k = torch.empty(B, K, 2, **f32)
+        p = torch.empty(B, K, H, **f32)
+        q = torch.empty(B, K, W, **f32)
+        m = torch.empty(B, K, H, W, **f32)
+        a = torch.empty(B, H + 2, W + 2, C, device=dev, dtype=phi_t.dtype)
+        mask_s = torch.empty(B, 1, H, W, **f32)
+        mask_t = torch.empty(B, 1, H, W, **f32)
+        arg_t = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
+        call('kp_keypoint_bottleneck_fwd_t', ptr(heat_s), ptr(heat_t), ptr(phi_s), ptr(phi_t), ptr(k), ptr(p), ptr(q), ptr(m),
+             ptr(a), ptr(mask_s), ptr(mask_t), ptr(arg_t), B, C, K, H, W, float(sigma), float(eps), code, stream_ptr())
+        ctx.save_for_backward(phi_s, phi_t, mask_s, mask_t, arg_t, k, p, q)
+        ctx.args = (float(sigma), float(eps), code)
+        ctx.mark_non_differentiable(p, q, mask_s, mask_t)
+        ctx.set_materialize_grads(False)
+        return a, k, p, q, m, mask_s, mask_t
+
+    @staticmethod
+    def backward(ctx, ga, gk, _gp, _gq, gm, _gs, _gt):
+        phi_s, phi_t, mask_s, mask_t, arg_t, k, p, q = ctx.saved_tensors
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            raise NotImplementedError('keypoint_bottleneck_t: the source branch carries no gradient (transporter.py:36-37)')
+        B, H, W, C = phi_t.shape
+        K = k.shape[1]
+        sigma, eps, code = ctx.args
+        if ga is None:
+            ga = torch.zeros(B, H + 2, W + 2, C, device=phi_t.device, dtype=phi_t.dtype)
+        ga = ga.to(phi_t.dtype).contiguous()
+        d_phi_t = torch.empty_like(phi_t)
+        d_heat = torch.empty(B, K, H, W, device=phi_t.device, dtype=torch.float32)
+        call('kp_keypoint_bottleneck_bwd_t', ptr(ga), ptr(f32c(gk)) if gk is not None else None,
+             ptr(f32c(gm)) if gm is not None else None, ptr(phi_s), ptr(phi_t), ptr(mask_s), ptr(mask_t), ptr(arg_t),
+             ptr(k), ptr(p), ptr(q), ptr(d_phi_t), ptr(d_heat), B, C, K, H, W, sigma, eps, code, stream_ptr())
+        return None, d_heat, None, d_phi_t, None, None, None
+
+
+def keypoint_bottleneck_t(heat_s, heat_t, phi_s, phi_t, code, sigma=0.1, eps=1e-6):
+    """keypoint_bottleneck between T tensors -> (a, k_t, (p_t, q_t), m_t, mask_s, mask_t); `a` = the blend as the decoder's padded
+    16-bit NHWC input.  `code`: the storage type's KP_* dtype code."""
+    a, k, p, q, m, mask_s, mask_t = _KeypointBottleneckT.apply(heat_s, heat_t, phi_s, phi_t, sigma, eps, code)
+    return a, k, (p, q), m, mask_s, mask_t
+
+
+class _PaddedTToNchw(torch.autograd.Function):
+    """kp_nhwc_to_nchw: the interior of a padded T image [B][H+2p][W+2p][C] as fp32 NCHW -- the blended feature map
+    TransporterNet.forward RETURNS (transporter.py:64) next to feeding it to the decoder.  Its backward (a loss on the returned
+    map: nothing in the reference's train loops) is a zero-bordered layout change in torch."""
+
+    @staticmethod
+    def forward(ctx, a, pad, code):
+        a = a.contiguous()
+        B, Hp, Wp, C = a.shape
+        H, W = Hp - 2 * pad, Wp - 2 * pad
+        out = torch.empty(B, C, H, W, device=a.device, dtype=torch.float32)
+        call('kp_nhwc_to_nchw', ptr(a), ptr(out), B, C, H, W, pad, code, stream_ptr())
+        ctx.pad, ctx.dt = pad, a.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ga = torch.nn.functional.pad(g.permute(0, 2, 3, 1), (0, 0, ctx.pad, ctx.pad, ctx.pad, ctx.pad))
+        return ga.to(ctx.dt).contiguous(), None, None
+
+
+def padded_t_to_nchw(a, pad, code):
+    return _PaddedTToNchw.apply(a, int(pad), code)
+
+
 def bottleneck_fusable(H, W, C):
     """Shapes the fused kernels take (include/kp_hip.h): everything else composes the piecewise kernels."""
     if H > 256 or W > 256:

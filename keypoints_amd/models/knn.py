@@ -115,7 +115,15 @@ class Unit(nn.Module):
         require_device(x)
         params = list(self.parameters())
         record = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
-        return UnitFunction.apply(x, self, record, *params)
+        return UnitFunction.apply(x, self, record, (False, False), *params)
+
+    def forward_t(self, x, in_t=False, out_t=False):
+        """`forward` with the 16-bit NHWC interchange formats of include/kp_hip.h at either end (UnitFunction.forward): what
+        TransporterNet uses between the feature encoder, the keypoint bottleneck and the decoder where the library has the kernels."""
+        require_device(x)
+        params = list(self.parameters())
+        record = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        return UnitFunction.apply(x, self, record, (bool(in_t), bool(out_t)), *params)
 
     # -- checkpoints: same files / keys as knn.py:143-167 ---------------------------------------
     def _blocks(self, in_block=True, core=True, out_block=True):

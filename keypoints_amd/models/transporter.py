@@ -4,8 +4,8 @@ import torch.nn as nn
 
 from . import functional as MF
 from . import knn, vgg
-from .. import runtime
-from ..unit_engine import prepack, shared_packs
+from .. import _lib, runtime
+from ..unit_engine import _first_cp, head_dims, prepack, shared_packs
 
 
 class TransporterNet(knn.Container):
@@ -32,6 +32,31 @@ class TransporterNet(knn.Container):
                 and type(self.key2map) is knn.GaussianLike
                 and MF.bottleneck_fusable(phi.size(2), phi.size(3), phi.size(1)))
 
+    def _t_route(self, xt):
+        """The storage type's dtype code if feature encoder -> 'max' bottleneck -> decoder can exchange 16-bit NHWC ("T") tensors
+        (include/kp_hip.h: kp_head_fwd_t, kp_keypoint_bottleneck_fwd_t; the Pong-class shapes), else None: the fp32 NCHW tensors of
+        the reference's Unit interface are then used between them.  Same arithmetic either way; the T route rounds the encoder
+        head's output once more (to the storage type the decoder's first layer would round the blend to anyway)."""
+        if not (runtime.t_interchange() and torch.is_tensor(xt) and xt.is_cuda and xt.dim() == 4 and self.combine_method == 'max'
+                and type(self.ssm) is knn.SpatialLogSoftmax and type(self.key2map) is knn.GaussianLike
+                and all(isinstance(u, knn.Unit) for u in (self.feature, self.keypoint, self.decoder))
+                and self.feature.precision == self.decoder.precision and self.feature.precision in ('bf16', 'fp16')):
+            return None
+        try:
+            fplan, dplan = self.feature.plan(), self.decoder.plan()
+        except NotImplementedError:
+            return None
+        N, _, H, W = xt.shape
+        code = runtime.precision_dtype(self.feature.precision)[1]
+        Hh, Wh, Ch, Kf = head_dims(self.feature, H, W)
+        Kp = self.keypoint.out_block[0].out_channels
+        L = _lib.lib()
+        if (dplan[0]['kind'] == 'conv3' and dplan[0]['conv'].in_channels == Kf and _first_cp(dplan, Kf, self.decoder.precision) == Kf
+                and L.kp_head_t_supported(N, Hh, Wh, Ch, Kf, code) == 1
+                and L.kp_keypoint_bottleneck_t_supported(N, Kf, Kp, Hh, Wh, code) == 1):
+            return code
+        return None
+
     def forward(self, xs, xt):
         with shared_packs():   # both branches run on the same weights: pack them once
             return self._forward(xs, xt)
@@ -49,9 +74,22 @@ class TransporterNet(knn.Container):
                     heatmap_xs = self.keypoint(xs)
                 heatmap_xt = self.keypoint(xt)
                 side.outputs(heatmap_xs, heatmap_xt)
+            tcode = self._t_route(xt)
             with torch.no_grad():   # source branch carries no gradient (transporter.py:36-37)
-                phi_xs = self.feature(xs)
-            phi_xt = self.feature(xt)
+                phi_xs = self.feature(xs) if tcode is None else self.feature.forward_t(xs, out_t=True)
+            phi_xt = self.feature(xt) if tcode is None else self.feature.forward_t(xt, out_t=True)
+
+        if tcode is not None:
+            # the bottleneck reads the heads' 16-bit NHWC output and writes the decoder's padded input; the fp32 NCHW copy of the
+            # blend that forward() also returns is made beside the decoder, on a side stream
+            a, k_xt, p_xt, m_xt, mask_xs, mask_xt = MF.keypoint_bottleneck_t(
+                heatmap_xs, heatmap_xt, phi_xs, phi_xt, tcode, sigma=self.key2map.sigma)
+            with runtime.fork('aux', a) as side:
+                with side:
+                    phi = MF.padded_t_to_nchw(a, 1, tcode)
+                    side.outputs(phi)
+                x_t = self.decoder.forward_t(a, in_t=True)
+            return x_t, phi, k_xt, m_xt, p_xt, heatmap_xt, mask_xs, mask_xt
 
         if self._fused_bottleneck_ok(phi_xt):
             # ssm + key2map of both branches and the 'max' blend: one kernel forward, one backward

@@ -216,3 +216,19 @@ def fuse_bn_reduce() -> bool:
 def set_fuse_bn_reduce(on: bool) -> None:
     global _FUSE_BN_REDUCE
     _FUSE_BN_REDUCE = bool(on)
+
+
+_T_INTERCHANGE = not bool(_os.environ.get('KP_NO_T_INTERCHANGE'))
+
+
+def t_interchange() -> bool:
+    """TransporterNet moves the feature maps between the encoder head, the 'max' keypoint bottleneck and the decoder as 16-bit NHWC
+    tensors (kp_head_fwd_t / kp_keypoint_bottleneck_fwd_t, include/kp_hip.h) where the library has those kernels (the Pong-class
+    nets in bf16 / fp16), instead of the fp32 NCHW tensors of the reference's Unit interface plus two layout kernels.
+    `set_t_interchange(False)` / KP_NO_T_INTERCHANGE=1 restore the fp32 route for A/B measurements and tests."""
+    return _T_INTERCHANGE
+
+
+def set_t_interchange(on: bool) -> None:
+    global _T_INTERCHANGE
+    _T_INTERCHANGE = bool(on)

@@ -241,6 +241,17 @@ def _tail_dims(H, W, tail):
     return H, W
 
 
+def head_dims(unit, H, W):
+    """(Hh, Wh, Ch, Kout): map size and channels at a Unit's 1x1 head for an H x W input (the pools / upsamplings of its plan)."""
+    plan = unit.plan()
+    C = None
+    for stp in plan[:-1]:
+        H, W = _tail_dims(H, W, stp['tail'])
+        C = stp['conv'].out_channels
+    hconv = plan[-1]['conv']
+    return H, W, (C if C is not None else hconv.in_channels), hconv.out_channels
+
+
 def _materialise(fin, N, H, W, C, pad, tdt, code, st):
     """The activation a fused consumer would have formed on its load path, written out: kp_bn_act_fwd of the saved conv output
     (`fin`: see UnitFunction.forward) with a replicate border of `pad`."""
@@ -254,19 +265,36 @@ class UnitFunction(torch.autograd.Function):
     Unit's GradArena (returned as None to autograd), the input gradient is returned normally."""
 
     @staticmethod
-    def forward(ctx, x, unit, record, *params):
+    def forward(ctx, x, unit, record, fmt, *params):
+        """fmt = (in_t, out_t): the "T" interchange formats of include/kp_hip.h (16-bit NHWC tensors between Units instead of the
+        reference's fp32 NCHW).  in_t: x is the first 3x3 layer's input as that layer reads it, T [N][H+2][W+2][Cin] with its
+        replicate border (written by the T form of the keypoint bottleneck), and the returned input gradient is the data
+        gradient over that padded domain (the producer folds the border).  out_t: the head writes T [N][H][W][K] and the
+        backward takes the output gradient in that form.  The callers (TransporterNet) ask *_t_supported first."""
         require_device(x, *params)
+        in_t, out_t = fmt
         plan = unit.plan()
         tdt, code = precision_dtype(unit.precision)
         st = stream_ptr()
         dev = x.device
-        x = f32c(x)
-        N, Cin, H, W = x.shape
         first = plan[0]
         pad0 = 1 if first['kind'] == 'conv3' else 0
-        Cp0 = _first_cp(plan, Cin, unit.precision)
-        a = torch.empty(N, H + 2 * pad0, W + 2 * pad0, Cp0, device=dev, dtype=tdt)
-        call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, Cin, Cp0, H, W, pad0, code, st)
+        if in_t:
+            if x.dtype != tdt or pad0 != 1:
+                raise RuntimeError('keypoints_amd Unit: a T-format input is the padded input of a first 3x3 layer in the Unit\'s storage type')
+            x = x.contiguous()
+            N, H, W, Cin = x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[3]
+            Cp0 = _first_cp(plan, Cin, unit.precision)
+            if Cp0 != Cin:
+                raise RuntimeError('keypoints_amd Unit: a T-format input cannot be channel-padded')
+            a = x
+        else:
+            x = f32c(x)
+            N, Cin, H, W = x.shape
+            Cp0 = _first_cp(plan, Cin, unit.precision)
+            a = torch.empty(N, H + 2 * pad0, W + 2 * pad0, Cp0, device=dev, dtype=tdt)
+            call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, Cin, Cp0, H, W, pad0, code, st)
+        H0, W0 = H, W
         saved = []
         fin = None   # pending BatchNorm-apply of the previous layer, fused into the next convolution (None: `a` is materialised)
         packs = _pack_unit(plan, Cin, Cp0, record, dev, tdt, code, st)
@@ -347,17 +375,27 @@ class UnitFunction(torch.autograd.Function):
         head = plan[-1]
         hconv = head['conv']
         Kout = hconv.out_channels
-        out = torch.empty(N, Kout, H, W, device=dev, dtype=torch.float32)
-        if fin is not None:   # the head reads the last layer's conv output; its BatchNorm-apply + activation run on the load path
-            call('kp_head_fwd_bnin', ptr(fin['y']), *fin['bn'], fin['slope'], ptr(hconv.weight), ptr(hconv.bias), head['slope'],
-                 ptr(out), N, H, W, C, Kout, code, st)
+        if out_t:
+            out = torch.empty(N, H, W, Kout, device=dev, dtype=tdt)
+            if fin is not None:
+                call('kp_head_fwd_t', ptr(fin['y']), 1, *fin['bn'], fin['slope'], ptr(hconv.weight), ptr(hconv.bias), head['slope'],
+                     ptr(out), N, H, W, C, Kout, code, st)
+            else:
+                call('kp_head_fwd_t', ptr(a), 0, None, None, None, None, 0.0, ptr(hconv.weight), ptr(hconv.bias), head['slope'],
+                     ptr(out), N, H, W, C, Kout, code, st)
         else:
-            call('kp_head_fwd', ptr(a), ptr(hconv.weight), ptr(hconv.bias), head['slope'], ptr(out), N, H, W, C, Kout, code, st)
+            out = torch.empty(N, Kout, H, W, device=dev, dtype=torch.float32)
+            if fin is not None:   # the head reads the last layer's conv output; its BatchNorm-apply + activation run on the load path
+                call('kp_head_fwd_bnin', ptr(fin['y']), *fin['bn'], fin['slope'], ptr(hconv.weight), ptr(hconv.bias), head['slope'],
+                     ptr(out), N, H, W, C, Kout, code, st)
+            else:
+                call('kp_head_fwd', ptr(a), ptr(hconv.weight), ptr(hconv.bias), head['slope'], ptr(out), N, H, W, C, Kout, code, st)
         if record:
             ctx.unit, ctx.saved, ctx.head_in = unit, saved, (a if fin is None else fin)
             ctx.save_for_backward(out)   # an OUTPUT kept as a plain ctx attribute would be a reference cycle
-            ctx.dims = (N, Cin, x.shape[2], x.shape[3], H, W, C, Kout, pad0)
+            ctx.dims = (N, Cin, H0, W0, H, W, C, Kout, pad0)
             ctx.cp0 = Cp0
+            ctx.fmt = (bool(in_t), bool(out_t))
         return out
 
     @staticmethod
@@ -383,7 +421,7 @@ class UnitFunction(torch.autograd.Function):
         gv = arena.views
         need_x = ctx.needs_input_grad[0]
 
-        gout = f32c(gout)
+        in_t, out_t = ctx.fmt
         head = plan[-1]
         hconv = head['conv']
         has_body = len(plan) > 1
@@ -391,13 +429,33 @@ class UnitFunction(torch.autograd.Function):
         # the workspace makes the head's weight gradient a fixed-order two-stage sum (bitwise reproducible step)
         hws = torch.empty(_lib.lib().kp_head_bwd_ws_floats(N, Hh, Wh, Ch, Kout, code), device=dev, dtype=torch.float32)
         hgrads = (ptr(g), ptr(gv[id(hconv.weight)]), ptr(gv[id(hconv.bias)]) if hconv.bias is not None else None, ptr(hws))
-        if isinstance(a_last, dict):   # the forward's fused form: the head's input is recomputed from the conv output
+        if out_t:
+            # output gradient and saved output are T [N][H][W][K] (see forward); should the library decline NOW (unaligned foreign
+            # gradient tensor), both are turned into the fp32 planes of the plain entry points and the code below runs as usual
+            gout = gout.to(tdt).contiguous()
+            if isinstance(a_last, dict):
+                done = try_call('kp_head_bwd_t', ptr(gout), ptr(out), ptr(a_last['y']), 1, *a_last['bn'], a_last['slope'], ptr(hconv.weight),
+                                head['slope'], *hgrads, N, Hh, Wh, Ch, Kout, code, st)
+            else:
+                done = try_call('kp_head_bwd_t', ptr(gout), ptr(out), ptr(a_last), 0, None, None, None, None, 0.0, ptr(hconv.weight),
+                                head['slope'], *hgrads, N, Hh, Wh, Ch, Kout, code, st)
+            if not done:
+                g32 = torch.empty(N, Kout, Hh, Wh, device=dev, dtype=torch.float32)
+                o32 = torch.empty(N, Kout, Hh, Wh, device=dev, dtype=torch.float32)
+                call('kp_nhwc_to_nchw', ptr(gout), ptr(g32), N, Kout, Hh, Wh, 0, code, st)
+                call('kp_nhwc_to_nchw', ptr(out), ptr(o32), N, Kout, Hh, Wh, 0, code, st)
+                gout, out, out_t = g32, o32, False
+        else:
+            gout = f32c(gout)
+        if out_t:
+            pass
+        elif isinstance(a_last, dict):   # the forward's fused form: the head's input is recomputed from the conv output
             if not try_call('kp_head_bwd_bnin', ptr(gout), ptr(out), ptr(a_last['y']), *a_last['bn'], a_last['slope'], ptr(hconv.weight),
                             head['slope'], *hgrads, N, Hh, Wh, Ch, Kout, code, st):
                 # declined in the backward although the forward's shape query accepted (unaligned gradient tensors, a knob that
                 # changed in between): rebuild the activation the forward never wrote and run the plain kernel
                 a_last = _materialise(a_last, N, Hh, Wh, Ch, 0, tdt, code, st)
-        if not isinstance(a_last, dict):
+        if not out_t and not isinstance(a_last, dict):
             if isinstance(ctx.head_in, dict):
                 hws = torch.empty(_lib.lib().kp_head_bwd_ws_floats(N, Hh, Wh, Ch, Kout, code), device=dev, dtype=torch.float32)
                 hgrads = hgrads[:3] + (ptr(hws),)
@@ -507,7 +565,9 @@ class UnitFunction(torch.autograd.Function):
                     cur.wait_stream(side)
             unit._layer_done(idx)   # the arena slots of plan steps >= idx (and of the head) are final from here on
         dx = None
-        if need_x:
+        if need_x and in_t:
+            dx = g   # the data gradient over the padded input domain [N][H+2][W+2][Cin] (T): the producer folds the border
+        elif need_x:
             dx = torch.empty(N, Cin, H0, W0, device=dev, dtype=torch.float32)
             call('kp_nhwc_grad_to_nchw', ptr(g), ptr(dx), N, Cin, ctx.cp0, H0, W0, gp, code, st)
         # release the saved activations now (not when the graph dies): hundreds of MB per Unit
@@ -518,4 +578,4 @@ class UnitFunction(torch.autograd.Function):
             keep.clear()
         runtime.join_after_backward()   # a backward that runs on a side stream itself is joined when the pass ends
         unit._after_backward()
-        return (dx, None, None) + (None,) * len(params)
+        return (dx, None, None, None) + (None,) * len(params)
