@@ -6,6 +6,7 @@
 // HBM/latency-class work.  Heat-maps are staged through LDS in row chunks (coalesced
 // reads over H x W), marginals are reduced per wavefront.
 #include "kp_common.h"
+#include "kp_rowsum.h"
 
 namespace {
 
@@ -29,10 +30,24 @@ __global__ __launch_bounds__(TPB) void spatial_softmax_fwd_k(const float* __rest
         __syncthreads();
         for (int e = tid; e < rows * W; e += TPB) tile[(e / W) * pitch + (e % W)] = src[(long long)r0 * W + e];
         __syncthreads();
-        for (int i = tid; i < rows; i += TPB) {   // row sums: lanes walk different rows, odd pitch => no conflicts
-            float s = 0.f;
-            for (int j = 0; j < W; ++j) s += tile[i * pitch + j];
-            rowv[r0 + i] = s / (float)W;
+        // row sums: eight rows per wavefront pass, a lane's partial over its columns lane, lane + 64, ... then the halving butterfly of
+        // kp_rowsum.h -- the order of the fused kernels' wave_keypoint (kp_bottleneck_dev.h), to which this kernel stays bit-identical
+        for (int b8 = tid >> 6; b8 * 8 < rows; b8 += TPB / 64) {
+            const int lane = tid & 63;
+            float pp[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = b8 * 8 + r;
+                float s = 0.f;
+                if (i < rows) {
+                    s = lane < W ? tile[i * pitch + lane] : 0.f;
+                    for (int j = lane + 64; j - lane < 256 || j < W; j += 64) s += j < W ? tile[i * pitch + j] : 0.f;
+                }
+                pp[r] = s;
+            }
+            int idx;
+            const float tot = kp_rows8_over64(pp, lane, idx);
+            if ((lane & 7) == 0 && b8 * 8 + idx < rows) rowv[r0 + b8 * 8 + idx] = tot / (float)W;
         }
         for (int j = tid; j < W; j += TPB) {      // column partial sums
             float s = colv[j];

@@ -4,12 +4,13 @@
 // masks are bit-identical whichever form runs.
 #pragma once
 #include "kp_common.h"
+#include "kp_rowsum.h"
 
 namespace {
 
 constexpr int NT = 1024;            // threads per workgroup
 constexpr int NW = NT / 64;
-constexpr int TILE_FLOATS = 1024;   // per-wave LDS staging tile (4 KiB)
+constexpr int TILE_FLOATS = 0;      // (the per-wave LDS staging tile of the first version: wave_keypoint reads the map straight from global memory now)
 constexpr int MAXDIM = 256;         // H, W <= MAXDIM (per-wave marginal vectors)
 constexpr int WAVE_FLOATS = TILE_FLOATS + 2 * MAXDIM;
 constexpr int BWD_LDS_FLOATS = 16384;
@@ -21,40 +22,59 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// marginal (log-)softmax of one heat-map by one wavefront; returns the keypoint coordinate pair in (ky, kx) on all lanes
+// marginal (log-)softmax of one heat-map by one wavefront; returns the keypoint coordinate pair in (ky, kx) on all lanes.
+// The marginals straight from global memory, no LDS tile: a lane owns columns lane, lane + 64, lane + 128, lane + 192 (W <= 256), the
+// wavefront walks the rows -- coalesced 4-byte loads, two batches of 8 rows in flight.  Column sums are the lane's running sums
+// over the rows in order (the order they always had); a row sum is the lane's partial over its <= 4 columns, then the halving
+// butterfly of kp_rows8_over64 (kp_rowsum.h), eight rows per pass.  (The first version staged 12-row chunks through an LDS tile and let <= 12 lanes walk a row each: 84
+// dependent LDS reads per chunk and lane -- the phase took 56 of the kernel's 128 us at 256 pairs x 8 maps of 84 x 84, 1 TB/s
+// of heat-map reads, tools/probes/bneck_t_abl.py.  The row-sum order changed with it, in kp_spatial_softmax_fwd too: the
+// fused and the piecewise kernels stay bit-identical to each other.)
 __device__ void wave_keypoint(const float* __restrict__ src, int H, int W, float* tile, float* rowv, float* colv,
                               float* __restrict__ pdst, float* __restrict__ qdst, float& ky, float& kx) {
+    (void)tile;
     const int lane = threadIdx.x & 63;
-    const int pitch = W | 1;
-    int rc = TILE_FLOATS / pitch;
-    if (rc > H) rc = H;
-    for (int j = lane; j < W; j += 64) colv[j] = 0.f;
-    const bool vec = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
-    for (int r0 = 0; r0 < H; r0 += rc) {
-        const int rows = (H - r0 < rc) ? H - r0 : rc;
-        const float* s = src + (long long)r0 * W;
-        if (vec) {
-            for (int e = lane * 4; e < rows * W; e += 256) {
-                const float4 v = *reinterpret_cast<const float4*>(s + e);
-                float* d = tile + (e / W) * pitch + (e % W);
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        } else {
-            for (int e = lane; e < rows * W; e += 64) tile[(e / W) * pitch + (e % W)] = s[e];
+    constexpr int RB = 8;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool on1 = lane + 64 < W, on2 = lane + 128 < W, on3 = lane + 192 < W, on0 = lane < W;
+    auto load_batch = [&](float (&buf)[RB][4], int r0) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int row = r0 + r;
+            const float* sp = src + (long long)(row < H ? row : 0) * W + lane;
+            const bool rv = row < H;
+            buf[r][0] = (rv && on0) ? sp[0] : 0.f;
+            buf[r][1] = (rv && on1) ? sp[64] : 0.f;
+            buf[r][2] = (rv && on2) ? sp[128] : 0.f;
+            buf[r][3] = (rv && on3) ? sp[192] : 0.f;
         }
-        wave_lds_sync();
-        for (int i = lane; i < rows; i += 64) {   // lanes walk different rows; odd pitch => conflict-free
-            float a = 0.f;
-            for (int j = 0; j < W; ++j) a += tile[i * pitch + j];
-            rowv[r0 + i] = a / (float)W;
+    };
+    auto reduce_batch = [&](const float (&buf)[RB][4], int r0) {
+        float pp[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {   // (rows beyond H were loaded as zeros)
+            pp[r] = buf[r][0];
+            cs[0] += buf[r][0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) { pp[r] += buf[r][q]; cs[q] += buf[r][q]; }
         }
-        for (int j = lane; j < W; j += 64) {
-            float a = colv[j];
-            for (int i = 0; i < rows; ++i) a += tile[i * pitch + j];
-            colv[j] = a;
-        }
-        wave_lds_sync();
+        int idx;
+        const float tot = kp_rows8_over64(pp, lane, idx);
+        if ((lane & 7) == 0 && r0 + idx < H) rowv[r0 + idx] = tot / (float)W;
+    };
+    float A[RB][4], B[RB][4];
+    load_batch(A, 0);
+    for (int r0 = 0; r0 < H; r0 += 2 * RB) {
+        load_batch(B, r0 + RB);
+        reduce_batch(A, r0);
+        load_batch(A, r0 + 2 * RB);
+        reduce_batch(B, r0 + RB);
     }
+    if (on0) colv[lane] = cs[0];
+    if (on1) colv[lane + 64] = cs[1];
+    if (on2) colv[lane + 128] = cs[2];
+    if (on3) colv[lane + 192] = cs[3];
+    wave_lds_sync();
     for (int j = lane; j < W; j += 64) colv[j] = colv[j] / (float)H;
     wave_lds_sync();
     float key[2];

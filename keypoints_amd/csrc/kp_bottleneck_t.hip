@@ -39,7 +39,7 @@ __global__ __launch_bounds__(NT) void bottleneck_fwd_t_k(const float* __restrict
                                                          float* __restrict__ q_t, float* __restrict__ m_t,
                                                          h16_t* __restrict__ a, float* __restrict__ mask_s,
                                                          float* __restrict__ mask_t, unsigned char* __restrict__ arg_t,
-                                                         int K, int H, int W, float inv2s2, float eps) {
+                                                         int K, int H, int W, float inv2s2, float eps, int dbg) {
     constexpr int C = 8 * LP;
     extern __shared__ float sm[];
     float* keys = sm;                     // [2][K][2]: branch, keypoint, (y, x)
@@ -48,7 +48,10 @@ __global__ __launch_bounds__(NT) void bottleneck_fwd_t_k(const float* __restrict
     const int HW = H * W, Wp = W + 2;
 
     // ---- phase A: 2K heat-maps -> keypoints (shared with the fp32 form) -------------------------------------------
-    {
+    // (dbg: kp_config(KP_CFG_DEBUG) ablation mask of tools/probes/bneck_t_abl.py -- 1: no phase A, 2: no phase B; 0 in normal operation)
+    if (dbg & 1) {
+        if (tid < 4 * K) keys[tid] = 0.5f;
+    } else {
         float* tile = wbase + wave * WAVE_FLOATS;
         float* rowv = tile + TILE_FLOATS;
         float* colv = rowv + MAXDIM;
@@ -66,6 +69,7 @@ __global__ __launch_bounds__(NT) void bottleneck_fwd_t_k(const float* __restrict
         }
     }
     __syncthreads();
+    if (dbg & 2) return;
 
     // ---- phase B: render, max over K, blend: one (pixel, 8-channel chunk) per thread ------------------------------
     const uint4* ps = reinterpret_cast<const uint4*>(phi_s + (long long)b * HW * C);
@@ -73,10 +77,27 @@ __global__ __launch_bounds__(NT) void bottleneck_fwd_t_k(const float* __restrict
     uint4* pa = reinterpret_cast<uint4*>(a + (long long)b * (H + 2) * Wp * C);
     const float* ks = keys;
     const float* kt = keys + 2 * K;
-    for (int item = tid; item < HW * LP; item += NT) {
-        const int pix = item / LP, ch = item - pix * LP;
+    // (one workgroup per CU, 16 waves: a lane keeps the chunks of its NEXT TWO items in flight under the renders of this one --
+    //  with one pair of 16-byte loads per lane the CU had 32 KB in flight, half of what its share of the HBM rate needs)
+    const int total = HW * LP;
+    uint4 ns[2], nt[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int it = tid + u * NT < total ? tid + u * NT : tid;
+        ns[u] = ps[it]; nt[u] = pt[it];
+    }
+    for (int item = tid; item < total; item += 2 * NT) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int itm = item + u * NT;
+        if (itm >= total) break;
+        const uint4 rs = ns[u], rt = nt[u];
+        {
+            const int nx = itm + 2 * NT < total ? itm + 2 * NT : itm;
+            ns[u] = ps[nx]; nt[u] = pt[nx];
+        }
+        const int pix = itm / LP, ch = itm - pix * LP;
         const int i = pix / W, j = pix - i * W;
-        const uint4 rs = ps[item], rt = pt[item];     // in flight under the renders
         const float ry = ruler_at(i, H), rx = ruler_at(j, W);
         const bool do_s = LP == 1 || (ch & 1) == 0, do_t = LP == 1 || (ch & 1) == 1;
         float bs = 0.f, bt = 0.f;
@@ -123,6 +144,7 @@ __global__ __launch_bounds__(NT) void bottleneck_fwd_t_k(const float* __restrict
         if (top && rig) put(0, W + 1);
         if (bot && lef) put(H + 1, 0);
         if (bot && rig) put(H + 1, W + 1);
+      }
     }
 }
 
@@ -148,10 +170,18 @@ __global__ __launch_bounds__(NT) void bottleneck_bwd_t_k(const h16_t* __restrict
     const uint4* ps = reinterpret_cast<const uint4*>(phi_s + (long long)b * HW * C);
     const uint4* pt = reinterpret_cast<const uint4*>(phi_t + (long long)b * HW * C);
     uint4* pd = reinterpret_cast<uint4*>(d_phi_t + (long long)b * HW * C);
-    for (int item = tid; item < HW * LP; item += NT) {
+    const int total = HW * LP;
+    // the next item's chunks (phi_s, phi_t, the gradient's centre position) are requested before this item is worked on
+    auto centre = [&](int it) { const int px = it / LP, c2 = it - px * LP, ii = px / W, jj = px - ii * W; return ((long long)(ii + 1) * Wp + jj + 1) * LP + c2; };
+    uint4 ns = ps[tid < total ? tid : 0], nt = pt[tid < total ? tid : 0], ng = pg[centre(tid < total ? tid : 0)];
+    for (int item = tid; item < total; item += NT) {
         const int pix = item / LP, ch = item - pix * LP;
         const int i = pix / W, j = pix - i * W;
-        const uint4 rs = ps[item], rt = pt[item];
+        const uint4 rs = ns, rt = nt, rg = ng;
+        {
+            const int nx = item + NT < total ? item + NT : item;
+            ns = ps[nx]; nt = pt[nx]; ng = pg[centre(nx)];
+        }
         const float ms = mask_s[(long long)b * HW + pix], mt = mask_t[(long long)b * HW + pix];
         // rows / columns of the padded domain that replicate onto (i, j): summed rows outer, columns inner, from 0 -- the order of
         // kp_nhwc_grad_to_nchw, so this kernel == that kernel + kp_keypoint_bottleneck_bwd on its fp32 output
@@ -163,7 +193,7 @@ __global__ __launch_bounds__(NT) void bottleneck_bwd_t_k(const h16_t* __restrict
         for (int pr = ilo; pr <= ihi; ++pr)
             for (int pc = jlo; pc <= jhi; ++pc) {
                 float v[8];
-                unpack8(pg[((long long)pr * Wp + pc) * LP + ch], v);
+                unpack8((pr == i + 1 && pc == j + 1) ? rg : pg[((long long)pr * Wp + pc) * LP + ch], v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g[e] += v[e];
             }
@@ -183,28 +213,43 @@ __global__ __launch_bounds__(NT) void bottleneck_bwd_t_k(const h16_t* __restrict
     }
     __syncthreads();
 
-    // ---- 2: through argmax_k and the Gaussian render onto the keypoints (one wavefront per keypoint) --------------
-    for (int k = wave; k < K; k += NW) {
-        const long long bk = (long long)b * K + k;
-        const float ky = k_t[bk * 2], kx = k_t[bk * 2 + 1];
-        float sy = 0.f, sx = 0.f;
-        for (int pix = lane; pix < HW; pix += 64) {
-            float gm = (arg_t[(long long)b * HW + pix] == k) ? gpart[pix] : 0.f;
-            if (g_m) gm += g_m[bk * HW + pix];
-            if (gm != 0.f) {
-                const int i = pix / W;
-                const float dy = ruler_at(i, H) - ky, dx = ruler_at(pix - i * W, W) - kx;
-                const float d = sqrtf(dy * dy + dx * dx + eps);
-                const float cc = gm * expf(-d * inv2s2) * inv2s2 / d;
-                sy += cc * dy;
-                sx += cc * dx;
+    // ---- 2: through argmax_k and the Gaussian render onto the keypoints: NW / K wavefronts per keypoint (K < NW: with one
+    // wavefront per keypoint 4 of the 16 waves of a Pong-class pair walked 7 056 pixels each while 12 idled), every part a
+    // strided share of the pixels, the parts' sums added in part order
+    {
+        const int parts = K >= NW ? 1 : NW / K;
+        float* dkp = dkv + 2 * K;                 // [K][parts][2]
+        for (int k = wave / parts; k < K; k += NW / parts) {
+            const int part = wave - (wave / parts) * parts;
+            const long long bk = (long long)b * K + k;
+            const float ky = k_t[bk * 2], kx = k_t[bk * 2 + 1];
+            float sy = 0.f, sx = 0.f;
+            for (int pix = part * 64 + lane; pix < HW; pix += 64 * parts) {
+                float gm = (arg_t[(long long)b * HW + pix] == k) ? gpart[pix] : 0.f;
+                if (g_m) gm += g_m[bk * HW + pix];
+                if (gm != 0.f) {
+                    const int i = pix / W;
+                    const float dy = ruler_at(i, H) - ky, dx = ruler_at(pix - i * W, W) - kx;
+                    const float d = sqrtf(dy * dy + dx * dx + eps);
+                    const float cc = gm * expf(-d * inv2s2) * inv2s2 / d;
+                    sy += cc * dy;
+                    sx += cc * dx;
+                }
+            }
+            sy = wave_sum(sy);
+            sx = wave_sum(sx);
+            if (lane == 0) {
+                dkp[(k * parts + part) * 2] = sy;
+                dkp[(k * parts + part) * 2 + 1] = sx;
             }
         }
-        sy = wave_sum(sy);
-        sx = wave_sum(sx);
-        if (lane == 0) {
-            dkv[2 * k] = sy + (g_k ? g_k[bk * 2] : 0.f);
-            dkv[2 * k + 1] = sx + (g_k ? g_k[bk * 2 + 1] : 0.f);
+        __syncthreads();
+        if (tid < K) {
+            float sy = 0.f, sx = 0.f;
+            for (int part = 0; part < parts; ++part) { sy += dkp[(tid * parts + part) * 2]; sx += dkp[(tid * parts + part) * 2 + 1]; }
+            const long long bk = (long long)b * K + tid;
+            dkv[2 * tid] = sy + (g_k ? g_k[bk * 2] : 0.f);
+            dkv[2 * tid + 1] = sx + (g_k ? g_k[bk * 2 + 1] : 0.f);
         }
     }
     __syncthreads();
@@ -254,6 +299,8 @@ int set_lds_attributes_t() {
 
 }  // namespace
 
+extern kp_knob_t g_kp_debug;   // kp_api.hip: kp_config(KP_CFG_DEBUG, mask)
+
 extern "C" {
 
 // 16-bit storage, 8 / 16 / 32 feature channels (the Pong-class nets, where the layout traffic is a measurable share of the
@@ -277,9 +324,10 @@ int kp_keypoint_bottleneck_fwd_t(const float* heat_s, const float* heat_t, const
     const size_t smem = (4 * (size_t)K + (size_t)NW * WAVE_FLOATS) * sizeof(float);
     if (int rc = set_lds_attributes_t()) return rc;
     hipStream_t st = (hipStream_t)stream;
+    const int dbg = g_kp_debug;
 #define KP_BF(LPv)                                                                                                             \
     bottleneck_fwd_t_k<LPv><<<B, NT, smem, st>>>(heat_s, heat_t, (const h16_t*)phi_s, (const h16_t*)phi_t, k_t, p_t, q_t, m_t, \
-                                                 (h16_t*)a, mask_s, mask_t, arg_t, K, H, W, inv2s2, eps)
+                                                 (h16_t*)a, mask_s, mask_t, arg_t, K, H, W, inv2s2, eps, dbg)
     if (C == 8) KP_BF(1);
     else if (C == 16) KP_BF(2);
     else KP_BF(4);
@@ -298,7 +346,7 @@ int kp_keypoint_bottleneck_bwd_t(const void* ga, const float* g_k, const float* 
         !aligned16(d_phi_t))
         return KP_E_UNSUPPORTED;
     const float inv2s2 = (float)(1.0 / (2.0 * (double)sigma * (double)sigma));
-    const size_t smem = ((size_t)BWD_LDS_FLOATS + 2 * (size_t)K) * sizeof(float);
+    const size_t smem = ((size_t)BWD_LDS_FLOATS + 2 * (size_t)K + 2 * (size_t)(K >= NW ? K : NW)) * sizeof(float);   // + the parts' partial sums
     if (int rc = set_lds_attributes_t()) return rc;
     hipStream_t st = (hipStream_t)stream;
     const bool vec = ((H * W) & 3) == 0 && aligned16(d_heat_t);
