@@ -269,12 +269,25 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
     const int fr = lane & 31, fh = lane >> 5;
     const int Ho = Hi - 2, Wo = Wi - 2;
     const int nseg = (Wo + 31) / 32, XPW = nseg * 32 + 2, xrow_l = XPW * PITCH;
-    // ---- staging tables of this thread's FSL chunks (band-independent): chunk id = tid + u * FTPB = (row * XPW + pixel) * CPP + c
+    // ---- staging tables of this thread's FSL chunks (band-independent).  A wave instruction covers 64 consecutive 16-byte chunks of
+    // the band (1 KB of the source, coalesced) whichever lane takes which; the lanes of a 16-lane group take the SAME channel chunk c of
+    // 16 consecutive pixels, so that their LDS stores are PITCH apart -- the conflict-free pattern of the fragment reads.  (With
+    // chunk id = tid the 16 lanes of a group wrote (pixel, c) pairs 16 bytes apart inside a pixel and PITCH - 16 * (CPP - 1) apart
+    // between pixels: two-way conflicts on a fifth of the banks, 18-25 % of the kernel's LDS cycles, profiles/r03m_pmc_summary.json.)
+#ifndef KP_FB_STAGE_LINEAR
+    const int c = ((tid & 63) >> 4) % CPP;
+#else
     const int c = tid % CPP;
+#endif
     int lo[FSL], so[FSL], rw[FSL];   // LDS byte offset; source byte offset (BNIN: of the clamped column only); band row (big: never staged)
 #pragma unroll
     for (int u = 0; u < FSL; ++u) {
+#ifndef KP_FB_STAGE_LINEAR
+        // block of 64 chunks = 64 / CPP pixels: lane group g = lane / 16, j = lane % 16 -> pixel 16 * (g / CPP) + j of the block, chunk g % CPP
+        const int pix = ((tid & ~63) + u * FTPB) / CPP + (((tid & 63) >> 4) / CPP) * 16 + (tid & 15);
+#else
         const int pix = (tid + u * FTPB) / CPP;
+#endif
         const int r = pix / XPW, px = pix - r * XPW;
         lo[u] = r * xrow_l + px * PITCH + c * 16;
         rw[u] = px < Wi ? r : (r | 0x4000);   // bit 14: zero fill beyond the image row
@@ -957,6 +970,24 @@ __global__ __launch_bounds__(TPB, 1) void wgrad3x3_small_band_k(const h16_t* __r
 // band (single LDS buffer, loads straight through registers) while the other multiplies.  Six wavefronts: 84-pixel rows are three
 // segments, x two halves of the band's rows = six column strips.  Same LDS image, staging code and partial-gradient protocol.
 constexpr int W16_TPB = 384, W16_LDS = 77824;
+#ifndef W16_SWZ
+#define W16_SWZ 0   // 1: bank-swizzled rows.  Measured (round 4): the swizzle takes SQ_LDS_BANK_CONFLICT from 25-30 % of the LDS cycles to
+                    // zero (tools/probes/small_pmc.sh) and the kernels do not move (49.5 -> 49.3, 66.1 -> 65.7 us: the transpose reads were
+                    // never what the multiply phase waits for), while the BatchNorm-input variants -- at their register cap already --
+                    // spill 4-22 registers for the extra lane constants: the config-2 step 2.83 -> 2.91 ms.  Off.
+#endif
+// chunk index c (16 bytes) within a staged row of CH-channel pixels -> its place under the bank swizzle (see the kernel): chunks of odd
+// 8-pixel groups move by +-D chunks (16 channels: D = 8, the group's two 4-pixel halves swap; 32 channels: D = 2, a pixel's two
+// 16-channel halves swap).  w16_swz_bits: bit 0 = moves, bit 1 = towards lower addresses; w16_delta: the move in chunks
+template <int CH> __device__ __forceinline__ unsigned w16_swz_bits(int c) {
+    if (!W16_SWZ) return 0u;
+    const unsigned mv = CH == 16 ? (c >> 4) & 1 : (c >> 5) & 1, dn = CH == 16 ? (c >> 3) & 1 : (c >> 1) & 1;
+    return mv | ((mv & dn) << 1);
+}
+template <int CH> __device__ __forceinline__ int w16_delta(unsigned bits) {
+    constexpr int D = CH == 16 ? 8 : 2;
+    return (bits & 1) ? ((bits & 2) ? -D : D) : 0;
+}
 // (32, 32): FOUR wavefronts per workgroup (two per SIMD with two workgroups per CU: 256 registers), each owning the two
 // gradient-channel tiles of one input-channel half -- they share the input window: 3 + 4 transpose reads per item and wavefront
 // W3 (the pairs with ONE 32-channel side): THREE wavefronts per workgroup (256 registers each), every one owning both tiles -- which share
@@ -987,8 +1018,14 @@ __global__ __launch_bounds__(w16_waves(K, C, W3) * 64, w16_waves(K, C, W3) == 6 
     const int dl_off = (R + 2) * xrow_b;                           // [(R + 2)][XP][C] input rows, then [R][Wp][K] gradient rows
     // transpose-read lane roles: t = lane & 15 -> (pixel t / 4, 4-channel chunk t % 4) of the lane group's 8-pixel run 8 * (lane >> 4)
     const int t16 = lane & 15, grp = lane >> 4;
-    const int xlane = (8 * grp + (t16 >> 2)) * (C * 2) + (t16 & 3) * 8;
-    const int dlane = (8 * grp + (t16 >> 2)) * (K * 2) + (t16 & 3) * 8;
+    // LDS bank swizzle of the staged rows (W16_SWZ).  A transpose read takes 8 bytes per lane, 512 bytes per wavefront = two passes of
+    // the 64 banks at best; with dense rows the four 16-lane groups start 8 pixels = 256 / 512 bytes apart and all land on the SAME 32
+    // banks (four passes: 25-30 % of the kernel's LDS cycles were bank conflicts, tools/probes/small_pmc.sh).  So the rows are stored
+    // with odd 8-pixel groups permuted -- 32-byte pixels (16 channels): their two 4-pixel halves swapped (byte bit 7); 64-byte pixels
+    // (32 channels): the two 16-channel halves of every pixel swapped (byte bit 5) -- which puts odd groups on the other 32 banks.
+    // w16_swz is the permutation on a row's 16-byte chunks (the staging stores), xoff / doff are the lanes' read offsets under it
+    // (lane constants: the three reads of an input row take pixels lp, lp + 4, lp + 8 of the strip, lp + 8 is in the next group).
+    const int lp = 8 * grp + (t16 >> 2), q8 = (t16 & 3) * 8, odd = W16_SWZ ? (grp & 1) : 0, nodd = W16_SWZ ? 1 - odd : 0;
     // ONE 16 x 16 tile per wavefront and tap (36 accumulator registers): with two tiles (32 channels on one side) the six wavefronts
     // are three pairs, wavefront w owns tile w % 2 for the whole kernel and takes two of the six column strips of a band -- both
     // tiles in one wavefront want 183-216 registers, and at the 168 of three waves per SIMD the spills made it slower than the old kernel
@@ -997,6 +1034,20 @@ __global__ __launch_bounds__(w16_waves(K, C, W3) * 64, w16_waves(K, C, W3) == 6 
     constexpr int TILES = KT * CT / (KW * CW);                       // tile owners among the wavefronts
     static_assert(TILES <= 2 && NWV % TILES == 0, "16 x 16 x 32 weight gradient: wavefronts pair up over at most two tile groups");
     const int tw = wave % TILES, kt = (KT == 2 && KW == 1) ? tw : 0, ct = (CT == 2 && CW == 1) ? tw : 0;
+    // input row reads of tile jc: pixels lp, lp + 4, lp + 8 at xa(jc), xa(jc) + x1i, xb(jc) + x2i; gradient reads of tile j: da(j), da(j) + d1i.
+    // 32-byte pixels: xa / xb = the lane's pixel with pixel bit 2 = odd / not odd (an odd group's halves are swapped), the third read's
+    // group has the other parity: xb + 256.  64-byte pixels: xa / xb = the lane's pixel with the channel half (ct + jc) ^ odd / ^ !odd;
+    // with both halves in one wavefront (CW == 2) tile 1's pair is tile 0's exchanged.  Two lane constants per tensor.
+#if W16_SWZ
+    const int xA = C == 16 ? (lp ^ (4 * odd)) * 32 + q8 : lp * 64 + q8 + (ct ^ odd) * 32;
+    const int xB = C == 16 ? (lp ^ (4 * nodd)) * 32 + q8 : lp * 64 + q8 + (ct ^ nodd) * 32;
+    const int dA = K == 16 ? (lp ^ (4 * odd)) * 32 + q8 : lp * 64 + q8 + (kt ^ odd) * 32;
+    const int dB = K == 16 ? (lp ^ (4 * nodd)) * 32 + q8 : lp * 64 + q8 + (kt ^ nodd) * 32;
+#else   // dense rows: the same reads written in the swizzled form's terms (xB = the next 4 pixels / the other channel half)
+    const int xA = lp * (C * 2) + q8 + ct * 32, xB = C == 16 ? xA + 128 : xA + 32;
+    const int dA = lp * (K * 2) + q8 + kt * 32, dB = K == 16 ? dA + 128 : dA + 32;
+    (void)odd; (void)nodd;
+#endif
     f32x4v acc[9][KW * CW];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -1023,12 +1074,14 @@ __global__ __launch_bounds__(w16_waves(K, C, W3) * 64, w16_waves(K, C, W3) == 6 
 #pragma unroll
         for (int u0 = 0; u0 < SLX; u0 += XB) {
             uint4 sbx[XB];
+            unsigned xsw = 0;    // two bits per slot: the chunk's place in LDS is its linear one + w16_delta (0, +D, -D chunks: w16_swz)
             unsigned livex = 0;
 #pragma unroll
             for (int v = 0; v < XB; ++v) {
                 const int u = u0 + v;
                 sbx[v] = make_uint4(0, 0, 0, 0);
                 if (u < SLX) {
+                    xsw |= w16_swz_bits<C>(c16) << (2 * v);
                     if (tid + u * TPBW < xtot && c16 < xvalid) {
                         if (BNIN) {   // chunk c16 of padded row p0 + r = (pixel c16 / CPP, channels 8 * (c16 % CPP) ..) <- clamped source
                             constexpr int CPP = C / 8;
@@ -1066,17 +1119,19 @@ __global__ __launch_bounds__(w16_waves(K, C, W3) * 64, w16_waves(K, C, W3) == 6 
             }
 #pragma unroll
             for (int v = 0; v < XB; ++v)
-                if (u0 + v < SLX && tid + (u0 + v) * TPBW < xtot) *reinterpret_cast<uint4*>(smem + (tid + (u0 + v) * TPBW) * 16) = sbx[v];
+                if (u0 + v < SLX && tid + (u0 + v) * TPBW < xtot) *reinterpret_cast<uint4*>(smem + (tid + (u0 + v) * TPBW + w16_delta<C>(xsw >> (2 * v))) * 16) = sbx[v];
         }
         int r2 = tid / dc, d16 = tid % dc;
 #pragma unroll
         for (int u0 = 0; u0 < SLD; u0 += DB) {
             uint4 sbd[DB];
+            unsigned dsw = 0;
 #pragma unroll
             for (int v = 0; v < DB; ++v) {
                 const int u = u0 + v;
                 sbd[v] = make_uint4(0, 0, 0, 0);
                 if (u < SLD) {
+                    dsw |= w16_swz_bits<K>(d16) << (2 * v);
                     if (tid + u * TPBW < dtot && d16 < dvalid) sbd[v] = *reinterpret_cast<const uint4*>(dg + (long long)r2 * drow_g + d16 * 16);
                     r2 += ddr; d16 += ddc;
                     if (d16 >= dc) { d16 -= dc; ++r2; }
@@ -1084,7 +1139,7 @@ __global__ __launch_bounds__(w16_waves(K, C, W3) * 64, w16_waves(K, C, W3) == 6 
             }
 #pragma unroll
             for (int v = 0; v < DB; ++v)
-                if (u0 + v < SLD && tid + (u0 + v) * TPBW < dtot) *reinterpret_cast<uint4*>(smem + dl_off + (tid + (u0 + v) * TPBW) * 16) = sbd[v];
+                if (u0 + v < SLD && tid + (u0 + v) * TPBW < dtot) *reinterpret_cast<uint4*>(smem + dl_off + (tid + (u0 + v) * TPBW + w16_delta<K>(dsw >> (2 * v))) * 16) = sbd[v];
         }
     };
 
@@ -1106,10 +1161,12 @@ __global__ __launch_bounds__(w16_waves(K, C, W3) * 64, w16_waves(K, C, W3) == 6 
             auto row_load = [&](int r, unsigned (&Rg)[CW][5]) {
 #pragma unroll
                 for (int jc = 0; jc < CW; ++jc) {
-                    const unsigned char* b = xl + r * xrow_b + sg * 32 * (C * 2) + xlane + (ct + jc) * 32;
-                    const uint2 q0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b)));
-                    const uint2 q1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + 4 * (C * 2))));
-                    const uint2 q2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + 8 * (C * 2))));
+                    const unsigned char* b = xl + r * xrow_b + sg * 32 * (C * 2);
+                    // (tile jc = 1 -- CW == 2, ct == 0 -- is the other channel half: the lane's pair exchanged)
+                    const int xa = jc == 0 ? xA : xB, xb = jc == 0 ? xB : xA;
+                    const uint2 q0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + xa)));
+                    const uint2 q1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + (C == 16 ? xb : xa + 4 * 64))));
+                    const uint2 q2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(b + (W16_SWZ ? xb + 8 * (C * 2) : xa + 8 * (C * 2)))));
                     Rg[jc][0] = q0.x; Rg[jc][1] = q0.y; Rg[jc][2] = q1.x; Rg[jc][3] = q1.y; Rg[jc][4] = q2.x;
                 }
             };
@@ -1133,12 +1190,13 @@ __global__ __launch_bounds__(w16_waves(K, C, W3) * 64, w16_waves(K, C, W3) == 6 
             row_load(rbeg, W0);
             row_load(rbeg + 1, W1);
             for (int r = rbeg; r < rend; ++r) {
-                const unsigned char* a = dl + r * drow_b + sg * 32 * (K * 2) + dlane + kt * 32;
+                const unsigned char* a = dl + r * drow_b + sg * 32 * (K * 2);
                 h16x8 af[KW];
 #pragma unroll
                 for (int j = 0; j < KW; ++j) {
-                    const h16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(a + j * 32));
-                    const h16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(a + j * 32 + 4 * (K * 2)));
+                    const int da = j == 0 ? dA : dB, db = j == 0 ? dB : dA;
+                    const h16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(a + da));
+                    const h16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS h16x4*)(a + (K == 16 ? db : da + 4 * 64)));
                     af[j] = h16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 }
                 row_load(r + 2, W2);
