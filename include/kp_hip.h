@@ -420,6 +420,37 @@ int kp_keypoint_bottleneck_bwd_t(const void* ga, const float* g_k, const float* 
                                  int W, float sigma, float eps, int dtype, void* stream);
 int kp_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int pad, int dtype, void* stream);
 
+/* ---- two half-batches in one launch ("pair" forms) ------------------------------------------------------------------------
+ * TransporterNet.forward runs every encoder twice on the same weights: the source frame under no_grad, then the target frame
+ * (transporter.py:36-39); nn.BatchNorm2d in training mode takes the batch statistics of EACH call and updates its running
+ * statistics twice.  The pair forms take both half-batches as one tensor [N = 2 x N/2] (half 0 = the first call's images) and launch
+ * each half exactly as a separate call of N / 2 images would be launched -- same grid, same work per workgroup, same statistics
+ * rows -- in ONE grid: results are bit-identical to the two calls, there are half as many launches, each twice as long.
+ *   kp_conv_fwd_pair       == kp_conv_fwd (R = 3, C <= 4: a Unit's first layer) on each half; stats = [2][rows][2][K] with
+ *                             rows = kp_conv_fwd_stats_rows(N / 2, Hi, Wi, C, K, 3, dtype)
+ *   kp_conv_fwd_bnin_pair  == kp_conv_fwd_bnin on each half; mean / invstd [2][C] (gamma / beta [C]: one layer);
+ *                             rows = kp_conv_fwd_stats_rows(N / 2, H + 2, W + 2, C, K, 3, dtype)
+ *   kp_bn_finalize_pair    == kp_bn_finalize on each half's rows, half 0 first: save_mean / save_invstd [2][C]; running statistics
+ *                             and num_batches_tracked take both updates in order.  count = pixels of ONE half.
+ *   kp_head_fwd_bnin_pair  == kp_head_fwd_bnin (t_out = 0: out0 / out1 fp32 NCHW [N/2][K][H][W]) or kp_head_fwd_t with bnin = 1
+ *                             (t_out = 1: T [N/2][H][W][K]) on each half
+ * *_pair_supported: 1 where the form exists (16-bit storage; conv: first = 1 the first-layer VALU kernel, first = 0 the C, K in
+ * {16, 32} band kernel; head: C == 32 on the matrix cores; finalize: 128 < rows <= 8192, C <= 32); otherwise KP_E_UNSUPPORTED,
+ * nothing launched, and the caller makes the two calls. */
+int kp_conv_pair_supported(int N, int H, int W, int C, int K, int first, int dtype);
+int kp_conv_fwd_pair(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C, int K,
+                     int dtype, void* stream);
+int kp_conv_fwd_bnin_pair(const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                          float slope, const void* w, const float* bias, void* y, float* stats, int N, int H, int W, int C, int K,
+                          int dtype, void* stream);
+int kp_bn_finalize_pair(const float* stats, long long rows, float* save_mean, float* save_invstd, float* running_mean,
+                        float* running_var, long long* num_batches_tracked, float momentum, float eps, long long count, int C,
+                        void* stream);
+int kp_head_pair_supported(int N, int H, int W, int C, int K, int t_out, int dtype);
+int kp_head_fwd_bnin_pair(const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                          float slope_in, const float* w, const float* bias, float slope, void* out0, void* out1, int t_out, int N,
+                          int H, int W, int C, int K, int dtype, void* stream);
+
 /* ---- input-side augmentation (keypoints/tps.py, keypoints/data_augments.py) ----------------------- */
 /* out = F.grid_sample(x, tps_grid(theta, ctrl, x.shape), padding_mode='zeros')   tps.py:60-87,128-131.
  * x/out fp32 NCHW; theta [N][T+3][2] (reduced != 0: [N][T+2][2], tps.py:48-50); ctrl [N][T][2] or, with

@@ -44,6 +44,10 @@ SIGNATURES = {
     'kp_keypoint_bottleneck_fwd_t': [_p] * 12 + [_i] * 5 + [_f, _f, _i, _p],
     'kp_keypoint_bottleneck_bwd_t': [_p] * 13 + [_i] * 5 + [_f, _f, _i, _p],
     'kp_nhwc_to_nchw': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'kp_conv_fwd_pair': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'kp_conv_fwd_bnin_pair': [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'kp_bn_finalize_pair': [_p, _ll, _p, _p, _p, _p, _p, _f, _f, _ll, _i, _p],
+    'kp_head_fwd_bnin_pair': [_p, _p, _p, _p, _p, _f, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'kp_unit_infer_pack': [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p],
     'kp_unit_infer_keypoints_fwd': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     'kp_unit_infer_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
@@ -86,7 +90,7 @@ SIGNATURES = {
     'kp_prof_collect': [_i, _p, _p, _p],
     'kp_prof_bytes': [_i, _p],
 }
-PLAIN = {'kp_comm_available': ([], _i), 'kp_head_t_supported': ([_i] * 6, _i), 'kp_keypoint_bottleneck_t_supported': ([_i] * 6, _i), 'kp_conv_wino_supported': ([_i] * 7, _i), 'kp_conv_fwd_wino_rows': ([_i] * 6, _ll), 'kp_conv_bnin_supported': ([_i] * 6, _i), 'kp_head_bnin_supported': ([_i] * 6, _i), 'kp_conv_dgrad_bnred_supported': ([_i] * 6, _i), 'kp_conv_dgrad_bnred_rows': ([_i] * 6, _ll), 'kp_unit_infer_param_floats': ([_i, _i, _p], _ll), 'kp_conv_wgrad_partials': ([_i] * 8, _i), 'kp_conv_fwd_stats_rows': ([_i] * 7, _ll), 'kp_bn_bwd_rows': ([_i] * 7, _ll), 'kp_head_bwd_ws_floats': ([_i] * 6, _ll), 'kp_last_rows': ([], _ll), 'kp_bn_ws_doubles': ([_i], _i), 'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
+PLAIN = {'kp_comm_available': ([], _i), 'kp_conv_pair_supported': ([_i] * 7, _i), 'kp_head_pair_supported': ([_i] * 7, _i), 'kp_head_t_supported': ([_i] * 6, _i), 'kp_keypoint_bottleneck_t_supported': ([_i] * 6, _i), 'kp_conv_wino_supported': ([_i] * 7, _i), 'kp_conv_fwd_wino_rows': ([_i] * 6, _ll), 'kp_conv_bnin_supported': ([_i] * 6, _i), 'kp_head_bnin_supported': ([_i] * 6, _i), 'kp_conv_dgrad_bnred_supported': ([_i] * 6, _i), 'kp_conv_dgrad_bnred_rows': ([_i] * 6, _ll), 'kp_unit_infer_param_floats': ([_i, _i, _p], _ll), 'kp_conv_wgrad_partials': ([_i] * 8, _i), 'kp_conv_fwd_stats_rows': ([_i] * 7, _ll), 'kp_bn_bwd_rows': ([_i] * 7, _ll), 'kp_head_bwd_ws_floats': ([_i] * 6, _ll), 'kp_last_rows': ([], _ll), 'kp_bn_ws_doubles': ([_i], _i), 'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
 
 _lib = None
 

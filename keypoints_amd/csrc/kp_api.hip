@@ -232,6 +232,14 @@ KP_DISPATCH(kp_head_fwd_t, (const void* x, int bnin, const float* mean, const fl
             (x, bnin, mean, invstd, gamma, beta, slope_in, w, bias, slope, out_t, N, H, W, C, K, dtype, stream))
 KP_DISPATCH(kp_head_bwd_t, (const void* gout_t, const void* out_t, const void* x, int bnin, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope_in, const float* w, float slope, void* dx, float* dw, float* db, float* ws, int N, int H, int W, int C, int K, int dtype, void* stream),
             (gout_t, out_t, x, bnin, mean, invstd, gamma, beta, slope_in, w, slope, dx, dw, db, ws, N, H, W, C, K, dtype, stream))
+KP_DISPATCH(kp_conv_pair_supported, (int N, int H, int W, int C, int K, int first, int dtype), (N, H, W, C, K, first, dtype))
+KP_DISPATCH(kp_conv_fwd_pair, (const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C, int K, int dtype, void* stream),
+            (x, w, bias, y, stats, N, Hi, Wi, C, K, dtype, stream))
+KP_DISPATCH(kp_conv_fwd_bnin_pair, (const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, const void* w, const float* bias, void* y, float* stats, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (yprev, mean, invstd, gamma, beta, slope, w, bias, y, stats, N, H, W, C, K, dtype, stream))
+KP_DISPATCH(kp_head_pair_supported, (int N, int H, int W, int C, int K, int t_out, int dtype), (N, H, W, C, K, t_out, dtype))
+KP_DISPATCH(kp_head_fwd_bnin_pair, (const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope_in, const float* w, const float* bias, float slope, void* out0, void* out1, int t_out, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (yprev, mean, invstd, gamma, beta, slope_in, w, bias, slope, out0, out1, t_out, N, H, W, C, K, dtype, stream))
 KP_DISPATCH(kp_keypoint_bottleneck_t_supported, (int B, int C, int K, int H, int W, int dtype), (B, C, K, H, W, dtype))
 
 // the T form of the fused bottleneck (kp_bottleneck_t.hip): dtype dispatch + the roofline leg's byte count

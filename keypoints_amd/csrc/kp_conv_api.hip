@@ -17,13 +17,15 @@ int kp_conv_small_wgrad(const void*, const void*, float*, int, int, int, int, in
 int kp_conv_small_fwd_bnin_ok(int, int, int, int, int);
 int kp_conv_small_fwd_bnin(const void*, const float*, const float*, const float*, const float*, float, const void*, const float*,
                            void*, float*, int, int, int, int, int, hipStream_t);
+int kp_conv_small_fwd_bnin_pair(const void*, const float*, const float*, const float*, const float*, float, const void*, const float*,
+                                void*, float*, int, int, int, int, int, hipStream_t);
 int kp_conv_small_wgrad_bnin_ok(int, int, int, int, int);
 int kp_conv_small_wgrad_bnin(const void*, const float*, const float*, const float*, const float*, float, const void*, float*, int,
                              int, int, int, int, int, hipStream_t);
 int kp_conv_small_dgrad_bnred_ok(int, int, int, int, int);
 int kp_conv_small_dgrad_bnred(const void*, const void*, void*, const void*, const float*, const float*, const float*, const float*, float,
                               float*, int, int, int, int, int, hipStream_t);
-int kp_conv_first_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
+int kp_conv_first_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t, int pair = 0);
 int kp_conv_first_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 long long kp_conv_first_wgrad_partials(int, int, int, int, int);
 int kp_conv_small_first_wgrad(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
@@ -195,6 +197,50 @@ int kp_conv_fwd_bnin(const void* yprev, const float* mean, const float* invstd, 
     const double bytes = 2.0 * ((double)N * H * W * C + (double)N * H * W * K + 9.0 * C * K);
     ProfScope ps(KP_PROF_CONV_SMALL, flops, (hipStream_t)stream, bytes);
     const int rc = kp_conv_small_fwd_bnin(yprev, mean, invstd, gamma, beta, slope, w, bias, y, stats, N, H, W, C, K, (hipStream_t)stream);
+    ps.done(KP_PROF_CONV_SMALL);
+    return rc;
+}
+
+// ---- two half-batches in one launch ("pair" forms) ------------------------------------------------------------------------
+// TransporterNet.forward runs every encoder twice on the same weights -- source frame under no_grad, then target frame
+// (transporter.py:36-39) -- with BatchNorm2d in training mode computing the batch statistics of EACH call.  The pair forms take
+// the two half-batches as one tensor [N = 2 x N/2] and launch each half exactly as a separate call of N / 2 images would be
+// launched (same grid, same work per workgroup, same statistics rows -- results bit-identical to the two calls), as ONE grid:
+// half as many launches, each twice as long (a third of a 30-60 us launch of these layers is its ends).
+int kp_conv_pair_supported(int N, int H, int W, int C, int K, int first, int dtype) {
+    if (dtype != KP_H16 || !use_mfma() || N < 2 || (N & 1) || H < 1 || W < 1) return 0;
+    if (first) {   // the first-layer VALU kernel (kp_conv_first.hip)
+        const long long M = (long long)(N / 2) * H * W;
+        const int CP = K / 8;
+        return C >= 1 && C <= 4 && K % 8 == 0 && K <= 128 && (CP & (CP - 1)) == 0 && M % 64 == 0 && !(K == 64 && C <= 3 && W % 32 == 0 && M >= 4096);
+    }
+    return kp_conv_small_fwd_bnin_ok(N / 2, H, W, C, K) ? 1 : 0;
+}
+
+int kp_conv_fwd_pair(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C, int K,
+                     int dtype, void* stream) {
+    KP_REQUIRE(kp_query_mode() || (x && w && y), "kp_conv_fwd_pair: null pointer");
+    KP_REQUIRE(N > 0 && C > 0 && K > 0 && Hi >= 3 && Wi >= 3, "kp_conv_fwd_pair: bad dims");
+    if (!kp_conv_pair_supported(N, Hi - 2, Wi - 2, C, K, 1, dtype)) return KP_E_UNSUPPORTED;
+    const double flops = 2.0 * N * (double)(Hi - 2) * (Wi - 2) * C * K * 9;
+    const double bytes = 2.0 * ((double)N * Hi * Wi * C + (double)N * (Hi - 2) * (Wi - 2) * K + 9.0 * C * K);
+    ProfScope ps(KP_PROF_CONV_FIRST, flops, (hipStream_t)stream, bytes);
+    const int rc = kp_conv_first_fwd(x, w, bias, y, stats, N, Hi, Wi, C, K, (hipStream_t)stream, 1);
+    ps.done(KP_PROF_CONV_FIRST);
+    return rc;
+}
+
+int kp_conv_fwd_bnin_pair(const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                          float slope, const void* w, const float* bias, void* y, float* stats, int N, int H, int W, int C, int K,
+                          int dtype, void* stream) {
+    KP_REQUIRE(kp_query_mode() || (yprev && w && y), "kp_conv_fwd_bnin_pair: null pointer");
+    KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "kp_conv_fwd_bnin_pair: bad dims");
+    KP_REQUIRE(!mean == !invstd && !mean == !gamma && !mean == !beta, "kp_conv_fwd_bnin_pair: mean / invstd / gamma / beta must be all set or all NULL");
+    if (!kp_conv_pair_supported(N, H, W, C, K, 0, dtype)) return KP_E_UNSUPPORTED;
+    const double flops = 2.0 * N * (double)H * W * C * K * 9;
+    const double bytes = 2.0 * ((double)N * H * W * C + (double)N * H * W * K + 9.0 * C * K);
+    ProfScope ps(KP_PROF_CONV_SMALL, flops, (hipStream_t)stream, bytes);
+    const int rc = kp_conv_small_fwd_bnin_pair(yprev, mean, invstd, gamma, beta, slope, w, bias, y, stats, N, H, W, C, K, (hipStream_t)stream);
     ps.done(KP_PROF_CONV_SMALL);
     return rc;
 }

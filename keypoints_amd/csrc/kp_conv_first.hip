@@ -47,7 +47,16 @@ template <int CIN>
 __global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
                                                          const float* __restrict__ bias, h16_t* __restrict__ y,
                                                          float* __restrict__ partials, int Hi, int Wi, int K,
-                                                         long long M) {
+                                                         long long M, int hb = 0, long long xh = 0, long long yh = 0) {
+    // hb != 0 (kp_conv_first_fwd_pair): the grid is two launches of hb workgroups, one per half-batch of M pixels -- its own input
+    // (+ xh elements), output (+ yh) and statistics rows (+ hb rows)
+    int bid = blockIdx.x, nblk = gridDim.x;
+    if (hb) {
+        const int hf = bid >= hb ? 1 : 0;
+        bid -= hf * hb; nblk = hb;
+        x += hf * xh; y += hf * yh;
+        if (partials) partials += (long long)hf * hb * 2 * K;
+    }
     constexpr int J = 9 * CIN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* wl = reinterpret_cast<float*>(smem);                           // [J][K] fp32
@@ -65,7 +74,7 @@ __global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const h16_t* __restrict
     // a wavefront walks 64-pixel groups blockIdx * 4 + wave, + 4 * grid, ... (M % 64 == 0: groups are all-or-nothing); the
     // weights are staged once per workgroup, and the statistics row of a workgroup covers all its groups (<= 2 048 rows
     // for the finalize instead of M / 256: 7 056 at 256 x 84 x 84, 15 -> 8 us four times per step)
-    for (long long m_wave = (long long)blockIdx.x * TPB + wave * 64; m_wave < M; m_wave += (long long)gridDim.x * TPB) {
+    for (long long m_wave = (long long)bid * TPB + wave * 64; m_wave < M; m_wave += (long long)nblk * TPB) {
     const long long m = m_wave + lane;
     const int q = (int)(m % Wo);
     const long long t = m / Wo;
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const h16_t* __restrict
     if (partials) {
         __syncthreads();
         for (int i = tid; i < 2 * K; i += TPB)
-            partials[(long long)blockIdx.x * 2 * K + i] = ((red[i] + red[2 * K + i]) + red[4 * K + i]) + red[6 * K + i];
+            partials[(long long)bid * 2 * K + i] = ((red[i] + red[2 * K + i]) + red[4 * K + i]) + red[6 * K + i];
     }
 }
 
@@ -518,12 +527,17 @@ __global__ __launch_bounds__(1024) void conv3_first_wgrad_mfma_k(const h16_t* __
 
 }  // namespace
 
+// pair != 0 (kp_conv_fwd_pair): N images = two half-batches, each launched exactly as a separate call of N / 2 images would be
+// (same grid, same statistics rows: bit-identical), in one grid; the VALU kernel only (the Pong-class first layers)
 int kp_conv_first_fwd(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi,
-                      int C, int K, hipStream_t st) {
-    const long long M = (long long)N * (Hi - 2) * (Wi - 2);
+                      int C, int K, hipStream_t st, int pair) {
+    if (pair && (N & 1)) return KP_E_UNSUPPORTED;
+    const int Nh = pair ? N / 2 : N;
+    const long long M = (long long)Nh * (Hi - 2) * (Wi - 2);
     const int CP = K / 8;
     if (C < 1 || C > 4 || K % 8 != 0 || K > 128 || (CP & (CP - 1)) != 0 || M % 64 != 0) return KP_E_UNSUPPORTED;
     if (K == 64 && C <= 3 && (Wi - 2) % FG == 0 && M >= 4096) {
+        if (pair) return KP_E_UNSUPPORTED;
         // MFMA path: 8 groups of 32 pixels per wavefront, one statistics row per wavefront (<= M / 64 rows)
         const long long groups = M / FG;
         const int gpw = 8;
@@ -547,9 +561,10 @@ int kp_conv_first_fwd(const void* x, const void* w, const float* bias, void* y, 
     if (stats) kp_set_last_rows((long long)grid);   // one statistics row per workgroup
     KP_QUERY_RETURN();
     const size_t lds = (size_t)9 * C * K * sizeof(float) + (size_t)4 * 64 * K * 2 + (size_t)4 * 2 * K * sizeof(float);
+    const long long xh = (long long)Nh * Hi * Wi * C, yh = M * K;
 #define KP_FIRST_FWD(CINv)                                                                                          \
-    conv3_first_fwd_k<CINv><<<grid, TPB, lds, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, \
-                                                    Wi, K, M)
+    conv3_first_fwd_k<CINv><<<pair ? 2 * grid : grid, TPB, lds, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, \
+                                                    Wi, K, M, pair ? (int)grid : 0, xh, yh)
     switch (C) {
         case 1: KP_FIRST_FWD(1); break;
         case 2: KP_FIRST_FWD(2); break;

@@ -169,6 +169,8 @@ __global__ __launch_bounds__(TPB) void conv3x3_small_k(const h16_t* __restrict__
 // kernels, and the padded activation tensor (write + read of the layer's output, one whole launch) never exists.  The
 // arithmetic is kp_bn_act_fwd's expression for expression ((y - mean) * invstd * gamma + beta, act, RNE to 16 bits), so the
 // fragments the MFMAs see are bit-identical to what the separate pass would have stored.
+// two half-batches in one launch (see conv3x3_small_band_k): workgroups per half, element offsets of the second half's tensors
+struct KpPair { int hb = 0; long long x = 0, y = 0, p = 0; };
 typedef KpBnIn BnIn;   // kp_common.h: {mean, invstd, gamma, beta, slope}; mean == nullptr: no BatchNorm, activation only
 // per-channel constants of the layer in LDS: [4][32] floats (mean, invstd, gamma, beta).  Without BatchNorm the constants are
 // the EXACT identity of the expression below: (y - (+0)) * 1 * 1 + (-0) == y for every y, signed zeros included.
@@ -253,8 +255,18 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
                                                             const float* __restrict__ bias, h16_t* __restrict__ y,
                                                             float* __restrict__ partials, int Hi, int Wi, int R,
                                                             int bands_per_img, int total_bands, BnIn bn,
-                                                            const h16_t* __restrict__ yred = nullptr) {
+                                                            const h16_t* __restrict__ yred = nullptr, KpPair pair = KpPair{}) {
     static_assert(!BRED || (!BNIN && !STATS && !WIN), "BRED: data-gradient form (plain input, no statistics, item-strided loop)");
+    // pair.hb != 0 (kp_conv_fwd_pair / kp_conv_fwd_bnin_pair): the grid is TWO independent launches of hb workgroups each, one per
+    // half-batch -- its own input, output, statistics rows and BatchNorm-input constants ([2][C] mean / invstd); total_bands is a half's
+    int bid = blockIdx.x, nblk = gridDim.x;
+    if (pair.hb) {
+        const int hf = bid >= pair.hb ? 1 : 0;
+        bid -= hf * pair.hb; nblk = pair.hb;
+        x += hf * pair.x; y += hf * pair.y;
+        if (STATS) partials += hf * pair.p;
+        if (BNIN && hf && bn.mean) { bn.mean += CB * 16; bn.invstd += CB * 16; }
+    }
     constexpr int C = CB * 16, K = KB * 16, PITCH = C * 2 + 16, CPP = C / 8;   // chunks of 16 bytes per pixel
     constexpr int JH = KB * 4;                                                   // register pairs of the accumulator that hold channels < K
     __shared__ h16x8 swf[WREG ? 1 : 9 * CB][64];
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
         bv[j] = f32x2{bias ? bias[k] : 0.f, bias ? bias[k + 1] : 0.f};
         if (STATS) ssum[j] = ssq[j] = f32x2{0.f, 0.f};
     }
-    for (int band = blockIdx.x; band < total_bands; band += gridDim.x) {
+    for (int band = bid; band < total_bands; band += nblk) {
         const int n = band / bands_per_img;
         const int p0 = (band - n * bands_per_img) * R;
         const int rows = Ho - p0 < R ? Ho - p0 : R;
@@ -620,7 +632,7 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
                 rsg[e] += __shfl_xor(rsg[e], o, 64);
             }
         }
-        const long long gw = (long long)blockIdx.x * FNW + wave;
+        const long long gw = (long long)bid * FNW + wave;
         if ((lane & (KB == 1 ? 31 : 15)) == 0) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -630,7 +642,7 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
         }
     }
     if constexpr (STATS) {
-        const long long gw = (long long)blockIdx.x * FNW + wave;
+        const long long gw = (long long)bid * FNW + wave;
         float s1[16], s2[16];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1310,19 +1322,19 @@ static int small_fwd_band_rows(int Ho, int Wo, int C) {
 // the 16 instances of the band kernel: input / output channels 16 | 32, BatchNorm input or stored activation, with / without statistics
 template <bool BNIN, int CB, int KB>
 static void small_band_launch_ck(unsigned grid, hipStream_t st, const void* x, const void* w, const float* bias, void* y, float* stats,
-                                 int Hi, int Wi, int R, int bpi, int bands, const BnIn& bn) {
+                                 int Hi, int Wi, int R, int bpi, int bands, const BnIn& bn, const KpPair& pr) {
     if (stats)
-        conv3x3_small_band_k<CB, KB, BNIN, true><<<grid, FTPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, R, bpi, bands, bn);
+        conv3x3_small_band_k<CB, KB, BNIN, true><<<grid, FTPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, R, bpi, bands, bn, nullptr, pr);
     else
-        conv3x3_small_band_k<CB, KB, BNIN, false><<<grid, FTPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, R, bpi, bands, bn);
+        conv3x3_small_band_k<CB, KB, BNIN, false><<<grid, FTPB, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, stats, Hi, Wi, R, bpi, bands, bn, nullptr, pr);
 }
 template <bool BNIN>
 static void small_band_launch(int C, int K, unsigned grid, hipStream_t st, const void* x, const void* w, const float* bias, void* y,
-                              float* stats, int Hi, int Wi, int R, int bpi, int bands, const BnIn& bn) {
-    if (C == 16 && K == 16) small_band_launch_ck<BNIN, 1, 1>(grid, st, x, w, bias, y, stats, Hi, Wi, R, bpi, bands, bn);
-    else if (C == 16) small_band_launch_ck<BNIN, 1, 2>(grid, st, x, w, bias, y, stats, Hi, Wi, R, bpi, bands, bn);
-    else if (K == 16) small_band_launch_ck<BNIN, 2, 1>(grid, st, x, w, bias, y, stats, Hi, Wi, R, bpi, bands, bn);
-    else small_band_launch_ck<BNIN, 2, 2>(grid, st, x, w, bias, y, stats, Hi, Wi, R, bpi, bands, bn);
+                              float* stats, int Hi, int Wi, int R, int bpi, int bands, const BnIn& bn, const KpPair& pr = KpPair{}) {
+    if (C == 16 && K == 16) small_band_launch_ck<BNIN, 1, 1>(grid, st, x, w, bias, y, stats, Hi, Wi, R, bpi, bands, bn, pr);
+    else if (C == 16) small_band_launch_ck<BNIN, 1, 2>(grid, st, x, w, bias, y, stats, Hi, Wi, R, bpi, bands, bn, pr);
+    else if (K == 16) small_band_launch_ck<BNIN, 2, 1>(grid, st, x, w, bias, y, stats, Hi, Wi, R, bpi, bands, bn, pr);
+    else small_band_launch_ck<BNIN, 2, 2>(grid, st, x, w, bias, y, stats, Hi, Wi, R, bpi, bands, bn, pr);
 }
 
 // band plan of the LDS-staged forward: rows per band, bands per image, grid (0: no band kernel for this shape)
@@ -1420,6 +1432,29 @@ int kp_conv_small_fwd_bnin(const void* yprev, const float* mean, const float* in
     const BnIn bn{mean, invstd, gamma, beta, slope};
     small_band_launch<true>(C, K, (unsigned)grid, st, yprev, w, bias, y, stats, Ho + 2, Wo + 2, R, bpi, (int)bands, bn);
     return kp_check_launch("conv3x3_small_band_bnin");
+}
+
+// kp_conv_fwd_bnin_pair: the launch above for TWO half-batches of N / 2 images at once -- each half exactly the launch of a separate
+// call (same grid, same bands per workgroup, same statistics rows: bit-identical results), the second half's workgroups behind the
+// first's in one grid.  mean / invstd: [2][C]; stats: [2][rows of a half].
+int kp_conv_small_fwd_bnin_pair(const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                float slope, const void* w, const float* bias, void* y, float* stats, int N, int Ho, int Wo, int C,
+                                int K, hipStream_t st) {
+    if ((N & 1) || !kp_conv_small_fwd_bnin_ok(N / 2, Ho, Wo, C, K) || !(slope >= 0.f && slope <= 1.f)) return KP_E_UNSUPPORTED;
+    int R, bpi;
+    long long bands;
+    const long long grid = small_fwd_band_plan(N / 2, Ho, Wo, C, stats != nullptr, R, bpi, bands);
+    if (!grid) return KP_E_UNSUPPORTED;
+    if (stats) kp_set_last_rows(grid * FNW);   // rows of ONE half
+    KP_QUERY_RETURN();
+    const BnIn bn{mean, invstd, gamma, beta, slope};
+    KpPair pr;
+    pr.hb = (int)grid;
+    pr.x = (long long)(N / 2) * Ho * Wo * C;
+    pr.y = (long long)(N / 2) * Ho * Wo * K;
+    pr.p = grid * FNW * 2 * K;
+    small_band_launch<true>(C, K, (unsigned)(2 * grid), st, yprev, w, bias, y, stats, Ho + 2, Wo + 2, R, bpi, (int)bands, bn, pr);
+    return kp_check_launch("conv3x3_small_band_bnin_pair");
 }
 
 // workgroups of the weight-gradient kernel = partial gradients in its scratch (0: not a small-channel shape)

@@ -502,7 +502,7 @@ __global__ void scale_k(const float* __restrict__ x, const float* __restrict__ s
     } while (0)
 
 int kp_head_fwd_fast(const void*, const float*, const float*, float, float*, long long, int, int, int, hipStream_t, const KpBnIn* = nullptr);
-int kp_head_fwd_mfma(const void*, const float*, const float*, float, float*, long long, int, int, int, hipStream_t, const KpBnIn* = nullptr);
+int kp_head_fwd_mfma(const void*, const float*, const float*, float, float*, long long, int, int, int, hipStream_t, const KpBnIn* = nullptr, const void* x1 = nullptr, float* out1 = nullptr);
 int kp_head_dx_mfma(const float*, const float*, const float*, float, void*, long long, int, int, int, hipStream_t);
 int kp_head_dw_mfma(const float*, const float*, const void*, float, float*, float*, float*, long long, int, int, int, hipStream_t, const KpBnIn* = nullptr);
 bool kp_head_small_shape(long long, int, int);
@@ -514,7 +514,7 @@ long long kp_head_dw_parts_fast(long long, int, int);
 int kp_head_dx_fast(const float*, const float*, const float*, float, void*, long long, int, int, int, hipStream_t);
 int kp_head_dw_fast(const float*, const float*, const void*, float, float*, float*, float*, long long, int, int, int, hipStream_t, const KpBnIn* = nullptr);
 bool kp_head_t_shape(long long, int, int, int);
-int kp_head_fwd_mfma_t(const void*, const float*, const float*, float, void*, long long, int, int, int, hipStream_t, const KpBnIn*);
+int kp_head_fwd_mfma_t(const void*, const float*, const float*, float, void*, long long, int, int, int, hipStream_t, const KpBnIn*, const void* x1 = nullptr, void* out1 = nullptr);
 int kp_head_dx_mfma_t(const void*, const void*, const float*, float, void*, long long, int, int, int, hipStream_t);
 int kp_head_dw_mfma_t(const void*, const void*, const void*, float, float*, float*, float*, long long, int, int, int, hipStream_t, const KpBnIn*);
 
@@ -751,6 +751,28 @@ int kp_head_fwd_t(const void* x, int bnin, const float* mean, const float* invst
     if (!kp_head_t_supported(N, H, W, C, K, dtype)) return KP_E_UNSUPPORTED;
     const KpBnIn bn{mean, invstd, gamma, beta, slope_in};
     return kp_head_fwd_mfma_t(x, w, bias, slope, out_t, (long long)N * H * W, H * W, C, K, (hipStream_t)stream, bnin ? &bn : nullptr);
+}
+
+// The two forward forms above for TWO half-batches in one launch (see kp_conv_fwd_pair): yprev [N = 2 x N/2][H][W][C] with mean /
+// invstd [2][C]; the halves' outputs go to out0 / out1 (fp32 NCHW [N/2][K][H][W] each; T [N/2][H][W][K] for the _t form).  Each half
+// is launched as a separate call of N / 2 images would be: bit-identical.  Only the 32-channel matrix-core head has this form.
+int kp_head_pair_supported(int N, int H, int W, int C, int K, int t_out, int dtype) {
+    if (dtype != KP_H16 || N < 2 || (N & 1) || H <= 0 || W <= 0 || C != 32) return 0;
+    const long long M = (long long)(N / 2) * H * W;
+    return (t_out ? kp_head_t_shape(M, H * W, C, K) : kp_head_mfma_fwd_shape(M, H * W, C, K)) ? 1 : 0;
+}
+
+int kp_head_fwd_bnin_pair(const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                          float slope_in, const float* w, const float* bias, float slope, void* out0, void* out1, int t_out, int N,
+                          int H, int W, int C, int K, int dtype, void* stream) {
+    KP_REQUIRE(yprev && w && out0 && out1 && N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "kp_head_fwd_bnin_pair: bad args");
+    if (int rc = head_t_bn("kp_head_fwd_bnin_pair", 1, mean, invstd, gamma, beta, slope_in)) return rc;
+    if (!kp_head_pair_supported(N, H, W, C, K, t_out, dtype)) return KP_E_UNSUPPORTED;
+    const long long M = (long long)(N / 2) * H * W;
+    const KpBnIn bn{mean, invstd, gamma, beta, slope_in};
+    const void* x1 = (const h16_t*)yprev + M * C;
+    if (t_out) return kp_head_fwd_mfma_t(yprev, w, bias, slope, out0, M, H * W, C, K, (hipStream_t)stream, &bn, x1, out1);
+    return kp_head_fwd_mfma(yprev, w, bias, slope, (float*)out0, M, H * W, C, K, (hipStream_t)stream, &bn, x1, (float*)out1);
 }
 
 int kp_head_bwd_t(const void* gout_t, const void* out_t, const void* x, int bnin, const float* mean, const float* invstd,

@@ -103,12 +103,23 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_k(const h16_t* __restrict__
 template <int KT, bool BNIN, bool TOUT = false>
 __global__ __launch_bounds__(256) void head_fwd_mfma32_k(const h16_t* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float slope,
-                                                         float* __restrict__ out, long long groups, int HW, int K, KpBnIn bn) {
+                                                         float* __restrict__ out, long long groups, int HW, int K, KpBnIn bn,
+                                                         int hb = 0, const h16_t* __restrict__ x1 = nullptr, float* __restrict__ out1 = nullptr) {
     constexpr int C = 32;
     static_assert(!TOUT || KT == 1, "T output: K == 16");
     const int lane = threadIdx.x & 63;
-    const long long waves = (long long)gridDim.x * 4;
-    long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // hb != 0 (kp_head_fwd_bnin_pair / kp_head_fwd_t with pair): the grid is two launches of hb workgroups, one per half-batch of
+    // `groups` pixel groups -- the second half reads x1, writes out1 and takes the second row of the [2][C] mean / invstd
+    int bid = blockIdx.x, nblk = gridDim.x;
+    if (hb) {
+        nblk = hb;
+        if (bid >= hb) {
+            bid -= hb; x = x1; out = out1;
+            if (BNIN && bn.mean) { bn.mean += C; bn.invstd += C; }
+        }
+    }
+    const long long waves = (long long)nblk * 4;
+    long long g = (long long)bid * 4 + (threadIdx.x >> 6);
     if (g >= groups) return;
     const int px = lane & 31, h = lane >> 5;
     h16x8 whi[KT][2], wlo[KT][2];
@@ -578,17 +589,21 @@ bool kp_head_mfma_fwd_shape(long long M, int HW, int C, int K) {
     return mfma_shape(M, HW, C, K) || (C == 32 && K >= 1 && K <= 4 && HW % 8 == 0 && M >= 32 && M % 32 == 0);
 }
 
+// x1 / out1 != nullptr (the pair forms): M is the pixel count of ONE half; the second half is read at x1, written at out1, with
+// the second row of bn's [2][C] mean / invstd -- each half launched as a separate call of M pixels would be (bit-identical)
 int kp_head_fwd_mfma(const void* x, const float* w, const float* bias, float slope, float* out, long long M, int HW,
-                     int C, int K, hipStream_t st, const KpBnIn* bn) {
+                     int C, int K, hipStream_t st, const KpBnIn* bn, const void* x1, float* out1) {
     if (!kp_head_mfma_fwd_shape(M, HW, C, K) || !aligned16(x, w)) return KP_E_UNSUPPORTED;
     if (bn && C != 32) return KP_E_UNSUPPORTED;
+    const bool pair = x1 != nullptr;
+    if (pair && (C != 32 || !bn || !out1 || !aligned16(x1))) return KP_E_UNSUPPORTED;
     const long long groups = M / 32;
     const unsigned grid = (unsigned)((groups + 3) / 4);
     if (C == 32) {   // ~8 groups per wavefront
         long long wg = (groups / 8 + 3) / 4;
         wg = wg < 1 ? 1 : wg;
         const KpBnIn b = bn ? *bn : KpBnIn{};
-#define KP_FW(KTv, Bv) head_fwd_mfma32_k<KTv, Bv><<<(unsigned)wg, 256, 0, st>>>((const h16_t*)x, w, bias, slope, out, groups, HW, K, b)
+#define KP_FW(KTv, Bv) head_fwd_mfma32_k<KTv, Bv><<<(unsigned)(pair ? 2 * wg : wg), 256, 0, st>>>((const h16_t*)x, w, bias, slope, out, groups, HW, K, b, pair ? (int)wg : 0, (const h16_t*)x1, out1)
         if (bn) { if (K <= 32) KP_FW(1, true); else KP_FW(2, true); }
         else { if (K <= 32) KP_FW(1, false); else KP_FW(2, false); }
 #undef KP_FW
@@ -661,14 +676,18 @@ int kp_head_dw_mfma(const float* gout, const float* out, const void* x, float sl
 bool kp_head_t_shape(long long M, int HW, int C, int K) { return C == 32 && K == 16 && mfma_shape(M, HW, C, K); }
 
 int kp_head_fwd_mfma_t(const void* x, const float* w, const float* bias, float slope, void* out_t, long long M, int HW, int C, int K,
-                       hipStream_t st, const KpBnIn* bn) {
+                       hipStream_t st, const KpBnIn* bn, const void* x1, void* out1) {
     if (!kp_head_t_shape(M, HW, C, K) || !aligned16(x, w, out_t)) return KP_E_UNSUPPORTED;
+    const bool pair = x1 != nullptr;
+    if (pair && (!bn || !out1 || !aligned16(x1, out1))) return KP_E_UNSUPPORTED;
     const long long groups = M / 32;
     long long wg = (groups / 8 + 3) / 4;   // ~8 groups per wavefront, as the fp32-output form
     wg = wg < 1 ? 1 : wg;
     const KpBnIn b = bn ? *bn : KpBnIn{};
-    if (bn) head_fwd_mfma32_k<1, true, true><<<(unsigned)wg, 256, 0, st>>>((const h16_t*)x, w, bias, slope, (float*)out_t, groups, HW, K, b);
-    else head_fwd_mfma32_k<1, false, true><<<(unsigned)wg, 256, 0, st>>>((const h16_t*)x, w, bias, slope, (float*)out_t, groups, HW, K, b);
+    const unsigned grid = (unsigned)(pair ? 2 * wg : wg);
+    const int hb = pair ? (int)wg : 0;
+    if (bn) head_fwd_mfma32_k<1, true, true><<<grid, 256, 0, st>>>((const h16_t*)x, w, bias, slope, (float*)out_t, groups, HW, K, b, hb, (const h16_t*)x1, (float*)out1);
+    else head_fwd_mfma32_k<1, false, true><<<grid, 256, 0, st>>>((const h16_t*)x, w, bias, slope, (float*)out_t, groups, HW, K, b);
     return kp_check_launch("head_fwd_mfma_t");
 }
 

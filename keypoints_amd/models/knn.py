@@ -7,7 +7,7 @@ import torch
 from torch import nn as nn
 
 from ..runtime import default_precision, require_device
-from ..unit_engine import GradArena, UnitFunction, build_plan
+from ..unit_engine import GradArena, UnitFunction, build_plan, pair_ok
 from .functional import gaussian_like_function, spacial_logsoftmax, spacial_softmax
 
 
@@ -115,7 +115,21 @@ class Unit(nn.Module):
         require_device(x)
         params = list(self.parameters())
         record = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
-        return UnitFunction.apply(x, self, record, (False, False), *params)
+        return UnitFunction.apply(x, self, record, (False, False), None, *params)
+
+    def forward_pair(self, xs, x, out_t=False):
+        """-> (self(xs) under no_grad, self(x)): the two calls TransporterNet.forward makes per encoder (transporter.py:36-39), as one
+        batch with per-half BatchNorm statistics where the library has the pair kernels (unit_engine.pair_ok: bit-identical to the
+        two calls), else as the two calls.  out_t: the outputs in the 16-bit NHWC interchange format (see forward_t)."""
+        require_device(xs, x)
+        if (torch.is_tensor(xs) and torch.is_tensor(x) and xs.shape == x.shape and x.dim() == 4
+                and pair_ok(self, x.size(0), x.size(1), x.size(2), x.size(3), out_t)):
+            params = list(self.parameters())
+            record = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+            return UnitFunction.apply(x, self, record, (False, bool(out_t)), xs.detach(), *params)
+        with torch.no_grad():
+            out_s = self.forward_t(xs, out_t=out_t) if out_t else self(xs)
+        return out_s, (self.forward_t(x, out_t=out_t) if out_t else self(x))
 
     def forward_t(self, x, in_t=False, out_t=False):
         """`forward` with the 16-bit NHWC interchange formats of include/kp_hip.h at either end (UnitFunction.forward): what
@@ -123,7 +137,7 @@ class Unit(nn.Module):
         require_device(x)
         params = list(self.parameters())
         record = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
-        return UnitFunction.apply(x, self, record, (bool(in_t), bool(out_t)), *params)
+        return UnitFunction.apply(x, self, record, (bool(in_t), bool(out_t)), None, *params)
 
     # -- checkpoints: same files / keys as knn.py:143-167 ---------------------------------------
     def _blocks(self, in_block=True, core=True, out_block=True):

@@ -69,15 +69,22 @@ class TransporterNet(knn.Container):
         # the keypoint encoder's two calls are independent of the feature encoder's: they go to a side stream (and,
         # the autograd engine running a node's backward on the stream of its forward, so does their backward)
         with runtime.fork('chain', xs, xt) as side:
+            units = isinstance(self.keypoint, knn.Unit) and isinstance(self.feature, knn.Unit)
             with side:
-                with torch.no_grad():
-                    heatmap_xs = self.keypoint(xs)
-                heatmap_xt = self.keypoint(xt)
+                if units:   # source frame under no_grad + target frame: one batch where the pair kernels exist (Unit.forward_pair)
+                    heatmap_xs, heatmap_xt = self.keypoint.forward_pair(xs, xt)
+                else:
+                    with torch.no_grad():
+                        heatmap_xs = self.keypoint(xs)
+                    heatmap_xt = self.keypoint(xt)
                 side.outputs(heatmap_xs, heatmap_xt)
             tcode = self._t_route(xt)
-            with torch.no_grad():   # source branch carries no gradient (transporter.py:36-37)
-                phi_xs = self.feature(xs) if tcode is None else self.feature.forward_t(xs, out_t=True)
-            phi_xt = self.feature(xt) if tcode is None else self.feature.forward_t(xt, out_t=True)
+            if units:
+                phi_xs, phi_xt = self.feature.forward_pair(xs, xt, out_t=tcode is not None)
+            else:
+                with torch.no_grad():   # source branch carries no gradient (transporter.py:36-37)
+                    phi_xs = self.feature(xs)
+                phi_xt = self.feature(xt)
 
         if tcode is not None:
             # the bottleneck reads the heads' 16-bit NHWC output and writes the decoder's padded input; the fp32 NCHW copy of the

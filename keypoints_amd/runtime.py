@@ -232,3 +232,18 @@ def t_interchange() -> bool:
 def set_t_interchange(on: bool) -> None:
     global _T_INTERCHANGE
     _T_INTERCHANGE = bool(on)
+
+
+_PAIR_CALLS = not bool(_os.environ.get('KP_NO_PAIR'))
+
+
+def pair_calls() -> bool:
+    """TransporterNet runs the source and the target frame through an encoder as ONE batch with per-half BatchNorm statistics
+    (Unit.forward_pair, the kp_*_pair entry points) where the library has those kernels; results are bit-identical to the two
+    calls.  `set_pair_calls(False)` / KP_NO_PAIR=1 restore the two calls for A/B measurements and tests."""
+    return _PAIR_CALLS
+
+
+def set_pair_calls(on: bool) -> None:
+    global _PAIR_CALLS
+    _PAIR_CALLS = bool(on)

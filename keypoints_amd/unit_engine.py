@@ -252,6 +252,40 @@ def head_dims(unit, H, W):
     return H, W, (C if C is not None else hconv.in_channels), hconv.out_channels
 
 
+def pair_ok(unit, N, Cin, H, W, out_t=False):
+    """True if `UnitFunction._forward_pair` can run source + target frame of N images each through this Unit as one batch: 16-bit
+    storage, train-mode BatchNorm with a momentum in every 3x3 layer, no pool / upsample, every layer and the head on a kernel that
+    has the pair form AND the fused BatchNorm-input forms the backward of the target half uses (the Pong-class nets of vgg.py:53,66)."""
+    if not (runtime.pair_calls() and runtime.fuse_bn_input() and unit.precision in ('bf16', 'fp16') and unit.sync_bn is None):
+        return False
+    try:
+        plan = unit.plan()
+    except NotImplementedError:
+        return False
+    code = precision_dtype(unit.precision)[1]
+    L = _lib.lib()
+    if len(plan) < 2 or plan[0]['kind'] != 'conv3' or _first_cp(plan, Cin, unit.precision) != Cin:
+        return False
+    C = Cin
+    for idx, stp in enumerate(plan[:-1]):
+        bn, K = stp['bn'], stp['conv'].out_channels
+        if (stp['tail'] is not None or bn is None or not bn.training or bn.momentum is None or not 0.0 <= stp['slope'] <= 1.0
+                or stp['conv'].in_channels != C):
+            return False
+        if L.kp_conv_pair_supported(2 * N, H, W, C, K, 1 if idx == 0 else 0, code) != 1:
+            return False
+        if idx > 0 and L.kp_conv_bnin_supported(N, H, W, C, K, code) != 1:
+            return False
+        rows = L.kp_conv_fwd_stats_rows(N, H + 2, W + 2, C, K, 3, code)
+        if not (128 < rows <= 8192 and K <= 32):
+            return False
+        C = K
+    Kout = plan[-1]['conv'].out_channels
+    if L.kp_head_pair_supported(2 * N, H, W, C, Kout, int(bool(out_t)), code) != 1:
+        return False
+    return (L.kp_head_t_supported if out_t else L.kp_head_bnin_supported)(N, H, W, C, Kout, code) == 1
+
+
 def _materialise(fin, N, H, W, C, pad, tdt, code, st):
     """The activation a fused consumer would have formed on its load path, written out: kp_bn_act_fwd of the saved conv output
     (`fin`: see UnitFunction.forward) with a replicate border of `pad`."""
@@ -265,14 +299,19 @@ class UnitFunction(torch.autograd.Function):
     Unit's GradArena (returned as None to autograd), the input gradient is returned normally."""
 
     @staticmethod
-    def forward(ctx, x, unit, record, fmt, *params):
-        """fmt = (in_t, out_t): the "T" interchange formats of include/kp_hip.h (16-bit NHWC tensors between Units instead of the
+    def forward(ctx, x, unit, record, fmt, xs, *params):
+        """xs (None, or the SOURCE frame of a Transporter pair -- same shape as x, no gradient): both frames go through the Unit as
+        ONE batch with per-half BatchNorm statistics (`_forward_pair`, the kp_*_pair entry points) and the call returns
+        (out_source, out); the caller (Unit.forward_pair) has asked `pair_ok` first.
+        fmt = (in_t, out_t): the "T" interchange formats of include/kp_hip.h (16-bit NHWC tensors between Units instead of the
         reference's fp32 NCHW).  in_t: x is the first 3x3 layer's input as that layer reads it, T [N][H+2][W+2][Cin] with its
         replicate border (written by the T form of the keypoint bottleneck), and the returned input gradient is the data
         gradient over that padded domain (the producer folds the border).  out_t: the head writes T [N][H][W][K] and the
         backward takes the output gradient in that form.  The callers (TransporterNet) ask *_t_supported first."""
         require_device(x, *params)
         in_t, out_t = fmt
+        if xs is not None:
+            return UnitFunction._forward_pair(ctx, xs, x, unit, record, out_t)
         plan = unit.plan()
         tdt, code = precision_dtype(unit.precision)
         st = stream_ptr()
@@ -399,7 +438,73 @@ class UnitFunction(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, gout):
+    def _forward_pair(ctx, xs, x, unit, record, out_t):
+        """Source and target frame through the Unit as one batch of 2 N images (kp_conv_fwd_pair / kp_conv_fwd_bnin_pair /
+        kp_bn_finalize_pair / kp_head_fwd_bnin_pair, include/kp_hip.h): every launch runs each half exactly as the separate call
+        would, so the results -- and the running statistics, updated source first -- are bit-identical to
+        `with no_grad: unit(xs)` followed by `unit(x)` (transporter.py:36-39), in half as many launches.  Only the target half
+        is recorded for the backward (views of the 2 N tensors)."""
+        require_device(xs)
+        plan = unit.plan()
+        tdt, code = precision_dtype(unit.precision)
+        st = stream_ptr()
+        dev = x.device
+        xs, x = f32c(xs), f32c(x)
+        N, Cin, H, W = x.shape
+        H0, W0 = H, W
+        a = torch.empty(2 * N, H + 2, W + 2, Cin, device=dev, dtype=tdt)
+        call('kp_nchw_to_nhwc', ptr(xs), ptr(a), N, Cin, Cin, H, W, 1, code, st)
+        call('kp_nchw_to_nhwc', ptr(x), ptr(a[N:]), N, Cin, Cin, H, W, 1, code, st)
+        packs = _pack_unit(plan, Cin, Cin, record, dev, tdt, code, st)
+        saved = []
+        fin2 = fin_t = None   # the previous layer's pending BatchNorm-apply: for both halves (y [2N], [2][K] constants) / the target half
+        C = Cin
+        for idx, stp in enumerate(plan[:-1]):
+            conv, bn = stp['conv'], stp['bn']
+            K = conv.out_channels
+            wf, wd = packs[idx]
+            y = torch.empty(2 * N, H, W, K, device=dev, dtype=tdt)
+            rows = _lib.lib().kp_conv_fwd_stats_rows(N, H + 2, W + 2, C, K, 3, code)
+            stats = torch.empty(2, rows, 2, K, device=dev, dtype=torch.float32)
+            if idx == 0:
+                call('kp_conv_fwd_pair', ptr(a), ptr(wf), ptr(conv.bias), ptr(y), ptr(stats), 2 * N, H + 2, W + 2, C, K, code, st)
+            else:
+                call('kp_conv_fwd_bnin_pair', ptr(fin2['y']), *fin2['bn'], fin2['slope'], ptr(wf), ptr(conv.bias), ptr(y), ptr(stats),
+                     2 * N, H, W, C, K, code, st)
+            ms = torch.empty(2, 2, K, device=dev, dtype=torch.float32)   # [mean | invstd][half][K]
+            track = bn.track_running_stats and bn.running_mean is not None
+            call('kp_bn_finalize_pair', ptr(stats), rows, ptr(ms[0]), ptr(ms[1]), ptr(bn.running_mean) if track else None,
+                 ptr(bn.running_var) if track else None, ptr(bn.num_batches_tracked) if track else None, float(bn.momentum),
+                 float(bn.eps), N * H * W, K, st)
+            mean_t, invstd_t = ms[0, 1], ms[1, 1]
+            if record:
+                saved.append(dict(a=a[N:] if idx == 0 else None, fin=fin_t, y=y[N:], mean=mean_t, invstd=invstd_t, argmax=None, wd=wd,
+                                  H=H, W=W, C=C, Cl=C, K=K))
+            fin2 = dict(y=y, bn=(ptr(ms[0]), ptr(ms[1]), ptr(bn.weight), ptr(bn.bias)), slope=stp['slope'], keep=(ms, bn.weight, bn.bias))
+            fin_t = dict(y=y[N:], bn=(ptr(mean_t), ptr(invstd_t), ptr(bn.weight), ptr(bn.bias)), slope=stp['slope'],
+                         keep=(ms, bn.weight, bn.bias, y))
+            C = K
+        head = plan[-1]
+        hconv = head['conv']
+        Kout = hconv.out_channels
+        shape = (N, H, W, Kout) if out_t else (N, Kout, H, W)
+        odt = tdt if out_t else torch.float32
+        out_s = torch.empty(shape, device=dev, dtype=odt)
+        out = torch.empty(shape, device=dev, dtype=odt)
+        call('kp_head_fwd_bnin_pair', ptr(fin2['y']), *fin2['bn'], fin2['slope'], ptr(hconv.weight), ptr(hconv.bias), head['slope'],
+             ptr(out_s), ptr(out), int(bool(out_t)), 2 * N, H, W, C, Kout, code, st)
+        ctx.mark_non_differentiable(out_s)
+        if record:
+            ctx.unit, ctx.saved, ctx.head_in = unit, saved, fin_t
+            ctx.save_for_backward(out)
+            ctx.dims = (N, Cin, H0, W0, H, W, C, Kout, 1)
+            ctx.cp0 = Cin
+            ctx.fmt = (False, bool(out_t))
+        return out_s, out
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        gout = gouts[-1]   # (a pair call has two outputs; the source half's is non-differentiable)
         if getattr(ctx, 'saved', None) is None:
             raise RuntimeError('keypoints_amd Unit: backward was already run for this forward; the saved activations are '
                                'released after the first backward (retain_graph=True is not supported)')
@@ -578,4 +683,4 @@ class UnitFunction(torch.autograd.Function):
             keep.clear()
         runtime.join_after_backward()   # a backward that runs on a side stream itself is joined when the pass ends
         unit._after_backward()
-        return (dx, None, None, None) + (None,) * len(params)
+        return (dx, None, None, None, None) + (None,) * len(params)
