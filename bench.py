@@ -417,7 +417,7 @@ def _run_leg(args, rank, world, dev):
         # inside the process, so it is the committed per-launch figure of the last profiled build (or null).
         traffic, pmc, pmc_file = None, None, None
         pmc_key = 'conv_small_band_bf16' if dom[0] == 'conv_small_16bit' else 'conv_patch_bf16_bn128'
-        for cand in ('r04b_pmc_summary.json', 'r03m_pmc_summary.json', 'r03k_pmc_summary.json', 'r03j_pmc_summary.json', 'r03i_pmc_summary.json', 'r03h_pmc_summary.json', 'r03b_pmc_summary.json', 'r02n_pmc_summary.json', 'r02j_pmc_summary.json', 'r02g_pmc_summary.json', 'r02_pmc_summary.json', 'r01_pmc_summary.json'):
+        for cand in ('r04e_pmc_summary.json', 'r04b_pmc_summary.json', 'r03m_pmc_summary.json', 'r03k_pmc_summary.json', 'r03j_pmc_summary.json', 'r03i_pmc_summary.json', 'r03h_pmc_summary.json', 'r03b_pmc_summary.json', 'r02n_pmc_summary.json', 'r02j_pmc_summary.json', 'r02g_pmc_summary.json', 'r02_pmc_summary.json', 'r01_pmc_summary.json'):
             try:
                 pmc = json.load(open(os.path.join(ROOT, 'profiles', cand)))[pmc_key]
                 traffic, pmc_file = pmc['hbm_bytes_per_launch'], cand
