@@ -519,9 +519,10 @@ class UnitFunction(torch.autograd.Function):
         arena = unit.grad_arena()
         arena.attach(params)
         cur = torch.cuda.current_stream()
-        side = runtime.side_stream('wgrad') if runtime.multi_stream('wgrad') else None
-        if side is not None and runtime.nested_fork_under_capture():
-            side = None   # (a side stream OF a side stream inside a stream capture crashes hipStreamEndCapture, ROCm 7.0)
+        # the weight-gradient side stream is taken when the first layer asks for it: a Unit whose weight gradients all run inline
+        # (Pong-class layers, below) then neither touches nor joins it (two events per Unit backward: 0.4 % of a config-2 step)
+        side = None
+        side_ok = runtime.multi_stream('wgrad') and not runtime.nested_fork_under_capture()   # (a side stream OF a side stream inside a stream capture crashes hipStreamEndCapture, ROCm 7.0)
         keep = []
         gv = arena.views
         need_x = ctx.needs_input_grad[0]
@@ -639,7 +640,11 @@ class UnitFunction(torch.autograd.Function):
             # (Pong-class layers, 16 / 32 channels: their weight gradient owns a CU's LDS -- two workgroups of 76 KB -- and nothing
             # of the next layer's passes runs beside it; with the reduce pass folded into the data gradient there is also less to
             # run: on the current stream the config-2 step measures 3.19 vs 3.22 ms, tools/probes/bred_roles_ab.sh.)
-            lside = None if (small_inline and C <= 32 and K <= 32) else side
+            lside = None
+            if side_ok and not (small_inline and C <= 32 and K <= 32):
+                if side is None:
+                    side = runtime.side_stream('wgrad')
+                lside = side
             if lside is not None:
                 lside.wait_stream(cur)
             with torch.cuda.stream(lside) if lside is not None else contextlib.nullcontext():
