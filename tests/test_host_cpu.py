@@ -243,3 +243,34 @@ def test_loss_scaler_refuses_an_optimizer_that_would_ignore_it():
     opt.param_groups.append(dict(params=[], lr=1e-3, betas=(0.9, 0.999), eps=1e-8))
     with pytest.raises(RuntimeError, match='param_groups'):
         opt.step()
+
+
+def test_round4_support_queries_answer_without_a_device():
+    """The *_supported / row-count queries behind TransporterNet's route selection (16-bit NHWC interchange, pair calls) are pure
+    functions of the shape: BASELINE config 2 (Pong 84x84, 16 feature channels, K = 4, 256 pairs) takes both routes in bf16 / fp16,
+    config 4 (model F, 64 feature channels at 16x16) and fp32 storage take neither -- and TransporterNet asks the same questions."""
+    import torch
+    from keypoints_amd import _lib
+    from keypoints_amd.models import transporter
+    from keypoints_amd.unit_engine import head_dims, pair_ok
+    L = _lib.lib()
+    BF, FP16, F32 = _lib.KP_BF16, _lib.KP_F16, _lib.KP_F32
+    for code in (BF, FP16):
+        assert L.kp_head_t_supported(256, 84, 84, 32, 16, code) == 1
+        assert L.kp_keypoint_bottleneck_t_supported(256, 16, 4, 84, 84, code) == 1
+        assert L.kp_conv_pair_supported(512, 84, 84, 1, 16, 1, code) == 1          # first layer, both frames
+        assert L.kp_conv_pair_supported(512, 84, 84, 16, 32, 0, code) == 1
+        assert L.kp_head_pair_supported(512, 84, 84, 32, 16, 1, code) == 1 and L.kp_head_pair_supported(512, 84, 84, 32, 4, 0, code) == 1
+    assert L.kp_head_t_supported(256, 84, 84, 32, 16, F32) == 0 and L.kp_keypoint_bottleneck_t_supported(256, 16, 4, 84, 84, F32) == 0
+    assert L.kp_head_t_supported(128, 16, 16, 512, 64, FP16) == 0 and L.kp_keypoint_bottleneck_t_supported(128, 64, 10, 16, 16, FP16) == 0
+    assert L.kp_conv_pair_supported(256, 128, 128, 3, 64, 1, FP16) == 0 and L.kp_conv_pair_supported(511, 84, 84, 1, 16, 1, BF) == 0
+    # a pair launch writes the rows of the separate call, per half
+    assert L.kp_conv_fwd_stats_rows(256, 86, 86, 1, 16, 3, BF) == 2048 and L.kp_conv_fwd_stats_rows(256, 86, 86, 16, 32, 3, BF) == 2048
+    torch.manual_seed(0)
+    net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 4, combine_mode='max').set_precision('bf16')
+    assert head_dims(net.feature, 84, 84) == (84, 84, 32, 16) and head_dims(net.keypoint, 84, 84) == (84, 84, 32, 4)
+    assert pair_ok(net.feature, 256, 1, 84, 84, True) and pair_ok(net.keypoint, 256, 1, 84, 84, False)
+    assert not pair_ok(net.feature.eval(), 256, 1, 84, 84, True)
+    netF = transporter.make('F', 3, 64, 10).set_precision('fp16')
+    assert head_dims(netF.feature, 128, 128)[:2] == (16, 16) and not pair_ok(netF.feature, 128, 3, 128, 128, False)
+    assert netF._t_route(torch.zeros(2, 3, 128, 128)) is None            # (a CPU tensor: no route; the forward itself raises loudly)
