@@ -551,7 +551,8 @@ def compact_line(line, detail_path):
             summary[key] = dict(error=r['error'][:200])
             continue
         rf = r.get('roofline') or {}
-        summary[key] = dict(value=_round(r['value'], 1), ms_per_step=_round(r['ms_per_step']), steps=r['steps'], dtype=r['dtype'],
+        summary[key] = dict(value=_round(r['value'], 1), ms_per_step=_round(r['ms_per_step']), ms_per_step_median=_round(r.get('ms_per_step_median_hipevent')),
+                            ms_per_step_max=_round(r.get('ms_per_step_max_hipevent')), steps=r['steps'], dtype=r['dtype'],
                             workload=r['config']['workload'], bound=rf.get('bound'), kernel=rf.get('kernel'),
                             achieved=_round(rf.get('achieved')), unit=rf.get('unit'), frac=_round(rf.get('frac')),
                             step_frac=_round(rf.get('step_frac')), traffic=rf.get('traffic'), algorithmic_bytes=rf.get('algorithmic_bytes'))
@@ -623,7 +624,11 @@ def main():
             leg = copy.copy(args)
             for k, v in over.items():
                 setattr(leg, k, v)
-            leg.steps, leg.warmup, leg.profile_steps, leg.no_augment = args.extra_steps * mult, 2 + mult, 1, False
+            # (profile steps: one for the 28-250 ms legs; three for config 2's 3 ms step -- a single one-stream step right after the
+            #  switch of stream mode measured its dominant family 8 % below the standalone run of the same workload)
+            # (warm-up: config 2's 3 ms steps get 16 -- the caching allocator starts this leg empty, and a step that needs a new block
+            #  after the warm-up stalls on hipMalloc for tens of steps' worth of time: one 25 ms step in 30 was measured once)
+            leg.steps, leg.warmup, leg.profile_steps, leg.no_augment = args.extra_steps * mult, (16 if mult > 1 else 2 + mult), (3 if mult > 1 else 1), False
             try:
                 r = run_leg(leg, rank, world, dev)
                 for k in ('n_gpus', 'higher_is_better', 'scaling', 'vs_baseline', 'data', 'unit'):
