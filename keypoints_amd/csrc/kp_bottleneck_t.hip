@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NT) void bottleneck_bwd_t_k(const h16_t* __restrict
                                                          const float* __restrict__ k_t, const float* __restrict__ p_t,
                                                          const float* __restrict__ q_t, h16_t* __restrict__ d_phi_t,
                                                          float* __restrict__ d_heat, int K, int H, int W, float inv2s2,
-                                                         float eps) {
+                                                         float eps, int dbg) {
     constexpr int C = 8 * LP;
     extern __shared__ float sm[];
     float* gpart = sm;                      // [HW]: sum over channels of g (phi_t - phi_s (1 - Ms))
@@ -174,7 +174,10 @@ __global__ __launch_bounds__(NT) void bottleneck_bwd_t_k(const h16_t* __restrict
     // the next item's chunks (phi_s, phi_t, the gradient's centre position) are requested before this item is worked on
     auto centre = [&](int it) { const int px = it / LP, c2 = it - px * LP, ii = px / W, jj = px - ii * W; return ((long long)(ii + 1) * Wp + jj + 1) * LP + c2; };
     uint4 ns = ps[tid < total ? tid : 0], nt = pt[tid < total ? tid : 0], ng = pg[centre(tid < total ? tid : 0)];
-    for (int item = tid; item < total; item += NT) {
+    // (dbg: kp_config(KP_CFG_DEBUG) ablation mask of tools/probes/bneck_t_abl.py -- 1: no step 1, 2: no steps 2-3; 0 in normal operation.
+    //  Measured at config-2 size, cold: 122 us whole, 88 without steps 2-3, 41 without step 1; the marginals staged through LDS for
+    //  step 3 instead of read from global memory in its item loop: no change, not kept)
+    for (int item = (dbg & 1) ? total : tid; item < total; item += NT) {
         const int pix = item / LP, ch = item - pix * LP;
         const int i = pix / W, j = pix - i * W;
         const uint4 rs = ns, rt = nt, rg = ng;
@@ -212,6 +215,7 @@ __global__ __launch_bounds__(NT) void bottleneck_bwd_t_k(const h16_t* __restrict
         if (ch == 0) gpart[pix] = acc;
     }
     __syncthreads();
+    if (dbg & 2) return;
 
     // ---- 2: through argmax_k and the Gaussian render onto the keypoints: NW / K wavefronts per keypoint (K < NW: with one
     // wavefront per keypoint 4 of the 16 waves of a Pong-class pair walked 7 056 pixels each while 12 idled), every part a
@@ -349,10 +353,11 @@ int kp_keypoint_bottleneck_bwd_t(const void* ga, const float* g_k, const float* 
     const size_t smem = ((size_t)BWD_LDS_FLOATS + 2 * (size_t)K + 2 * (size_t)(K >= NW ? K : NW)) * sizeof(float);   // + the parts' partial sums
     if (int rc = set_lds_attributes_t()) return rc;
     hipStream_t st = (hipStream_t)stream;
+    const int dbg = g_kp_debug;
     const bool vec = ((H * W) & 3) == 0 && aligned16(d_heat_t);
 #define KP_BB(LPv, Vv)                                                                                                           \
     bottleneck_bwd_t_k<LPv, Vv><<<B, NT, smem, st>>>((const h16_t*)ga, g_k, g_m, (const h16_t*)phi_s, (const h16_t*)phi_t, mask_s, \
-                                                     mask_t, arg_t, k_t, p_t, q_t, (h16_t*)d_phi_t, d_heat_t, K, H, W, inv2s2, eps)
+                                                     mask_t, arg_t, k_t, p_t, q_t, (h16_t*)d_phi_t, d_heat_t, K, H, W, inv2s2, eps, dbg)
     if (vec) {
         if (C == 8) KP_BB(1, 4);
         else if (C == 16) KP_BB(2, 4);

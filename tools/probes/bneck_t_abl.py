@@ -35,3 +35,23 @@ for mask, name in ((0, 'whole'), (1, 'no phase A'), (2, 'no phase B'), (0, 'whol
     ts = sorted(ts[2:])
     print(f'{name:12s} median {ts[len(ts) // 2]:7.1f} us  min {ts[0]:7.1f}')
 L.kp_config(1, 0)
+
+# ---- backward
+ga = (torch.randn(B, H + 2, W + 2, C, generator=g) * 0.1).to(tdt).cuda()
+d_phi = torch.empty(B, H, W, C, device='cuda', dtype=tdt); d_heat = torch.empty(B, K, H, W, **f32)
+call('kp_keypoint_bottleneck_fwd_t', ptr(heat_s), ptr(heat_t), ptr(phi_s), ptr(phi_t), ptr(k), ptr(p), ptr(q), ptr(m), ptr(a), ptr(ms), ptr(mt),
+     ptr(arg), B, C, K, H, W, 0.1, 1e-6, code, st)
+for mask, name in ((0, 'bwd whole'), (1, 'bwd no step 1'), (2, 'bwd no steps 2-3'), (0, 'bwd whole')):
+    L.kp_config(1, mask)
+    ts = []
+    for it in range(12):
+        flush.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call('kp_keypoint_bottleneck_bwd_t', ptr(ga), None, None, ptr(phi_s), ptr(phi_t), ptr(ms), ptr(mt), ptr(arg), ptr(k), ptr(p), ptr(q),
+             ptr(d_phi), ptr(d_heat), B, C, K, H, W, 0.1, 1e-6, code, st)
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts = sorted(ts[2:])
+    print(f'{name:18s} median {ts[len(ts) // 2]:7.1f} us  min {ts[0]:7.1f}')
+L.kp_config(1, 0)
