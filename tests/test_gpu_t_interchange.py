@@ -255,3 +255,40 @@ def test_gradient_through_the_returned_blend_reaches_the_encoder():
     gsum = sum(float(p.grad.abs().sum()) for p in net.feature.parameters())
     assert gsum > 0 and all(torch.isfinite(p.grad).all() for p in net.feature.parameters())
     assert all(p.grad is None or float(p.grad.abs().sum()) == 0 for p in net.decoder.parameters())
+
+
+def test_training_through_the_t_route_follows_the_fp32_plane_route():
+    """60 Adam steps of the Pong-class Transporter on structured pairs (tests/structured.py), bf16, once with the 16-bit NHWC
+    interchange + pair calls (the default) and once with the reference's fp32 NCHW tensors between the Units and two calls per
+    encoder: the extra rounding of the feature maps must not show in the training curve -- every step's loss within 3 % of the other
+    route's (both fall > 10x), the final keypoints within 2e-2."""
+    import keypoints_amd as ka
+    from keypoints_amd.models import transporter
+    from structured import structured_pairs
+    curves, keys = [], []
+    for on in (True, False):
+        ka.set_t_interchange(on); ka.set_pair_calls(on)
+        try:
+            torch.manual_seed(3)
+            net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 4, combine_mode='max').cuda().set_precision('bf16')
+            assert (net._t_route(torch.zeros(32, 1, 84, 84, device='cuda')) is not None) == on
+            opt = ka.FusedAdam(net.parameters(), lr=1e-3).bind(net)
+            g = torch.Generator().manual_seed(17)
+            losses = []
+            for it in range(60):
+                xs, xt = structured_pairs(32, 84, g, channels=1, device='cuda')
+                opt.zero_grad()
+                out = net(xs, xt)
+                loss = ka.l2_reconstruction_loss(out[0], xt)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss))
+            curves.append(losses)
+            keys.append(out[2].detach().cpu())
+        finally:
+            ka.set_t_interchange(True); ka.set_pair_calls(True)
+    a, b = curves
+    assert a[-1] < 0.1 * a[0] and b[-1] < 0.1 * b[0], (a[0], a[-1], b[0], b[-1])
+    worst = max(abs(x - y) / y for x, y in zip(a, b))
+    assert worst <= 0.05, worst
+    assert (keys[0] - keys[1]).abs().max() <= 2e-2
