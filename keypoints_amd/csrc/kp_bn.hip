@@ -194,16 +194,19 @@ __global__ __launch_bounds__(TPB) void bn_reduce_finalize_k(const float* __restr
 // 512 registers, 152 KB of LDS) it never finds them and the launch -- 6 us of work on the critical path of the backward -- sat
 // out the whole weight gradient: 80-100 us per layer in the config-2 timeline (tools/probes/cfg2_timeline.sh).  Four waves of
 // 16 registers do fit.  (For model F the 256-thread form measured no difference in round 2; its layers keep 1024.)
-// halves == 2 (kp_bn_finalize_pair, MODE 0): partials = [2][rows][2][C], the statistics of two half-batches that went through a
+// HALVES == 2 (kp_bn_finalize_pair, MODE 0): partials = [2][rows][2][C], the statistics of two half-batches that went through a
 // layer in one launch; the workgroup finalizes half 0, then half 1 -- o0 / o1 are [2][C], the running statistics take the two
 // momentum updates in that order (two forward calls of nn.BatchNorm2d in training mode: source frame, then target frame)
-template <int MODE, int CPW, int NT = 1024>
+// (HALVES is a template parameter: as a run-time argument the loop made every finalize of model F 0.5 us longer -- 56 launches on
+// the critical path of a step, each amplified by the side streams' schedule: +0.15 ms per step, tools/r04_run24.sh)
+template <int MODE, int CPW, int NT = 1024, int HALVES = 1>
 __global__ __launch_bounds__(NT) void bn_reduce_finalize_wide_k(const float* __restrict__ partials, long long rows, int C,
                                                                   float* __restrict__ o0, float* __restrict__ o1,
                                                                   float* __restrict__ r0p, float* __restrict__ r1p,
                                                                   long long* __restrict__ nbt, float momentum, float eps,
-                                                                  long long count, int halves = 1) {
-  for (int hf = 0; hf < halves; ++hf) {
+                                                                  long long count) {
+#pragma unroll
+  for (int hf = 0; hf < HALVES; ++hf) {
     if (hf) {
         __syncthreads();
         partials += rows * 2 * C; o0 += C; o1 += C;
@@ -606,8 +609,8 @@ int kp_bn_finalize_pair(const float* stats, long long rows, float* save_mean, fl
                         void* stream) {
     KP_REQUIRE(C > 0 && count > 0 && rows > 0 && stats && save_mean && save_invstd, "kp_bn_finalize_pair: bad args");
     if (!(rows > 128 && rows <= WIDE_ROWS && C <= 32) || g_kp_fin_wide) return KP_E_UNSUPPORTED;
-    bn_reduce_finalize_wide_k<0, 4, 256><<<cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(stats, rows, C, save_mean, save_invstd, running_mean,
-                                                                                     running_var, num_batches_tracked, momentum, eps, count, 2);
+    bn_reduce_finalize_wide_k<0, 4, 256, 2><<<cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(stats, rows, C, save_mean, save_invstd, running_mean,
+                                                                                        running_var, num_batches_tracked, momentum, eps, count);
     return kp_check_launch("bn_reduce_finalize_pair");
 }
 
