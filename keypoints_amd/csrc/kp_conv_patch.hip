@@ -34,6 +34,10 @@ constexpr int PBYTES = PINSTR * 1024;
 constexpr int PSLICES = (PINSTR + NWAVE - 1) / NWAVE;   // patch DMA instructions per wave per chunk (6)
 constexpr int ROWB = 128;               // bytes per LDS row (64 bf16)
 constexpr int NWBUF = 4;               // weight ring slots (power of two: the slot of a step is a run-time counter)
+#ifndef KP_PATCH_CROWS
+#define KP_PATCH_CROWS 1
+#endif
+constexpr int CROWS = KP_PATCH_CROWS;   // statistics rows a persistent workgroup leaves in compact mode: 1, or 4 (one per pixel-row group: rounds 1-3)
 
 struct PatchArgs {
     const h16_t* x; const h16_t* w; const float* bias; h16_t* y; float* partials;
@@ -94,9 +98,9 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     const int tile_hi = A.linear ? A.ntiles : ((xcd + 1) * Q < A.ntiles ? (xcd + 1) * Q : A.ntiles);
     const int tstride = A.linear ? (int)gridDim.x : per_xcd;   // ids between two consecutive tiles of a workgroup
     int tile = A.linear ? xcd * per_xcd + jb : xcd * Q + jb;
-    if (STATS && A.compact) {   // this workgroup's 4 rows: zero everywhere, its own k-tile columns are set at the end
-        float* rowp = A.partials + (long long)blockIdx.x * 4 * 2 * K;
-        for (int i = tid; i < 4 * 2 * K; i += TPB) rowp[i] = 0.f;
+    if (STATS && A.compact) {   // this workgroup's row(s): zero everywhere, its own k-tile columns are set at the end
+        float* rowp = A.partials + (long long)blockIdx.x * CROWS * 2 * K;
+        for (int i = tid; i < CROWS * 2 * K; i += TPB) rowp[i] = 0.f;
     }
     if (BRED) {   // this workgroup's 4 rows of the BatchNorm-backward sums: zero everywhere, its own k-tile columns are set at the end
         float* rowp = A.rpart + (long long)blockIdx.x * 4 * 2 * K;
@@ -521,16 +525,33 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         tile = ntile_id; cur = nxt; xr = xrn; wr = wrn;
     }
     if constexpr (STATS) if (A.compact && !(dbg & 2)) {
+        // CROWS == 1: the four pixel-row groups' sums are added through LDS (fixed order wm = 0..3) and the workgroup leaves ONE row:
+        // the finalize behind this launch -- a latency chain on the critical path of the layer -- reads a quarter of the rows
+        float* red = reinterpret_cast<float*>(smem);   // [4 wm][2][BN] (the patch buffers are free: the last epilogue is behind a barrier-free tail, see below)
+        if (CROWS == 1) __syncthreads();               // every wave is past its last epilogue's LDS reads
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
             int rg, r2;
             const float ts = reduce16_over32(sm[a], lane, rg);
             const float tq = reduce16_over32(sq[a], lane, r2);
             if ((lane & 1) == 0) {
-                const int k = cur.k0 + wn * WN + a * 32 + 8 * (rg >> 2) + 4 * fh + (rg & 3);
-                const long long prow = (long long)blockIdx.x * 4 + wm;
-                A.partials[(prow * 2 + 0) * K + k] = ts;
-                A.partials[(prow * 2 + 1) * K + k] = tq;
+                const int kl = wn * WN + a * 32 + 8 * (rg >> 2) + 4 * fh + (rg & 3);
+                if (CROWS == 1) {
+                    red[(wm * 2 + 0) * BN + kl] = ts;
+                    red[(wm * 2 + 1) * BN + kl] = tq;
+                } else {
+                    const long long prow = (long long)blockIdx.x * 4 + wm;
+                    A.partials[(prow * 2 + 0) * K + cur.k0 + kl] = ts;
+                    A.partials[(prow * 2 + 1) * K + cur.k0 + kl] = tq;
+                }
+            }
+        }
+        if (CROWS == 1) {
+            __syncthreads();
+            for (int i = tid; i < 2 * BN; i += TPB) {
+                const int which = i / BN, kl = i - which * BN;
+                const float t = ((red[(0 * 2 + which) * BN + kl] + red[(1 * 2 + which) * BN + kl]) + red[(2 * 2 + which) * BN + kl]) + red[(3 * 2 + which) * BN + kl];
+                A.partials[((long long)blockIdx.x * 2 + which) * K + cur.k0 + kl] = t;
             }
         }
     }
@@ -639,7 +660,7 @@ int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* 
     const int need = ((a.ntiles + 7) / 8) * 8;
     if (grid > need) grid = need;
     a.compact = (stats && ptiles >= grid && ((grid / 8) % a.ktiles) == 0) ? 1 : 0;
-    if (stats) kp_set_last_rows(a.compact ? (long long)grid * 4 : ptiles * 4);
+    if (stats) kp_set_last_rows(a.compact ? (long long)grid * CROWS : ptiles * 4);
     KP_QUERY_RETURN();
     if ((a.trace || a.dbg) && bn == 128 && stats) conv3x3_patch_k<128, true, true><<<grid, TPB, 0, st>>>(a);
     else if (bn == 128 && stats) conv3x3_patch_k<128, true, false><<<grid, TPB, 0, st>>>(a);

