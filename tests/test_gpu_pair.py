@@ -111,3 +111,66 @@ def test_pair_declines_where_it_has_no_kernels_and_the_two_calls_run():
     x = torch.rand(2, 1, 21, 21).cuda()
     o_s, o_t = u.forward_pair(x, x * 0.5)               # falls back to the two calls
     assert o_s.shape == o_t.shape == (2, 4, 21, 21) and not o_s.requires_grad and o_t.requires_grad
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+# rel-L2 of a 16-bit Unit (three BatchNorm layers deep) against fp64.  Outputs and running statistics: the storage type's half-ulp
+# (2^-12 fp16) per stored tensor, a handful of stored tensors in sequence -- measured 7e-4 / 1.2e-4 in fp16; bf16 = fp16 x 8 (3 fewer
+# mantissa bits, the fixed rule of oracle.TOL16; measured 5.6e-3 / 7.5e-4).  Gradients along a random direction: a pre-activation
+# inside the rounding error of zero takes the other LeakyReLU branch (derivative 1 <-> 0.01), a fraction f ~ 1e-3 (fp16) of the
+# terms of every sum, and a sum of M random-sign terms with f M of them changed moves by sqrt(f) of its norm: measured 1.6-4.8e-2
+# in fp16, 5.5-9.1e-2 in bf16 (x sqrt(8)).  A wrong or missing half would show as O(1).
+PAIR_TOL = {'fp16': dict(out=2e-3, grad=0.1, stat=4e-4), 'bf16': dict(out=1.6e-2, grad=0.28, stat=3.2e-3)}
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('K,out_t', [(4, False), (16, True)])
+def test_forward_pair_against_the_oracle(dt, K, out_t):
+    """The pair launches against the CPU oracle directly (the bit-for-bit tests above compare them with the two HIP calls): the
+    reference's two encoder calls of a Transporter step (transporter.py:36-39), source under no_grad then target, each with ITS OWN
+    batch statistics, the running statistics updated twice in that order (nn.BatchNorm2d momentum 0.1), gradients of the target
+    call only -- oracle.unit_forward in fp64 + autograd."""
+    from keypoints_amd.unit_engine import pair_ok
+    from oracle import kp_oracle as O
+    N, H, W = 8, 84, 84
+    g = torch.Generator().manual_seed(100 + K)
+    xs = torch.rand(N, 1, H, W, generator=g) * 2 - 1
+    xt = torch.rand(N, 1, H, W, generator=g) * 2 - 1
+    u = _unit(K, dt)
+    sd = _state(u)
+    P = {'u.' + k: v.double().requires_grad_(True) for k, v in sd.items() if 'running' not in k and 'num_batches' not in k}
+    Bf = {'u.' + k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items() if 'running' in k or 'num_batches' in k}
+    plan = O.unit_plan(O.ENCODER_CORES['VGG_PONG_LAYERNECK'], 1, K, O.LEAKY)
+    assert pair_ok(u, N, 1, H, W, out_t)
+    o_s, o_t = u.forward_pair(xs.cuda(), xt.cuda(), out_t=out_t)
+    wgt = torch.randn(N, K, H, W, generator=g) * 0.1
+    if out_t:   # T [N][H][W][K]
+        gout = wgt.permute(0, 2, 3, 1).contiguous().to(o_t.dtype)
+        o_t.backward(gout.cuda())
+        wgt = gout.float().permute(0, 3, 1, 2)
+        o_s, o_t = o_s.float().permute(0, 3, 1, 2), o_t.float().permute(0, 3, 1, 2)
+    else:
+        o_t.backward(wgt.cuda())
+    with torch.no_grad():
+        oo_s = O.unit_forward(plan, P, 'u', xs.double(), Bf, training=True)
+    oo_t = O.unit_forward(plan, P, 'u', xt.double(), Bf, training=True)
+    (oo_t * wgt.double()).sum().backward()
+    tol = PAIR_TOL[dt]
+    assert _rel(o_s, oo_s) <= tol['out'] and _rel(o_t, oo_t) <= tol['out'], (_rel(o_s, oo_s), _rel(o_t, oo_t))
+    after = _state(u)
+    for k, v in Bf.items():
+        if 'num_batches' in k:
+            assert int(after[k[2:]]) == int(v) == 2
+        else:
+            assert _rel(after[k[2:]], v) <= tol['stat'], (k, _rel(after[k[2:]], v))
+    worst = {}
+    for n, p in u.named_parameters():
+        og = P['u.' + n].grad
+        if og is None or float(og.norm()) < 1e-9 * og.numel():   # conv biases in front of a BatchNorm: analytically zero
+            continue
+        worst[n] = _rel(p.grad, og)
+    assert len(worst) >= 6 and max(worst.values()) <= tol['grad'], worst
