@@ -184,6 +184,23 @@ def _check_dgrad_bnred(N, H, W, K, C, dt, bn_on, slope):
     ref = yred.float()
     scale = float(gx0.float().abs().sum() / C) * max(1.0, float(ref.abs().max()))
     assert (s0 - s1).abs().max() <= 2e-5 * scale + 1e-6, ((s0 - s1).abs().max(), scale)
+    # ... and an independent fp64 restatement of the two sums from the header's definition (include/kp_hip.h: gh = fold(gx) * act'(z),
+    # sums of gh and gh * xhat over layer L - 1's conv output with ITS BatchNorm; fold = adjoint of ReplicationPad2d(1), vgg.py:30)
+    gxd = gx1.double().cpu()
+    ridx = (torch.arange(H + 2) - 1).clamp(0, H - 1)
+    cidx = (torch.arange(W + 2) - 1).clamp(0, W - 1)
+    gh = torch.zeros(N, H, W + 2, C, dtype=torch.float64).index_add_(1, ridx, gxd)
+    gh = torch.zeros(N, H, W, C, dtype=torch.float64).index_add_(2, cidx, gh)
+    yd = yred.double().cpu()
+    if bn_on:
+        mean, invstd, gamma, beta = [t.double().cpu() for t in bn]
+        xhat = (yd - mean) * invstd
+        z = xhat * gamma + beta
+    else:
+        xhat = z = yd
+    gh = gh * torch.where(z > 0, 1.0, float(slope))
+    want = torch.stack((gh.sum(dim=(0, 1, 2)), (gh * xhat).sum(dim=(0, 1, 2))))
+    assert (s1 - want).abs().max() <= 2e-5 * scale + 1e-6, ((s1 - want).abs().max(), scale)
 
 
 def test_unsupported_shapes_launch_nothing():
