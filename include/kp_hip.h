@@ -435,7 +435,7 @@ int kp_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int
  *   kp_head_fwd_bnin_pair  == kp_head_fwd_bnin (t_out = 0: out0 / out1 fp32 NCHW [N/2][K][H][W]) or kp_head_fwd_t with bnin = 1
  *                             (t_out = 1: T [N/2][H][W][K]) on each half
  * *_pair_supported: 1 where the form exists (16-bit storage; conv: first = 1 the first-layer VALU kernel, first = 0 the C, K in
- * {16, 32} band kernel; head: C == 32 on the matrix cores; finalize: 128 < rows <= 8192, C <= 32); otherwise KP_E_UNSUPPORTED,
+ * {16, 32} band kernel; head: C == 32 on the matrix cores; finalize: rows <= 8192, C <= 32); otherwise KP_E_UNSUPPORTED,
  * nothing launched, and the caller makes the two calls. */
 int kp_conv_pair_supported(int N, int H, int W, int C, int K, int first, int dtype);
 int kp_conv_fwd_pair(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C, int K,

@@ -578,7 +578,9 @@ int kp_bn_finalize(const float* stats, long long rows, double* ws, float* save_m
                    long long count, int C, void* stream) {
     KP_REQUIRE(C > 0 && count > 0 && rows > 0 && stats && ws, "kp_bn_finalize: bad args");
     hipStream_t st = (hipStream_t)stream;
-    if (rows <= 128) {
+    const bool narrow = C <= 32 && !g_kp_fin_wide;   // Pong-class layers: the 4-wave kernel below at every row count (its pair form,
+                                                     // kp_bn_finalize_pair, must be this call bit for bit)
+    if (rows <= 128 && !narrow) {
         bn_reduce_finalize_k<0><<<cdiv(C, 32), TPB, 0, st>>>(stats, rows, C, save_mean, save_invstd, running_mean,
                                                              running_var, num_batches_tracked, momentum, eps, count);
         return kp_check_launch("bn_reduce_finalize");
@@ -586,7 +588,7 @@ int kp_bn_finalize(const float* stats, long long rows, double* ws, float* save_m
     if (rows <= WIDE_ROWS) {
 #define KP_WIDE0(CPWv) bn_reduce_finalize_wide_k<0, CPWv><<<cdiv(C, CPWv), 1024, 0, st>>>(stats, rows, C, save_mean, save_invstd, running_mean, \
                                                                                running_var, num_batches_tracked, momentum, eps, count)
-        if (C <= 32 && !g_kp_fin_wide)   // Pong-class layers: a 4-wave workgroup (see the kernel)
+        if (narrow)   // a 4-wave workgroup (see the kernel)
             bn_reduce_finalize_wide_k<0, 4, 256><<<cdiv(C, 4), 256, 0, st>>>(stats, rows, C, save_mean, save_invstd, running_mean,
                                                                               running_var, num_batches_tracked, momentum, eps, count);
         else if (C >= 256) KP_WIDE0(16); else if (C >= 128) KP_WIDE0(8); else KP_WIDE0(4);
@@ -603,12 +605,12 @@ int kp_bn_finalize(const float* stats, long long rows, double* ws, float* save_m
 // The statistics of TWO half-batches (kp_conv_fwd_pair / kp_conv_fwd_bnin_pair: stats = [2][rows][2][C]) in one launch: save_mean /
 // save_invstd are [2][C]; the running statistics (and num_batches_tracked) are updated twice, half 0 first.  Each half's numbers
 // are those of kp_bn_finalize on its rows, bit for bit.  Only the one-launch reduction of the narrow layers has this form
-// (128 < rows <= 8192 per half, C <= 32: the Pong-class layers); otherwise KP_E_UNSUPPORTED.
+// (rows <= 8192 per half, C <= 32: the Pong-class layers); otherwise KP_E_UNSUPPORTED.
 int kp_bn_finalize_pair(const float* stats, long long rows, float* save_mean, float* save_invstd, float* running_mean,
                         float* running_var, long long* num_batches_tracked, float momentum, float eps, long long count, int C,
                         void* stream) {
     KP_REQUIRE(C > 0 && count > 0 && rows > 0 && stats && save_mean && save_invstd, "kp_bn_finalize_pair: bad args");
-    if (!(rows > 128 && rows <= WIDE_ROWS && C <= 32) || g_kp_fin_wide) return KP_E_UNSUPPORTED;
+    if (!(rows <= WIDE_ROWS && C <= 32) || g_kp_fin_wide) return KP_E_UNSUPPORTED;
     bn_reduce_finalize_wide_k<0, 4, 256, 2><<<cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(stats, rows, C, save_mean, save_invstd, running_mean,
                                                                                         running_var, num_batches_tracked, momentum, eps, count);
     return kp_check_launch("bn_reduce_finalize_pair");

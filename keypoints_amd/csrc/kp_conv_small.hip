@@ -226,6 +226,12 @@ constexpr int FB_LDS = 61440;   // band bytes (the weights take 9 / 18 KB more):
 #define KP_FB_TPB 256
 #endif
 constexpr int FTPB = KP_FB_TPB, FNW = FTPB / 64;
+// statistics / BatchNorm-backward rows a band-kernel workgroup leaves: 1 (its wavefronts' rows summed through LDS in the kernel's
+// tail, in wave order: the dependent finalize launch reads 512 rows instead of 2 048) or FNW (one per wavefront)
+#ifndef KP_FB_ROWS
+#define KP_FB_ROWS 1
+#endif
+constexpr int FROWS = KP_FB_ROWS == 1 ? 1 : FNW;
 constexpr int FSL = 12 * 256 / FTPB;   // 16-byte chunks per thread in one band (FTPB x FSL x 16 B = 48 KB of input)
 // BNIN: x is the previous layer's conv output [N][Hi - 2][Wi - 2][C] and `bn` its BatchNorm / activation (see BnIn above);
 // otherwise x is the padded activation [N][Hi][Wi][C] as stored.
@@ -622,6 +628,10 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
         }
     }
     stamp();
+    // FROWS == 1: the wavefronts' rows go to LDS (the band buffers, once every wavefront has left them) and are summed below
+    float* const red = reinterpret_cast<float*>(xl);
+    if constexpr ((STATS || BRED) && FROWS == 1) __syncthreads();
+    float* const rowp = FROWS == 1 ? red + wave * 2 * K : partials + ((long long)bid * FNW + wave) * 2 * K;
     if constexpr (BRED) {
         // lanes that hold the same chunk: the 32 of a half-wave (16 channels) / the 16 of a row (32 channels)
 #pragma unroll
@@ -632,17 +642,15 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
                 rsg[e] += __shfl_xor(rsg[e], o, 64);
             }
         }
-        const long long gw = (long long)bid * FNW + wave;
         if ((lane & (KB == 1 ? 31 : 15)) == 0) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                partials[(gw * 2 + 0) * K + rchunk * 8 + e] = rsb[e];
-                partials[(gw * 2 + 1) * K + rchunk * 8 + e] = rsg[e];
+                rowp[0 * K + rchunk * 8 + e] = rsb[e];
+                rowp[1 * K + rchunk * 8 + e] = rsg[e];
             }
         }
     }
     if constexpr (STATS) {
-        const long long gw = (long long)bid * FNW + wave;
         float s1[16], s2[16];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -655,8 +663,17 @@ __global__ __launch_bounds__(FTPB, FTPB / 128) void conv3x3_small_band_k(const h
         const float tq = reduce16_over32(s2, lane, r2);
         const int k = 8 * (r1 >> 2) + 4 * fh + (r1 & 3);
         if ((lane & 1) == 0 && k < K) {
-            partials[(gw * 2 + 0) * K + k] = ts;
-            partials[(gw * 2 + 1) * K + k] = tq;
+            rowp[0 * K + k] = ts;
+            rowp[1 * K + k] = tq;
+        }
+    }
+    if constexpr ((STATS || BRED) && FROWS == 1) {
+        __syncthreads();
+        for (int i = tid; i < 2 * K; i += FTPB) {
+            float t = red[i];
+#pragma unroll
+            for (int wv = 1; wv < FNW; ++wv) t += red[wv * 2 * K + i];
+            partials[(long long)bid * 2 * K + i] = t;
         }
     }
 }
@@ -1346,7 +1363,7 @@ static long long small_fwd_band_plan(int N, int Ho, int Wo, int C, bool stats, i
     if (bands > 0x7fffffffLL) return 0;   // the kernel counts bands in 32 bits
     long long grid = bands < 512 ? bands : 512;
     const long long max_rows = ((long long)N * Ho * Wo + 63) / 64;   // the caller's statistics buffer
-    if (stats && grid * FNW > max_rows) grid = max_rows / FNW;
+    if (stats && grid * FROWS > max_rows) grid = max_rows / FROWS;
     return grid >= 1 ? grid : 0;
 }
 
@@ -1358,7 +1375,7 @@ int kp_conv_small_fwd(const void* x, const void* w, const float* bias, void* y, 
         int R, bpi;
         long long bands;
         if (const long long grid = small_fwd_band_plan(N, Ho, Wo, C, stats != nullptr, R, bpi, bands)) {
-            if (stats) kp_set_last_rows(grid * FNW);
+            if (stats) kp_set_last_rows(grid * FROWS);
             KP_QUERY_RETURN();
             small_band_launch<false>(C, K, (unsigned)grid, st, x, w, bias, y, stats, Hi, Wi, R, bpi, (int)bands, BnIn{});
             return kp_check_launch("conv3x3_small_band");
@@ -1397,7 +1414,7 @@ int kp_conv_small_dgrad_bnred(const void* dy, const void* w_dgrad, void* gx, con
     long long bands;
     const long long grid = small_fwd_band_plan(N, H + 2, W + 2, K, true, R, bpi, bands);   // (statistics-style rows: one per wavefront)
     if (!grid) return KP_E_UNSUPPORTED;
-    kp_set_last_rows(grid * FNW);
+    kp_set_last_rows(grid * FROWS);
     KP_QUERY_RETURN();
     const BnIn bn{mean, invstd, gamma, beta, slope};
     // kernel roles: input channels = K (the gradient's), output channels = C
@@ -1427,7 +1444,7 @@ int kp_conv_small_fwd_bnin(const void* yprev, const float* mean, const float* in
     long long bands;
     const long long grid = small_fwd_band_plan(N, Ho, Wo, C, stats != nullptr, R, bpi, bands);
     if (!grid) return KP_E_UNSUPPORTED;
-    if (stats) kp_set_last_rows(grid * FNW);
+    if (stats) kp_set_last_rows(grid * FROWS);
     KP_QUERY_RETURN();
     const BnIn bn{mean, invstd, gamma, beta, slope};
     small_band_launch<true>(C, K, (unsigned)grid, st, yprev, w, bias, y, stats, Ho + 2, Wo + 2, R, bpi, (int)bands, bn);
@@ -1445,14 +1462,14 @@ int kp_conv_small_fwd_bnin_pair(const void* yprev, const float* mean, const floa
     long long bands;
     const long long grid = small_fwd_band_plan(N / 2, Ho, Wo, C, stats != nullptr, R, bpi, bands);
     if (!grid) return KP_E_UNSUPPORTED;
-    if (stats) kp_set_last_rows(grid * FNW);   // rows of ONE half
+    if (stats) kp_set_last_rows(grid * FROWS);   // rows of ONE half
     KP_QUERY_RETURN();
     const BnIn bn{mean, invstd, gamma, beta, slope};
     KpPair pr;
     pr.hb = (int)grid;
     pr.x = (long long)(N / 2) * Ho * Wo * C;
     pr.y = (long long)(N / 2) * Ho * Wo * K;
-    pr.p = grid * FNW * 2 * K;
+    pr.p = grid * FROWS * 2 * K;
     small_band_launch<true>(C, K, (unsigned)(2 * grid), st, yprev, w, bias, y, stats, Ho + 2, Wo + 2, R, bpi, (int)bands, bn, pr);
     return kp_check_launch("conv3x3_small_band_bnin_pair");
 }

@@ -277,7 +277,7 @@ def pair_ok(unit, N, Cin, H, W, out_t=False):
         if idx > 0 and L.kp_conv_bnin_supported(N, H, W, C, K, code) != 1:
             return False
         rows = L.kp_conv_fwd_stats_rows(N, H + 2, W + 2, C, K, 3, code)
-        if not (128 < rows <= 8192 and K <= 32):
+        if not (0 < rows <= 8192 and K <= 32):
             return False
         C = K
     Kout = plan[-1]['conv'].out_channels

@@ -100,7 +100,7 @@ def test_pair_declines_where_it_has_no_kernels_and_the_two_calls_run():
     u = _unit(4, 'bf16')
     assert pair_ok(u, 8, 1, 84, 84)
     assert not pair_ok(u, 3, 1, 84, 84)                 # 3 x 7 056 pixels: not a multiple of the first layer's 64-pixel groups
-    assert not pair_ok(u, 4, 1, 84, 84)                 # 110 statistics rows per half: the two-stage finalize has no pair form
+    assert pair_ok(u, 4, 1, 84, 84)                     # (few statistics rows per half: the narrow finalize has the pair form at every row count)
     assert not pair_ok(u, 8, 1, 21, 21)                 # 441 pixels per image: not the kernels' granularity
     u.precision = 'fp32'
     assert not pair_ok(u, 8, 1, 84, 84)
@@ -174,3 +174,4 @@ def test_forward_pair_against_the_oracle(dt, K, out_t):
             continue
         worst[n] = _rel(p.grad, og)
     assert len(worst) >= 6 and max(worst.values()) <= tol['grad'], worst
+
