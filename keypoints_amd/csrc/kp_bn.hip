@@ -200,19 +200,18 @@ __global__ __launch_bounds__(TPB) void bn_reduce_finalize_k(const float* __restr
 // (HALVES is a template parameter: as a run-time argument the loop made every finalize of model F 0.5 us longer -- 56 launches on
 // the critical path of a step, each amplified by the side streams' schedule: +0.15 ms per step, tools/r04_run24.sh)
 template <int MODE, int CPW, int NT = 1024, int HALVES = 1>
-__global__ __launch_bounds__(NT) void bn_reduce_finalize_wide_k(const float* __restrict__ partials, long long rows, int C,
-                                                                  float* __restrict__ o0, float* __restrict__ o1,
-                                                                  float* __restrict__ r0p, float* __restrict__ r1p,
-                                                                  long long* __restrict__ nbt, float momentum, float eps,
-                                                                  long long count) {
-#pragma unroll
-  for (int hf = 0; hf < HALVES; ++hf) {
-    if (hf) {
-        __syncthreads();
-        partials += rows * 2 * C; o0 += C; o1 += C;
-    }
+__global__ __launch_bounds__(NT * HALVES) void bn_reduce_finalize_wide_k(const float* __restrict__ partials, long long rows, int C,
+                                                                           float* __restrict__ o0, float* __restrict__ o1,
+                                                                           float* __restrict__ r0p, float* __restrict__ r1p,
+                                                                           long long* __restrict__ nbt, float momentum, float eps,
+                                                                           long long count) {
+    // HALVES == 2 (kp_bn_finalize_pair): NT threads per half reduce their half's rows AT THE SAME TIME, each exactly as the one-half
+    // launch would; only the updates of the running statistics take turns (half 0 first)
+    const int hf = HALVES > 1 ? (int)threadIdx.x / NT : 0;
+    const int tx = HALVES > 1 ? (int)threadIdx.x - hf * NT : (int)threadIdx.x;
+    if (HALVES > 1 && hf) { partials += rows * 2 * C; o0 += C; o1 += C; }
     constexpr int RL = NT / (2 * CPW);   // row lanes
-    const int cl = threadIdx.x & (CPW - 1), which = (threadIdx.x / CPW) & 1, rl = threadIdx.x / (2 * CPW);
+    const int cl = tx & (CPW - 1), which = (tx / CPW) & 1, rl = tx / (2 * CPW);
     const int c = blockIdx.x * CPW + cl;
     double s = 0.0;
     if (c < C) {
@@ -228,41 +227,44 @@ __global__ __launch_bounds__(NT) void bn_reduce_finalize_wide_k(const float* __r
         }
         for (; r < rows; r += RL) s += (double)col[r * stride];
     }
-    __shared__ double red[RL][2 * CPW];
-    red[rl][threadIdx.x & (2 * CPW - 1)] = s;
+    __shared__ double red[HALVES][RL][2 * CPW];
+    red[hf][rl][tx & (2 * CPW - 1)] = s;
     __syncthreads();
     // fold the row lanes in index order (deterministic): 8 partial chains per column, then their sum
-    __shared__ double red2[8][2 * CPW];
-    if (threadIdx.x < 8 * 2 * CPW) {
-        const int col2 = threadIdx.x % (2 * CPW), part = threadIdx.x / (2 * CPW);
+    __shared__ double red2[HALVES][8][2 * CPW];
+    if (tx < 8 * 2 * CPW) {
+        const int col2 = tx % (2 * CPW), part = tx / (2 * CPW);
         double a = 0.0;
-        for (int r = part * (RL / 8); r < (part + 1) * (RL / 8); ++r) a += red[r][col2];
-        red2[part][col2] = a;
+        for (int r = part * (RL / 8); r < (part + 1) * (RL / 8); ++r) a += red[hf][r][col2];
+        red2[hf][part][col2] = a;
     }
     __syncthreads();
-    if (threadIdx.x < CPW && c < C) {
-        double sum = 0.0, sq = 0.0;
-        for (int r = 0; r < 8; ++r) { sum += red2[r][cl]; sq += red2[r][CPW + cl]; }
-        if (MODE == 0) {
-            const double mu = sum / (double)count;
-            double var = sq / (double)count - mu * mu;
-            if (var < 0.0) var = 0.0;
-            o0[c] = (float)mu;
-            o1[c] = (float)(1.0 / sqrt(var + (double)eps));
-            if (r0p) r0p[c] = (1.f - momentum) * r0p[c] + momentum * (float)mu;
-            if (r1p) {
-                const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
-                r1p[c] = (1.f - momentum) * r1p[c] + momentum * (float)unbiased;
+#pragma unroll
+    for (int turn = 0; turn < HALVES; ++turn) {
+        if (turn) __syncthreads();
+        if (hf == turn && tx < CPW && c < C) {
+            double sum = 0.0, sq = 0.0;
+            for (int r = 0; r < 8; ++r) { sum += red2[hf][r][cl]; sq += red2[hf][r][CPW + cl]; }
+            if (MODE == 0) {
+                const double mu = sum / (double)count;
+                double var = sq / (double)count - mu * mu;
+                if (var < 0.0) var = 0.0;
+                o0[c] = (float)mu;
+                o1[c] = (float)(1.0 / sqrt(var + (double)eps));
+                if (r0p) r0p[c] = (1.f - momentum) * r0p[c] + momentum * (float)mu;
+                if (r1p) {
+                    const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+                    r1p[c] = (1.f - momentum) * r1p[c] + momentum * (float)unbiased;
+                }
+            } else {
+                o0[c] = (float)sum;
+                o0[C + c] = (float)sq;
+                if (r0p) r0p[c] += (float)sum;   // dbeta
+                if (r1p) r1p[c] += (float)sq;    // dgamma
             }
-        } else {
-            o0[c] = (float)sum;
-            o0[C + c] = (float)sq;
-            if (r0p) r0p[c] += (float)sum;   // dbeta
-            if (r1p) r1p[c] += (float)sq;    // dgamma
         }
+        if (MODE == 0 && nbt && blockIdx.x == 0 && hf == turn && tx == 0) *nbt += 1;
     }
-    if (MODE == 0 && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
-  }
 }
 
 // ---- forward ----------------------------------------------------------------------------------------
@@ -611,7 +613,7 @@ int kp_bn_finalize_pair(const float* stats, long long rows, float* save_mean, fl
                         void* stream) {
     KP_REQUIRE(C > 0 && count > 0 && rows > 0 && stats && save_mean && save_invstd, "kp_bn_finalize_pair: bad args");
     if (!(rows <= WIDE_ROWS && C <= 32) || g_kp_fin_wide) return KP_E_UNSUPPORTED;
-    bn_reduce_finalize_wide_k<0, 4, 256, 2><<<cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(stats, rows, C, save_mean, save_invstd, running_mean,
+    bn_reduce_finalize_wide_k<0, 4, 256, 2><<<cdiv(C, 4), 512, 0, (hipStream_t)stream>>>(stats, rows, C, save_mean, save_invstd, running_mean,
                                                                                         running_var, num_batches_tracked, momentum, eps, count);
     return kp_check_launch("bn_reduce_finalize_pair");
 }

@@ -188,13 +188,13 @@ __global__ __launch_bounds__(256) void pack_weights_tile_k(const PackBatch B) {
 
 // dw[k][c][r][s] += sum_p scratch[p][k][r][s][c].  A workgroup = 256 / Q element groups (VEC consecutive c of one
 // (k, r, s) of the scratch layout: coalesced 16-byte lanes) x Q partial lanes; lane q sums the partials p = q, q + Q, ...
-// (4 loads in flight), the Q lanes are combined through LDS in a fixed order -> deterministic.  Q = 4, or 16 for the few-KB
+// (4 loads in flight), the Q lanes are combined through LDS in a fixed order -> deterministic.  Q = 4, or 16 / 64 (a 1024-thread workgroup) for the few-KB
 // gradients of the Pong-class layers with hundreds of partials (18 workgroups walking 128 dependent rounds each took 14 us).
-template <int VEC, int Q>
-__global__ __launch_bounds__(256) void wgrad_unpack_k(const float* __restrict__ scratch, int partials,
-                                                      float* __restrict__ dw, int K, int Cd, int C, int R) {
+template <int VEC, int Q, int NT = 256>
+__global__ __launch_bounds__(NT) void wgrad_unpack_k(const float* __restrict__ scratch, int partials,
+                                                     float* __restrict__ dw, int K, int Cd, int C, int R) {
     // C = channels of the scratch layout (possibly padded), Cd <= C = channels of dw
-    constexpr int EG = 256 / Q;
+    constexpr int EG = NT / Q;
     const long long total = (long long)K * C * R * R;
     const int el = threadIdx.x % EG, q = threadIdx.x / EG;
     const long long t = ((long long)blockIdx.x * EG + el) * VEC;
@@ -403,31 +403,46 @@ __global__ __launch_bounds__(TPB) void head_bwd_dw_k(const float* __restrict__ g
 
 // dw[i] += sum_p ws[p][i], db[k] += sum_p ws[p][K*C + k], p ascending: the fixed-order second stage of the head's
 // weight gradient (first stage: one partial per workgroup / pixel split, plain stores)
-__global__ __launch_bounds__(TPB) void head_dw_reduce_k(const float* __restrict__ ws, int P, long long n, long long KC,
-                                                        float* __restrict__ dw, float* __restrict__ db) {
-    // a workgroup owns 16 consecutive elements (one 64-byte sector per partial); 16 lanes of partials per element,
-    // each summing p = pl, pl + 16, ... in order, then the 16 lane sums in order: a fixed summation tree
-    __shared__ float red[16][17];
+template <int PL>
+__global__ __launch_bounds__(16 * PL) void head_dw_reduce_k(const float* __restrict__ ws, int P, long long n, long long KC,
+                                                            float* __restrict__ dw, float* __restrict__ db) {
+    // a workgroup owns 16 consecutive elements (one 64-byte sector per partial); PL lanes of partials per element, each summing
+    // p = pl, pl + PL, ... in order (4 / 8 loads in flight), then the PL lane sums in order: a fixed summation tree.  PL = 64 for
+    // the Pong-class heads (2 048 partials of 528 floats: with 16 lanes a thread walked 32 dependent rounds, 12 us per launch,
+    // three launches on the critical path of a config-2 step)
+    constexpr int U = PL == 16 ? 4 : 8;
+    __shared__ float red[PL][17];
     const int e = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const long long i = (long long)blockIdx.x * 16 + e;
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    float s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) s[u] = 0.f;
     if (i < n) {
         int p = pl;
-        for (; p + 48 < P; p += 64) {
+        for (; p + (U - 1) * PL < P; p += U * PL) {
+            float v[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) s[u] += ws[(long long)(p + 16 * u) * n + i];
+            for (int u = 0; u < U; ++u) v[u] = ws[(long long)(p + PL * u) * n + i];
+#pragma unroll
+            for (int u = 0; u < U; ++u) s[u] += v[u];
         }
-        for (int u = 0; p < P; p += 16, ++u) s[u & 3] += ws[(long long)p * n + i];
+        for (int u = 0; p < P; p += PL, ++u) s[u & (U - 1)] += ws[(long long)p * n + i];
     }
-    red[pl][e] = ((s[0] + s[1]) + s[2]) + s[3];
+    float t = ((s[0] + s[1]) + s[2]) + s[3];
+    if (U == 8) t += ((s[4] + s[5]) + s[6]) + s[7];
+    red[pl][e] = t;
     __syncthreads();
     if (pl == 0 && i < n) {
         float tot = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tot += red[r][e];
+        for (int r = 0; r < PL; ++r) tot += red[r][e];
         if (i < KC) dw[i] += tot;
         else if (db) db[i - KC] += tot;
     }
+}
+static void head_dw_reduce(const float* ws, long long parts, long long n, long long KC, float* dw, float* db, hipStream_t st) {
+    if (parts > 256 && n <= 4096) head_dw_reduce_k<64><<<cdiv(n, 16), 1024, 0, st>>>(ws, (int)parts, n, KC, dw, db);
+    else head_dw_reduce_k<16><<<cdiv(n, 16), 256, 0, st>>>(ws, (int)parts, n, KC, dw, db);
 }
 
 // ---------------------------------------------------------------- loss / Adam
@@ -576,10 +591,12 @@ int kp_wgrad_unpack(const float* scratch, int partials, float* dw, int K, int C,
         return kp_check_launch("wgrad_unpack_tile");
     }
     if (Cp % 4 == 0)
-        if (partials >= 128 && total <= 16384)
+        if (partials >= 128 && total <= 16384)   // (64 lanes in a 1024-thread workgroup: measured no faster, 7.4 vs 7.2 us at 512 partials)
             wgrad_unpack_k<4, 16><<<cdiv(total / 4, 16), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, Cp, R);
         else
             wgrad_unpack_k<4, 4><<<cdiv(total / 4, 64), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, Cp, R);
+    else if (partials >= 256 && total <= 16384)   // (first layers: thousands of partials of a few hundred floats: 9.0 -> 5.1 us)
+        wgrad_unpack_k<1, 64, 1024><<<cdiv(total, 16), 1024, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, Cp, R);
     else
         wgrad_unpack_k<1, 4><<<cdiv(total, 64), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, Cp, R);
     return kp_check_launch("wgrad_unpack");
@@ -699,7 +716,7 @@ static int head_bwd_impl(const float* gout, const float* out, const void* x, con
     }
     if (parts > 0) {   // deterministic mode: sum the partial gradients in a fixed order
         const long long n = (long long)K * C + K;
-        head_dw_reduce_k<<<cdiv(n, 16), TPB, 0, st>>>(ws, (int)parts, n, (long long)K * C, dw_out, db);
+        head_dw_reduce(ws, parts, n, (long long)K * C, dw_out, db, st);
         return kp_check_launch("head_dw_reduce");
     }
     return KP_OK;
@@ -790,7 +807,7 @@ int kp_head_bwd_t(const void* gout_t, const void* out_t, const void* x, int bnin
         if (int rc = kp_head_dw_mfma_t(gout_t, out_t, x, slope, dw, db, ws, M, H * W, C, K, st, bnin ? &bn : nullptr)) return rc;
         if (ws) {   // deterministic mode: sum the partial gradients in a fixed order
             const long long n = (long long)K * C + K, parts = kp_head_dw_parts_mfma(M, H * W, C, K);
-            head_dw_reduce_k<<<cdiv(n, 16), TPB, 0, st>>>(ws, (int)parts, n, (long long)K * C, dw, db);
+            head_dw_reduce(ws, parts, n, (long long)K * C, dw, db, st);
             return kp_check_launch("head_dw_reduce");
         }
     }
