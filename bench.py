@@ -564,9 +564,10 @@ def compact_line(line, detail_path):
 
 EXTRA_CONFIGS = [
     # (key, overrides, steps as a multiple of --extra-steps): the other BASELINE.json configurations a single MI355X can hold, in
-    # their named precision and per-GPU batch (config 2's step is 4 ms: it gets 6x the steps so that its leg is not all ramp)
+    # their named precision and per-GPU batch (config 2's step is 2.8 ms, and the first timed step behind the synchronisation runs at
+    # the host's launch rate -- 3.9 ms, tools/probes/step_jitter.py: it gets 20x the steps so that its leg is not ramp)
     ('config2_pong_bf16_b256', dict(net='transporter', model_type='VGG_PONG_LAYERNECK', model_in_channels=1, model_z_channels=16,
-                                    model_keypoints=4, size=84, batch=256, precision='bf16'), 6),
+                                    model_keypoints=4, size=84, batch=256, precision='bf16'), 20),
     ('config3_keynet_tps_bf16_b128', dict(net='keynet', model_type='F', model_in_channels=3, model_z_channels=64, model_keypoints=10,
                                           size=128, batch=128, precision='bf16'), 2),
     ('config5_F256_K30_fp16_b256', dict(net='transporter', model_type='F', model_in_channels=3, model_z_channels=64,
