@@ -141,7 +141,7 @@ class GradReducer:
         total = arena.flat.numel()
         best = None
         for idx in range(1, len(plan) - 1):
-            off = arena.views[id(plan[idx]['conv'].weight)].storage_offset()
+            off = arena.views[id(plan[idx]['conv'].weight)].storage_offset() - arena.flat.storage_offset()   # (the arena may be a slice)
             if total - off >= tail_fraction * total:
                 best = (idx, off)
         return best

@@ -57,6 +57,7 @@ class FusedAdam:
         self.step_count = 0
         self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps)]
         self._units = []
+        self._whole = []   # (params, grads, exp_avg, exp_avg_sq) of all Units of a device as one buffer each (bind)
         self._loose = []
         self._state = {}
         self.scaler = None   # keypoints_amd.amp.LossScaler for the fp16 mode (amp.initialize attaches it)
@@ -66,31 +67,69 @@ class FusedAdam:
     def bind(self, root: torch.nn.Module) -> 'FusedAdam':
         """Flatten the parameters of every `Unit` under `root` (call after `.to(device)`)."""
         from .models.knn import Unit
+        from .unit_engine import GradArena
         owned = set()
         wanted = {id(p) for p in self.params}
+        todo = []
         for m in root.modules():
             if isinstance(m, Unit):
                 ps = [p for p in m.parameters()]
-                if not ps or not all(id(p) in wanted for p in ps):
+                if not ps or not all(id(p) in wanted for p in ps) or any(id(p) in owned for p in ps):
                     continue
                 require_device(*ps)
-                flat = torch.empty(sum(p.numel() for p in ps), device=ps[0].device, dtype=torch.float32)
+                todo.append((m, ps))
+                owned.update(id(p) for p in ps)
+        # ONE parameter / gradient / moment buffer per device for all Units (a Unit's arena is a 256-byte-aligned slice of it):
+        # the step and zero_grad are then one launch each for the whole network, whatever the number of Units
+        by_dev = {}
+        for m, ps in todo:
+            by_dev.setdefault(ps[0].device, []).append((m, ps))
+        for dev, group in by_dev.items():
+            sizes = [sum(p.numel() for p in ps) for _, ps in group]
+            starts, total = [], 0
+            for n in sizes:
+                starts.append(total)
+                total += (n + 63) // 64 * 64
+            w_all = torch.zeros(total, device=dev, dtype=torch.float32)
+            g_all, m_all, v_all = torch.zeros_like(w_all), torch.zeros_like(w_all), torch.zeros_like(w_all)
+            self._whole.append((w_all, g_all, m_all, v_all))
+            for (m, ps), s0, n in zip(group, starts, sizes):
+                flat = w_all[s0:s0 + n]
                 off = 0
                 for p in ps:
                     view = flat[off:off + p.numel()].view_as(p)
                     view.copy_(p.data)
                     p.data = view
                     off += p.numel()
-                m._arena = None   # grad views must be rebuilt against the same ordering
-                self._units.append((m, flat, torch.zeros_like(flat), torch.zeros_like(flat)))
-                owned.update(id(p) for p in ps)
+                m._arena = GradArena(ps, flat=g_all[s0:s0 + n])   # grad views in the same ordering
+                self._units.append((m, flat, m_all[s0:s0 + n], v_all[s0:s0 + n]))
         self._loose = [p for p in self.params if id(p) not in owned]
         return self
 
+    def _whole_ok(self):
+        """True while every Unit still accumulates into its slice of the shared gradient buffer (a Unit moved to another device,
+        or given a fresh arena by hand, takes the per-Unit path again)."""
+        return bool(self._whole) and all(m._arena is not None and m._arena.flat.data_ptr() == g.data_ptr()
+                                         for (m, *_), g in zip(self._units, self._grad_slices()))
+
+    def _grad_slices(self):
+        out = []
+        for w_all, g_all, *_ in self._whole:
+            for m, flat, *_ in self._units:
+                if flat.device == w_all.device:
+                    off = (flat.data_ptr() - w_all.data_ptr()) // 4
+                    out.append(g_all[off:off + flat.numel()])
+        return out
+
     def zero_grad(self, set_to_none: bool = False):
+        whole = self._whole_ok()
+        if whole:
+            for _, g_all, *_ in self._whole:
+                g_all.zero_()
         for m, *_ in self._units:
             arena = m.grad_arena()
-            arena.flat.zero_()
+            if not whole:
+                arena.flat.zero_()
             for p in m.parameters():
                 p.grad = arena.views[id(p)]
         for p in self._loose:
@@ -114,7 +153,10 @@ class FusedAdam:
         b1, b2 = self.betas
         bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
         st = stream_ptr()
-        work = [(flat, m.grad_arena().flat, em, ev) for m, flat, em, ev in self._units]
+        if self._whole_ok():   # (the padding between the Units' slices is zero in all four buffers and stays zero)
+            work = list(self._whole)
+        else:
+            work = [(flat, m.grad_arena().flat, em, ev) for m, flat, em, ev in self._units]
         for p in self._loose:
             if p.grad is None:
                 continue

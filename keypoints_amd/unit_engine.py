@@ -202,9 +202,14 @@ class GradArena:
     `views[p]` aliases the arena; backward accumulates into the views and installs them as `p.grad`.
     """
 
-    def __init__(self, params: List[nn.Parameter]):
+    def __init__(self, params: List[nn.Parameter], flat: torch.Tensor = None):
+        """flat: a zeroed fp32 buffer of the parameters' total size to use instead of an own one (FusedAdam.bind hands every
+        Unit a slice of ONE buffer, so that the optimizer step and zero_grad are one launch each for the whole network)."""
         dev = params[0].device
-        self.flat = torch.zeros(sum(p.numel() for p in params), device=dev, dtype=torch.float32)
+        n = sum(p.numel() for p in params)
+        if flat is not None and (flat.numel() != n or flat.dtype != torch.float32 or flat.device != dev or not flat.is_contiguous()):
+            raise ValueError('GradArena: the external buffer does not match the parameters')
+        self.flat = flat if flat is not None else torch.zeros(n, device=dev, dtype=torch.float32)
         self.views, off = {}, 0
         for p in params:
             self.views[id(p)] = self.flat[off:off + p.numel()].view_as(p)

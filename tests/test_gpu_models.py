@@ -593,3 +593,50 @@ def test_memory_walk_order_changes_nothing_but_the_partial_sum_order():
     assert float((x0 - x1).abs().max()) <= 2e-2 * float(x0.abs().max())     # a bf16 ulp here and there after 25 layers
     assert float((k0 - k1).abs().max()) <= 2e-3
     assert float((g0 - g1).norm() / g0.norm()) <= 2e-2
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_fused_adam_one_buffer_equals_the_per_unit_launches(precision):
+    """FusedAdam.bind re-homes the parameters, gradients and moments of ALL Units in one buffer each (one Adam launch + one
+    zero_grad fill per step for the whole network; a Unit's arena is a slice).  Adam is element-wise: three train steps must
+    leave bit-identical parameters and moments to the per-Unit launches (forced by dropping the whole-buffer record), with and
+    without the fp16 loss scaler; a Unit given a fresh arena falls back to the per-Unit path by itself."""
+    import keypoints_amd as ka
+    from keypoints_amd import amp
+    from keypoints_amd.models import transporter
+    g = torch.Generator().manual_seed(2)
+    xs = (torch.rand(8, 1, 84, 84, generator=g) * 2 - 1).cuda()
+    xt = (torch.rand(8, 1, 84, 84, generator=g) * 2 - 1).cuda()
+    res = []
+    for whole in (True, False):
+        torch.manual_seed(4)
+        net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 4).cuda().set_precision(precision)
+        opt = ka.FusedAdam(net.parameters(), lr=1e-3).bind(net)
+        if precision == 'fp16':
+            net, opt = amp.initialize(net, opt, opt_level='O2')
+        assert opt._whole_ok() and len(opt._whole) == 1 and len(opt._units) == 3
+        w_all, g_all = opt._whole[0][0], opt._whole[0][1]
+        lo, hi = w_all.data_ptr(), w_all.data_ptr() + 4 * w_all.numel()
+        assert all(lo <= p.data_ptr() < hi for p in net.parameters())
+        if not whole:
+            opt._whole = []
+            assert not opt._whole_ok()
+        for _ in range(3):
+            opt.zero_grad()
+            loss = ka.l2_reconstruction_loss(net(xs, xt)[0], xt)
+            if precision == 'fp16':
+                with amp.scale_loss(loss, opt) as scaled:
+                    scaled.backward()
+            else:
+                loss.backward()
+            glo = g_all.data_ptr()
+            assert all(glo <= p.grad.data_ptr() < glo + 4 * g_all.numel() for p in net.parameters())
+            opt.step()
+        torch.cuda.synchronize()
+        res.append(([p.detach().clone() for p in net.parameters()], [t.clone() for _, _, em, ev in opt._units for t in (em, ev)]))
+    for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    # a Unit that gets a fresh gradient arena: the optimizer notices and steps per Unit
+    net.decoder._arena = None
+    net.decoder.grad_arena()
+    assert not opt._whole_ok()
