@@ -153,8 +153,10 @@ struct PackBatch {
 // 8-9 M weights of a model-F Unit).  Here the source rows come in 1152-byte runs, both packs leave in 64-byte runs; the tile
 // pitch is odd (289 words), so the c-major and the k-major sweeps over it are both conflict-free.
 constexpr int PT = 32, PPITCH = PT * 9 + 1;
-template <typename T>
-__global__ __launch_bounds__(256) void pack_weights_tile_k(const PackBatch B) {
+// NT = 1024 for the nets of a few tiles (a Pong-class Transporter is 8 tiles: the launch takes as long as ONE workgroup walks its
+// 3 x 9 216 tile elements -- 36 trips per sweep with 256 threads, 20 us at the start of every forward)
+template <typename T, int NT = 256>
+__global__ __launch_bounds__(NT) void pack_weights_tile_k(const PackBatch B) {
     __shared__ float tile[PT * PPITCH];
     int l = 0;
     while (l + 1 < B.n && blockIdx.x >= B.first_block[l + 1]) ++l;   // (uniform; n <= 24)
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void pack_weights_tile_k(const PackBatch B) {
     const int tid = threadIdx.x;
     const int cw = (C - c0 < PT ? C - c0 : PT) * 9;          // source floats per k row in this tile (may be <= 0: padding tile)
     const float* __restrict__ w = B.w[l];
-    for (int e = tid; e < PT * PT * 9; e += 256) {
+    for (int e = tid; e < PT * PT * 9; e += NT) {
         const int kk = e / (PT * 9), j = e - kk * (PT * 9);   // j = cc * 9 + tap
         float v = 0.f;
         if (k0 + kk < K && j < cw) v = w[((long long)(k0 + kk) * C + c0) * 9 + j];
@@ -173,13 +175,13 @@ __global__ __launch_bounds__(256) void pack_weights_tile_k(const PackBatch B) {
     }
     __syncthreads();
     T* __restrict__ wf = (T*)B.wf[l];
-    for (int e = tid; e < PT * 9 * PT; e += 256) {            // wf[k][tap][c]: lanes walk c
+    for (int e = tid; e < PT * 9 * PT; e += NT) {             // wf[k][tap][c]: lanes walk c
         const int cc = e % PT, tap = (e / PT) % 9, kk = e / (PT * 9);
         if (k0 + kk < K && c0 + cc < Cp) st<T>(wf + ((long long)(k0 + kk) * 9 + tap) * Cp + c0 + cc, tile[kk * PPITCH + cc * 9 + tap]);
     }
     if (B.wd[l]) {
         T* __restrict__ wd = (T*)B.wd[l];
-        for (int e = tid; e < PT * 9 * PT; e += 256) {        // wd[c][8 - tap][k]: lanes walk k
+        for (int e = tid; e < PT * 9 * PT; e += NT) {         // wd[c][8 - tap][k]: lanes walk k
             const int kk = e % PT, tap = (e / PT) % 9, cc = e / (PT * 9);
             if (k0 + kk < K && c0 + cc < Cp) st<T>(wd + ((long long)(c0 + cc) * 9 + (8 - tap)) * K + k0 + kk, tile[kk * PPITCH + cc * 9 + tap]);
         }
@@ -578,7 +580,8 @@ int kp_pack_weights_batch(int n, const float* const* w, void* const* w_fwd, void
         blocks += cdiv((size_t)K[i], PT) * cdiv((size_t)Cp[i], PT);
     }
     B.first_block[n] = blocks;
-    DISPATCH_T(dtype, pack_weights_tile_k<T><<<blocks, 256, 0, (hipStream_t)stream>>>(B));
+    if (blocks <= 64) { DISPATCH_T(dtype, (pack_weights_tile_k<T, 1024><<<blocks, 1024, 0, (hipStream_t)stream>>>(B))); }
+    else { DISPATCH_T(dtype, pack_weights_tile_k<T><<<blocks, 256, 0, (hipStream_t)stream>>>(B)); }
     return kp_check_launch("pack_weights_batch");
 }
 
