@@ -128,6 +128,10 @@ TOL16 = {
                  xt_rel_l2=5e-3, xt_beyond=2e-2, xt_frac_beyond=1e-4, xt_worst=5e-3 / (2 * 0.1 ** 2),
                  xt_rel_l2_random_init=4.5e-2, xt_worst_random_init=5e-3 / (2 * 0.1 ** 2)),
 }
+# A single conditioned network scatters around the clauses above (which one a conditioning trajectory ends in depends on the last
+# bits of the fp32 path): tests assert each clause on the median of three trajectories and every single network inside this factor.
+# Measured: fp16 keypoints of config 3 over six trajectories 3.95 - 6.00 e-3 (median 4.2e-3), of config 4 over four 2.74 - 5.13 e-3.
+TOL16_PER_NETWORK = 1.5
 TOL16['bf16'] = {k: (v if k in ('loss', 'xt_frac_beyond') else min(1.0, 8.0 * v)) for k, v in TOL16['fp16'].items()}   # (a relative error clause above 1 says nothing)
 
 
