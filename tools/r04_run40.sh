@@ -1,6 +1,7 @@
 #!/bin/bash
 # how does the model-F step respond to MORE small dependent launches on the forward chain (one / two extra 3-us kernels behind every
-# forward finalize: 40 / 80 per step)?  linear (0.12 / 0.24 ms) or amplified?
+# forward finalize: 40 / 80 per step)?  linear (0.12 / 0.24 ms) or amplified?  Result: +0.06 / +0.07 ms.
+# (KP_EXTRA_TINY was a temporary hook in unit_engine.py behind kp_bn_finalize: `for _ in range(n): mean.add_(0.0)`; removed.)
 O=$PWD/gpurun_out
 F="--steps 30 --warmup 8 --no-cpu-baseline --extra 0 --profile-steps 0"
 run() {
