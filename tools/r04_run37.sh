@@ -1,6 +1,6 @@
 #!/bin/bash
 # final records of this build on one box: the driver's default command, config 2 alone, config 2 as a HIP graph, kernel stats
-O=$PWD/gpurun_out; R=$PWD; T=r04h
+O=$PWD/gpurun_out; R=$PWD; T=${1:-r04i}
 python bench.py --out $O/${T}_bench.json > $O/${T}_bench.line 2>$O/${T}_bench.err
 C2="--no-cpu-baseline --precision bf16 --model_type VGG_PONG_LAYERNECK --model_in_channels 1 --model_z_channels 16 --model_keypoints 4 --size 84 --batch 256"
 python bench.py --steps 60 --warmup 16 $C2 --out $O/${T}_cfg2_bench.json > /dev/null 2>&1
