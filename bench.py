@@ -357,7 +357,8 @@ def _run_leg(args, rank, world, dev):
             ex = reducer.exposed_ms()
             dp['modes'][f'dp_overlap_{ov}'] = dict(ms_per_step=1e3 * el / args.steps, ms_per_step_median_hipevent=med(sm),
                                                    value=B * world / (el / args.steps),
-                                                   exposed_allreduce_ms_median=med(sorted(ex)) if ex else None)
+                                                   exposed_allreduce_ms_median=med(sorted(ex)) if ex else None,
+                                                   collectives_per_step=reducer.collectives_last_finish)
         reducer.overlap = bool(args.dp_overlap)
         reducer.time_finish(False)
 

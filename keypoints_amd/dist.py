@@ -118,6 +118,7 @@ class GradReducer:
         self._avg = self.native is not None or dist.get_backend(group) == 'nccl'   # RCCL has ncclAvg; gloo sums then scales
         self._sync = True
         self.pieces_issued = 0   # since the last finish() (tests / diagnostics)
+        self.collectives_last_finish = 0   # all-reduces the last finish() waited for
         self.timing = None       # list of (start, end) HIP event pairs around finish() while `time_finish(True)` (bench.py)
         if broadcast_init:
             for t in list(root.parameters()) + list(root.buffers()):
@@ -210,6 +211,39 @@ class GradReducer:
             self._reduce(flat)
         self._done.add(id(unit))
 
+    @staticmethod
+    def _coalesce(ts):
+        """overlap=False: the arenas noted during the backward, merged where they are neighbours in memory -- FusedAdam.bind keeps
+        every Unit's gradients in ONE buffer (slices a few zero floats apart), so the whole network goes out as one collective
+        instead of one per Unit (fewer, larger all-reduces: what a ring over xGMI wants).  Anything else passes through unchanged."""
+        flat = [t for t in ts if t.dim() == 1 and t.is_contiguous()]
+        rest = [t for t in ts if not (t.dim() == 1 and t.is_contiguous())]
+        groups = {}
+        for t in flat:
+            groups.setdefault((t.untyped_storage().data_ptr(), t.dtype, t.device), []).append(t)
+        out = []
+        for g in groups.values():
+            g.sort(key=lambda t: t.storage_offset())
+            run = [g[0]]
+            for t in g[1:]:
+                prev = run[-1]
+                gap = t.storage_offset() - (prev.storage_offset() + prev.numel())
+                if 0 <= gap < 64:
+                    run.append(t)
+                else:
+                    out.append(run); run = [t]
+            out.append(run)
+        merged = []
+        for run in out:
+            if len(run) == 1:
+                merged.append(run[0])
+            else:
+                first, last = run[0], run[-1]
+                n = last.storage_offset() + last.numel() - first.storage_offset()
+                merged.append(torch.empty(0, dtype=first.dtype, device=first.device).set_(
+                    first.untyped_storage(), first.storage_offset(), (n,), (1,)))
+        return merged + rest
+
     def ranks_seen(self) -> dict:
         """How many ranks the gradient exchange really spans, asked of the transport itself rather than of the launcher's
         environment: a SUM all-reduce of a one on the device through the very communicator / process group the gradients
@@ -244,7 +278,7 @@ class GradReducer:
             t0 = torch.cuda.Event(enable_timing=True); t0.record()
         if self._early:
             raise RuntimeError('GradReducer.finish(): a Unit sent its arena tail but never finished its backward')
-        for t in self._ready:
+        for t in self._coalesce(self._ready):
             self._launch(t)
         self._ready.clear()
         for work, flat, wire in self._pending:
@@ -253,6 +287,7 @@ class GradReducer:
                 flat.copy_(wire)
             if not self._avg:
                 flat.div_(self.world)
+        self.collectives_last_finish = len(self._pending)
         self._pending.clear()
         self._done.clear()
         self.pieces_issued = 0

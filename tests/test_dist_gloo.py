@@ -107,6 +107,46 @@ def _worker(rank, world, port, q):
         late_ok = late_ok and torch.allclose(arena.flat, torch.full_like(arena.flat, sum(range(1, world + 1)) / world))
         late_ok = late_ok and not red_late._ready and not red_late._pending
 
+        # (4c) overlap=False with every Unit's arena a slice of ONE buffer (what FusedAdam.bind sets up on the device): finish()
+        # sends the whole network as ONE collective; Units with arenas of their own still go out one by one
+        from keypoints_amd.unit_engine import GradArena
+        sizes = [sum(p.numel() for p in u.parameters()) for u in units]
+        starts, tot = [], 0
+        for n in sizes:
+            starts.append(tot); tot += (n + 63) // 64 * 64
+        g_all = torch.zeros(tot)
+        for u, s0, n in zip(units, starts, sizes):
+            u._arena = GradArena(list(u.parameters()), flat=g_all[s0:s0 + n])
+        red_one = GradReducer(net, broadcast_init=False, overlap=False)
+        for i, u in enumerate(units):
+            u.grad_arena().flat.fill_(float(rank + 1) + i)
+            for idx in range(len(u.plan()) - 2, -1, -1):
+                u._layer_done(idx)
+            u._after_backward()
+        one_ok = len(red_one._ready) == 3
+        red_one.finish()
+        one_ok = one_ok and red_one.collectives_last_finish == 1
+        for i, u in enumerate(units):
+            want = sum(range(1, world + 1)) / world + i
+            one_ok = one_ok and torch.allclose(u.grad_arena().flat, torch.full_like(u.grad_arena().flat, want))
+        gaps = torch.ones(tot, dtype=torch.bool)
+        for s0, n in zip(starts, sizes):
+            gaps[s0:s0 + n] = False
+        one_ok = one_ok and float(g_all[gaps].abs().sum()) == 0.0       # the padding between the slices stays zero
+        units[1]._arena = None                                           # a Unit with an arena of its own again
+        units[1].grad_arena()
+        red_mix = GradReducer(net, broadcast_init=False, overlap=False)
+        for u in units:
+            u.grad_arena().flat.fill_(float(rank + 1))
+            for idx in range(len(u.plan()) - 2, -1, -1):
+                u._layer_done(idx)
+            u._after_backward()
+        red_mix.finish()
+        one_ok = one_ok and red_mix.collectives_last_finish == 3         # (the two slices are no longer neighbours: gap of a whole arena)
+        one_ok = one_ok and all(torch.allclose(u.grad_arena().flat, torch.full_like(u.grad_arena().flat, sum(range(1, world + 1)) / world))
+                                for u in units)
+        late_ok = late_ok and one_ok
+
         # (5) checkpoint: per-rank BatchNorm buffers -> rank 0's on every rank, rank 0 writes the reference's layout
         import tempfile
         for b in net.buffers():
