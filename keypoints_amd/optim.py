@@ -65,9 +65,11 @@ class FusedAdam:
             self.bind(modules)
 
     def bind(self, root: torch.nn.Module) -> 'FusedAdam':
-        """Flatten the parameters of every `Unit` under `root` (call after `.to(device)`)."""
+        """Flatten the parameters of every `Unit` under `root` (call once, after `.to(device)` and before the first step: binding
+        again re-homes the parameters and starts the Adam moments from zero)."""
         from .models.knn import Unit
         from .unit_engine import GradArena
+        self._units.clear(); self._whole.clear()   # (a second bind re-homes everything again: no Unit is stepped twice)
         owned = set()
         wanted = {id(p) for p in self.params}
         todo = []
