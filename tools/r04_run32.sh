@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B on one box, config 2 (medians of the per-step HIP-event times): band-kernel statistics rows 1 per workgroup (new) vs 1 per
-# (KP_NO_SHARED_INPUT and build_ab/libkp_rows4.so = -DKP_FB_ROWS=4 were temporary: the shared input conversion was removed, DESIGN.md 3.9b)
 # wavefront (build_ab/libkp_rows4.so), and the shared input conversion on / off
+# (KP_NO_SHARED_INPUT and build_ab/libkp_rows4.so = -DKP_FB_ROWS=4 were temporary: the shared input conversion was removed, DESIGN.md 3.9b)
 O=$PWD/gpurun_out
 C2="--steps 60 --warmup 16 --no-cpu-baseline --extra 0 --profile-steps 0 --precision bf16 --model_type VGG_PONG_LAYERNECK --model_in_channels 1 --model_z_channels 16 --model_keypoints 4 --size 84 --batch 256"
 run() {  # tag, env, extra args
