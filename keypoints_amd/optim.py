@@ -26,7 +26,8 @@ class _L2Loss(torch.autograd.Function):
         grad = torch.empty_like(x)
         call('kp_l2_loss', ptr(x), ptr(target), ptr(mask), ptr(acc), ptr(grad), 1.0 / n, n, stream_ptr())
         ctx.save_for_backward(grad)
-        return (acc / n).to(torch.float32).reshape(())
+        # (acc / n in fp64, rounded once to fp32 -- `(acc / n).to(float32)` in ONE launch: this sits between the forward and the backward)
+        return torch.div(acc, n, out=torch.empty(1, device=x.device, dtype=torch.float32)).reshape(())
 
     @staticmethod
     def backward(ctx, g):
