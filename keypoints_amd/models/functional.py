@@ -30,6 +30,7 @@ class _SpatialSoftmax(torch.autograd.Function):
         ctx.save_for_backward(k, p, q)
         ctx.shape = (B, K, H, W)
         ctx.mark_non_differentiable(p, q)   # marginals are display-only in the reference (utils.py:142)
+        ctx.set_materialize_grads(False)    # (no zero-filled gradients for them at every backward; k's is the only one there can be)
         return k, p, q
 
     @staticmethod
@@ -106,6 +107,7 @@ class _TransportMax(torch.autograd.Function):
         ctx.save_for_backward(phi_s, phi_t, mask_s, mask_t, arg_s, arg_t)
         ctx.K = K
         ctx.mark_non_differentiable(mask_s, mask_t)
+        ctx.set_materialize_grads(False)
         return phi, mask_s, mask_t
 
     @staticmethod
@@ -148,6 +150,7 @@ class _TransportMode(torch.autograd.Function):
         ctx.save_for_backward(phi_s, phi_t, m_s, m_t)
         ctx.mode = COMBINE[mode]
         ctx.mark_non_differentiable(mask_s, mask_t)
+        ctx.set_materialize_grads(False)
         return phi, mask_s, mask_t
 
     @staticmethod

@@ -499,6 +499,7 @@ class UnitFunction(torch.autograd.Function):
         call('kp_head_fwd_bnin_pair', ptr(fin2['y']), *fin2['bn'], fin2['slope'], ptr(hconv.weight), ptr(hconv.bias), head['slope'],
              ptr(out_s), ptr(out), int(bool(out_t)), 2 * N, H, W, C, Kout, code, st)
         ctx.mark_non_differentiable(out_s)
+        ctx.set_materialize_grads(False)   # (else autograd fills a zero gradient for out_s at every backward: 58 / 29 MB per encoder at 256 x 84 x 84)
         if record:
             ctx.unit, ctx.saved, ctx.head_in = unit, saved, fin_t
             ctx.save_for_backward(out)
@@ -509,7 +510,9 @@ class UnitFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
-        gout = gouts[-1]   # (a pair call has two outputs; the source half's is non-differentiable)
+        gout = gouts[-1]   # (a pair call has two outputs; the source half's is non-differentiable, its gradient None)
+        if gout is None:
+            raise RuntimeError('keypoints_amd Unit: backward without an output gradient')
         if getattr(ctx, 'saved', None) is None:
             raise RuntimeError('keypoints_amd Unit: backward was already run for this forward; the saved activations are '
                                'released after the first backward (retain_graph=True is not supported)')
