@@ -49,25 +49,18 @@ class LossScaler:
 
 
 class _ScaleLoss(torch.autograd.Function):
+    """loss * scale with the scale a device tensor (never read on the host); one element-wise launch each way."""
+
     @staticmethod
     def forward(ctx, loss, scale):
         require_device(loss, scale)
-        x = f32c(loss).reshape(1)
-        buf = torch.empty(4, device=x.device, dtype=torch.float32)   # 16-byte aligned scratch for the 1-element kernel
-        src = torch.zeros(4, device=x.device, dtype=torch.float32)
-        src[:1] = x
-        call('kp_scale', ptr(src), ptr(scale), ptr(buf), 1, stream_ptr())
         ctx.save_for_backward(scale)
-        return buf[0].reshape(())
+        return (f32c(loss).reshape(()) * scale.reshape(())).reshape(())
 
     @staticmethod
     def backward(ctx, g):
         (scale,) = ctx.saved_tensors
-        src = torch.zeros(4, device=g.device, dtype=torch.float32)
-        src[:1] = f32c(g).reshape(1)
-        out = torch.empty(4, device=g.device, dtype=torch.float32)
-        call('kp_scale', ptr(src), ptr(scale), ptr(out), 1, stream_ptr())
-        return out[0].reshape(()), None
+        return (f32c(g).reshape(()) * scale.reshape(())).reshape(()), None
 
 
 def _require_scaling_optimizer(optimizer, who):
