@@ -117,7 +117,7 @@ __global__ void render_fwd_k(const float* __restrict__ k, float* __restrict__ m,
     const long long bk = t / ((long long)W * H);
     const float dy = ruler_at(i, H) - k[bk * 2], dx = ruler_at(j, W) - k[bk * 2 + 1];
     const float d2 = dy * dy + dx * dx;
-    if (MODE == 0) m[t] = expf(-sqrtf(d2 + eps) * inv2s2);
+    if (MODE == 0) m[t] = kp_gauss(d2 + eps, inv2s2);
     else m[t] = -d2;
 }
 
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(TPB) void gaussian_bwd_k(const float* __restrict__ 
     for (int e = threadIdx.x; e < H * W; e += TPB) {
         const int i = e / W, j = e % W;
         const float dy = ruler_at(i, H) - ky, dx = ruler_at(j, W) - kx;
-        const float d = sqrtf(dy * dy + dx * dx + eps);
-        const float mv = expf(-d * inv2s2);
+        const float d = kp_fast_sqrt(dy * dy + dx * dx + eps);
+        const float mv = kp_fast_exp(-d * inv2s2);
         const float c = gm[(long long)bk * H * W + e] * mv * inv2s2 / d;
         sy += c * dy;
         sx += c * dx;

@@ -85,9 +85,9 @@ __global__ __launch_bounds__(NT) void bottleneck_fwd_k(const float* __restrict__
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 float dy = ry[v] - sy, dx = rx[v] - sx;
-                const float vs = expf(-sqrtf(dy * dy + dx * dx + eps) * inv2s2);
+                const float vs = kp_gauss(dy * dy + dx * dx + eps, inv2s2);
                 dy = ry[v] - ty; dx = rx[v] - tx;
-                mt[v] = expf(-sqrtf(dy * dy + dx * dx + eps) * inv2s2);
+                mt[v] = kp_gauss(dy * dy + dx * dx + eps, inv2s2);
                 if (k == 0 || vs > bs[v]) bs[v] = vs;
                 if (k == 0 || mt[v] > bt[v]) { bt[v] = mt[v]; at[v] = k; }   // first maximum wins, like torch.max
             }
@@ -209,8 +209,8 @@ __global__ __launch_bounds__(NT) void bottleneck_bwd_k(const float* __restrict__
             if (gm != 0.f) {
                 const int i = pix / W;
                 const float dy = ruler_at(i, H) - ky, dx = ruler_at(pix - i * W, W) - kx;
-                const float d = sqrtf(dy * dy + dx * dx + eps);
-                const float cc = gm * expf(-d * inv2s2) * inv2s2 / d;
+                const float d = kp_fast_sqrt(dy * dy + dx * dx + eps);
+                const float cc = gm * kp_fast_exp(-d * inv2s2) * inv2s2 / d;
                 sy += cc * dy;
                 sx += cc * dx;
             }

@@ -105,12 +105,12 @@ __global__ __launch_bounds__(NT) void bottleneck_fwd_t_k(const float* __restrict
         for (int k = 0; k < K; ++k) {
             if (do_s) {
                 const float dy = ry - ks[2 * k], dx = rx - ks[2 * k + 1];
-                const float vs = expf(-sqrtf(dy * dy + dx * dx + eps) * inv2s2);
+                const float vs = kp_gauss(dy * dy + dx * dx + eps, inv2s2);
                 if (k == 0 || vs > bs) bs = vs;
             }
             if (do_t) {
                 const float dy = ry - kt[2 * k], dx = rx - kt[2 * k + 1];
-                const float mt = expf(-sqrtf(dy * dy + dx * dx + eps) * inv2s2);
+                const float mt = kp_gauss(dy * dy + dx * dx + eps, inv2s2);
                 if (k == 0 || mt > bt) { bt = mt; at = k; }   // first maximum wins, like torch.max
                 if (ch == (LP == 1 ? 0 : 1)) m_t[((long long)b * K + k) * HW + pix] = mt;
             }
@@ -234,8 +234,8 @@ __global__ __launch_bounds__(NT) void bottleneck_bwd_t_k(const h16_t* __restrict
                 if (gm != 0.f) {
                     const int i = pix / W;
                     const float dy = ruler_at(i, H) - ky, dx = ruler_at(pix - i * W, W) - kx;
-                    const float d = sqrtf(dy * dy + dx * dx + eps);
-                    const float cc = gm * expf(-d * inv2s2) * inv2s2 / d;
+                    const float d = kp_fast_sqrt(dy * dy + dx * dx + eps);
+                    const float cc = gm * kp_fast_exp(-d * inv2s2) * inv2s2 / d;
                     sy += cc * dy;
                     sx += cc * dx;
                 }

@@ -181,6 +181,14 @@ struct KpBnIn8 {
 };
 
 // torch.linspace(0, 1, n)[i] in fp32, built the way ATen builds it (symmetric halves).
+// exp(-sqrt(dd) * inv2s2): one Gaussian-like map value from dd = dy^2 + dx^2 + eps (functional.py:56-63), on the hardware's
+// v_sqrt_f32 / v_exp_f32 (1 ulp each; the exponent's rounding adds |x| * 2^-24 relative, |x| <= 71 here: the value is within 1e-5
+// relative and 1e-7 absolute of the IEEE expression, SURVEY 8c asks atol 2.5e-4).  The correctly rounded sqrtf + expf are ~40 VALU
+// instructions per value and were most of the fused bottleneck's second phase; every kernel that renders the maps calls THIS, so the
+// fused, the T and the piecewise forms stay bit-identical.
+__device__ __forceinline__ float kp_fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float kp_fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float kp_gauss(float dd, float inv2s2) { return kp_fast_exp(-kp_fast_sqrt(dd) * inv2s2); }
 __device__ __forceinline__ float ruler_at(int i, int n) {
     if (n <= 1) return 0.f;
     float step = 1.0f / (float)(n - 1);
