@@ -133,6 +133,11 @@ TOL16 = {
 # Measured: fp16 keypoints of config 3 over six trajectories 3.95 - 6.00 e-3 (median 4.2e-3), of config 4 over four 2.74 - 5.13 e-3.
 TOL16_PER_NETWORK = 1.5
 TOL16['bf16'] = {k: (v if k in ('loss', 'xt_frac_beyond') else min(1.0, 8.0 * v)) for k, v in TOL16['fp16'].items()}   # (a relative error clause above 1 says nothing)
+# ... except the keypoints: a softmax expectation over sharp heat-maps is linear in the logit noise only while that noise is << 1; at
+# bf16's roundoff (8 x fp16's: logit noise of a few tenths on a conditioned network) it is not, and the measured ratio to fp16 is 7 - 16
+# (conditioned networks, nine trajectories per config: config 3 2.6 - 6.4 e-2, config 4 2.0 - 2.9 e-2, config 5 0.85 - 1.1 e-2, against
+# fp16's 3.9 - 6.0 / 2.7 - 5.1 / 0.85 - 1.2 e-3): 2^4 instead of 2^3 for this one clause.
+TOL16['bf16']['keypoints'] = 16.0 * TOL16['fp16']['keypoints']
 
 
 def fp16_storage(t: Tensor) -> Tensor:

@@ -525,7 +525,7 @@ def test_conditioned_networks_meet_the_16bit_contract(cfg):
     strict-fp32 HIP path on structured pairs (tests/structured.py), the SAME weights then go to the fp64 oracle and to fresh fp16 /
     bf16 HIP networks, one train-mode step each.  fp16 (+ dynamic loss scaling: the reference's O2 recipe, transporter.py:51,84-86,
     configs/transporter_celeba.yaml:7, configs/keypoints_celeba.yaml:7) is the contract type and bench.py's headline dtype; bf16 is
-    held to the same clauses x 8 (3 fewer mantissa bits).
+    held to the same clauses x 8 (3 fewer mantissa bits; keypoints x 16: oracle.TOL16).
 
     Measured, config 4 (tools/probes/conditioned.py, 0 / 50 / 200 / 600 steps): conditioning shrinks the rel-L2 distances 10-20x
     (x_t 2.1e-1 -> 1.4e-2 bf16, 3.3e-2 -> 1.8e-3 fp16) but NOT the keypoint error, which is storage rounding through ten BatchNorm
