@@ -230,8 +230,8 @@ int kp_conv_dgrad_bnred(const void* dy, const void* w_dgrad, void* gx, const voi
 int kp_bn_ws_doubles(int C);
 /* stats rows (from kp_conv_fwd; rows = kp_last_rows()) -> batch mean / 1/sqrt(var+eps); updates running stats
  * with momentum (unbiased var) like nn.BatchNorm2d in train mode.  count = N*H*W.
- * Deterministic fp64 reduction (one fused launch for rows <= 128, else two-stage through `ws`,
- * kp_bn_ws_doubles(C) doubles). */
+ * Deterministic fp64 reduction (one fused launch for rows <= 8192 -- a wide kernel above 128 rows, and for C <= 32 at every
+ * row count --, else two-stage through `ws`, kp_bn_ws_doubles(C) doubles). */
 int kp_bn_finalize(const float* stats, long long rows, double* ws, float* save_mean, float* save_invstd, float* running_mean,
                    float* running_var, long long* num_batches_tracked, float momentum, float eps, long long count,
                    int C, void* stream);
