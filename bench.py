@@ -70,7 +70,7 @@ def parse():
     ap.add_argument('--cpu-warmup', type=int, default=3)
     ap.add_argument('--extra', type=int, default=1,
                     help='N = 1, default workload only: after the headline legs run short legs of the other BASELINE configurations '
-                         '(config 2 bf16 256 pairs, config 3 KeyNet+TPS 128 images, config 5 fp16 256 pairs at 256x256 K=30) and the '
+                         '(config 2 bf16 256 pairs, config 3 KeyNet+TPS fp16 128 images, config 5 fp16 256 pairs at 256x256 K=30) and the '
                          "headline workload in the other 16-bit type; nested under `extra_configs` / `extra` of the same JSON line")
     ap.add_argument('--extra-steps', type=int, default=5)
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -238,6 +238,8 @@ def _run_leg(args, rank, world, dev):
     ka.set_multi_stream(bool(args.streams))
     ka.set_fuse_bn_input(bool(args.fuse_bn))
     ka.runtime.set_fuse_bn_reduce(bool(args.fuse_bn_reduce))
+    from keypoints_amd import _probe
+    probe_knobs = _probe.apply_env()   # (KP_* variables of tools/probes: the package itself reads none; what was set goes into the record)
     torch.manual_seed(0)
     if args.net == 'keynet':
         from keypoints_amd.models import keynet
@@ -397,6 +399,21 @@ def _run_leg(args, rank, world, dev):
             fam_alone = profile_leg()
             ka.set_multi_stream(True)
 
+    # ---- step-level algorithmic HBM bytes (kp_prof_enable(2): every kp_* entry point adds the bytes of its launch, operands +
+    # results each once; no events): the HBM fraction of the WHOLE step, which is the roofline that says something about the
+    # HBM-bound configurations (their `step_frac` is an MFMA figure)
+    step_bytes = step_launches = None
+    if args.profile_steps > 0:
+        barrier()
+        _lib.call('kp_prof_enable', 2)
+        for _ in range(2):
+            eager_step()
+        barrier()
+        by, n = ctypes.c_double(), ctypes.c_longlong()
+        _lib.call('kp_prof_step_bytes', ctypes.addressof(by), ctypes.addressof(n))
+        _lib.call('kp_prof_enable', 0)
+        step_bytes, step_launches = by.value / 2, n.value / 2
+
     if os.environ.get('KP_MEMSTATS'):
         ms_ = torch.cuda.memory_stats()
         print('memstats', {k: ms_[k] for k in ('num_device_alloc', 'num_device_free', 'num_alloc_retries', 'reserved_bytes.all.peak')}, file=sys.stderr)
@@ -451,6 +468,9 @@ def _run_leg(args, rank, world, dev):
                                         '157.3 TFLOP/s fp32 matrix, 8 TB/s HBM3E (spec), 256 CUs at 2.4 GHz',
                             device=dict(name=prop.name, arch=getattr(prop, 'gcnArchName', ''), cus=prop.multi_processor_count,
                                         hbm_gib=round(prop.total_memory / 2 ** 30, 1)))
+            if step_bytes:
+                roofline.update(step_bytes=step_bytes, step_kp_launches=step_launches,
+                                step_hbm_gbs=step_bytes / (ms_step * 1e-3) / 1e9, step_hbm_frac=step_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS)
             roofline.update(step_tflops=value / world * flop_pair / 1e12, step_frac=value / world * flop_pair / 1e12 / peak,
                             measured='HIP events around each launch on the launch stream, '
                                      f'{args.profile_steps} steps after the timed region', kernels=fam,
@@ -487,7 +507,7 @@ def _run_leg(args, rank, world, dev):
                                          f'{"augment+" if args.net == "keynet" and not args.no_augment else ""}fwd+loss+bwd+Adam',
                                 global_batch=B * world, per_gpu_batch=B, parallelism=f'dp{world}',
                                 dp_overlap=bool(args.dp_overlap) if world > 1 else None, side_streams=bool(args.streams), hip_graph=bool(args.graph),
-                                gflop_per_pair=flop_pair / 1e9, loss=float(loss.item())),
+                                gflop_per_pair=flop_pair / 1e9, loss=float(loss.item()), **({'probe_knobs': probe_knobs} if probe_knobs else {})),
                     roofline=roofline)
         if dp is not None:
             line['dp'] = dp
@@ -507,7 +527,7 @@ def compact_roofline(r):
     if not r:
         return r
     keep = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes', 'avg_launch_us', 'launches_per_step',
-            'step_tflops', 'step_frac', 'frac_at_measured_clock', 'pmc_mfma_util', 'pmc_effective_clock_ghz')
+            'step_tflops', 'step_frac', 'step_bytes', 'step_kp_launches', 'step_hbm_frac', 'frac_at_measured_clock', 'pmc_mfma_util', 'pmc_effective_clock_ghz')
     out = {k: _round(r[k]) for k in keep if k in r and r[k] is not None}
     if 'traffic' not in out:
         out['traffic'] = None
@@ -557,6 +577,10 @@ def compact_line(line, detail_path):
                             workload=r['config']['workload'], bound=rf.get('bound'), kernel=rf.get('kernel'),
                             achieved=_round(rf.get('achieved')), unit=rf.get('unit'), frac=_round(rf.get('frac')),
                             step_frac=_round(rf.get('step_frac')), traffic=rf.get('traffic'), algorithmic_bytes=rf.get('algorithmic_bytes'))
+        if r.get('bf16_secondary'):
+            summary[key]['bf16_secondary'] = dict(value=_round(r['bf16_secondary']['value'], 1), ms_per_step=_round(r['bf16_secondary']['ms_per_step']))
+        if rf.get('step_hbm_frac') is not None:
+            summary[key]['step_hbm_frac'] = _round(rf['step_hbm_frac'])
     if detail_path:
         out['detail_file'] = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT) else detail_path
     out['summary'] = summary
@@ -569,8 +593,11 @@ EXTRA_CONFIGS = [
     # the host's launch rate -- 3.9 ms, tools/probes/step_jitter.py: it gets 20x the steps so that its leg is not ramp)
     ('config2_pong_bf16_b256', dict(net='transporter', model_type='VGG_PONG_LAYERNECK', model_in_channels=1, model_z_channels=16,
                                     model_keypoints=4, size=84, batch=256, precision='bf16'), 20),
-    ('config3_keynet_tps_bf16_b128', dict(net='keynet', model_type='F', model_in_channels=3, model_z_channels=64, model_keypoints=10,
-                                          size=128, batch=128, precision='bf16'), 2),
+    # config 3 in the CONTRACT type: the reference's config-3 recipe is apex O2 = fp16 + dynamic loss scaling (configs/keypoints_celeba.yaml:7,
+    # keypoints.py:79-81), and fp16 is the 16-bit type whose keypoints meet SURVEY 8c on conditioned KeyNets (oracle.TOL16); the bf16
+    # figure rides along as `bf16_secondary` (faster, outside the stated keypoint tolerance: not the leg's value)
+    ('config3_keynet_tps_fp16_b128', dict(net='keynet', model_type='F', model_in_channels=3, model_z_channels=64, model_keypoints=10,
+                                          size=128, batch=128, precision='fp16'), 2),
     ('config5_F256_K30_fp16_b256', dict(net='transporter', model_type='F', model_in_channels=3, model_z_channels=64,
                                         model_keypoints=30, size=256, batch=256, precision='fp16'), 1),
 ]
@@ -635,6 +662,12 @@ def main():
                 r = run_leg(leg, rank, world, dev)
                 for k in ('n_gpus', 'higher_is_better', 'scaling', 'vs_baseline', 'data', 'unit'):
                     r.pop(k, None)
+                if key.startswith('config3') and leg.precision == 'fp16':   # the same leg in bf16, timing only
+                    sec = copy.copy(leg)
+                    sec.precision, sec.profile_steps = 'bf16', 0
+                    o2 = run_leg(sec, rank, world, dev)
+                    r['bf16_secondary'] = dict(value=o2['value'], ms_per_step=o2['ms_per_step'], dtype=o2['dtype'], steps=o2['steps'],
+                                               note='outside the stated 16-bit keypoint tolerance on conditioned KeyNets (oracle.TOL16): timing only')
                 line['extra_configs'][key] = r
             except Exception as e:   # a leg that fails must not take the headline number with it
                 line['extra_configs'][key] = dict(error=f'{type(e).__name__}: {e}')

@@ -109,6 +109,10 @@ int kp_prof_enable(int on);
 int kp_prof_collect(int family, double* ms, double* flops, long long* launches);
 /* Summed algorithmic HBM bytes (operands + result, each counted once) of the recorded launches of a family. */
 int kp_prof_bytes(int family, double* bytes);
+/* kp_prof_enable(2): no events -- every kp_* entry point adds the algorithmic HBM bytes (operands + results, each once) of the
+ * launch it makes to one running total; kp_prof_step_bytes returns the total and the number of launches since then (bench.py: the
+ * step-level HBM fraction of the HBM-bound configurations = bytes per step / step time / peak).  kp_prof_enable(0) ends it. */
+int kp_prof_step_bytes(double* bytes, long long* launches);
 
 /* ---- layout ------------------------------------------------------------ */
 /* NCHW fp32 -> NHWC T with a replicated border of `pad` pixels.
@@ -123,6 +127,16 @@ int kp_nchw_to_nhwc(const float* src, void* dst, int N, int C, int Cp, int H, in
  * edge pixels and the result is written NCHW fp32. */
 int kp_nhwc_grad_to_nchw(const void* gsrc, float* dst, int N, int C, int Cp, int H, int W, int pad, int dtype,
                          void* stream);
+
+/* The two above for an input that the reference forms with torch.cat((z, m), dim=1) in front of a Unit -- KeyNet.forward,
+ * keynet.py:29: the encoder's z [N][C0][H][W] and the Gaussian maps m [N][C1][H][W], decoder input width C0 + C1 = 74
+ * (keynet.py:55) -- so that the concatenated fp32 tensor is never written: channels [0, C0) of dst come from src0, [C0, C0 + C1)
+ * from src1, [C0 + C1, Cp) are zeros; same values as kp_nchw_to_nhwc of the concatenation.  The adjoint splits the folded gradient
+ * back into the two inputs' (dst0 / dst1 NULL: that input needs no gradient); same sums as kp_nhwc_grad_to_nchw. */
+int kp_nchw2_to_nhwc(const float* src0, int C0, const float* src1, int C1, void* dst, int N, int Cp, int H, int W, int pad, int dtype,
+                     void* stream);
+int kp_nhwc_grad_to_nchw2(const void* gsrc, float* dst0, int C0, float* dst1, int C1, int N, int Cp, int H, int W, int pad, int dtype,
+                          void* stream);
 
 /* ---- weights ----------------------------------------------------------- */
 /* fp32 [K][C][R][R] (nn.Conv2d.weight) -> T [K][R][R][Cp] (forward operand) and,
@@ -443,6 +457,7 @@ int kp_conv_fwd_pair(const void* x, const void* w, const float* bias, void* y, f
 int kp_conv_fwd_bnin_pair(const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta,
                           float slope, const void* w, const float* bias, void* y, float* stats, int N, int H, int W, int C, int K,
                           int dtype, void* stream);
+int kp_bn_finalize_pair_supported(long long rows, int C);   /* 1: kp_bn_finalize_pair takes `rows` rows per half of C channels */
 int kp_bn_finalize_pair(const float* stats, long long rows, float* save_mean, float* save_invstd, float* running_mean,
                         float* running_var, long long* num_batches_tracked, float momentum, float eps, long long count, int C,
                         void* stream);
@@ -468,6 +483,11 @@ int kp_warp_rotate(const float* x, const float* angle, float* out, int N, int C,
  * grad = 2*(x-t)*mask*scale  (scale = 1/numel).  mask may be NULL. */
 int kp_l2_loss(const float* x, const float* t, const float* mask, double* loss_sum, float* grad, float scale,
                size_t n, void* stream);
+/* The same in ONE launch including the scalar: loss[0] = (float)(sum / n) (the mean formed in fp64, rounded once: what
+ * `((x - x_)**2 * mask).mean()` of transporter.py:56-60 returns), grad = 2*(x-t)*mask/n.  ws2: two doubles, zero before the FIRST
+ * call and left zero by every call (the last workgroup to arrive writes the mean and clears them): a persistent per-stream
+ * workspace, so that neither a zero-fill nor a division kernel sits between the forward and the backward of a step. */
+int kp_l2_loss_mean(const float* x, const float* t, const float* mask, double* ws2, float* loss, float* grad, size_t n, void* stream);
 /* y[i] = x[i] * s[0] with s a DEVICE scalar: chains the loss gradient (autograd hands the upstream gradient of the
  * scalar loss as a device tensor) without a host synchronisation.  x, y 16-byte aligned; y may alias x. */
 int kp_scale(const float* x, const float* s, float* y, size_t n, void* stream);
@@ -485,6 +505,9 @@ int kp_adam_step(float* p, const float* g, float* m, float* v, size_t n, float l
  * with the host except kp_amp_init. */
 int kp_amp_init(double* state, double init_scale, void* stream);
 int kp_amp_check(const float* g, size_t n, double* state, void* stream);
+/* y[i] = x[i] * (float)state[0]: `amp.scale_loss` itself (transporter.py:84-85) -- the loss on the way forward, its incoming gradient
+ * on the way back -- with the scale read from the device state block. */
+int kp_amp_scale(const float* x, const double* state, float* y, size_t n, void* stream);
 int kp_amp_prepare(double* state, float b1, float b2, void* stream);
 int kp_adam_step_scaled(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                         const double* state, void* stream);

@@ -49,18 +49,24 @@ class LossScaler:
 
 
 class _ScaleLoss(torch.autograd.Function):
-    """loss * scale with the scale a device tensor (never read on the host); one element-wise launch each way."""
+    """loss * scale with the scale read from the scaler's device state block (never on the host): ONE kp_amp_scale launch each
+    way -- no fp64 -> fp32 copy of the scale, no torch multiplication between the loss kernel and the backward's first kernel."""
 
     @staticmethod
-    def forward(ctx, loss, scale):
-        require_device(loss, scale)
-        ctx.save_for_backward(scale)
-        return (f32c(loss).reshape(()) * scale.reshape(())).reshape(())
+    def forward(ctx, loss, state):
+        require_device(loss, state)
+        ctx.state = state          # (the scaler's own buffer: it outlives the step)
+        x = f32c(loss).reshape(1)
+        y = torch.empty_like(x)
+        call('kp_amp_scale', ptr(x), ptr(state), ptr(y), 1, stream_ptr())
+        return y.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        (scale,) = ctx.saved_tensors
-        return (f32c(g).reshape(()) * scale.reshape(())).reshape(()), None
+        x = f32c(g).reshape(1)
+        y = torch.empty_like(x)
+        call('kp_amp_scale', ptr(x), ptr(ctx.state), ptr(y), 1, stream_ptr())
+        return y.reshape(()), None
 
 
 def _require_scaling_optimizer(optimizer, who):
@@ -98,4 +104,4 @@ def scale_loss(loss, optimizer):
     if scaler is None or getattr(scaler, 'unit', False):   # (unit: constant scale 1, keypoints_amd.graph)
         yield loss
     else:
-        yield _ScaleLoss.apply(loss, scaler.scale_tensor())
+        yield _ScaleLoss.apply(loss, scaler.state)

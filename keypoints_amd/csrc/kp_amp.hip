@@ -69,9 +69,22 @@ __global__ __launch_bounds__(TPB) void adam_scaled_k(float* __restrict__ p, cons
     p[i] -= (lr / bc1) * (mi / denom);
 }
 
+// y = x * (float)scale, the scale read from the state block: amp.scale_loss's multiplication, forward (the loss) and backward (its
+// incoming gradient), without a host read or an fp64 -> fp32 conversion launch in front
+__global__ void amp_scale_k(const float* __restrict__ x, const double* __restrict__ state, float* __restrict__ y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] * (float)state[0];
+}
+
 }  // namespace
 
 extern "C" {
+
+int kp_amp_scale(const float* x, const double* state, float* y, size_t n, void* stream) {
+    KP_REQUIRE(x && state && y && n > 0, "kp_amp_scale: bad args");
+    amp_scale_k<<<cdiv(n, TPB), TPB, 0, (hipStream_t)stream>>>(x, state, y, n);
+    return kp_check_launch("amp_scale");
+}
 
 int kp_amp_init(double* state, double init_scale, void* stream) {
     KP_REQUIRE(state && init_scale >= 1.0, "kp_amp_init: bad args");
@@ -87,6 +100,7 @@ int kp_amp_init(double* state, double init_scale, void* stream) {
 int kp_amp_check(const float* g, size_t n, double* state, void* stream) {
     KP_REQUIRE(g && state && n > 0, "kp_amp_check: bad args");
     KP_REQUIRE(((size_t)g & 15) == 0, "kp_amp_check: gradient buffer must be 16-byte aligned");
+    kp_count_bytes(4.0 * n);
     unsigned grid = cdiv(n / 4 + 1, TPB * 4);
     if (grid > 2048) grid = 2048;
     amp_check_k<<<grid, TPB, 0, (hipStream_t)stream>>>(g, n, state);
@@ -102,6 +116,7 @@ int kp_amp_prepare(double* state, float b1, float b2, void* stream) {
 int kp_adam_step_scaled(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                         const double* state, void* stream) {
     KP_REQUIRE(p && g && m && v && state && n > 0, "kp_adam_step_scaled: bad args");
+    kp_count_bytes(28.0 * n);
     adam_scaled_k<<<cdiv(n, TPB), TPB, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, b1, b2, eps, state);
     return kp_check_launch("adam_step_scaled");
 }

@@ -54,6 +54,18 @@ int kp_check_launch(const char* what) {
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::mutex g_prof_mu;
+
+static std::atomic<int> g_bytes_on{0};
+static double g_bytes_total = 0.0;
+static long long g_bytes_launches = 0;
+
+void kp_count_bytes(double bytes, int launch) {
+    if (!g_bytes_on.load(std::memory_order_relaxed) || kp_query_mode()) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_bytes_total += bytes;
+    g_bytes_launches += launch;
+}
+
 static std::vector<hipEvent_t> g_event_pool;
 hipEvent_t kp_prof_event() {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -108,7 +120,16 @@ int kp_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) { g_event_pool.push_back(r.e0); g_event_pool.push_back(r.e1); }
     g_prof.clear();
-    g_prof_on = on != 0;
+    g_prof_on = on == 1;
+    g_bytes_on.store(on == 2 ? 1 : 0);
+    if (on == 2) { g_bytes_total = 0.0; g_bytes_launches = 0; }
+    return KP_OK;
+}
+
+int kp_prof_step_bytes(double* bytes, long long* launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (bytes) *bytes = g_bytes_total;
+    if (launches) *launches = g_bytes_launches;
     return KP_OK;
 }
 
@@ -183,6 +204,10 @@ KP_DISPATCH(kp_nchw_to_nhwc, (const float* src, void* dst, int N, int C, int Cp,
             (src, dst, N, C, Cp, H, W, pad, dtype, stream))
 KP_DISPATCH(kp_nhwc_grad_to_nchw, (const void* gsrc, float* dst, int N, int C, int Cp, int H, int W, int pad, int dtype, void* stream),
             (gsrc, dst, N, C, Cp, H, W, pad, dtype, stream))
+KP_DISPATCH(kp_nchw2_to_nhwc, (const float* src0, int C0, const float* src1, int C1, void* dst, int N, int Cp, int H, int W, int pad, int dtype, void* stream),
+            (src0, C0, src1, C1, dst, N, Cp, H, W, pad, dtype, stream))
+KP_DISPATCH(kp_nhwc_grad_to_nchw2, (const void* gsrc, float* dst0, int C0, float* dst1, int C1, int N, int Cp, int H, int W, int pad, int dtype, void* stream),
+            (gsrc, dst0, C0, dst1, C1, N, Cp, H, W, pad, dtype, stream))
 KP_DISPATCH(kp_pack_weights, (const float* w, void* w_fwd, void* w_dgrad, int K, int C, int Cp, int R, int dtype, void* stream),
             (w, w_fwd, w_dgrad, K, C, Cp, R, dtype, stream))
 KP_DISPATCH(kp_pack_weights_batch, (int n, const float* const* w, void* const* w_fwd, void* const* w_dgrad, const int* K, const int* C, const int* Cp, int dtype, void* stream),

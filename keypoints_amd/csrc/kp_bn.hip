@@ -579,6 +579,7 @@ int kp_bn_finalize(const float* stats, long long rows, double* ws, float* save_m
                    float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
                    long long count, int C, void* stream) {
     KP_REQUIRE(C > 0 && count > 0 && rows > 0 && stats && ws, "kp_bn_finalize: bad args");
+    kp_count_bytes(8.0 * rows * C);
     hipStream_t st = (hipStream_t)stream;
     const bool narrow = C <= 32 && !g_kp_fin_wide;   // Pong-class layers: the 4-wave kernel below at every row count (its pair form,
                                                      // kp_bn_finalize_pair, must be this call bit for bit)
@@ -608,11 +609,16 @@ int kp_bn_finalize(const float* stats, long long rows, double* ws, float* save_m
 // save_invstd are [2][C]; the running statistics (and num_batches_tracked) are updated twice, half 0 first.  Each half's numbers
 // are those of kp_bn_finalize on its rows, bit for bit.  Only the one-launch reduction of the narrow layers has this form
 // (rows <= 8192 per half, C <= 32: the Pong-class layers); otherwise KP_E_UNSUPPORTED.
+int kp_bn_finalize_pair_supported(long long rows, int C) {
+    return (rows > 0 && rows <= WIDE_ROWS && C > 0 && C <= 32 && !g_kp_fin_wide) ? 1 : 0;
+}
+
 int kp_bn_finalize_pair(const float* stats, long long rows, float* save_mean, float* save_invstd, float* running_mean,
                         float* running_var, long long* num_batches_tracked, float momentum, float eps, long long count, int C,
                         void* stream) {
     KP_REQUIRE(C > 0 && count > 0 && rows > 0 && stats && save_mean && save_invstd, "kp_bn_finalize_pair: bad args");
-    if (!(rows <= WIDE_ROWS && C <= 32) || g_kp_fin_wide) return KP_E_UNSUPPORTED;
+    if (!kp_bn_finalize_pair_supported(rows, C)) return KP_E_UNSUPPORTED;
+    kp_count_bytes(16.0 * rows * C);
     bn_reduce_finalize_wide_k<0, 4, 256, 2><<<cdiv(C, 4), 512, 0, (hipStream_t)stream>>>(stats, rows, C, save_mean, save_invstd, running_mean,
                                                                                         running_var, num_batches_tracked, momentum, eps, count);
     return kp_check_launch("bn_reduce_finalize_pair");
@@ -625,6 +631,7 @@ int kp_bn_act_fwd(const void* y, const float* mean, const float* invstd, const f
                   int dtype, void* stream) {
     KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && out_pad >= 0 && tail >= 0 && tail <= 2, "kp_bn_act_fwd: bad dims");
     KP_REQUIRE(tail != KP_TAIL_MAXPOOL2 || (H >= 2 && W >= 2), "kp_bn_act_fwd: maxpool needs H,W >= 2");
+    kp_count_bytes((dtype == KP_F32 ? 4.0 : 2.0) * ((double)N * H * W * C + (double)N * ((tail == 1 ? H / 2 : tail == 2 ? 2 * H : H) + 2 * out_pad) * ((tail == 1 ? W / 2 : tail == 2 ? 2 * W : W) + 2 * out_pad) * C) + (argmax ? (double)N * (H / 2) * (W / 2) * C : 0.0));
     const int Ho = tail == KP_TAIL_MAXPOOL2 ? H / 2 : (tail == KP_TAIL_UPSAMPLE2 ? 2 * H : H);
     BnP bn{mean, invstd, gamma, beta};
     const unsigned grid = (unsigned)((long long)N * (Ho + 2 * out_pad));
@@ -642,6 +649,7 @@ int kp_bn_act_bwd_reduce(const void* gsrc, int gp, int tail, const unsigned char
                          float* partials, int N, int H, int W, int C, int dtype, void* stream) {
     KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && gp >= 0 && (tail == 0 || tail == 1) && (partials || kp_query_mode()), "kp_bn_act_bwd_reduce: bad args");
     KP_REQUIRE(tail == 0 || argmax != nullptr || kp_query_mode(), "kp_bn_act_bwd_reduce: maxpool needs argmax");
+    kp_count_bytes((dtype == KP_F32 ? 4.0 : 2.0) * (((double)N * ((tail == 1 ? H / 2 : H) + 2 * gp) * ((tail == 1 ? W / 2 : W) + 2 * gp) * C) + (double)N * H * W * C) + (tail == 1 ? (double)N * (H / 2) * (W / 2) * C : 0.0));
     BnP bn{mean, invstd, gamma, beta};
     const unsigned grid = (unsigned)((long long)N * H);
     hipStream_t st = (hipStream_t)stream;
@@ -660,6 +668,7 @@ int kp_bn_act_bwd_reduce(const void* gsrc, int gp, int tail, const unsigned char
 int kp_bn_bwd_finalize(const float* partials, double* ws, long long rows, int C, float* sums, float* dgamma,
                        float* dbeta, void* stream) {
     KP_REQUIRE(partials && ws && sums && rows > 0 && C > 0, "kp_bn_bwd_finalize: bad args");
+    kp_count_bytes(8.0 * rows * C);
     hipStream_t st = (hipStream_t)stream;
     if (rows <= 128) {
         bn_reduce_finalize_k<1><<<cdiv(C, 32), TPB, 0, st>>>(partials, rows, C, sums, nullptr, dbeta, dgamma, nullptr, 0.f,
@@ -689,6 +698,7 @@ int kp_bn_act_bwd_apply(const void* gsrc, int gp, int tail, const unsigned char*
                         const float* sums, void* dy, int dp, int N, int H, int W, int C, int dtype, void* stream) {
     KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && gp >= 0 && dp >= 0 && (tail == 0 || tail == 1), "kp_bn_act_bwd_apply: bad args");
     KP_REQUIRE(mean == nullptr || sums != nullptr, "kp_bn_act_bwd_apply: sums required with BatchNorm");
+    kp_count_bytes((dtype == KP_F32 ? 4.0 : 2.0) * (((double)N * ((tail == 1 ? H / 2 : H) + 2 * gp) * ((tail == 1 ? W / 2 : W) + 2 * gp) * C) + (double)N * H * W * C + (double)N * (H + 2 * dp) * (W + 2 * dp) * C) + (tail == 1 ? (double)N * (H / 2) * (W / 2) * C : 0.0));
     BnP bn{mean, invstd, gamma, beta};
     const unsigned grid = (unsigned)((long long)N * (H + 2 * dp));
     hipStream_t st = (hipStream_t)stream;
@@ -703,6 +713,7 @@ int kp_bn_act_bwd_apply(const void* gsrc, int gp, int tail, const unsigned char*
 
 int kp_upsample2_bwd(const void* gsrc, int gp, void* g, int N, int H, int W, int C, int dtype, void* stream) {
     KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && gp >= 0, "kp_upsample2_bwd: bad dims");
+    kp_count_bytes((dtype == KP_F32 ? 4.0 : 2.0) * ((double)N * (2 * H + 2 * gp) * (2 * W + 2 * gp) * C + (double)N * H * W * C));
     const unsigned grid = (unsigned)((long long)N * H);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == KP_H16 && g_kp_bn_fast) {

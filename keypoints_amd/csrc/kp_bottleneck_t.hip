@@ -83,7 +83,7 @@ __global__ __launch_bounds__(NT) void bottleneck_fwd_t_k(const float* __restrict
     uint4 ns[2], nt[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int it = tid + u * NT < total ? tid + u * NT : tid;
+        const int it = tid + u * NT < total ? tid + u * NT : (tid < total ? tid : 0);   // (small maps: HW * LP < NT -- never past the image)
         ns[u] = ps[it]; nt[u] = pt[it];
     }
     for (int item = tid; item < total; item += 2 * NT) {

@@ -204,6 +204,9 @@ typedef std::atomic<int> kp_knob_t;
 typedef std::atomic<long long*> kp_knob_ptr_t;
 
 int kp_check_launch(const char* what);
+// Step-level byte accounting (kp_prof_enable(2), bench.py's step HBM fraction): every entry point adds the ALGORITHMIC HBM bytes of
+// the launch it is about to make (operands + results, each once); `launch` = 0 adds bytes to the launch counted before.
+void kp_count_bytes(double bytes, int launch = 1);
 void kp_set_last_rows(long long rows);   // see kp_last_rows() in kp_hip.h
 // Query mode (kp_conv_fwd_stats_rows / kp_bn_bwd_rows): the dispatch runs as usual, every launcher records its row count
 // and returns before launching anything.  Thread-local, set and cleared inside ONE public call.

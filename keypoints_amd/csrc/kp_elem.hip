@@ -124,6 +124,63 @@ __global__ void nhwc_to_nchw_v4_k(const T* __restrict__ src, float* __restrict__
     for (int e = 0; e < 4; ++e) dst[(((long long)n * C + c0 + e) * H + h) * W + w] = v[e];
 }
 
+// Two NCHW fp32 sources as ONE padded NHWC image: channels [0, C0) from s0, [C0, C0 + C1) from s1, zeros up to Cp -- torch.cat((z, m),
+// dim=1) in front of the KeyNet decoder (keynet.py:29) folded into the layout change its first layer needs anyway.  One thread per
+// (padded pixel, group of 4 channels); lanes = adjacent pixels (coalesced plane loads).  Same values, same rounding as
+// kp_nchw_to_nhwc of the concatenated tensor.
+template <typename T>
+__global__ void nchw2_to_nhwc_k(const float* __restrict__ s0, int C0, const float* __restrict__ s1, int C1, T* __restrict__ dst, int N,
+                                int Cp, int H, int W, int p) {
+    const int Hp = H + 2 * p, Wp = W + 2 * p;
+    const long long total = (long long)N * Hp * Wp;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c0 = blockIdx.y * 4;
+    const int j = (int)(t % Wp);
+    const int i = (int)((t / Wp) % Hp);
+    const int n = (int)(t / ((long long)Wp * Hp));
+    const int h = clampi(i - p, 0, H - 1), w = clampi(j - p, 0, W - 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e;
+        if (c >= Cp) break;
+        float v = 0.f;   // channel padding: zeros
+        if (c < C0) v = s0[(((long long)n * C0 + c) * H + h) * W + w];
+        else if (c < C0 + C1) v = s1[(((long long)n * C1 + (c - C0)) * H + h) * W + w];
+        st<T>(dst + t * Cp + c, v);
+    }
+}
+
+// Its adjoint: the fold of kp_nhwc_grad_to_nchw, channels [0, C0) to d0 and [C0, C0 + C1) to d1 (either may be NULL: that input
+// carries no gradient).  Sums in the order of nhwc_grad_to_nchw_k (rows, then columns of the folded range).
+template <typename T>
+__global__ void nhwc_grad_to_nchw2_k(const T* __restrict__ g, float* __restrict__ d0, int C0, float* __restrict__ d1, int C1, int N,
+                                     int Cp, int H, int W, int p) {
+    const int Wp = W + 2 * p, Hp = H + 2 * p;
+    const long long total = (long long)N * H * W;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c0 = blockIdx.y * 4;
+    if (t >= total) return;
+    const int w = (int)(t % W);
+    const int h = (int)((t / W) % H);
+    const int n = (int)(t / ((long long)W * H));
+    int ilo, ihi, jlo, jhi;
+    fold_range(h, H, p, ilo, ihi);
+    fold_range(w, W, p, jlo, jhi);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e;
+        if (c >= C0 + C1) break;
+        float* d = c < C0 ? d0 : d1;
+        if (!d) continue;
+        float a = 0.f;
+        for (int i = ilo; i <= ihi; ++i)
+            for (int j = jlo; j <= jhi; ++j) a += ld<T>(g + (((long long)n * Hp + i) * Wp + j) * Cp + c);
+        if (c < C0) d[(((long long)n * C0 + c) * H + h) * W + w] = a;
+        else d[(((long long)n * C1 + (c - C0)) * H + h) * W + w] = a;
+    }
+}
+
 // ---------------------------------------------------------------- weights
 template <typename T>
 __global__ void pack_weights_k(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int K, int C,
@@ -451,9 +508,13 @@ static void head_dw_reduce(const float* ws, long long parts, long long n, long l
 // 16-byte lanes (n4 = number of whole float4 groups when all pointers are 16-byte aligned, else 0), the remainder element
 // by element; per-thread fp64 partial sums, one fp64 atomic per workgroup (<= 512 of them: at 2048 the atomics on one
 // address were most of the kernel's 40 us at 128 x 3 x 128 x 128).
+// loss_out != NULL (kp_l2_loss_mean): loss_sum is a persistent workspace of two doubles, [0] the sum and [1] (as an integer) the
+// number of workgroups that have added theirs; the LAST one to arrive writes loss_out = (float)(sum / n) -- the mean in fp64, rounded
+// once -- and leaves both zero for the next call: no zero-fill and no division launch around the kernel.
 __global__ __launch_bounds__(TPB) void l2_loss_k(const float* __restrict__ x, const float* __restrict__ t,
                                                  const float* __restrict__ mask, double* __restrict__ loss_sum,
-                                                 float* __restrict__ grad, float scale, size_t n, size_t n4) {
+                                                 float* __restrict__ grad, float scale, size_t n, size_t n4,
+                                                 float* __restrict__ loss_out = nullptr) {
     double acc = 0.0;
     const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = gtid; i < n4; i += stride) {
@@ -479,6 +540,17 @@ __global__ __launch_bounds__(TPB) void l2_loss_k(const float* __restrict__ x, co
         double s = 0.0;
         for (int i = 0; i < TPB / 64; ++i) s += part[i];
         atomicAdd(loss_sum, s);
+        if (loss_out) {
+            __threadfence();
+            unsigned long long* cnt = reinterpret_cast<unsigned long long*>(loss_sum + 1);
+            if (atomicAdd(cnt, 1ull) == (unsigned long long)gridDim.x - 1) {
+                __threadfence();
+                const double tot = atomicAdd(loss_sum, 0.0);   // (device-scope read of the finished sum)
+                loss_out[0] = (float)(tot / (double)n);
+                atomicExch(reinterpret_cast<unsigned long long*>(loss_sum), 0ull);
+                atomicExch(cnt, 0ull);
+            }
+        }
     }
 }
 
@@ -539,6 +611,7 @@ extern "C" {
 
 int kp_nchw_to_nhwc(const float* src, void* dst, int N, int C, int Cp, int H, int W, int pad, int dtype, void* stream) {
     KP_REQUIRE(N > 0 && C > 0 && Cp >= C && H > 0 && W > 0 && pad >= 0, "kp_nchw_to_nhwc: bad dims");
+    kp_count_bytes(4.0 * N * C * H * W + (dtype == KP_F32 ? 4.0 : 2.0) * N * (H + 2 * pad) * (W + 2 * pad) * Cp);
     const long long total = (long long)N * (H + 2 * pad) * (W + 2 * pad);
     if (dtype == KP_H16 && Cp % 8 == 0 && Cp / 8 <= 65535 && ((size_t)dst & 15) == 0) {   // (same values, same rounding: pack_h16x2 = st<h16_t>)
         nchw_to_nhwc_v8_k<<<dim3(cdiv(total, 256), Cp / 8), 256, 0, (hipStream_t)stream>>>(src, (h16_t*)dst, N, C, Cp, H, W, pad);
@@ -548,9 +621,30 @@ int kp_nchw_to_nhwc(const float* src, void* dst, int N, int C, int Cp, int H, in
     return kp_check_launch("nchw_to_nhwc");
 }
 
+int kp_nchw2_to_nhwc(const float* src0, int C0, const float* src1, int C1, void* dst, int N, int Cp, int H, int W, int pad, int dtype,
+                     void* stream) {
+    KP_REQUIRE(src0 && src1 && dst && N > 0 && C0 > 0 && C1 > 0 && Cp >= C0 + C1 && H > 0 && W > 0 && pad >= 0 && cdiv(Cp, 4) <= 65535,
+               "kp_nchw2_to_nhwc: bad args");
+    kp_count_bytes(4.0 * N * (C0 + C1) * H * W + (dtype == KP_F32 ? 4.0 : 2.0) * N * (H + 2 * pad) * (W + 2 * pad) * Cp);
+    const long long total = (long long)N * (H + 2 * pad) * (W + 2 * pad);
+    DISPATCH_T(dtype, nchw2_to_nhwc_k<T><<<dim3(cdiv(total, TPB), cdiv(Cp, 4)), TPB, 0, (hipStream_t)stream>>>(src0, C0, src1, C1, (T*)dst, N, Cp, H, W, pad));
+    return kp_check_launch("nchw2_to_nhwc");
+}
+
+int kp_nhwc_grad_to_nchw2(const void* gsrc, float* dst0, int C0, float* dst1, int C1, int N, int Cp, int H, int W, int pad, int dtype,
+                          void* stream) {
+    KP_REQUIRE(gsrc && (dst0 || dst1) && N > 0 && C0 > 0 && C1 > 0 && Cp >= C0 + C1 && H > 0 && W > 0 && pad >= 0 && cdiv(C0 + C1, 4) <= 65535,
+               "kp_nhwc_grad_to_nchw2: bad args");
+    kp_count_bytes(4.0 * N * ((dst0 ? C0 : 0) + (dst1 ? C1 : 0)) * H * W + (dtype == KP_F32 ? 4.0 : 2.0) * N * (H + 2 * pad) * (W + 2 * pad) * Cp);
+    const long long total = (long long)N * H * W;
+    DISPATCH_T(dtype, nhwc_grad_to_nchw2_k<T><<<dim3(cdiv(total, TPB), cdiv(C0 + C1, 4)), TPB, 0, (hipStream_t)stream>>>((const T*)gsrc, dst0, C0, dst1, C1, N, Cp, H, W, pad));
+    return kp_check_launch("nhwc_grad_to_nchw2");
+}
+
 int kp_nhwc_grad_to_nchw(const void* gsrc, float* dst, int N, int C, int Cp, int H, int W, int pad, int dtype,
                          void* stream) {
     KP_REQUIRE(N > 0 && C > 0 && Cp >= C && H > 0 && W > 0 && pad >= 0, "kp_nhwc_grad_to_nchw: bad dims");
+    kp_count_bytes(4.0 * N * C * H * W + (dtype == KP_F32 ? 4.0 : 2.0) * N * (H + 2 * pad) * (W + 2 * pad) * Cp);
     const long long total = (long long)N * H * W;
     if (Cp % 4 == 0 && C > 4 && Cp / 4 <= 65535) {   // same sums in the same order (rows, then columns of the folded range)
         DISPATCH_T(dtype, nhwc_grad_to_nchw_v4_k<T><<<dim3(cdiv(total, TPB), Cp / 4), TPB, 0, (hipStream_t)stream>>>((const T*)gsrc, dst, N, C, Cp, H, W, pad));
@@ -562,6 +656,7 @@ int kp_nhwc_grad_to_nchw(const void* gsrc, float* dst, int N, int C, int Cp, int
 
 int kp_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int K, int C, int Cp, int R, int dtype, void* stream) {
     KP_REQUIRE(K > 0 && C > 0 && Cp >= C && (R == 1 || R == 3), "kp_pack_weights: bad dims");
+    kp_count_bytes(4.0 * K * C * R * R + (dtype == KP_F32 ? 4.0 : 2.0) * (w_dgrad ? 2.0 : 1.0) * K * R * R * Cp);
     const long long total = (long long)K * Cp * R * R;
     DISPATCH_T(dtype, pack_weights_k<T><<<cdiv(total, TPB), TPB, 0, (hipStream_t)stream>>>(w, (T*)w_fwd, (T*)w_dgrad, K, C, Cp, R));
     return kp_check_launch("pack_weights");
@@ -580,6 +675,7 @@ int kp_pack_weights_batch(int n, const float* const* w, void* const* w_fwd, void
         blocks += cdiv((size_t)K[i], PT) * cdiv((size_t)Cp[i], PT);
     }
     B.first_block[n] = blocks;
+    for (int i = 0; i < n; ++i) kp_count_bytes(4.0 * K[i] * C[i] * 9 + (dtype == KP_F32 ? 4.0 : 2.0) * (w_dgrad[i] ? 2.0 : 1.0) * K[i] * 9 * Cp[i], i == 0);
     if (blocks <= 64) { DISPATCH_T(dtype, (pack_weights_tile_k<T, 1024><<<blocks, 1024, 0, (hipStream_t)stream>>>(B))); }
     else { DISPATCH_T(dtype, pack_weights_tile_k<T><<<blocks, 256, 0, (hipStream_t)stream>>>(B)); }
     return kp_check_launch("pack_weights_batch");
@@ -588,6 +684,7 @@ int kp_pack_weights_batch(int n, const float* const* w, void* const* w_fwd, void
 #ifndef KP_F16_BUILD   // no dtype: defined once, by the bf16 build of this source
 int kp_wgrad_unpack(const float* scratch, int partials, float* dw, int K, int C, int Cp, int R, void* stream) {
     KP_REQUIRE(K > 0 && C > 0 && Cp >= C && (R == 1 || R == 3) && partials >= 1, "kp_wgrad_unpack: bad dims");
+    kp_count_bytes(4.0 * partials * K * R * R * Cp + 8.0 * K * C * R * R);
     const long long total = (long long)K * Cp * R * R;
     if (Cp % 64 == 0 && K <= 65535) {
         wgrad_unpack_tile_k<<<dim3(K, cdiv(Cp, 128)), 256, 0, (hipStream_t)stream>>>(scratch, partials, dw, K, C, Cp, R);
@@ -611,6 +708,7 @@ int kp_head_fwd(const void* x, const float* w, const float* bias, float slope, f
                 int K, int dtype, void* stream) {
     KP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "kp_head_fwd: bad dims");
     KP_REQUIRE(C <= 2048, "kp_head_fwd: C too large for the LDS tile");
+    kp_count_bytes((dtype == KP_F32 ? 4.0 : 2.0) * N * H * W * C + 4.0 * N * H * W * K);
     const long long M = (long long)N * H * W;
     if (dtype == KP_H16) {
         int rc = kp_head_fwd_mfma(x, w, bias, slope, out, M, H * W, C, K, (hipStream_t)stream);
@@ -646,6 +744,7 @@ int kp_head_fwd_bnin(const void* yprev, const float* mean, const float* invstd, 
     KP_REQUIRE(slope_in >= 0.f && slope_in <= 1.f, "kp_head_fwd_bnin: activation slope of the producing layer must be in [0, 1]");
     KP_REQUIRE((mean != nullptr) == (invstd != nullptr) && (mean != nullptr) == (gamma != nullptr) && (mean != nullptr) == (beta != nullptr),
                "kp_head_fwd_bnin: mean / invstd / gamma / beta: all or none");
+    kp_count_bytes((dtype == KP_F32 ? 4.0 : 2.0) * N * H * W * C + 4.0 * N * H * W * K);
     const long long M = (long long)N * H * W;
     if (!head_bnin_ok(M, H * W, C, K, dtype)) return KP_E_UNSUPPORTED;
     const KpBnIn bn{mean, invstd, gamma, beta, slope_in};
@@ -727,6 +826,7 @@ static int head_bwd_impl(const float* gout, const float* out, const void* x, con
 
 int kp_head_bwd(const float* gout, const float* out, const void* x, const float* w, float slope, void* dx, float* dw,
                 float* db, float* ws, int N, int H, int W, int C, int K, int dtype, void* stream) {
+    kp_count_bytes(8.0 * N * H * W * K + (dtype == KP_F32 ? 4.0 : 2.0) * N * H * W * C * (dx ? 2.0 : 1.0));
     return head_bwd_impl(gout, out, x, w, slope, dx, dw, db, ws, N, H, W, C, K, dtype, stream, nullptr);
 }
 
@@ -737,6 +837,7 @@ int kp_head_bwd_bnin(const float* gout, const float* out, const void* yprev, con
     KP_REQUIRE(slope_in >= 0.f && slope_in <= 1.f, "kp_head_bwd_bnin: activation slope of the producing layer must be in [0, 1]");
     KP_REQUIRE((mean != nullptr) == (invstd != nullptr) && (mean != nullptr) == (gamma != nullptr) && (mean != nullptr) == (beta != nullptr),
                "kp_head_bwd_bnin: mean / invstd / gamma / beta: all or none");
+    kp_count_bytes(8.0 * N * H * W * K + (dtype == KP_F32 ? 4.0 : 2.0) * N * H * W * C * (dx ? 2.0 : 1.0));
     if (!head_bnin_ok((long long)N * H * W, H * W, C, K, dtype)) return KP_E_UNSUPPORTED;
     const KpBnIn bn{mean, invstd, gamma, beta, slope_in};
     return head_bwd_impl(gout, out, yprev, w, slope, dx, dw, db, ws, N, H, W, C, K, dtype, stream, &bn);
@@ -744,6 +845,7 @@ int kp_head_bwd_bnin(const float* gout, const float* out, const void* yprev, con
 
 int kp_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int pad, int dtype, void* stream) {
     KP_REQUIRE(src && dst && N > 0 && C > 0 && C % 4 == 0 && C / 4 <= 65535 && H > 0 && W > 0 && pad >= 0, "kp_nhwc_to_nchw: bad dims (C a multiple of 4)");
+    kp_count_bytes((dtype == KP_F32 ? 4.0 : 2.0) * N * H * W * C + 4.0 * N * H * W * C);
     const long long total = (long long)N * H * W;
     DISPATCH_T(dtype, nhwc_to_nchw_v4_k<T><<<dim3(cdiv(total, TPB), C / 4), TPB, 0, (hipStream_t)stream>>>((const T*)src, dst, N, C, H, W, pad));
     return kp_check_launch("nhwc_to_nchw");
@@ -769,6 +871,7 @@ int kp_head_fwd_t(const void* x, int bnin, const float* mean, const float* invst
     KP_REQUIRE(x && w && out_t && N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "kp_head_fwd_t: bad args");
     if (int rc = head_t_bn("kp_head_fwd_t", bnin, mean, invstd, gamma, beta, slope_in)) return rc;
     if (!kp_head_t_supported(N, H, W, C, K, dtype)) return KP_E_UNSUPPORTED;
+    kp_count_bytes((dtype == KP_F32 ? 4.0 : 2.0) * N * H * W * (C + K));
     const KpBnIn bn{mean, invstd, gamma, beta, slope_in};
     return kp_head_fwd_mfma_t(x, w, bias, slope, out_t, (long long)N * H * W, H * W, C, K, (hipStream_t)stream, bnin ? &bn : nullptr);
 }
@@ -788,6 +891,7 @@ int kp_head_fwd_bnin_pair(const void* yprev, const float* mean, const float* inv
     KP_REQUIRE(yprev && w && out0 && out1 && N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "kp_head_fwd_bnin_pair: bad args");
     if (int rc = head_t_bn("kp_head_fwd_bnin_pair", 1, mean, invstd, gamma, beta, slope_in)) return rc;
     if (!kp_head_pair_supported(N, H, W, C, K, t_out, dtype)) return KP_E_UNSUPPORTED;
+    kp_count_bytes((dtype == KP_F32 ? 4.0 : 2.0) * N * H * W * C + (t_out ? (dtype == KP_F32 ? 4.0 : 2.0) : 4.0) * N * H * W * K);
     const long long M = (long long)(N / 2) * H * W;
     const KpBnIn bn{mean, invstd, gamma, beta, slope_in};
     const void* x1 = (const h16_t*)yprev + M * C;
@@ -801,6 +905,10 @@ int kp_head_bwd_t(const void* gout_t, const void* out_t, const void* x, int bnin
     KP_REQUIRE(gout_t && out_t && x && w && N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "kp_head_bwd_t: bad args");
     if (int rc = head_t_bn("kp_head_bwd_t", bnin, mean, invstd, gamma, beta, slope_in)) return rc;
     if (!kp_head_t_supported(N, H, W, C, K, dtype)) return KP_E_UNSUPPORTED;
+    // every sub-kernel's alignment rule, checked BEFORE the first launch: KP_E_UNSUPPORTED means nothing ran (the caller's fallback
+    // accumulates into the same `+=` gradient slots)
+    if ((((size_t)gout_t | (size_t)out_t | (size_t)x | (size_t)dx) & 15) != 0) return KP_E_UNSUPPORTED;
+    kp_count_bytes((dtype == KP_F32 ? 4.0 : 2.0) * N * H * W * (2.0 * K + C * (dx ? 2.0 : 1.0)));
     const long long M = (long long)N * H * W;
     hipStream_t st = (hipStream_t)stream;
     const KpBnIn bn{mean, invstd, gamma, beta, slope_in};
@@ -821,6 +929,7 @@ int kp_head_bwd_t(const void* gout_t, const void* out_t, const void* x, int bnin
 int kp_l2_loss(const float* x, const float* t, const float* mask, double* loss_sum, float* grad, float scale, size_t n,
                void* stream) {
     KP_REQUIRE(n > 0, "kp_l2_loss: empty");
+    kp_count_bytes(4.0 * n * (mask ? 3.0 : 2.0) + (grad ? 4.0 * n : 0.0));
     const bool al = ((((size_t)x | (size_t)t | (size_t)mask | (size_t)grad) & 15) == 0);
     const size_t n4 = al ? n / 4 : 0;
     unsigned grid = cdiv(n, TPB * 16);
@@ -829,9 +938,21 @@ int kp_l2_loss(const float* x, const float* t, const float* mask, double* loss_s
     return kp_check_launch("l2_loss");
 }
 
+int kp_l2_loss_mean(const float* x, const float* t, const float* mask, double* ws2, float* loss, float* grad, size_t n, void* stream) {
+    KP_REQUIRE(x && t && ws2 && loss && n > 0, "kp_l2_loss_mean: bad args");
+    kp_count_bytes(4.0 * n * (mask ? 3.0 : 2.0) + (grad ? 4.0 * n : 0.0));
+    const bool al = ((((size_t)x | (size_t)t | (size_t)mask | (size_t)grad) & 15) == 0);
+    const size_t n4 = al ? n / 4 : 0;
+    unsigned grid = cdiv(n, TPB * 16);
+    if (grid > 512) grid = 512;
+    l2_loss_k<<<grid, TPB, 0, (hipStream_t)stream>>>(x, t, mask, ws2, grad, 1.0f / (float)n, n, n4, loss);
+    return kp_check_launch("l2_loss_mean");
+}
+
 int kp_scale(const float* x, const float* s, float* y, size_t n, void* stream) {
     KP_REQUIRE(x && s && y && n > 0, "kp_scale: bad args");
     KP_REQUIRE((((size_t)x | (size_t)y) & 15) == 0, "kp_scale: pointers must be 16-byte aligned");
+    kp_count_bytes(8.0 * n);
     scale_k<<<cdiv((n + 3) / 4, TPB), TPB, 0, (hipStream_t)stream>>>(x, s, y, n);
     return kp_check_launch("scale");
 }
@@ -839,6 +960,7 @@ int kp_scale(const float* x, const float* s, float* y, size_t n, void* stream) {
 int kp_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                  float bc1, float bc2, void* stream) {
     KP_REQUIRE(n > 0, "kp_adam_step: empty");
+    kp_count_bytes(28.0 * n);
     adam_k<<<cdiv(n, TPB), TPB, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2));
     return kp_check_launch("adam_step");
 }

@@ -14,12 +14,15 @@ void kp_prof_event_release(hipEvent_t e);
 
 struct ProfScope {
     bool on; ProfRec r; hipStream_t st;
-    ProfScope(int family, double flops, hipStream_t s, double bytes = 0.0) : on(g_prof_on && !kp_query_mode()), st(s) {
+    double counted;
+    ProfScope(int family, double flops, hipStream_t s, double bytes = 0.0) : on(g_prof_on && !kp_query_mode()), st(s), counted(bytes) {
+        kp_count_bytes(bytes);   // (step-level byte accounting, kp_prof_enable(2): no events)
         if (!on) return;
         r.family = family; r.flops = flops; r.bytes = bytes; r.e0 = kp_prof_event(); r.e1 = kp_prof_event();
         (void)hipEventRecord(r.e0, st);
     }
     void cancel() {   // nothing was launched under this scope: give the events back
+        kp_count_bytes(-counted, -1); counted = 0.0;
         if (!on) return;
         kp_prof_event_release(r.e0); kp_prof_event_release(r.e1);
         on = false;

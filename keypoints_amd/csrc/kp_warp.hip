@@ -115,6 +115,7 @@ int kp_warp_tps(const float* x, const float* theta, const float* ctrl, float* ou
                 int reduced, int ctrl_batched, void* stream) {
     KP_REQUIRE(x && theta && ctrl && out, "kp_warp_tps: null pointer");
     KP_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && T >= 1 && T <= 4096, "kp_warp_tps: bad dims");
+    kp_count_bytes(8.0 * N * C * H * W);
     const long long pix = (long long)N * H * W;
     warp_tps_k<<<cdiv(pix, TPB), TPB, 0, (hipStream_t)stream>>>(x, theta, ctrl, out, N, C, H, W, T, reduced, ctrl_batched);
     return kp_check_launch("warp_tps");
@@ -123,6 +124,7 @@ int kp_warp_tps(const float* x, const float* theta, const float* ctrl, float* ou
 int kp_warp_affine(const float* x, const float* mat, float* out, int N, int C, int H, int W, void* stream) {
     KP_REQUIRE(x && mat && out, "kp_warp_affine: null pointer");
     KP_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "kp_warp_affine: bad dims");
+    kp_count_bytes(8.0 * N * C * H * W);
     const long long pix = (long long)N * H * W;
     warp_affine_k<<<cdiv(pix, TPB), TPB, 0, (hipStream_t)stream>>>(x, mat, out, N, C, H, W);
     return kp_check_launch("warp_affine");
@@ -131,6 +133,7 @@ int kp_warp_affine(const float* x, const float* mat, float* out, int N, int C, i
 int kp_warp_rotate(const float* x, const float* angle, float* out, int N, int C, int H, int W, void* stream) {
     KP_REQUIRE(x && angle && out, "kp_warp_rotate: null pointer");
     KP_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "kp_warp_rotate: bad dims");
+    kp_count_bytes(8.0 * N * C * H * W);
     const long long pix = (long long)N * H * W;
     warp_rotate_k<<<cdiv(pix, TPB), TPB, 0, (hipStream_t)stream>>>(x, angle, out, N, C, H, W);
     return kp_check_launch("warp_rotate");

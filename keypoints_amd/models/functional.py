@@ -35,6 +35,8 @@ class _SpatialSoftmax(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gk, gp, gq):
+        if gk is None:   # (set_materialize_grads(False): an undefined incoming gradient is zero, and so is this op's)
+            return None, None
         k, p, q = ctx.saved_tensors
         B, K, H, W = ctx.shape
         dh = torch.empty(B, K, H, W, device=k.device, dtype=torch.float32)
@@ -112,6 +114,8 @@ class _TransportMax(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gphi, _gs, _gt):
+        if gphi is None:   # (undefined incoming gradient = zero)
+            return None, None, None, None
         phi_s, phi_t, mask_s, mask_t, arg_s, arg_t = ctx.saved_tensors
         B, C, H, W = phi_s.shape
         K = ctx.K
@@ -155,6 +159,8 @@ class _TransportMode(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gphi, _gs, _gt):
+        if gphi is None:   # (undefined incoming gradient = zero)
+            return None, None, None, None, None
         phi_s, phi_t, m_s, m_t = ctx.saved_tensors
         B, C, H, W = phi_s.shape
         K = m_s.shape[1]

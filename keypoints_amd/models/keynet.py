@@ -31,7 +31,10 @@ class KeyNet(knn.Container):
                 z = self.encoder(x)
             k, p = self.ssm(heatmap, probs=True)
             m = self.key2map(k, height=z.size(2), width=z.size(3))
-            x_t = self.decoder(torch.cat((z, m), dim=1))
+            if isinstance(self.decoder, knn.Unit) and z.dim() == 4 and m.dim() == 4:
+                x_t = self.decoder.forward_cat(z, m)   # decoder(torch.cat((z, m), dim=1)), keynet.py:29, without the concatenated tensor
+            else:
+                x_t = self.decoder(torch.cat((z, m), dim=1))
         return x_t, z, k, m, p, heatmap
 
     def load(self, directory):

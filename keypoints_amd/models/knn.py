@@ -115,7 +115,16 @@ class Unit(nn.Module):
         require_device(x)
         params = list(self.parameters())
         record = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
-        return UnitFunction.apply(x, self, record, (False, False), None, *params)
+        return UnitFunction.apply(x, self, record, (False, False), None, None, *params)
+
+    def forward_cat(self, x, x2):
+        """self(torch.cat((x, x2), dim=1)) without forming the concatenated tensor (KeyNet.forward, keynet.py:29: the decoder reads
+        the encoder's z and the Gaussian maps m): the first layer's layout kernel reads both sources, the backward splits the input
+        gradient.  Same values as the cat + forward."""
+        require_device(x, x2)
+        params = list(self.parameters())
+        record = torch.is_grad_enabled() and (x.requires_grad or x2.requires_grad or any(p.requires_grad for p in params))
+        return UnitFunction.apply(x, self, record, (False, False), None, x2, *params)
 
     def forward_pair(self, xs, x, out_t=False):
         """-> (self(xs) under no_grad, self(x)): the two calls TransporterNet.forward makes per encoder (transporter.py:36-39), as one
@@ -126,7 +135,7 @@ class Unit(nn.Module):
                 and pair_ok(self, x.size(0), x.size(1), x.size(2), x.size(3), out_t)):
             params = list(self.parameters())
             record = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
-            return UnitFunction.apply(x, self, record, (False, bool(out_t)), xs.detach(), *params)
+            return UnitFunction.apply(x, self, record, (False, bool(out_t)), xs.detach(), None, *params)
         with torch.no_grad():
             out_s = self.forward_t(xs, out_t=out_t) if out_t else self(xs)
         return out_s, (self.forward_t(x, out_t=out_t) if out_t else self(x))
@@ -137,7 +146,7 @@ class Unit(nn.Module):
         require_device(x)
         params = list(self.parameters())
         record = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
-        return UnitFunction.apply(x, self, record, (bool(in_t), bool(out_t)), None, *params)
+        return UnitFunction.apply(x, self, record, (bool(in_t), bool(out_t)), None, None, *params)
 
     # -- checkpoints: same files / keys as knn.py:143-167 ---------------------------------------
     def _blocks(self, in_block=True, core=True, out_block=True):
@@ -147,7 +156,9 @@ class Unit(nn.Module):
     def save(self, directory):
         Path(directory).mkdir(parents=True, exist_ok=True)
         for name, block in self._blocks():
-            torch.save(block.state_dict(), str(Path(directory) / f'{name}.mdl'))
+            # (FusedAdam.bind homes every parameter as a view of ONE per-device buffer and torch.save serialises the whole storage
+            #  behind a view: detached copies keep each file at its block's own size, same keys and values)
+            torch.save({k: v.detach().clone() for k, v in block.state_dict().items()}, str(Path(directory) / f'{name}.mdl'))
 
     def load(self, directory, in_block=True, core=True, out_block=True, map_device=None):
         for name, block in self._blocks(in_block, core, out_block):

@@ -14,6 +14,19 @@ from ._lib import call, ptr
 from .runtime import f32c, require_device, stream_ptr
 
 
+_LOSS_WS = {}
+
+
+def _loss_ws(device):
+    """The two-double workspace of kp_l2_loss_mean for torch's current stream on `device` (zero at creation; every call leaves it
+    zero, so calls on one stream share it; calls on different streams may overlap and get their own)."""
+    key = (device.index, torch.cuda.current_stream(device).stream_id)
+    ws = _LOSS_WS.get(key)
+    if ws is None:
+        ws = _LOSS_WS[key] = torch.zeros(2, device=device, dtype=torch.float64)
+    return ws
+
+
 class _L2Loss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, target, mask):
@@ -22,12 +35,13 @@ class _L2Loss(torch.autograd.Function):
         if mask is not None:
             mask = f32c(mask).expand_as(x).contiguous()
         n = x.numel()
-        acc = torch.zeros(1, device=x.device, dtype=torch.float64)
         grad = torch.empty_like(x)
-        call('kp_l2_loss', ptr(x), ptr(target), ptr(mask), ptr(acc), ptr(grad), 1.0 / n, n, stream_ptr())
+        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        # (the mean -- fp64 sum / n, rounded once to fp32 -- is written by the kernel's last workgroup: no zero-fill, no division
+        #  launch between the forward and the backward)
+        call('kp_l2_loss_mean', ptr(x), ptr(target), ptr(mask), ptr(_loss_ws(x.device)), ptr(loss), ptr(grad), n, stream_ptr())
         ctx.save_for_backward(grad)
-        # (acc / n in fp64, rounded once to fp32 -- `(acc / n).to(float32)` in ONE launch: this sits between the forward and the backward)
-        return torch.div(acc, n, out=torch.empty(1, device=x.device, dtype=torch.float32)).reshape(())
+        return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):

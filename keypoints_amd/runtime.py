@@ -64,9 +64,8 @@ def set_multi_stream(on: bool) -> None:
     _multi_stream = bool(on)
 
 
-import os as _os
-# measurement / debugging: side-stream roles ('wgrad', 'chain', 'ring') that stay on the parent stream (KP_NO_ROLES=a,b)
-_disabled_roles = set(filter(None, _os.environ.get('KP_NO_ROLES', '').split(',')))
+# side-stream roles ('wgrad', 'chain', 'aux') that stay on the parent stream (A/B measurements: keypoints_amd._probe.disable_roles)
+_disabled_roles = set()
 
 
 def multi_stream(role: str = None) -> bool:
@@ -198,7 +197,7 @@ def set_fuse_bn_input(on: bool) -> None:
     _FUSE_BN_INPUT = bool(on)
 
 
-_FUSE_BN_REDUCE = not bool(_os.environ.get('KP_NO_BN_REDUCE_FUSION'))
+_FUSE_BN_REDUCE = True
 
 
 def fuse_bn_reduce() -> bool:
@@ -209,7 +208,7 @@ def fuse_bn_reduce() -> bool:
     gone, the five data gradients 18-30 us longer: they read the conv output the pass read); with the small-channel weight
     gradients on a side stream the step does not move (3.22 -> 3.23 ms: the HBM-bound pass ran beside them, the longer data
     gradient does not), with them on the current stream (unit_engine, the default for these layers) 3.26 -> 3.19 ms.
-    `set_fuse_bn_reduce(False)` / KP_NO_BN_REDUCE_FUSION=1 restore the separate pass."""
+    `set_fuse_bn_reduce(False)` restores the separate pass."""
     return _FUSE_BN_REDUCE
 
 
@@ -218,14 +217,14 @@ def set_fuse_bn_reduce(on: bool) -> None:
     _FUSE_BN_REDUCE = bool(on)
 
 
-_T_INTERCHANGE = not bool(_os.environ.get('KP_NO_T_INTERCHANGE'))
+_T_INTERCHANGE = True
 
 
 def t_interchange() -> bool:
     """TransporterNet moves the feature maps between the encoder head, the 'max' keypoint bottleneck and the decoder as 16-bit NHWC
     tensors (kp_head_fwd_t / kp_keypoint_bottleneck_fwd_t, include/kp_hip.h) where the library has those kernels (the Pong-class
     nets in bf16 / fp16), instead of the fp32 NCHW tensors of the reference's Unit interface plus two layout kernels.
-    `set_t_interchange(False)` / KP_NO_T_INTERCHANGE=1 restore the fp32 route for A/B measurements and tests."""
+    `set_t_interchange(False)` restores the fp32 route for A/B measurements and tests."""
     return _T_INTERCHANGE
 
 
@@ -234,13 +233,13 @@ def set_t_interchange(on: bool) -> None:
     _T_INTERCHANGE = bool(on)
 
 
-_PAIR_CALLS = not bool(_os.environ.get('KP_NO_PAIR'))
+_PAIR_CALLS = True
 
 
 def pair_calls() -> bool:
     """TransporterNet runs the source and the target frame through an encoder as ONE batch with per-half BatchNorm statistics
     (Unit.forward_pair, the kp_*_pair entry points) where the library has those kernels; results are bit-identical to the two
-    calls.  `set_pair_calls(False)` / KP_NO_PAIR=1 restore the two calls for A/B measurements and tests."""
+    calls.  `set_pair_calls(False)` restores the two calls for A/B measurements and tests."""
     return _PAIR_CALLS
 
 

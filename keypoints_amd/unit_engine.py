@@ -17,6 +17,7 @@ consumer of gx (bn_act_bwd_* of layer l-1).
 from __future__ import annotations
 
 import contextlib
+import contextvars
 from typing import List
 
 import torch
@@ -32,8 +33,13 @@ TAILS = {None: _lib.TAIL_NONE, 'M': _lib.TAIL_MAXPOOL2, 'U': _lib.TAIL_UPSAMPLE2
 
 # Packed (bf16, tap-major) copies of the conv weights shared between the Unit calls of ONE network forward: the
 # Transporter runs every encoder twice (source / target, transporter.py:36-39) on the same weights, which cannot
-# change inside a forward.  None outside of `shared_packs()`.
-_PACKS = None
+# change inside a forward.  None outside of `shared_packs()`.  Context-local (contextvars): two networks driven from two
+# threads / tasks of one process each see their own store.
+_PACKS_VAR = contextvars.ContextVar('keypoints_amd_packs', default=None)
+
+
+def _packs():
+    return _PACKS_VAR.get()
 
 
 class shared_packs:
@@ -44,17 +50,12 @@ class shared_packs:
         self._store = store
 
     def __enter__(self):
-        global _PACKS
-        self._outer = _PACKS
-        if self._store is not None:
-            _PACKS = self._store
-        elif _PACKS is None:
-            _PACKS = {}
+        outer = _PACKS_VAR.get()
+        self._token = _PACKS_VAR.set(self._store if self._store is not None else (outer if outer is not None else {}))
         return self
 
     def __exit__(self, *exc):
-        global _PACKS
-        _PACKS = self._outer
+        _PACKS_VAR.reset(self._token)
         return False
 
 
@@ -80,19 +81,20 @@ def _collect_packs(plan, Cin, Cp0, record, dev, tdt, code):
     """Pack buffers of every 3x3 weight of a Unit (from the shared store where they exist) + the list of layers still to pack."""
     out, todo = [], []
     C = Cin
+    packs = _packs()
     for idx, stp in enumerate(plan[:-1]):
         conv = stp['conv']
         K, Cl = conv.out_channels, C
         Cp = Cp0 if idx == 0 else C
         pkey = (id(conv.weight), Cp, code)
-        ent = _PACKS.get(pkey) if _PACKS is not None else None
+        ent = packs.get(pkey) if packs is not None else None
         if ent is None or (record and ent[1] is None):
             wf = torch.empty(K, 3, 3, Cp, device=dev, dtype=tdt)
-            wd = torch.empty(Cp, 3, 3, K, device=dev, dtype=tdt) if (record or _PACKS is not None) else None
+            wd = torch.empty(Cp, 3, 3, K, device=dev, dtype=tdt) if (record or packs is not None) else None
             ent = (wf, wd)
             todo.append((conv.weight, wf, wd, K, Cl, Cp))
-            if _PACKS is not None:
-                _PACKS[pkey] = ent
+            if packs is not None:
+                packs[pkey] = ent
         out.append(ent)
         C = K
     return out, todo
@@ -118,13 +120,10 @@ def _pack_unit(plan, Cin, Cp0, record, dev, tdt, code, st):
     return out
 
 
-import os as _os
-_NO_PREPACK = bool(_os.environ.get('KP_NO_PREPACK'))   # measurement: every Unit packs at its own first call again
-_ABL = set(filter(None, _os.environ.get('KP_ABLATE', '').split(',')))   # measurement ONLY (wrong gradients): 'wgrad' skips the 3x3 weight-gradient launches (tools/probes/ablate.sh)
-if _ABL:
-    import warnings as _warnings
-    _warnings.warn(f'KP_ABLATE={",".join(sorted(_ABL))}: measurement mode -- the 3x3 weight gradients are NOT computed (their arena slots '
-                   'stay zero); do not train with this set', RuntimeWarning)
+# Two scheduling choices with an A/B switch (plain module attributes; keypoints_amd._probe sets them for tools/probes -- nothing here
+# reads the environment):
+PREPACK = True        # the weight packs of all Units of a network in one launch at the start of its forward (`prepack` below)
+SMALL_INLINE = True   # the weight gradients of 16 / 32-channel layers on the backward's own stream instead of the 'wgrad' side stream
 
 
 def prepack(units_cin):
@@ -132,7 +131,7 @@ def prepack(units_cin):
     (the decoder behind the bottleneck) does not find its pack launch on the critical path in the middle of the step.
     `units_cin`: [(unit, input channels)].  Units of one storage type share the launch; anything this cannot plan is left to
     the Unit's own forward."""
-    if _PACKS is None or _NO_PREPACK:
+    if _packs() is None or not PREPACK:
         return
     groups = {}
     for unit, cin in units_cin:
@@ -282,7 +281,7 @@ def pair_ok(unit, N, Cin, H, W, out_t=False):
         if idx > 0 and L.kp_conv_bnin_supported(N, H, W, C, K, code) != 1:
             return False
         rows = L.kp_conv_fwd_stats_rows(N, H + 2, W + 2, C, K, 3, code)
-        if not (0 < rows <= 8192 and K <= 32):
+        if L.kp_bn_finalize_pair_supported(rows, K) != 1:   # (the library's own rule: nothing about the finalize is restated here)
             return False
         C = K
     Kout = plan[-1]['conv'].out_channels
@@ -299,13 +298,39 @@ def _materialise(fin, N, H, W, C, pad, tdt, code, st):
     return a
 
 
+def _wgrad_layer(sv, dy, gw, parts, N, H, W, C, K, dp, tdt, code, dev):
+    """Weight gradient of one 3x3 layer on torch's current stream: kp_conv_wgrad (or its fused-BatchNorm-input form) into `parts`
+    partial buffers, then kp_wgrad_unpack adds them into the arena view `gw` in a fixed order.  (A module-level function so that
+    tools/probes can time a step without it: keypoints_amd._probe.ablate_wgrad.)"""
+    wst = stream_ptr()
+    scratch = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device=dev, dtype=torch.float32)
+    fused = False
+    if sv['fin'] is not None:   # the input side is read from the previous layer's conv output (see forward)
+        f = sv['fin']
+        fused = try_call('kp_conv_wgrad_bnin', ptr(f['y']), *f['bn'], f['slope'], ptr(dy), ptr(scratch), N, H, W, C, K, dp, code, wst)
+        if not fused:
+            # the library declined the fused form NOW (a library knob changed since the forward): materialise the
+            # activation the forward skipped and take the plain kernel -- same values bit for bit
+            sv['a'] = _materialise(f, N, H, W, C, 1, tdt, code, wst)
+            parts2 = _lib.lib().kp_conv_wgrad_partials(N, H, W, C, K, 3, dp, code)
+            if parts2 != parts:
+                parts = parts2
+                scratch = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device=dev, dtype=torch.float32)
+    if not fused:
+        call('kp_conv_wgrad', ptr(sv['a']), ptr(dy), ptr(scratch), N, H, W, C, K, 3, dp, code, wst)
+    call('kp_wgrad_unpack', ptr(scratch), parts, ptr(gw), K, sv['Cl'], C, 3, wst)
+
+
 class UnitFunction(torch.autograd.Function):
     """forward(x NCHW fp32) -> out NCHW fp32; parameter gradients are accumulated straight into the
     Unit's GradArena (returned as None to autograd), the input gradient is returned normally."""
 
     @staticmethod
-    def forward(ctx, x, unit, record, fmt, xs, *params):
-        """xs (None, or the SOURCE frame of a Transporter pair -- same shape as x, no gradient): both frames go through the Unit as
+    def forward(ctx, x, unit, record, fmt, xs, x2, *params):
+        """x2 (None, or a second fp32 NCHW input of the same batch and map size): the Unit runs on torch.cat((x, x2), dim=1) --
+        KeyNet's decoder input, keynet.py:29 -- without that tensor being formed (kp_nchw2_to_nhwc; the backward splits the input
+        gradient, kp_nhwc_grad_to_nchw2).
+        xs (None, or the SOURCE frame of a Transporter pair -- same shape as x, no gradient): both frames go through the Unit as
         ONE batch with per-half BatchNorm statistics (`_forward_pair`, the kp_*_pair entry points) and the call returns
         (out_source, out); the caller (Unit.forward_pair) has asked `pair_ok` first.
         fmt = (in_t, out_t): the "T" interchange formats of include/kp_hip.h (16-bit NHWC tensors between Units instead of the
@@ -313,9 +338,11 @@ class UnitFunction(torch.autograd.Function):
         replicate border (written by the T form of the keypoint bottleneck), and the returned input gradient is the data
         gradient over that padded domain (the producer folds the border).  out_t: the head writes T [N][H][W][K] and the
         backward takes the output gradient in that form.  The callers (TransporterNet) ask *_t_supported first."""
-        require_device(x, *params)
+        require_device(x, x2, *params)
         in_t, out_t = fmt
         if xs is not None:
+            if x2 is not None:
+                raise RuntimeError('keypoints_amd Unit: a pair call takes one input tensor per frame')
             return UnitFunction._forward_pair(ctx, xs, x, unit, record, out_t)
         plan = unit.plan()
         tdt, code = precision_dtype(unit.precision)
@@ -323,7 +350,10 @@ class UnitFunction(torch.autograd.Function):
         dev = x.device
         first = plan[0]
         pad0 = 1 if first['kind'] == 'conv3' else 0
+        C1 = 0
         if in_t:
+            if x2 is not None:
+                raise RuntimeError('keypoints_amd Unit: a T-format input cannot be concatenated')
             if x.dtype != tdt or pad0 != 1:
                 raise RuntimeError('keypoints_amd Unit: a T-format input is the padded input of a first 3x3 layer in the Unit\'s storage type')
             x = x.contiguous()
@@ -335,9 +365,18 @@ class UnitFunction(torch.autograd.Function):
         else:
             x = f32c(x)
             N, Cin, H, W = x.shape
+            if x2 is not None:
+                x2 = f32c(x2)
+                if x2.dim() != 4 or x2.shape[0] != N or x2.shape[2:] != x.shape[2:]:
+                    raise RuntimeError(f'keypoints_amd Unit: cannot concatenate {tuple(x.shape)} and {tuple(x2.shape)} along the channels')
+                C1 = x2.shape[1]
+                Cin += C1
             Cp0 = _first_cp(plan, Cin, unit.precision)
             a = torch.empty(N, H + 2 * pad0, W + 2 * pad0, Cp0, device=dev, dtype=tdt)
-            call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, Cin, Cp0, H, W, pad0, code, st)
+            if x2 is not None:
+                call('kp_nchw2_to_nhwc', ptr(x), Cin - C1, ptr(x2), C1, ptr(a), N, Cp0, H, W, pad0, code, st)
+            else:
+                call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, Cin, Cp0, H, W, pad0, code, st)
         H0, W0 = H, W
         saved = []
         fin = None   # pending BatchNorm-apply of the previous layer, fused into the next convolution (None: `a` is materialised)
@@ -439,6 +478,7 @@ class UnitFunction(torch.autograd.Function):
             ctx.save_for_backward(out)   # an OUTPUT kept as a plain ctx attribute would be a reference cycle
             ctx.dims = (N, Cin, H0, W0, H, W, C, Kout, pad0)
             ctx.cp0 = Cp0
+            ctx.c1 = C1
             ctx.fmt = (bool(in_t), bool(out_t))
         return out
 
@@ -476,6 +516,9 @@ class UnitFunction(torch.autograd.Function):
             else:
                 call('kp_conv_fwd_bnin_pair', ptr(fin2['y']), *fin2['bn'], fin2['slope'], ptr(wf), ptr(conv.bias), ptr(y), ptr(stats),
                      2 * N, H, W, C, K, code, st)
+            if _lib.last_rows() != rows:   # (the statistics buffer above was sized by the plain kernel's row query: the pair form must agree)
+                raise RuntimeError(f'keypoints_amd Unit: the pair convolution left {_lib.last_rows()} statistics rows per half, the '
+                                   f'row query said {rows}')
             ms = torch.empty(2, 2, K, device=dev, dtype=torch.float32)   # [mean | invstd][half][K]
             track = bn.track_running_stats and bn.running_mean is not None
             call('kp_bn_finalize_pair', ptr(stats), rows, ptr(ms[0]), ptr(ms[1]), ptr(bn.running_mean) if track else None,
@@ -505,6 +548,7 @@ class UnitFunction(torch.autograd.Function):
             ctx.save_for_backward(out)
             ctx.dims = (N, Cin, H0, W0, H, W, C, Kout, 1)
             ctx.cp0 = Cin
+            ctx.c1 = 0
             ctx.fmt = (False, bool(out_t))
         return out_s, out
 
@@ -533,7 +577,9 @@ class UnitFunction(torch.autograd.Function):
         side_ok = runtime.multi_stream('wgrad') and not runtime.nested_fork_under_capture()   # (a side stream OF a side stream inside a stream capture crashes hipStreamEndCapture, ROCm 7.0)
         keep = []
         gv = arena.views
-        need_x = ctx.needs_input_grad[0]
+        c1 = ctx.c1
+        need_x2 = c1 > 0 and ctx.needs_input_grad[5]
+        need_x = ctx.needs_input_grad[0] or need_x2
 
         in_t, out_t = ctx.fmt
         head = plan[-1]
@@ -577,7 +623,6 @@ class UnitFunction(torch.autograd.Function):
                  N, Hh, Wh, Ch, Kout, code, st)
         gp = 0   # border width of g (0 = plain, 1 = padded-domain gradient that still needs folding)
         pending_red = None   # (partial rows, count) of the NEXT layer's BatchNorm-backward sums, left by a fused data gradient
-        small_inline = not _os.environ.get('KP_SMALL_SIDE')   # (measurement: KP_SMALL_SIDE=1 puts the small-channel weight gradients back on the side stream)
         for idx in range(len(saved) - 1, -1, -1):
             stp, sv = plan[idx], saved[idx]
             conv, bn = stp['conv'], stp['bn']
@@ -649,31 +694,14 @@ class UnitFunction(torch.autograd.Function):
             # of the next layer's passes runs beside it; with the reduce pass folded into the data gradient there is also less to
             # run: on the current stream the config-2 step measures 3.19 vs 3.22 ms, tools/probes/bred_roles_ab.sh.)
             lside = None
-            if side_ok and not (small_inline and C <= 32 and K <= 32):
+            if side_ok and not (SMALL_INLINE and C <= 32 and K <= 32):
                 if side is None:
                     side = runtime.side_stream('wgrad')
                 lside = side
             if lside is not None:
                 lside.wait_stream(cur)
             with torch.cuda.stream(lside) if lside is not None else contextlib.nullcontext():
-                wst = stream_ptr()
-                if 'wgrad' not in _ABL:   # (measurement mode: neither the kernel nor the unpack of its -- then uninitialised -- scratch)
-                    scratch = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device=dev, dtype=torch.float32)
-                    fused = False
-                    if sv['fin'] is not None:   # the input side is read from the previous layer's conv output (see forward)
-                        f = sv['fin']
-                        fused = try_call('kp_conv_wgrad_bnin', ptr(f['y']), *f['bn'], f['slope'], ptr(dy), ptr(scratch), N, H, W, C, K, dp, code, wst)
-                        if not fused:
-                            # the library declined the fused form NOW (a measurement knob changed since the forward): materialise the
-                            # activation the forward skipped and take the plain kernel -- same values bit for bit
-                            sv['a'] = _materialise(f, N, H, W, C, 1, tdt, code, wst)
-                            parts2 = _lib.lib().kp_conv_wgrad_partials(N, H, W, C, K, 3, dp, code)
-                            if parts2 != parts:
-                                parts = parts2
-                                scratch = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device=dev, dtype=torch.float32)
-                    if not fused:
-                        call('kp_conv_wgrad', ptr(sv['a']), ptr(dy), ptr(scratch), N, H, W, C, K, 3, dp, code, wst)
-                    call('kp_wgrad_unpack', ptr(scratch), parts, ptr(gv[id(conv.weight)]), K, sv['Cl'], C, 3, wst)
+                _wgrad_layer(sv, dy, gv[id(conv.weight)], parts, N, H, W, C, K, dp, tdt, code, dev)
             if lside is not None:
                 # dy and the saved input are read on the side stream: they stay referenced until this stream has waited
                 # for it (end of the Unit's backward) -- the caching allocator recycles a block in the order of ITS stream
@@ -682,9 +710,13 @@ class UnitFunction(torch.autograd.Function):
                 if unit.layer_done is not None:   # a gradient reducer reads the arena from this stream
                     cur.wait_stream(side)
             unit._layer_done(idx)   # the arena slots of plan steps >= idx (and of the head) are final from here on
-        dx = None
+        dx = dx2 = None
         if need_x and in_t:
             dx = g   # the data gradient over the padded input domain [N][H+2][W+2][Cin] (T): the producer folds the border
+        elif need_x and c1:   # the two inputs of a concatenated call (forward: x2) get their channel ranges of the folded gradient
+            dx = torch.empty(N, Cin - c1, H0, W0, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+            dx2 = torch.empty(N, c1, H0, W0, device=dev, dtype=torch.float32) if need_x2 else None
+            call('kp_nhwc_grad_to_nchw2', ptr(g), ptr(dx), Cin - c1, ptr(dx2), c1, N, ctx.cp0, H0, W0, gp, code, st)
         elif need_x:
             dx = torch.empty(N, Cin, H0, W0, device=dev, dtype=torch.float32)
             call('kp_nhwc_grad_to_nchw', ptr(g), ptr(dx), N, Cin, ctx.cp0, H0, W0, gp, code, st)
@@ -696,4 +728,4 @@ class UnitFunction(torch.autograd.Function):
             keep.clear()
         runtime.join_after_backward()   # a backward that runs on a side stream itself is joined when the pass ends
         unit._after_backward()
-        return (dx, None, None, None, None) + (None,) * len(params)
+        return (dx, None, None, None, None, dx2) + (None,) * len(params)

@@ -112,3 +112,35 @@ def test_full_size_properties():
         # the map is rendered from this implementation's keypoints: a 1-ulp (2.4e-7) difference of a coordinate
         # against the oracle's moves exp(-50 d) by up to 50*sqrt(2)*ulp = 1.7e-5 relative
         close(m[:4], O.gaussian_like(ok, H, H).numpy(), atol=2e-6, rtol=1e-4)
+
+
+class _DropGrad(torch.autograd.Function):
+    """A downstream op that hands back an UNDEFINED gradient (None) for its input."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return None
+
+
+@pytest.mark.parametrize('mode', ['softmax', 'max', 'sum_and_clamp', 'loop'])
+def test_undefined_incoming_gradient_is_zero_not_an_error(mode):
+    """The ops run with set_materialize_grads(False): an undefined (None) gradient of their one differentiable output must come back
+    as an undefined gradient of the inputs -- torch's meaning of "zero" -- not as an AttributeError on None."""
+    from keypoints_amd.models import functional as MF
+    g = torch.Generator().manual_seed(0)
+    if mode == 'softmax':
+        h = torch.randn(2, 3, 8, 8, generator=g).cuda().requires_grad_(True)
+        k = MF.spacial_logsoftmax(h)
+        (_DropGrad.apply(k).sum() + 0.0 * h.sum()).backward()
+        assert float(h.grad.abs().max()) == 0.0
+        return
+    phi_s, phi_t = (torch.randn(2, 4, 8, 8, generator=g).cuda().requires_grad_(True) for _ in range(2))
+    m_s, m_t = (torch.rand(2, 3, 8, 8, generator=g).cuda().requires_grad_(True) for _ in range(2))
+    phi, _, _ = MF.transport(phi_s, phi_t, m_s, m_t, mode)
+    (_DropGrad.apply(phi).sum() + 0.0 * (phi_s.sum() + phi_t.sum() + m_s.sum() + m_t.sum())).backward()
+    for t in (phi_s, phi_t, m_s, m_t):
+        assert float(t.grad.abs().max()) == 0.0

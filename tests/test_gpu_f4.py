@@ -137,6 +137,29 @@ def test_autoencoder_loads_reference_checkpoint_and_transfers(golden, tmp_path):
             close(sd[n], ref, atol=1e-7)
 
 
+def test_checkpoint_files_hold_only_their_block_after_bind(tmp_path):
+    """FusedAdam.bind re-homes every parameter as a view of one per-device buffer; Unit.save (knn.py:143-154's files) must still write
+    each block's own tensors, not the whole buffer behind the view: file size ~ the block's parameter bytes, values round-trip."""
+    import keypoints_amd as ka
+    from keypoints_amd.models import transporter
+    torch.manual_seed(3)
+    net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 3).cuda()
+    ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
+    total = 4 * sum(p.numel() for p in net.parameters())
+    out = str(tmp_path / 'ck')
+    net.save(out)
+    for unit, mod in (('encoder', net.feature), ('keypoint', net.keypoint), ('decoder', net.decoder)):
+        for blk in ('in_block', 'core', 'out_block'):
+            path = os.path.join(out, unit, blk + '.mdl')
+            own = sum(v.numel() * v.element_size() for v in getattr(mod, blk).state_dict().values())
+            size = os.path.getsize(path)
+            assert size <= own + 16384, (unit, blk, size, own)       # (pickle framing: a few KB)
+            assert size < total, (unit, blk, size, total)
+            sd = torch.load(path)
+            for k, v in getattr(mod, blk).state_dict().items():
+                assert torch.equal(sd[k].cpu(), v.cpu()), (unit, blk, k)
+
+
 def test_amp_initialize_mirrors_the_reference_recipe():
     """`amp.initialize(net, optim, opt_level=...)` + `with amp.scale_loss(loss, optim)` (transporter.py:51,84-86) on the
     native implementation: O0 -> strict fp32 Units and no scaler (scale_loss is the identity), O2 -> fp16 Units with a

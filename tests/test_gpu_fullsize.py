@@ -562,6 +562,7 @@ def test_conditioned_networks_meet_the_16bit_contract(cfg):
 
     xs0, xt0 = structured_pairs(nev, size, torch.Generator().manual_seed(7), device='cuda')
     results = {'fp16': [], 'bf16': []}
+    emus = {'fp16': [], 'bf16': []}
     for seed in seeds:
         g = torch.Generator().manual_seed(seed)
 
@@ -589,20 +590,35 @@ def test_conditioned_networks_meet_the_16bit_contract(cfg):
         else:
             l64, o64, G64, P64, B64 = oracle_step(O, O.transporter_train_step, plans, Pn, Bn, torch.float64, xs, xt)
         xmax = float(o64[0].abs().max())
+
+        def clauses(loss, x_t, feat, k, T):
+            err = (x_t.double() - o64[0]).abs() / xmax
+            return dict(loss=abs(float(loss) - float(l64)) / float(l64), keypoints=maxerr(k, o64[2]), features_rel_l2=rel(feat, o64[1]),
+                        xt_rel_l2=rel(x_t, o64[0]), xt_worst=float(err.max()), xt_frac_beyond=float((err > T['xt_beyond']).double().mean()))
         for precision in ('fp16', 'bf16'):
             T = O.TOL16[precision]
+            # the REFERENCE's own arithmetic with this storage type emulated (oracle quant=*_storage: fp32 sums, operands and stored
+            # activations rounded where apex O2 / the HIP engine store them), same conditioned weights, same batch, against the same
+            # fp64 run: what the storage type costs the reference itself on THIS network
+            qf = O.fp16_storage if precision == 'fp16' else O.bf16_storage
+            if cfg == 'c3':
+                le, oe, _, _, _ = oracle_step(O, O.keynet_train_step, plans, Pn, Bn, torch.float32, xs, xt, mask, quant=qf)
+            else:
+                le, oe, _, _, _ = oracle_step(O, O.transporter_train_step, plans, Pn, Bn, torch.float32, xs, xt, quant=qf)
+            emu = clauses(le, oe[0], oe[1], oe[2], T)
+            del le, oe
+            print(f'emulation   {cfg}, {precision}, {nev} pairs, seed {seed}:', {a_: f'{b_:.2e}' for a_, b_ in emu.items()})
             net, opt = hip_net(mk, Pn, Bn, precision)
 
             def f():
                 out = net(xs, xt)
                 return ka.l2_reconstruction_loss(out[0], xt, mask), out
             loss, out, G = hip_step(net, opt, f)
-            x_t, feat, k = out[0], out[1], out[2]
-            err = (x_t.double() - o64[0]).abs() / xmax
-            meas = dict(loss=abs(float(loss) - float(l64)) / float(l64), keypoints=maxerr(k, o64[2]), features_rel_l2=rel(feat, o64[1]),
-                        xt_rel_l2=rel(x_t, o64[0]), xt_worst=float(err.max()), xt_frac_beyond=float((err > T['xt_beyond']).double().mean()))
+            meas = clauses(loss, out[0], out[1], out[2], T)
             print(f'conditioned {cfg}, {precision}, {nev} pairs, seed {seed}:', {a_: f'{b_:.2e}' for a_, b_ in meas.items()})
+            print(f'hip / emu   {cfg}, {precision}, {nev} pairs, seed {seed}:', {a_: f'{meas[a_] / max(emu[a_], 1e-30):.2f}' for a_ in meas})
             results[precision].append(meas)
+            emus[precision].append(emu)
             if opt.scaler is not None:
                 assert opt.scaler.steps_skipped == 0
             del net, opt

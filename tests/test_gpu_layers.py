@@ -368,3 +368,104 @@ def test_nchw_to_nhwc(N, C, Cp, H, W, pad, dt):
     ref = torch.nn.functional.pad(x, (pad,) * 4, mode='replicate') if pad else x
     ref = torch.nn.functional.pad(ref.permute(0, 2, 3, 1), (0, Cp - C)).to(tdt)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize('n,masked', [(4096 * 3, False), (1001, True), (7, True), (128 * 3 * 128 * 128, False), (2 * 3 * 84 * 84 + 3, True)])
+def test_l2_loss_mean_kernel_one_launch_and_reusable_workspace(n, masked):
+    """kp_l2_loss_mean: the loss VALUE of transporter.py:56-60 (mean in fp64, rounded once to fp32) written by the kernel's last
+    workgroup, which also leaves the two-double workspace zero -- three calls in a row on one workspace give the same value."""
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g).cuda()
+    t = torch.randn(n, generator=g).cuda()
+    m = (torch.rand(n, generator=g) > 0.3).float().cuda() if masked else None
+    ws = torch.zeros(2, device='cuda', dtype=torch.float64)
+    d = (x.double() - t.double())
+    mk = m.double() if masked else torch.ones_like(d)
+    ref = float((d * d * mk).sum() / n)
+    gref = (2.0 * d * mk / n).float()
+    for _ in range(3):
+        loss = torch.full((1,), float('nan'), device='cuda')
+        grad = torch.full((n,), float('nan'), device='cuda')
+        call('kp_l2_loss_mean', ptr(x), ptr(t), ptr(m), ptr(ws), ptr(loss), ptr(grad), n, stream_ptr())
+        assert abs(loss.item() - ref) <= 2e-7 * abs(ref) + 1e-12, (loss.item(), ref)
+        assert float(ws.abs().max()) == 0.0
+        assert (grad - gref).abs().max().item() <= 1e-6 * gref.abs().max().item() + 1e-12
+
+
+def test_l2_reconstruction_loss_matches_oracle_and_scales_its_gradient():
+    """keypoints_amd.l2_reconstruction_loss (one launch forward, kp_scale backward) against the oracle, with an upstream factor."""
+    import keypoints_amd as ka
+    from oracle import kp_oracle as O
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 3, 20, 20, generator=g)
+    t = torch.randn(3, 3, 20, 20, generator=g)
+    m = (torch.rand(3, 3, 20, 20, generator=g) > 0.2).float()
+    for mask in (None, m):
+        xo = x.clone().double().requires_grad_(True)
+        lo = O.l2_reconstruction_loss(xo, t.double(), None if mask is None else mask.double())
+        (3.0 * lo).backward()
+        xh = x.clone().cuda().requires_grad_(True)
+        lh = ka.l2_reconstruction_loss(xh, t.cuda(), None if mask is None else mask.cuda())
+        (3.0 * lh).backward()
+        assert abs(lh.item() - lo.item()) <= 1e-6 * lo.item()
+        assert float((xh.grad.cpu().double() - xo.grad).abs().max()) <= 1e-6 * float(xo.grad.abs().max())
+
+
+@pytest.mark.parametrize('dt', ['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('N,C0,C1,Cp,H,W', [(3, 64, 10, 128, 16, 16), (2, 64, 10, 74, 16, 16), (2, 5, 3, 8, 7, 5), (1, 1, 1, 4, 4, 6)])
+def test_two_source_layout_kernels_equal_the_concatenation(N, C0, C1, Cp, H, W, dt):
+    """kp_nchw2_to_nhwc / kp_nhwc_grad_to_nchw2 (torch.cat((z, m), dim=1) of keynet.py:29 folded into the Unit's layout change):
+    bit-identical to kp_nchw_to_nhwc / kp_nhwc_grad_to_nchw of the concatenated tensor, either output optional."""
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import precision_dtype, stream_ptr
+    tdt, code = precision_dtype(dt)
+    g = torch.Generator().manual_seed(N * 100 + C0)
+    a = torch.randn(N, C0, H, W, generator=g).cuda()
+    b = torch.randn(N, C1, H, W, generator=g).cuda()
+    cat = torch.cat((a, b), dim=1).contiguous()
+    st = stream_ptr()
+    for pad in (0, 1):
+        want = torch.empty(N, H + 2 * pad, W + 2 * pad, Cp, device='cuda', dtype=tdt)
+        got = torch.full_like(want, float('nan'))
+        call('kp_nchw_to_nhwc', ptr(cat), ptr(want), N, C0 + C1, Cp, H, W, pad, code, st)
+        call('kp_nchw2_to_nhwc', ptr(a), C0, ptr(b), C1, ptr(got), N, Cp, H, W, pad, code, st)
+        assert torch.equal(got.float(), want.float())
+        gsrc = torch.randn(N, H + 2 * pad, W + 2 * pad, Cp, generator=g).cuda().to(tdt)
+        dcat = torch.empty(N, C0 + C1, H, W, device='cuda')
+        call('kp_nhwc_grad_to_nchw', ptr(gsrc), ptr(dcat), N, C0 + C1, Cp, H, W, pad, code, st)
+        d0 = torch.full((N, C0, H, W), float('nan'), device='cuda')
+        d1 = torch.full((N, C1, H, W), float('nan'), device='cuda')
+        call('kp_nhwc_grad_to_nchw2', ptr(gsrc), ptr(d0), C0, ptr(d1), C1, N, Cp, H, W, pad, code, st)
+        assert torch.equal(d0, dcat[:, :C0]) and torch.equal(d1, dcat[:, C0:])
+        d1b = torch.full((N, C1, H, W), float('nan'), device='cuda')
+        call('kp_nhwc_grad_to_nchw2', ptr(gsrc), None, C0, ptr(d1b), C1, N, Cp, H, W, pad, code, st)
+        assert torch.equal(d1b, d1)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'fp16'])
+def test_unit_forward_cat_equals_cat_then_forward(precision):
+    """Unit.forward_cat(z, m) == Unit(torch.cat((z, m), dim=1)) (KeyNet's decoder call, keynet.py:29): outputs, both input
+    gradients and every parameter gradient bit for bit."""
+    from keypoints_amd.models import knn, vgg
+    torch.manual_seed(11)
+    unit = knn.Unit(64 + 10, 3, vgg.make_layers([64, 64, 'U', 64])).cuda()
+    unit.precision = precision
+    g = torch.Generator().manual_seed(2)
+    z0 = torch.randn(4, 64, 16, 16, generator=g).cuda()
+    m0 = torch.rand(4, 10, 16, 16, generator=g).cuda()
+    w = torch.randn(4, 3, 32, 32, generator=g).cuda()
+    res = []
+    for cat in (True, False):
+        z, m = z0.clone().requires_grad_(True), m0.clone().requires_grad_(True)
+        for p in unit.parameters():
+            p.grad = None
+        unit._arena = None
+        out = unit(torch.cat((z, m), dim=1)) if cat else unit.forward_cat(z, m)
+        (out * w).sum().backward()
+        res.append((out.detach().clone(), z.grad.clone(), m.grad.clone(), [p.grad.clone() for p in unit.parameters()]))
+    (o1, z1, m1, p1), (o2, z2, m2, p2) = res
+    assert torch.equal(o1, o2) and torch.equal(z1, z2) and torch.equal(m1, m2)
+    for a, b in zip(p1, p2):
+        assert torch.equal(a, b)

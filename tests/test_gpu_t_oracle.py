@@ -180,3 +180,41 @@ def test_head_t_against_the_oracle(N, H, W, dt, bnin):
     # ... and statistically far inside it (independent roundings): 2 % of the gradient's scale
     assert float((dw.double().cpu() - ow.grad).abs().max()) <= 2e-2 * float(ow.grad.abs().max())
     assert float((db.double().cpu() - ob.grad).abs().max()) <= 2e-2 * float(ob.grad.abs().max())
+
+
+@pytest.mark.parametrize('C,K,H,W', [(16, 3, 5, 6), (16, 4, 16, 16), (8, 2, 3, 3)])
+def test_bottleneck_t_small_maps_read_nothing_past_the_last_image(C, K, H, W):
+    """Maps with H*W*(C/8) below the workgroup size (advisor, round 4): the forward's two-deep prefetch must clamp to the image.
+    The feature maps are placed so that the LAST image ends exactly at the end of a dedicated 20 MiB device allocation (the caching
+    allocator hands allocations above 10 MiB out at their own size, rounded to 2 MiB): a read past it leaves the allocation.  The
+    results must equal those of the same call on tensors in the middle of an allocation."""
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    tdt, code, B = torch.bfloat16, _code('bf16'), 2
+    g = torch.Generator().manual_seed(C + H)
+    heat_s = (torch.randn(B, K, H, W, generator=g) * 3).cuda()
+    heat_t = (torch.randn(B, K, H, W, generator=g) * 3).cuda()
+    phi_s = torch.randn(B, H, W, C, generator=g).to(tdt)
+    phi_t = torch.randn(B, H, W, C, generator=g).to(tdt)
+    n = B * H * W * C
+    outs = []
+    for at_end in (False, True):
+        if at_end:
+            big_s = torch.empty(20 * 2 ** 20 // 2, device='cuda', dtype=tdt)
+            big_t = torch.empty(20 * 2 ** 20 // 2, device='cuda', dtype=tdt)
+            ps_d, pt_d = big_s[-n:].view(B, H, W, C), big_t[-n:].view(B, H, W, C)
+            ps_d.copy_(phi_s); pt_d.copy_(phi_t)
+            assert ps_d.data_ptr() + 2 * n == big_s.data_ptr() + 20 * 2 ** 20
+        else:
+            ps_d, pt_d = phi_s.cuda(), phi_t.cuda()
+        f32 = dict(device='cuda', dtype=torch.float32)
+        k = torch.empty(B, K, 2, **f32); p = torch.empty(B, K, H, **f32); q = torch.empty(B, K, W, **f32)
+        m = torch.empty(B, K, H, W, **f32); ms = torch.empty(B, 1, H, W, **f32); mt = torch.empty(B, 1, H, W, **f32)
+        arg = torch.empty(B, H, W, device='cuda', dtype=torch.uint8)
+        a = torch.empty(B, H + 2, W + 2, C, device='cuda', dtype=tdt)
+        call('kp_keypoint_bottleneck_fwd_t', ptr(heat_s), ptr(heat_t), ptr(ps_d), ptr(pt_d), ptr(k), ptr(p), ptr(q), ptr(m),
+             ptr(a), ptr(ms), ptr(mt), ptr(arg), B, C, K, H, W, 0.1, 1e-6, code, stream_ptr())
+        torch.cuda.synchronize()
+        outs.append((k.clone(), m.clone(), a.float().clone(), arg.clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)

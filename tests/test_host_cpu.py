@@ -275,3 +275,35 @@ def test_round4_support_queries_answer_without_a_device():
     netF = transporter.make('F', 3, 64, 10).set_precision('fp16')
     assert head_dims(netF.feature, 128, 128)[:2] == (16, 16) and not pair_ok(netF.feature, 128, 3, 128, 128, False)
     assert netF._t_route(torch.zeros(2, 3, 128, 128)) is None            # (a CPU tensor: no route; the forward itself raises loudly)
+
+
+def test_package_reads_no_environment_variable_outside_probe():
+    """Measurement knobs live in keypoints_amd/_probe.py (called by bench.py / tools, never by the package): no other module of the
+    product path reads os.environ / getenv."""
+    import pathlib
+    import re
+    import keypoints_amd
+    root = pathlib.Path(keypoints_amd.__file__).parent
+    bad = []
+    for f in list(root.glob('*.py')) + list((root / 'models').glob('*.py')):
+        if f.name == '_probe.py':
+            continue
+        for i, ln in enumerate(f.read_text().splitlines(), 1):
+            code = ln.split('#', 1)[0]
+            if re.search(r'os\.environ|getenv|_os\.environ', code):
+                bad.append(f'{f.name}:{i}: {ln.strip()}')
+    assert not bad, bad
+
+
+def test_probe_apply_env_turns_variables_into_setters():
+    import keypoints_amd as ka
+    from keypoints_amd import _probe, runtime, unit_engine
+    try:
+        used = _probe.apply_env({'KP_NO_PAIR': '1', 'KP_NO_ROLES': 'wgrad,aux', 'KP_NO_PREPACK': '1', 'KP_SMALL_SIDE': '1'})
+        assert set(used) == {'KP_NO_PAIR', 'KP_NO_ROLES=wgrad,aux', 'KP_NO_PREPACK', 'KP_SMALL_SIDE'}
+        assert not runtime.pair_calls() and not runtime.multi_stream('wgrad') and runtime.multi_stream('chain')
+        assert unit_engine.PREPACK is False and unit_engine.SMALL_INLINE is False
+        assert _probe.apply_env({}) == []
+    finally:
+        runtime.set_pair_calls(True); runtime._disabled_roles.clear()
+        unit_engine.PREPACK = True; unit_engine.SMALL_INLINE = True
