@@ -419,6 +419,8 @@ def _run_leg(args, rank, world, dev):
         print('memstats', {k: ms_[k] for k in ('num_device_alloc', 'num_device_free', 'num_alloc_retries', 'reserved_bytes.all.peak')}, file=sys.stderr)
     line = {}
     if rank == 0:
+        import hashlib
+        lib_sha16 = hashlib.sha256(open(_lib.LIB_PATH, 'rb').read()).hexdigest()[:16]   # (= what __graft_entry__.build() prints)
         flop_pair = conv_flops_per_pair(net, args.size, args.size)
         ms_step = 1e3 * elapsed / args.steps
         value = B * world / (elapsed / args.steps)
@@ -433,21 +435,31 @@ def _run_leg(args, rank, world, dev):
         # HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the
         # gfx950 correction + WRITE_SIZE), condensed by tools/pmc_summary.py into profiles/ -- not measurable from
         # inside the process, so it is the committed per-launch figure of the last profiled build (or null).
-        traffic, pmc, pmc_file = None, None, None
+        # Only a summary STAMPED with the sha256 of the library that is loaded now is quoted (tools/r05_records.sh writes the stamp):
+        # a figure of another build is reported as null with the reason, not as this build's.
+        traffic, pmc, pmc_file, traffic_reason = None, None, None, None
         pmc_key = 'conv_small_band_bf16' if dom[0] == 'conv_small_16bit' else 'conv_patch_bf16_bn128'
-        for cand in ('r04e_pmc_summary.json', 'r04b_pmc_summary.json', 'r03m_pmc_summary.json', 'r03k_pmc_summary.json', 'r03j_pmc_summary.json', 'r03i_pmc_summary.json', 'r03h_pmc_summary.json', 'r03b_pmc_summary.json', 'r02n_pmc_summary.json', 'r02j_pmc_summary.json', 'r02g_pmc_summary.json', 'r02_pmc_summary.json', 'r01_pmc_summary.json'):
+        import glob
+        stamps = []
+        for cand in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_summary.json')), reverse=True):
             try:
-                pmc = json.load(open(os.path.join(ROOT, 'profiles', cand)))[pmc_key]
-                traffic, pmc_file = pmc['hbm_bytes_per_launch'], cand
+                doc = json.load(open(cand))
+            except (OSError, ValueError):
+                continue
+            stamps.append((os.path.basename(cand), doc.get('lib_sha16')))
+            if doc.get('lib_sha16') == lib_sha16 and pmc_key in doc:
+                pmc = doc[pmc_key]
+                traffic, pmc_file = pmc['hbm_bytes_per_launch'], os.path.basename(cand)
                 break
-            except (OSError, KeyError, ValueError):
-                pmc = None
+        if pmc is None:
+            newest = next((f'{n} (lib {s_ or "unstamped"})' for n, s_ in stamps), 'none')
+            traffic_reason = f'no profiles/*_pmc_summary.json is stamped with the loaded library {lib_sha16}; newest: {newest}'
         hbm = dom[0] in HBM_BOUND
         if dom[1] is None:
             roofline = None
         elif hbm:     # small-channel nets (Pong): the dominant kernels stream activations, the roofline is HBM
             roofline = dict(bound='hbm', kernel=dom[0], achieved=dom[1]['algorithmic_gbs'], peak=PEAK_HBM_GBS, unit='GB/s',
-                            frac=dom[1]['algorithmic_gbs'] / PEAK_HBM_GBS, traffic=traffic,
+                            frac=dom[1]['algorithmic_gbs'] / PEAK_HBM_GBS, traffic=traffic, traffic_reason=traffic_reason,
                             traffic_unit=f'HBM bytes per launch (rocprofv3 PMC, profiles/{pmc_file})' if pmc_file else None,
                             algorithmic_bytes=dom[1]['algorithmic_bytes_per_launch'], avg_launch_us=dom[1]['avg_us'],
                             launches_per_step=dom[1]['launches_per_step'])
@@ -456,7 +468,8 @@ def _run_leg(args, rank, world, dev):
                             frac=dom[1]['tflops'] / peak,
                             # (the PMC passes were taken on the headline workload: other shapes get no traffic figure)
                             traffic=traffic if (dom[0] == 'conv_mfma_16bit' and config_name(args) == 'BASELINE config 4 shape') else None,
-                            traffic_unit=f'HBM bytes per launch (rocprofv3 PMC of a committed profile run of this command, profiles/{pmc_file}; '
+                            traffic_reason=traffic_reason if config_name(args) == 'BASELINE config 4 shape' else 'the PMC passes are taken on configs 4 and 2',
+                            traffic_unit=f'HBM bytes per launch (rocprofv3 PMC of this library build on this command, profiles/{pmc_file}; '
                                          'not a measurement of this run)' if pmc_file else None,
                             algorithmic_bytes=dom[1]['algorithmic_bytes_per_launch'],
                             pmc_mfma_util=pmc['mfma_util'] if pmc else None,
@@ -507,7 +520,7 @@ def _run_leg(args, rank, world, dev):
                                          f'{"augment+" if args.net == "keynet" and not args.no_augment else ""}fwd+loss+bwd+Adam',
                                 global_batch=B * world, per_gpu_batch=B, parallelism=f'dp{world}',
                                 dp_overlap=bool(args.dp_overlap) if world > 1 else None, side_streams=bool(args.streams), hip_graph=bool(args.graph),
-                                gflop_per_pair=flop_pair / 1e9, loss=float(loss.item()), **({'probe_knobs': probe_knobs} if probe_knobs else {})),
+                                gflop_per_pair=flop_pair / 1e9, loss=float(loss.item()), lib_sha16=lib_sha16, **({'probe_knobs': probe_knobs} if probe_knobs else {})),
                     roofline=roofline)
         if dp is not None:
             line['dp'] = dp
@@ -526,7 +539,7 @@ def compact_roofline(r):
     """The `roofline` object without its per-kernel tables and provenance prose (those stay in the --detail file)."""
     if not r:
         return r
-    keep = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes', 'avg_launch_us', 'launches_per_step',
+    keep = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_reason', 'algorithmic_bytes', 'avg_launch_us', 'launches_per_step',
             'step_tflops', 'step_frac', 'step_bytes', 'step_kp_launches', 'step_hbm_frac', 'frac_at_measured_clock', 'pmc_mfma_util', 'pmc_effective_clock_ghz')
     out = {k: _round(r[k]) for k in keep if k in r and r[k] is not None}
     if 'traffic' not in out:

@@ -307,3 +307,15 @@ def test_probe_apply_env_turns_variables_into_setters():
     finally:
         runtime.set_pair_calls(True); runtime._disabled_roles.clear()
         unit_engine.PREPACK = True; unit_engine.SMALL_INLINE = True
+
+
+def test_the_16bit_contract_is_frozen():
+    """oracle.TOL16 and the rules around it (per-network factor, the emulation anchor) as frozen in round 5: any edit of a constant
+    changes this hash and has to be argued in DESIGN.md section 4 together with the new hash -- the contract does not follow the
+    measurements."""
+    import hashlib
+    import json
+    from oracle import kp_oracle as O
+    blob = json.dumps(dict(TOL16=O.TOL16, per_network=O.TOL16_PER_NETWORK, vs_emulation=O.TOL16_VS_EMULATION,
+                           floor=O.TOL16_EMULATION_FLOOR), sort_keys=True)
+    assert hashlib.sha256(blob.encode()).hexdigest() == 'b6d8cbaf36daf2f9e04a32b04ad528de20bf75ab87079cf6f1abc292cd1eae87', blob

@@ -35,8 +35,10 @@ def load(name):
     return list(csv.DictReader(open(max(fs, key=os.path.getmtime))))
 
 
-def main(tag):
+def main(tag, lib_sha16=None):
     out = {}
+    if lib_sha16:   # the library the counters were collected on (tools/r05_records.sh): bench.py quotes `traffic` only from a summary
+        out['lib_sha16'] = lib_sha16   # whose stamp equals the loaded library's
     for suffix, kernels in (('', KERNELS), ('c2', KERNELS_C2)):
         summarise(out, suffix, kernels)
     json.dump(out, open(f'profiles/{tag}_pmc_summary.json', 'w'), indent=1)
@@ -76,4 +78,4 @@ def summarise(out, suffix, kernels):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1] if len(sys.argv) > 1 else 'r01')
+    main(sys.argv[1] if len(sys.argv) > 1 else 'r01', sys.argv[2] if len(sys.argv) > 2 else None)
