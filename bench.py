@@ -58,6 +58,12 @@ def parse():
                     help='N > 1: 1 = all-reduce each gradient piece from the backward hooks (overlapped with the backward); '
                          '0 (default) = reduce the arenas back to back after the backward: ~1 ms exposed, but no RCCL kernel '
                          'shares CUs with the statically partitioned persistent MFMA kernels (DESIGN.md section 6)')
+    ap.add_argument('--reserve-cus', type=int, default=16,
+                    help='N > 1 with --dp-overlap 1: CUs the persistent kernels leave free for RCCL (a fixed grid of device CUs minus '
+                         'this; NCCL_MAX_NCHANNELS is set to the same number unless the environment already has it)')
+    ap.add_argument('--grid-cus', type=int, default=0,
+                    help='N = 1: run the persistent kernels on a fixed grid of this many CUs (kp_config(KP_CFG_CUS)): what the reduced grid '
+                         'of --dp-overlap 1 costs on the compute side, measurable on one GPU')
     ap.add_argument('--comm', default='torch', choices=['torch', 'native'],
                     help="N > 1: 'torch' = torch.distributed all-reduces (ProcessGroupNCCL = RCCL); 'native' = the C ABI's own RCCL "
                          "communicator (kp_comm_*), torch.distributed only carries its unique id")
@@ -219,6 +225,9 @@ def run_leg(args, rank, world, dev):
     try:
         return _run_leg(args, rank, world, dev)
     finally:
+        if world == 1 and args.grid_cus:
+            from keypoints_amd import _lib
+            _lib.call('kp_config', _lib.KP_CFG_CUS, 0)
         gc.unfreeze()
         gc.collect()
         torch.cuda.synchronize()
@@ -253,7 +262,9 @@ def _run_leg(args, rank, world, dev):
     opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
     if args.precision == 'fp16':   # the reference's O2 recipe: fp16 storage + dynamic loss scaling (transporter.py:51,84-86)
         opt.scaler = ka.amp.LossScaler(dev)
-    reducer = GradReducer(net, overlap=bool(args.dp_overlap), comm=args.comm) if world > 1 else None
+    reducer = GradReducer(net, overlap=bool(args.dp_overlap), comm=args.comm, reserve_cus=args.reserve_cus) if world > 1 else None
+    if world == 1 and args.grid_cus:   # (single-GPU measurement of what a reduced persistent grid costs: the overlap mode's compute side)
+        _lib.call('kp_config', _lib.KP_CFG_CUS, args.grid_cus)
 
     g = torch.Generator().manual_seed(1234 + rank)
     B = args.batch
@@ -343,7 +354,8 @@ def _run_leg(args, rank, world, dev):
     dp = None
     if reducer is not None:
         exposed = reducer.exposed_ms()
-        dp = dict(nccl_ranks=reducer.ranks_seen(), backend=args.backend, comm=args.comm,
+        dp = dict(nccl_ranks=reducer.ranks_seen(), backend=args.backend, comm=args.comm, grid_cus=reducer.grid_cus, reserve_cus=reducer.reserve_cus,
+                  nccl_max_nchannels=os.environ.get('NCCL_MAX_NCHANNELS'),
                   gradient_bytes_per_step=4 * sum(u.grad_arena().flat.numel() for u in reducer.units),
                   exposed_allreduce_ms_median=med(sorted(exposed)) if exposed else None,
                   exposed_allreduce_ms_max=max(exposed) if exposed else None,
@@ -360,7 +372,7 @@ def _run_leg(args, rank, world, dev):
             dp['modes'][f'dp_overlap_{ov}'] = dict(ms_per_step=1e3 * el / args.steps, ms_per_step_median_hipevent=med(sm),
                                                    value=B * world / (el / args.steps),
                                                    exposed_allreduce_ms_median=med(sorted(ex)) if ex else None,
-                                                   collectives_per_step=reducer.collectives_last_finish)
+                                                   collectives_per_step=reducer.collectives_last_finish, grid_cus=reducer.grid_cus)
         reducer.overlap = bool(args.dp_overlap)
         reducer.time_finish(False)
 
@@ -519,7 +531,7 @@ def _run_leg(args, rank, world, dev):
                                          f'{B} pairs/GPU ({config_name(args)}), '
                                          f'{"augment+" if args.net == "keynet" and not args.no_augment else ""}fwd+loss+bwd+Adam',
                                 global_batch=B * world, per_gpu_batch=B, parallelism=f'dp{world}',
-                                dp_overlap=bool(args.dp_overlap) if world > 1 else None, side_streams=bool(args.streams), hip_graph=bool(args.graph),
+                                dp_overlap=bool(args.dp_overlap) if world > 1 else None, grid_cus=(reducer.grid_cus if reducer is not None else (args.grid_cus or None)), side_streams=bool(args.streams), hip_graph=bool(args.graph),
                                 gflop_per_pair=flop_pair / 1e9, loss=float(loss.item()), lib_sha16=lib_sha16, **({'probe_knobs': probe_knobs} if probe_knobs else {})),
                     roofline=roofline)
         if dp is not None:
@@ -629,6 +641,8 @@ def main():
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.dp_overlap and args.reserve_cus > 0:   # RCCL's channel workgroups fit the CUs the persistent kernels leave free
+            os.environ.setdefault('NCCL_MAX_NCHANNELS', str(args.reserve_cus))
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:

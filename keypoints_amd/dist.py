@@ -88,11 +88,18 @@ class NativeComm:
 
 class GradReducer:
     def __init__(self, root: torch.nn.Module, group=None, broadcast_init: bool = True, tail_fraction: float = 0.6,
-                 transport: str = 'fp32', overlap: bool = True, sync_bn: bool = False, comm: str = 'torch'):
+                 transport: str = 'fp32', overlap: bool = True, sync_bn: bool = False, comm: str = 'torch', reserve_cus: int = 16):
         """overlap: True -- pieces are all-reduced from the backward hooks, concurrently with the rest of the backward;
         False -- the hooks only note which arenas are final and `finish()` reduces them back to back (the exchange is then
         fully exposed, ~1 ms for model F over xGMI, but no RCCL kernel ever shares the CUs with the persistent MFMA
-        kernels, whose tile partition is static: see DESIGN.md section 6).
+        kernels, whose tile partition is static: see DESIGN.md section 7).
+        reserve_cus: while overlap is True the persistent kernels of this process size their grids to `device CUs - reserve_cus`
+        (kp_config(KP_CFG_CUS): a FIXED grid, so tile lists and BatchNorm statistics rows stay a pure function of the
+        configuration -- data bit-identical to the full grid, statistics equal up to the order of fp32 additions), which leaves
+        that many CUs -- 2 per XCD at the default 16 -- permanently free for RCCL's channel workgroups: a collective that starts in
+        the middle of a persistent launch finds CUs of its own instead of queueing workgroups of the NEXT launch behind it.  Cap
+        RCCL to as many channels (`NCCL_MAX_NCHANNELS=<reserve_cus>` in the launcher's environment, before the communicator is
+        created: bench.py --dp-overlap 1 does).  0 = the whole device for the kernels (round 4's behaviour).
         transport: 'fp32' (exact mean of the fp32 gradients) or 'bf16' (each piece is rounded to bf16 for the wire
         and the reduction: half the xGMI bytes, gradient error 2^-9 relative per element -- SURVEY.md 8e option).
         comm: 'torch' -- the all-reduces go through torch.distributed (ProcessGroupNCCL = RCCL on ROCm, or gloo);
@@ -108,7 +115,10 @@ class GradReducer:
         self.group = group
         self.world = dist.get_world_size(group)
         self.transport = transport
-        self.overlap = overlap
+        self.reserve_cus = max(0, int(reserve_cus))
+        self.grid_cus = None     # CU budget of the persistent kernels while overlap is on (None: the whole device)
+        self._overlap = False
+        self.overlap = overlap   # (property: reserves / releases the CUs)
         self._ready = []     # overlap=False: arena slices noted by the hooks, reduced in finish()
         self.units: List[Unit] = [m for m in root.modules() if isinstance(m, Unit)]
         self._pending = []   # (work, fp32 arena slice, wire tensor or None)
@@ -131,6 +141,24 @@ class GradReducer:
             u.layer_done = self._on_layer_done
             u.sync_bn = (group, self.world) if sync_bn and self.world > 1 else None
             self._split[id(u)] = self._choose_split(u, tail_fraction)
+
+    @property
+    def overlap(self) -> bool:
+        return self._overlap
+
+    @overlap.setter
+    def overlap(self, on: bool) -> None:
+        on = bool(on)
+        p0 = next(self.root.parameters(), None)
+        on_device = p0 is not None and p0.is_cuda   # (the CPU / gloo tests of the bookkeeping have no library knob to set)
+        self.grid_cus = None
+        if on and self.reserve_cus > 0 and on_device:
+            total = torch.cuda.get_device_properties(p0.device).multi_processor_count
+            # a multiple of the 8 XCDs (the persistent kernels round their grids down to one anyway), never below one CU per XCD
+            self.grid_cus = max(8, (total - self.reserve_cus) // 8 * 8)
+        if on_device:
+            _lib.call('kp_config', _lib.KP_CFG_CUS, self.grid_cus or 0)
+        self._overlap = on
 
     @staticmethod
     def _choose_split(unit, tail_fraction):
@@ -310,6 +338,7 @@ class GradReducer:
         dist.barrier(group=self.group)
 
     def detach(self) -> None:
+        self.overlap = False   # (gives the reserved CUs back to the persistent kernels)
         if self.native is not None:
             self.native.close()
             self.native = None

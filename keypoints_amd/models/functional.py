@@ -45,12 +45,12 @@ class _SpatialSoftmax(torch.autograd.Function):
 
 
 def spacial_logsoftmax(heatmap, probs=False):
-    k, p, q = _SpatialSoftmax.apply(heatmap, True)
+    k, p, q = _SpatialSoftmax.apply(unlazy(heatmap), True)
     return (k, (p, q)) if probs else k
 
 
 def spacial_softmax(heatmap, probs=False):
-    k, p, q = _SpatialSoftmax.apply(heatmap, False)
+    k, p, q = _SpatialSoftmax.apply(unlazy(heatmap), False)
     return (k, (p, q)) if probs else k
 
 
@@ -131,7 +131,7 @@ class _TransportMax(torch.autograd.Function):
 
 def transport_max(phi_s, phi_t, m_s, m_t):
     """phi_s*(1-max_k m_s)*(1-max_k m_t) + phi_t*max_k m_t -> (phi, mask_s, mask_t)."""
-    return _TransportMax.apply(phi_s, phi_t, m_s, m_t)
+    return _TransportMax.apply(unlazy(phi_s), unlazy(phi_t), unlazy(m_s), unlazy(m_t))
 
 
 class _TransportMode(torch.autograd.Function):
@@ -177,6 +177,7 @@ class _TransportMode(torch.autograd.Function):
 def transport(phi_s, phi_t, m_s, m_t, mode):
     """TransporterNet.forward's combine step (transporter.py:41-60) for any `combine_method`
     -> (phi, mask_s, mask_t); gradients flow to all four inputs that require them."""
+    phi_s, phi_t, m_s, m_t = unlazy(phi_s), unlazy(phi_t), unlazy(m_s), unlazy(m_t)
     if mode == 'max':
         return _TransportMax.apply(phi_s, phi_t, m_s, m_t)
     if mode not in ('sum_and_clamp', 'pretrained_network', 'loop'):
@@ -322,6 +323,71 @@ class _PaddedTToNchw(torch.autograd.Function):
 
 def padded_t_to_nchw(a, pad, code):
     return _PaddedTToNchw.apply(a, int(pad), code)
+
+
+class LazyNCHW(torch.Tensor):
+    """The fp32 NCHW image of a padded 16-bit NHWC tensor, made on FIRST USE.
+
+    `TransporterNet.forward` returns the blended feature map (transporter.py:64) next to feeding it to the decoder; on the T route the
+    decoder reads the 16-bit NHWC blend the bottleneck kernel wrote, and the fp32 NCHW copy exists only for the caller.  The
+    reference's train loops look at it when they log images (transporter.py:98-108 through utils), never inside a step -- at 256 x 16 x
+    84 x 84 the copy is 261 MB of HBM traffic per step for nothing.  This object IS a torch.Tensor to the caller (shape, dtype, device,
+    isinstance); the first torch function applied to it (arithmetic, indexing, `.cpu()`, `.data_ptr()`, `backward` ...) runs
+    kp_nhwc_to_nchw on the then-current stream and continues on the real tensor.  Autograd: the conversion is recorded when it runs
+    (`padded_t_to_nchw` is an autograd Function), so a loss on the returned map reaches the encoders like any other -- as long as it is
+    formed before the graph of that forward is freed by a backward, which is when the reference's tensor would have to be used too.
+    keypoints_amd's own entry points (`Unit.forward*`, `l2_reconstruction_loss`, the functional ops) unwrap it explicitly."""
+
+    @staticmethod
+    def __new__(cls, a, pad, code):
+        B, Hp, Wp, C = a.shape
+        return torch.Tensor._make_wrapper_subclass(cls, (B, C, Hp - 2 * pad, Wp - 2 * pad), dtype=torch.float32, device=a.device,
+                                                   requires_grad=False)
+
+    def __init__(self, a, pad, code):
+        self._kp_src = (a, int(pad), code)
+        self._kp_val = None
+
+    def materialize(self) -> torch.Tensor:
+        if self._kp_val is None:
+            a, pad, code = self._kp_src
+            self._kp_val = padded_t_to_nchw(a, pad, code)
+            self._kp_src = None
+        return self._kp_val
+
+    # metadata that is known without the values
+    _META = {'shape', 'dtype', 'device', 'ndim', 'layout', 'is_cuda', 'is_sparse', 'is_quantized', 'is_meta', 'names'}
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, '__name__', '')
+        owner = getattr(func, '__self__', None)
+        if name == '__get__' and getattr(owner, '__name__', None) in cls._META:      # t.shape, t.dtype, t.device ...
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        if func in (torch.Tensor.size, torch.Tensor.dim, torch.Tensor.numel, torch.Tensor.is_floating_point, torch.Tensor.get_device,
+                    torch.Tensor.element_size, torch.Tensor.is_complex):
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        import torch.utils._pytree as pytree
+        unwrap = lambda t: t.materialize() if isinstance(t, LazyNCHW) else t
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*pytree.tree_map(unwrap, args), **pytree.tree_map(unwrap, kwargs))
+
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        # the net under __torch_function__: an ATen operator reached with the wrapper itself (C++ call sites that skip the Python
+        # override) runs on the real tensor as well
+        import torch.utils._pytree as pytree
+        unwrap = lambda t: t.materialize() if isinstance(t, LazyNCHW) else t
+        return func(*pytree.tree_map(unwrap, args), **pytree.tree_map(unwrap, kwargs or {}))
+
+
+def unlazy(t):
+    """A LazyNCHW as its real tensor (anything else unchanged): the entry points of this package call it on their tensor arguments."""
+    return t.materialize() if isinstance(t, LazyNCHW) else t
 
 
 def bottleneck_fusable(H, W, C):

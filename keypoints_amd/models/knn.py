@@ -8,7 +8,7 @@ from torch import nn as nn
 
 from ..runtime import default_precision, require_device
 from ..unit_engine import GradArena, UnitFunction, build_plan, pair_ok
-from .functional import gaussian_like_function, spacial_logsoftmax, spacial_softmax
+from .functional import gaussian_like_function, spacial_logsoftmax, spacial_softmax, unlazy
 
 
 class Container(nn.Module):
@@ -112,6 +112,7 @@ class Unit(nn.Module):
             self.layer_done(self, idx)
 
     def forward(self, x):
+        x = unlazy(x)
         require_device(x)
         params = list(self.parameters())
         record = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
@@ -121,6 +122,7 @@ class Unit(nn.Module):
         """self(torch.cat((x, x2), dim=1)) without forming the concatenated tensor (KeyNet.forward, keynet.py:29: the decoder reads
         the encoder's z and the Gaussian maps m): the first layer's layout kernel reads both sources, the backward splits the input
         gradient.  Same values as the cat + forward."""
+        x, x2 = unlazy(x), unlazy(x2)
         require_device(x, x2)
         params = list(self.parameters())
         record = torch.is_grad_enabled() and (x.requires_grad or x2.requires_grad or any(p.requires_grad for p in params))
@@ -130,6 +132,7 @@ class Unit(nn.Module):
         """-> (self(xs) under no_grad, self(x)): the two calls TransporterNet.forward makes per encoder (transporter.py:36-39), as one
         batch with per-half BatchNorm statistics where the library has the pair kernels (unit_engine.pair_ok: bit-identical to the
         two calls), else as the two calls.  out_t: the outputs in the 16-bit NHWC interchange format (see forward_t)."""
+        xs, x = unlazy(xs), unlazy(x)
         require_device(xs, x)
         if (torch.is_tensor(xs) and torch.is_tensor(x) and xs.shape == x.shape and x.dim() == 4
                 and pair_ok(self, x.size(0), x.size(1), x.size(2), x.size(3), out_t)):
@@ -143,6 +146,7 @@ class Unit(nn.Module):
     def forward_t(self, x, in_t=False, out_t=False):
         """`forward` with the 16-bit NHWC interchange formats of include/kp_hip.h at either end (UnitFunction.forward): what
         TransporterNet uses between the feature encoder, the keypoint bottleneck and the decoder where the library has the kernels."""
+        x = unlazy(x)
         require_device(x)
         params = list(self.parameters())
         record = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))

@@ -91,6 +91,11 @@ class TransporterNet(knn.Container):
             # blend that forward() also returns is made beside the decoder, on a side stream
             a, k_xt, p_xt, m_xt, mask_xs, mask_xt = MF.keypoint_bottleneck_t(
                 heatmap_xs, heatmap_xt, phi_xs, phi_xt, tcode, sigma=self.key2map.sigma)
+            if runtime.lazy_outputs():
+                # ... made when the caller first looks at it (MF.LazyNCHW): inside a train step nobody does (transporter.py:80-89)
+                phi = MF.LazyNCHW(a, 1, tcode)
+                x_t = self.decoder.forward_t(a, in_t=True)
+                return x_t, phi, k_xt, m_xt, p_xt, heatmap_xt, mask_xs, mask_xt
             with runtime.fork('aux', a) as side:
                 with side:
                     phi = MF.padded_t_to_nchw(a, 1, tcode)

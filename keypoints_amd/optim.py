@@ -54,6 +54,8 @@ class _L2Loss(torch.autograd.Function):
 
 def l2_reconstruction_loss(x, x_, loss_mask=None):
     """mean((x - x_)^2 [* loss_mask]); gradient flows to `x` only (x_ is data)."""
+    from .models.functional import unlazy
+    x, x_, loss_mask = unlazy(x), unlazy(x_), unlazy(loss_mask)
     return _L2Loss.apply(x, x_.detach(), loss_mask)
 
 

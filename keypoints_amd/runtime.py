@@ -246,3 +246,19 @@ def pair_calls() -> bool:
 def set_pair_calls(on: bool) -> None:
     global _PAIR_CALLS
     _PAIR_CALLS = bool(on)
+
+
+_LAZY_OUTPUTS = True
+
+
+def lazy_outputs() -> bool:
+    """TransporterNet.forward's T route returns the blended feature map (transporter.py:64) as a `functional.LazyNCHW`: a torch.Tensor
+    whose fp32 NCHW values are produced by kp_nhwc_to_nchw on first use instead of in every forward (261 MB of traffic per step at
+    config 2 for a tensor the train loop only looks at when it logs images).  `set_lazy_outputs(False)` makes the copy eagerly, on a
+    side stream beside the decoder, as round 4 did."""
+    return _LAZY_OUTPUTS
+
+
+def set_lazy_outputs(on: bool) -> None:
+    global _LAZY_OUTPUTS
+    _LAZY_OUTPUTS = bool(on)

@@ -53,7 +53,9 @@ def test_grad_reducer_nccl_world1_real_backward(nccl_world1, transport):
         torch.manual_seed(11)
         net = transporter.make('F', 3, 64, 10).cuda().set_precision('bf16')
         opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
-        red = GradReducer(net, transport=transport) if with_dp else None
+        # (reserve_cus=0: the persistent kernels keep the whole device, so that the DP step can be compared BIT FOR BIT with the
+        #  non-DP one; the reduced grid of the default overlap mode has its own test below)
+        red = GradReducer(net, transport=transport, reserve_cus=0) if with_dp else None
         if red is not None:
             assert all(red._split[id(u)] is not None for u in red.units)      # model F: every Unit sends its tail early
         for _ in range(2):
@@ -170,7 +172,7 @@ def test_native_comm_world1(nccl_world1):
         torch.manual_seed(11)
         net = transporter.make('F', 3, 64, 10).cuda().set_precision('bf16')
         opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
-        red = GradReducer(net, comm='native', overlap=(mode == 'overlap')) if mode else None
+        red = GradReducer(net, comm='native', overlap=(mode == 'overlap'), reserve_cus=0) if mode else None   # (full grid: bitwise comparison)
         for _ in range(2):
             loss, issued = _step(net, opt, xs, xt, red)
         if red is not None:
@@ -182,3 +184,96 @@ def test_native_comm_world1(nccl_world1):
     for other in nets[1:]:
         for (n, a), (_, b) in zip(nets[0].named_parameters(), other.named_parameters()):
             assert torch.equal(a, b), n
+
+
+def test_overlap_mode_runs_the_persistent_kernels_on_a_fixed_reduced_grid(nccl_world1):
+    """GradReducer(overlap=True) leaves `reserve_cus` CUs to RCCL: the persistent kernels size their grids to a FIXED budget
+    (kp_config(KP_CFG_CUS) = device CUs - 16, a multiple of the 8 XCDs), restored by overlap=False / detach().  With the reduced grid
+    every convolution output and data gradient is bit-identical to the full grid's (a tile's arithmetic does not depend on which
+    workgroup runs it); BatchNorm statistics and weight gradients are sums over another fixed partition: equal up to the order of
+    fp32 additions; the step is still bitwise reproducible on the reduced grid; one whole step agrees with the full grid's to
+    storage rounding."""
+    import keypoints_amd as ka
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.dist import GradReducer
+    from keypoints_amd.models import transporter
+    from keypoints_amd.runtime import precision_dtype, stream_ptr
+    L = _lib.lib()
+    total = torch.cuda.get_device_properties(0).multi_processor_count
+    assert L.kp_device_cus() == total
+    torch.manual_seed(5)
+    net = transporter.make('F', 3, 64, 10).cuda().set_precision('fp16')
+    red = GradReducer(net, overlap=True)
+    want = (total - 16) // 8 * 8
+    assert red.grid_cus == want and L.kp_device_cus() == want
+    red.overlap = False
+    assert red.grid_cus is None and L.kp_device_cus() == total
+    red.overlap = True
+    assert L.kp_device_cus() == want
+    red.detach()
+    assert L.kp_device_cus() == total
+
+    # ---- op level, through the C ABI: one layer of model F at the bench's shape, full grid vs reduced grid
+    tdt, code = precision_dtype('fp16')
+    N, H, W, C, K = 32, 64, 64, 128, 256
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(N, H + 2, W + 2, C, generator=g).cuda().to(tdt)
+    wf = (torch.randn(K, 3, 3, C, generator=g) * 0.05).cuda().to(tdt)
+    wd = (torch.randn(C, 3, 3, K, generator=g) * 0.05).cuda().to(tdt)
+    bias = torch.randn(K, generator=g).cuda()
+    dy = torch.zeros(N, H + 4, W + 4, K, device='cuda', dtype=tdt)
+    dy[:, 2:-2, 2:-2] = torch.randn(N, H, W, K, generator=g).cuda().to(tdt)
+    st = stream_ptr()
+    res = {}
+    for cus in (0, want):
+        call('kp_config', _lib.KP_CFG_CUS, cus)
+        try:
+            y = torch.full((N, H, W, K), float('nan'), device='cuda', dtype=tdt)
+            rows = L.kp_conv_fwd_stats_rows(N, H + 2, W + 2, C, K, 3, code)
+            stats = torch.zeros((N * H * W + 63) // 64, 2, K, device='cuda')
+            call('kp_conv_fwd', ptr(a), ptr(wf), ptr(bias), ptr(y), ptr(stats), N, H + 2, W + 2, C, K, 3, code, st)
+            mean, invstd = torch.empty(K, device='cuda'), torch.empty(K, device='cuda')
+            ws = torch.empty(128 * K, device='cuda', dtype=torch.float64)
+            call('kp_bn_finalize', ptr(stats), rows, ptr(ws), ptr(mean), ptr(invstd), None, None, None, 0.1, 1e-5, N * H * W, K, st)
+            gx = torch.full((N, H + 2, W + 2, C), float('nan'), device='cuda', dtype=tdt)
+            call('kp_conv_dgrad', ptr(dy), ptr(wd), ptr(gx), N, H, W, K, C, code, st)
+            parts = L.kp_conv_wgrad_partials(N, H, W, C, K, 3, 2, code)
+            scratch = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device='cuda')
+            call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, W, C, K, 3, 2, code, st)
+            dw = torch.zeros(K, C, 3, 3, device='cuda')
+            call('kp_wgrad_unpack', ptr(scratch), parts, ptr(dw), K, C, C, 3, st)
+            torch.cuda.synchronize()
+            res[cus] = (y, gx, mean, invstd, dw, rows)
+        finally:
+            call('kp_config', _lib.KP_CFG_CUS, 0)
+    (y0, gx0, m0, i0, dw0, r0), (y1, gx1, m1, i1, dw1, r1) = res[0], res[want]
+    assert torch.equal(y0, y1) and torch.equal(gx0, gx1)                       # data: bit for bit
+    assert float((m0 - m1).abs().max()) <= 1e-6 * float(m0.abs().max()) + 1e-7   # statistics: summation order
+    assert float((i0 / i1 - 1).abs().max()) <= 1e-6
+    assert float((dw0 - dw1).abs().max()) <= 2e-6 * float(dw0.abs().max())
+
+    # ---- one whole train step on the reduced grid: reproducible bit for bit, and equal to the full grid's to storage rounding
+    g = torch.Generator().manual_seed(3)
+    xs = torch.rand(16, 3, 128, 128, generator=g).cuda()
+    xt = torch.rand(16, 3, 128, 128, generator=g).cuda()
+    outs = []
+    for cus in (0, want, want):
+        call('kp_config', _lib.KP_CFG_CUS, cus)
+        try:
+            torch.manual_seed(11)
+            net = transporter.make('F', 3, 64, 10).cuda().set_precision('bf16')
+            opt = ka.FusedAdam(net.parameters(), lr=1e-4).bind(net)
+            opt.zero_grad()
+            out = net(xs, xt)
+            loss = ka.l2_reconstruction_loss(out[0], xt)
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize()
+            outs.append((float(loss), out[0].detach().clone(), [p.detach().clone() for p in net.parameters()]))
+        finally:
+            call('kp_config', _lib.KP_CFG_CUS, 0)
+    (l0, x0, p0), (l1, x1, p1), (l2, x2, p2) = outs
+    assert l1 == l2 and torch.equal(x1, x2) and all(torch.equal(a_, b_) for a_, b_ in zip(p1, p2))    # reduced grid: reproducible
+    assert abs(l0 - l1) <= 1e-4 * abs(l0)
+    assert float((x0 - x1).norm() / x0.norm()) <= 5e-3     # (bf16 storage: a statistic's last bit flips single roundings)

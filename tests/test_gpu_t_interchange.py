@@ -293,3 +293,36 @@ def test_training_through_the_t_route_follows_the_fp32_plane_route():
     assert a[-1] < 0.1 * a[0] and b[-1] < 0.1 * b[0], (a[0], a[-1], b[0], b[-1])
     worst = max(abs(x - y) / y for x, y in zip(a, b))
     assert worst <= 0.12, worst
+
+
+def test_returned_blend_is_made_on_first_use_and_equals_the_eager_copy():
+    """forward()'s second output on the T route is a functional.LazyNCHW: a torch.Tensor by every test a caller can make (isinstance,
+    shape, dtype, device) whose values appear at first use -- bit-identical to the eager copy of set_lazy_outputs(False), usable after
+    the step's backward (logging), in arithmetic with other tensors, and as the input of another Unit."""
+    import keypoints_amd as ka
+    from keypoints_amd.models import functional as MF
+    from keypoints_amd.optim import l2_reconstruction_loss
+    g = torch.Generator().manual_seed(23)
+    xs = torch.rand(4, 1, 84, 84, generator=g).cuda()
+    xt = torch.rand(4, 1, 84, 84, generator=g).cuda()
+    vals = []
+    for lazy in (True, False):
+        ka.set_lazy_outputs(lazy)
+        try:
+            net = _pong_net('bf16')
+            out = net(xs, xt)
+            phi = out[1]
+            assert isinstance(phi, torch.Tensor) and (type(phi) is MF.LazyNCHW) == lazy
+            assert phi.shape == (4, 16, 84, 84) and phi.dtype == torch.float32 and phi.device == xs.device and phi.dim() == 4
+            if lazy:
+                assert phi._kp_val is None                      # nothing has been computed for it yet
+            l2_reconstruction_loss(out[0], xt).backward()       # the train step never touches it
+            if lazy:
+                assert phi._kp_val is None
+            vals.append((phi.detach().cpu(), (phi * 2 + 1).sum().item(), float(phi[1, 2, 3, 4]), net.decoder(phi).detach().cpu()))
+            if lazy:
+                assert phi._kp_val is not None and phi._kp_src is None
+        finally:
+            ka.set_lazy_outputs(True)
+    (a0, s0, e0, d0), (a1, s1, e1, d1) = vals
+    assert torch.equal(a0, a1) and s0 == s1 and e0 == e1 and torch.equal(d0, d1)

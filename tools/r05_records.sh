@@ -65,7 +65,7 @@ man = dict(tag=T, lib_sha16=SHA, lib_sha256=hashlib.sha256(open('keypoints_amd/c
            gpu=subprocess.run(['bash', '-c', 'rocminfo | grep -m1 "Marketing Name:.*MI" || true'], capture_output=True, text=True).stdout.strip(),
            files={os.path.basename(f): hashlib.sha256(open(f, 'rb').read()).hexdigest()[:16] for f in files})
 # the bench line's per-launch time of the dominant family (HIP events, one-stream profile steps) against rocprofv3's of the same
-# kernels in the --streams 0 trace: profiled passes clock 2.5-7 % lower (MI355X_MICROARCH.md), so `rocprof_over_bench` > 1 is expected
+# kernels in the --streams 0 trace: profiled passes clock 2.5-7 % lower (MI355X_MICROARCH.md), so rocprof_over_bench > 1 is expected
 import csv, re
 def fam_ms(path, pat, steps):
     tot = sum(float(r['TotalDurationNs']) for r in csv.DictReader(open(path)) if re.search(pat, r['Name']))
