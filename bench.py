@@ -58,7 +58,7 @@ def parse():
                     help='N > 1: 1 = all-reduce each gradient piece from the backward hooks (overlapped with the backward); '
                          '0 (default) = reduce the arenas back to back after the backward: ~1 ms exposed, but no RCCL kernel '
                          'shares CUs with the statically partitioned persistent MFMA kernels (DESIGN.md section 6)')
-    ap.add_argument('--reserve-cus', type=int, default=16,
+    ap.add_argument('--reserve-cus', type=int, default=32,
                     help='N > 1 with --dp-overlap 1: CUs the persistent kernels leave free for RCCL (a fixed grid of device CUs minus '
                          'this; NCCL_MAX_NCHANNELS is set to the same number unless the environment already has it)')
     ap.add_argument('--grid-cus', type=int, default=0,

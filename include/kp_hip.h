@@ -138,6 +138,36 @@ int kp_nchw2_to_nhwc(const float* src0, int C0, const float* src1, int C1, void*
 int kp_nhwc_grad_to_nchw2(const void* gsrc, float* dst0, int C0, float* dst1, int C1, int N, int Cp, int H, int W, int pad, int dtype,
                           void* stream);
 
+/* ---- the image-sized first layer with its conv output recomputed, not stored ---------------------------------------------------
+ * A Unit's first layer -- ReplicationPad2d(1) + Conv2d(Cin <= 3 -> 64, 3x3) + BatchNorm2d (train) + LeakyReLU, knn.py:115-119 -- is bound
+ * by streaming its [N][H][W][64] output, which the plain entry points move five times per call (kp_conv_fwd writes y; kp_bn_act_fwd
+ * reads it and writes the next layer's input; both BatchNorm-backward passes read it again; the weight gradient reads dy).  The input
+ * image is 48 x smaller and 27 x 64 MACs per pixel are four MFMAs per 32 pixels: these entry points RECOMPUTE y wherever it is needed,
+ * and neither y nor dy ever exists in memory.  x [N][H+2][W+2][C] is the padded image in the storage type (kp_nchw_to_nhwc), w the
+ * forward pack [64][3][3][C] (kp_pack_weights); every call streams at most one 64-channel tensor.
+ *   kp_conv_first_stats      == the statistics of kp_conv_fwd(x, w, bias, stats): rows = kp_conv_first_fused_rows, each [2][64]
+ *   kp_conv_first_fwd_bnact  == kp_conv_fwd + kp_bn_act_fwd(tail none, out_pad 1): a_out [N][H+2][W+2][64] with its replicate border;
+ *                               bit-identical to the two calls given the same mean / invstd
+ *   kp_conv_first_bwd_reduce == kp_bn_act_bwd_reduce(g, gp = 1, tail none, y = conv(x)): rows = kp_conv_first_fused_rows of [2][64]
+ *                               for kp_bn_bwd_finalize; g = dL/da over the padded domain [N][H+2][W+2][64] (kp_conv_dgrad of the layer above)
+ *   kp_conv_first_bwd_wgrad  == kp_bn_act_bwd_apply + kp_conv_wgrad: scratch = kp_conv_first_fused_rows partial gradients [64][3][3][C]
+ *                               for kp_wgrad_unpack; sums = kp_bn_bwd_finalize's [2][64].  (The image needs no gradient: no data gradient.)
+ * Same arithmetic on the same rounded values as the calls they replace (y and dy rounded to the storage type where those store
+ * them); the partition of the sums differs: equal up to the order of fp32 additions.  16-bit storage, K == 64, C <= 3, W % 32 == 0;
+ * otherwise kp_conv_first_fused_supported is 0 and the calls return KP_E_UNSUPPORTED without launching. */
+int kp_conv_first_fused_supported(int N, int H, int W, int C, int K, int dtype);
+long long kp_conv_first_fused_rows(int N, int H, int W, int C, int K, int dtype);
+int kp_conv_first_stats(const void* x, const void* w, const float* bias, float* stats, int N, int H, int W, int C, int K, int dtype,
+                        void* stream);
+int kp_conv_first_fwd_bnact(const void* x, const void* w, const float* bias, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, float slope, void* a_out, int N, int H, int W, int C, int K, int dtype, void* stream);
+int kp_conv_first_bwd_reduce(const void* g, const void* x, const void* w, const float* bias, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, float slope, float* partials, int N, int H, int W, int C, int K,
+                             int dtype, void* stream);
+int kp_conv_first_bwd_wgrad(const void* g, const void* x, const void* w, const float* bias, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, float slope, const float* sums, float* scratch, int N, int H, int W,
+                            int C, int K, int dtype, void* stream);
+
 /* ---- weights ----------------------------------------------------------- */
 /* fp32 [K][C][R][R] (nn.Conv2d.weight) -> T [K][R][R][Cp] (forward operand) and,
  * if w_dgrad != NULL, T [Cp][R][R][K] with the taps flipped (dgrad operand); channels C..Cp-1 are zero. */

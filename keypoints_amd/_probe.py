@@ -56,6 +56,8 @@ def apply_env(env=None) -> list:
         no_prepack(); used.append('KP_NO_PREPACK')
     if env.get('KP_SMALL_SIDE'):
         small_wgrad_on_side_stream(); used.append('KP_SMALL_SIDE')
+    if env.get('KP_EAGER_BLEND'):
+        runtime.set_lazy_outputs(False); used.append('KP_EAGER_BLEND')
     if 'wgrad' in env.get('KP_ABLATE', '').split(','):
         ablate_wgrad(); used.append('KP_ABLATE=wgrad')
     return used

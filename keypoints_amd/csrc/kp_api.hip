@@ -208,6 +208,15 @@ KP_DISPATCH(kp_nchw2_to_nhwc, (const float* src0, int C0, const float* src1, int
             (src0, C0, src1, C1, dst, N, Cp, H, W, pad, dtype, stream))
 KP_DISPATCH(kp_nhwc_grad_to_nchw2, (const void* gsrc, float* dst0, int C0, float* dst1, int C1, int N, int Cp, int H, int W, int pad, int dtype, void* stream),
             (gsrc, dst0, C0, dst1, C1, N, Cp, H, W, pad, dtype, stream))
+KP_DISPATCH(kp_conv_first_fused_supported, (int N, int H, int W, int C, int K, int dtype), (N, H, W, C, K, dtype))
+KP_DISPATCH(kp_conv_first_stats, (const void* x, const void* w, const float* bias, float* stats, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (x, w, bias, stats, N, H, W, C, K, dtype, stream))
+KP_DISPATCH(kp_conv_first_fwd_bnact, (const void* x, const void* w, const float* bias, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, void* a_out, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (x, w, bias, mean, invstd, gamma, beta, slope, a_out, N, H, W, C, K, dtype, stream))
+KP_DISPATCH(kp_conv_first_bwd_reduce, (const void* g, const void* x, const void* w, const float* bias, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, float* partials, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (g, x, w, bias, mean, invstd, gamma, beta, slope, partials, N, H, W, C, K, dtype, stream))
+KP_DISPATCH(kp_conv_first_bwd_wgrad, (const void* g, const void* x, const void* w, const float* bias, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, const float* sums, float* scratch, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (g, x, w, bias, mean, invstd, gamma, beta, slope, sums, scratch, N, H, W, C, K, dtype, stream))
 KP_DISPATCH(kp_pack_weights, (const float* w, void* w_fwd, void* w_dgrad, int K, int C, int Cp, int R, int dtype, void* stream),
             (w, w_fwd, w_dgrad, K, C, Cp, R, dtype, stream))
 KP_DISPATCH(kp_pack_weights_batch, (int n, const float* const* w, void* const* w_fwd, void* const* w_dgrad, const int* K, const int* C, const int* Cp, int dtype, void* stream),
@@ -302,6 +311,12 @@ int kp_keypoint_bottleneck_bwd_t(const void* ga, const float* g_k, const float* 
         : kp_keypoint_bottleneck_bwd_t__bf16(ga, g_k, g_m, phi_s, phi_t, mask_s, mask_t, arg_t, k_t, p_t, q_t, d_phi_t, d_heat_t, B, C, K, H, W, sigma, eps, dtype, stream);
     ps.done(KP_PROF_BOTTLENECK);
     return rc;
+}
+
+long long kp_conv_first_fused_rows__bf16(int, int, int, int, int, int);
+long long kp_conv_first_fused_rows__f16(int, int, int, int, int, int);
+long long kp_conv_first_fused_rows(int N, int H, int W, int C, int K, int dtype) {
+    return dtype == KP_F16 ? kp_conv_first_fused_rows__f16(N, H, W, C, K, dtype) : kp_conv_first_fused_rows__bf16(N, H, W, C, K, dtype);
 }
 
 long long kp_head_bwd_ws_floats__bf16(int, int, int, int, int, int);

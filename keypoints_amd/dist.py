@@ -88,7 +88,7 @@ class NativeComm:
 
 class GradReducer:
     def __init__(self, root: torch.nn.Module, group=None, broadcast_init: bool = True, tail_fraction: float = 0.6,
-                 transport: str = 'fp32', overlap: bool = True, sync_bn: bool = False, comm: str = 'torch', reserve_cus: int = 16):
+                 transport: str = 'fp32', overlap: bool = True, sync_bn: bool = False, comm: str = 'torch', reserve_cus: int = 32):
         """overlap: True -- pieces are all-reduced from the backward hooks, concurrently with the rest of the backward;
         False -- the hooks only note which arenas are final and `finish()` reduces them back to back (the exchange is then
         fully exposed, ~1 ms for model F over xGMI, but no RCCL kernel ever shares the CUs with the persistent MFMA
@@ -96,10 +96,13 @@ class GradReducer:
         reserve_cus: while overlap is True the persistent kernels of this process size their grids to `device CUs - reserve_cus`
         (kp_config(KP_CFG_CUS): a FIXED grid, so tile lists and BatchNorm statistics rows stay a pure function of the
         configuration -- data bit-identical to the full grid, statistics equal up to the order of fp32 additions), which leaves
-        that many CUs -- 2 per XCD at the default 16 -- permanently free for RCCL's channel workgroups: a collective that starts in
+        that many CUs -- 4 per XCD at the default 32 -- permanently free for RCCL's channel workgroups: a collective that starts in
         the middle of a persistent launch finds CUs of its own instead of queueing workgroups of the NEXT launch behind it.  Cap
         RCCL to as many channels (`NCCL_MAX_NCHANNELS=<reserve_cus>` in the launcher's environment, before the communicator is
         created: bench.py --dp-overlap 1 does).  0 = the whole device for the kernels (round 4's behaviour).
+        Why 32: measured on one GPU (bench.py --grid-cus, profiles/r05c_grid_cus.txt), model F fp16 step: 256 CUs 33.08 ms, 248
+        34.39, 240 34.06, 224 33.66 -- the tile lists of the BASELINE layers divide evenly over 28 workgroups per XCD and not over
+        30 or 31, so 224 costs 1.8 % where 240 costs 3 %.
         transport: 'fp32' (exact mean of the fp32 gradients) or 'bf16' (each piece is rounded to bf16 for the wire
         and the reduction: half the xGMI bytes, gradient error 2^-9 relative per element -- SURVEY.md 8e option).
         comm: 'torch' -- the all-reduces go through torch.distributed (ProcessGroupNCCL = RCCL on ROCm, or gloo);

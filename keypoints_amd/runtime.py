@@ -262,3 +262,20 @@ def lazy_outputs() -> bool:
 def set_lazy_outputs(on: bool) -> None:
     global _LAZY_OUTPUTS
     _LAZY_OUTPUTS = bool(on)
+
+
+_FUSE_FIRST = True
+
+
+def fuse_first_layer() -> bool:
+    """A Unit's image-sized first layer (Cin <= 3 -> 64, 16-bit storage: model F's encoders) runs on the recompute kernels
+    (kp_conv_first_stats / _fwd_bnact / _bwd_reduce / _bwd_wgrad, include/kp_hip.h): its conv output and its BatchNorm-backward
+    gradient are recomputed from the 48 x smaller image wherever they are needed and never written -- 4 of the 5 passes over the
+    layer's [N][H][W][64] tensor per call are gone.  Same values as the plain sequence up to the order of the fp32 additions in the
+    statistics / backward sums / weight-gradient partials.  `set_fuse_first_layer(False)` restores the plain sequence (A/B, tests)."""
+    return _FUSE_FIRST
+
+
+def set_fuse_first_layer(on: bool) -> None:
+    global _FUSE_FIRST
+    _FUSE_FIRST = bool(on)

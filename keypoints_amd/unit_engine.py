@@ -390,8 +390,33 @@ class UnitFunction(torch.autograd.Function):
             Cl = C                       # logical input channels of this layer (the conv's)
             C = Cp0 if idx == 0 else C   # physical channels of `a`
             wf, wd = packs[idx]
-            y = torch.empty(N, H, W, K, device=dev, dtype=tdt)
             training = bn is not None and bn.training
+            # the image-sized first layer (Cin <= 3 -> 64, model F's encoders) on the recompute kernels: statistics from one pass
+            # over the image, then conv + BatchNorm + activation straight into the next layer's padded input; the conv output is
+            # never written (the backward recomputes it too: kp_conv_first_bwd_*)
+            if (idx == 0 and fin is None and not in_t and C1 == 0 and Cp0 == Cin and training and bn.momentum is not None
+                    and stp['tail'] is None and plan[1]['kind'] == 'conv3' and unit.sync_bn is None and 0.0 <= stp['slope'] <= 1.0
+                    and runtime.fuse_first_layer() and not (record and x.requires_grad)
+                    and _lib.lib().kp_conv_first_fused_supported(N, H, W, Cin, K, code) == 1):
+                srows = _lib.lib().kp_conv_first_fused_rows(N, H, W, Cin, K, code)
+                stats = torch.empty(srows, 2, K, device=dev, dtype=torch.float32)
+                call('kp_conv_first_stats', ptr(a), ptr(wf), ptr(conv.bias), ptr(stats), N, H, W, Cin, K, code, st)
+                mean = torch.empty(K, device=dev, dtype=torch.float32)
+                invstd = torch.empty(K, device=dev, dtype=torch.float32)
+                track = bn.track_running_stats and bn.running_mean is not None
+                ws = torch.empty(128 * K, device=dev, dtype=torch.float64)
+                call('kp_bn_finalize', ptr(stats), srows, ptr(ws), ptr(mean), ptr(invstd),
+                     ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                     ptr(bn.num_batches_tracked) if track else None, float(bn.momentum), float(bn.eps), N * H * W, K, st)
+                a_next = torch.empty(N, H + 2, W + 2, K, device=dev, dtype=tdt)
+                call('kp_conv_first_fwd_bnact', ptr(a), ptr(wf), ptr(conv.bias), ptr(mean), ptr(invstd), ptr(bn.weight), ptr(bn.bias),
+                     stp['slope'], ptr(a_next), N, H, W, Cin, K, code, st)
+                if record:
+                    saved.append(dict(a=a, fin=None, y=None, mean=mean, invstd=invstd, argmax=None, wd=wd, wf=wf, first_fused=True,
+                                      H=H, W=W, C=C, Cl=Cl, K=K))
+                a, fin, C = a_next, None, K
+                continue
+            y = torch.empty(N, H, W, K, device=dev, dtype=tdt)
             stats = torch.empty((N * H * W + 63) // 64, 2, K, device=dev, dtype=torch.float32) if training else None
             if fin is not None:
                 # the previous layer's BatchNorm-apply + activation + replicate pad run on this convolution's staging path
@@ -637,6 +662,24 @@ class UnitFunction(torch.autograd.Function):
             gamma = bn.weight if bn is not None else None
             beta = bn.bias if bn is not None else None
             bn_args = (ptr(sv['mean']), ptr(sv['invstd']), ptr(gamma), ptr(beta))
+            if sv.get('first_fused'):
+                # the recompute form of the first layer's whole backward: two passes over the incoming gradient, the conv output
+                # recomputed from the image in both; dy never exists, the image needs no gradient
+                if gp != 1 or pending_red is not None:
+                    raise RuntimeError('keypoints_amd Unit: the fused first layer expects the padded-domain gradient of the layer above')
+                rows_f = _lib.lib().kp_conv_first_fused_rows(N, H, W, C, K, code)
+                partials = torch.empty(rows_f, 2, K, device=dev, dtype=torch.float32)
+                fargs = (ptr(g), ptr(sv['a']), ptr(sv['wf']), ptr(conv.bias), *bn_args, stp['slope'])
+                call('kp_conv_first_bwd_reduce', *fargs, ptr(partials), N, H, W, C, K, code, st)
+                sums = torch.empty(2 * K, device=dev, dtype=torch.float32)
+                ws = torch.empty(128 * K, device=dev, dtype=torch.float64)
+                call('kp_bn_bwd_finalize', ptr(partials), ptr(ws), rows_f, K, ptr(sums), ptr(gv[id(bn.weight)]), ptr(gv[id(bn.bias)]), st)
+                scratch = torch.empty(rows_f, K, 3, 3, C, device=dev, dtype=torch.float32)
+                call('kp_conv_first_bwd_wgrad', *fargs, ptr(sums), ptr(scratch), N, H, W, C, K, code, st)
+                call('kp_wgrad_unpack', ptr(scratch), rows_f, ptr(gv[id(conv.weight)]), K, sv['Cl'], C, 3, st)
+                g = None
+                unit._layer_done(idx)
+                continue
             if pending_red is not None:   # the layer above left this layer's sums in its data gradient's epilogue (below)
                 partials, prows = pending_red
                 pending_red = None
@@ -673,6 +716,7 @@ class UnitFunction(torch.autograd.Function):
                 # BatchNorm backward -- sums over gx and its conv output -- in this data gradient's epilogue where the kernel exists
                 below = plan[idx - 1] if idx > 0 else None
                 if (below is not None and below['kind'] == 'conv3' and below['tail'] is None and runtime.fuse_bn_reduce() and 0.0 <= below['slope'] <= 1.0
+                        and not saved[idx - 1].get('first_fused')   # (that layer's sums need ITS conv output, which was never stored)
                         and _lib.lib().kp_conv_dgrad_bnred_supported(N, H, W, K, C, code) == 1):
                     svb, bnb = saved[idx - 1], below['bn']
                     rows_b = _lib.lib().kp_conv_dgrad_bnred_rows(N, H, W, K, C, code)
