@@ -86,6 +86,7 @@ int kp_config(int key, int value);
                                  gradient has 64 output channels per tile (C % 128 != 0: a gain); 2: for 128-channel tiles too (measured slower: register
                                  spills); 0: only for the 16/32-channel layers */
 #define KP_CFG_SMALL_BAND 7   /* 1 (default): LDS-staged weight gradient of the 16/32-channel layers where a band of rows fits; 0: gather kernel */
+#define KP_CFG_FIRST_KTN 10  /* kp_conv_first_fwd_bnact: 2 (default) one wavefront computes all 64 channels of its groups (66 us at 128 x 128 x 128: the plain convolution's time); 1: a pair of wavefronts, 32 channels each (75 us) */
 #define KP_CFG_CUS 6          /* CU budget the persistent kernels size their grids to (launches on a CU-masked stream); 0 = whole device */
 #define KP_CFG_TRACE 2        /* device buffer of 512 int64: s_memtime stamps of workgroup 0 of the patch conv kernel */
 int kp_config_ptr(int key, void* value);

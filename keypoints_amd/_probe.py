@@ -56,6 +56,11 @@ def apply_env(env=None) -> list:
         no_prepack(); used.append('KP_NO_PREPACK')
     if env.get('KP_SMALL_SIDE'):
         small_wgrad_on_side_stream(); used.append('KP_SMALL_SIDE')
+    if env.get('KP_FIRST_KTN'):   # 32-channel blocks per wavefront in kp_conv_first_fwd_bnact (library knob KP_CFG_FIRST_KTN = 10)
+        from ._lib import call
+        call('kp_config', 10, int(env['KP_FIRST_KTN'])); used.append('KP_FIRST_KTN=' + env['KP_FIRST_KTN'])
+    if env.get('KP_NO_FIRST_FUSE'):
+        runtime.set_fuse_first_layer(False); used.append('KP_NO_FIRST_FUSE')
     if env.get('KP_EAGER_BLEND'):
         runtime.set_lazy_outputs(False); used.append('KP_EAGER_BLEND')
     if 'wgrad' in env.get('KP_ABLATE', '').split(','):

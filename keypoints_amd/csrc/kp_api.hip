@@ -22,6 +22,7 @@ kp_knob_t g_kp_small_band{1};    // kp_config(KP_CFG_SMALL_BAND, v)
 kp_knob_t g_kp_bn_fast{1};       // kp_config(KP_CFG_BN_FAST, v)
 kp_knob_t g_kp_bn_flat{1};       // kp_config(KP_CFG_BN_FLAT, v)
 kp_knob_t g_kp_bred_patch{1};    // kp_config(KP_CFG_BRED_PATCH, v)
+kp_knob_t g_kp_first_ktn{2};     // kp_config(KP_CFG_FIRST_KTN, v): 32-channel blocks per wavefront in kp_conv_first_fwd_bnact (2 default, 1)
 // Memory walk order of the passes (kp_common.h: KP_WALK_*; kp_config(KP_CFG_WALK, mask), 0 = every pass front to back):
 // a pass that follows a producer sweeps the producer's output back to front, so that it starts on what is still in the
 // 256 MiB Infinity Cache, and reads what nobody re-reads soon with streaming loads
@@ -103,6 +104,7 @@ int kp_config(int key, int value) {
     if (key == KP_CFG_CUS) { g_kp_cus = value > 0 ? value : 0; return KP_OK; }
     if (key == KP_CFG_BN_FAST) { g_kp_bn_fast = value ? 1 : 0; return KP_OK; }
     if (key == KP_CFG_BN_FLAT) { g_kp_bn_flat = value ? 1 : 0; return KP_OK; }
+    if (key == KP_CFG_FIRST_KTN) { g_kp_first_ktn = value == 1 ? 1 : 2; return KP_OK; }
     if (key == KP_CFG_BRED_PATCH) { g_kp_bred_patch = value < 0 ? 0 : (value > 2 ? 2 : value); return KP_OK; }
     if (key == KP_CFG_WGRAD_PATCH) { g_kp_wgrad_patch = value ? 1 : 0; return KP_OK; }
     if (key == KP_CFG_SMALL_BAND) { g_kp_small_band = value ? 1 : 0; return KP_OK; }
