@@ -56,6 +56,11 @@ def apply_env(env=None) -> list:
         no_prepack(); used.append('KP_NO_PREPACK')
     if env.get('KP_SMALL_SIDE'):
         small_wgrad_on_side_stream(); used.append('KP_SMALL_SIDE')
+    # library-side knobs (kp_config keys of include/kp_hip.h): the library reads no environment variable either
+    for var, key in (('KP_WALK', 5), ('KP_FIN_WIDE', 11), ('KP_DISABLE_MFMA', 12), ('KP_WG16', 13), ('KP_CONV_PATCH', 0)):
+        if env.get(var):
+            from ._lib import call
+            call('kp_config', key, int(env[var], 0)); used.append(f'{var}={env[var]}')
     if env.get('KP_FIRST_KTN'):   # 32-channel blocks per wavefront in kp_conv_first_fwd_bnact (library knob KP_CFG_FIRST_KTN = 10)
         from ._lib import call
         call('kp_config', 10, int(env['KP_FIRST_KTN'])); used.append('KP_FIRST_KTN=' + env['KP_FIRST_KTN'])

@@ -22,15 +22,14 @@ kp_knob_t g_kp_small_band{1};    // kp_config(KP_CFG_SMALL_BAND, v)
 kp_knob_t g_kp_bn_fast{1};       // kp_config(KP_CFG_BN_FAST, v)
 kp_knob_t g_kp_bn_flat{1};       // kp_config(KP_CFG_BN_FLAT, v)
 kp_knob_t g_kp_bred_patch{1};    // kp_config(KP_CFG_BRED_PATCH, v)
+kp_knob_t g_kp_fin_wide{0};      // kp_config(KP_CFG_FIN_WIDE, 1): the 1024-thread statistics finalize for every layer (measurement)
+kp_knob_t g_kp_disable_mfma{0};  // kp_config(KP_CFG_DISABLE_MFMA, 1): every convolution on the generic VALU kernels (measurement / debugging)
+kp_knob_t g_kp_wg16{7};          // kp_config(KP_CFG_WG16, bits): which small-channel weight gradients take the 16 x 16 x 32 kernel
 kp_knob_t g_kp_first_ktn{2};     // kp_config(KP_CFG_FIRST_KTN, v): 32-channel blocks per wavefront in kp_conv_first_fwd_bnact (2 default, 1)
 // Memory walk order of the passes (kp_common.h: KP_WALK_*; kp_config(KP_CFG_WALK, mask), 0 = every pass front to back):
 // a pass that follows a producer sweeps the producer's output back to front, so that it starts on what is still in the
 // 256 MiB Infinity Cache, and reads what nobody re-reads soon with streaming loads
-static int walk_default() {   // KP_WALK=<mask> in the environment overrides the default (A/B runs of whole test files)
-    const char* e = getenv("KP_WALK");
-    return e ? (int)strtol(e, nullptr, 0) : KP_WALK_DEFAULT;
-}
-kp_knob_t g_kp_walk{walk_default()};
+kp_knob_t g_kp_walk{KP_WALK_DEFAULT};   // kp_config(KP_CFG_WALK, mask)
 kp_knob_t g_kp_cus{0};     // kp_config(KP_CFG_CUS, n): CU budget that persistent kernels size their grids to (0 = the whole device)
 kp_knob_t g_kp_debug{0};   // kp_config(KP_CFG_DEBUG, mask): kernel ablation switches for measurements
 
@@ -78,7 +77,7 @@ void kp_prof_event_release(hipEvent_t e) {
     g_event_pool.push_back(e);
 }
 
-kp_knob_t g_kp_conv_patch{-1};   // kp_config(KP_CFG_CONV_PATCH, v); -1 = kp_conv_mfma reads KP_CONV_PATCH from the environment once
+kp_knob_t g_kp_conv_patch{1};    // kp_config(KP_CFG_CONV_PATCH, v): 1 (default) the LDS-patch kernel, 0 linear, 2 pair tile first
 
 extern "C" {
 
@@ -104,6 +103,9 @@ int kp_config(int key, int value) {
     if (key == KP_CFG_CUS) { g_kp_cus = value > 0 ? value : 0; return KP_OK; }
     if (key == KP_CFG_BN_FAST) { g_kp_bn_fast = value ? 1 : 0; return KP_OK; }
     if (key == KP_CFG_BN_FLAT) { g_kp_bn_flat = value ? 1 : 0; return KP_OK; }
+    if (key == KP_CFG_FIN_WIDE) { g_kp_fin_wide = value ? 1 : 0; return KP_OK; }
+    if (key == KP_CFG_DISABLE_MFMA) { g_kp_disable_mfma = value ? 1 : 0; return KP_OK; }
+    if (key == KP_CFG_WG16) { g_kp_wg16 = value & 7; return KP_OK; }
     if (key == KP_CFG_FIRST_KTN) { g_kp_first_ktn = value == 1 ? 1 : 2; return KP_OK; }
     if (key == KP_CFG_BRED_PATCH) { g_kp_bred_patch = value < 0 ? 0 : (value > 2 ? 2 : value); return KP_OK; }
     if (key == KP_CFG_WGRAD_PATCH) { g_kp_wgrad_patch = value ? 1 : 0; return KP_OK; }

@@ -568,7 +568,7 @@ int kp_bn_bwd_fast(int, const void*, int, int, const unsigned char*, const void*
                    const float*, const float*, float, float*, const float*, void*, int, int, int, int, int, hipStream_t);
 int kp_upsample2_bwd_fast(const void*, int, void*, int, int, int, int, hipStream_t);
 extern kp_knob_t g_kp_bn_fast;
-static const int g_kp_fin_wide = getenv("KP_FIN_WIDE") ? atoi(getenv("KP_FIN_WIDE")) : 0;   // measurement: 1 = the 1024-thread finalize for every layer
+extern kp_knob_t g_kp_fin_wide;   // kp_config(KP_CFG_FIN_WIDE, 1): measurement -- the 1024-thread finalize for every layer
 
 extern "C" {
 

@@ -115,15 +115,8 @@ int rows_per_block(long long total_rows, int vec_per_row, int cus, int max_block
 #ifndef KP_BN_REDUCE_BLOCKS
 #define KP_BN_REDUCE_BLOCKS 1024   // (2048 -> 1024: the reduce passes themselves 5-17 % faster at model F shapes, tools/probes/bn_ab3.sh)
 #endif
-// measurement: KP_BN_BLOCKS="fwd,reduce,apply" in the environment overrides the three caps (0 = none) for sweeps without a rebuild
-static int bn_blocks_cap(int which, int dflt) {
-    static int v[3] = {-1, -1, -1};
-    if (v[0] == -1) {
-        v[0] = v[1] = v[2] = -2;
-        if (const char* e = getenv("KP_BN_BLOCKS")) sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
-    }
-    return v[which] >= 0 ? v[which] : dflt;
-}
+// (grid caps of the three pass classes: compile-time constants; -DKP_BN_REDUCE_BLOCKS / -DKP_BN_APPLY_BLOCKS for sweeps)
+static int bn_blocks_cap(int, int dflt) { return dflt; }
 #ifndef KP_BN_APPLY_BLOCKS
 #define KP_BN_APPLY_BLOCKS 0   // (apply / forward passes: no finalize behind them; A/B knob)
 #endif

@@ -51,14 +51,8 @@ int kp_conv_ring_dgrad_bred(const void*, const void*, void*, const void*, const 
 extern kp_knob_t g_kp_bred_patch;   // kp_config(KP_CFG_BRED_PATCH, v): 1 (default) the matrix-core layers' data gradient offers the fused form
 extern kp_knob_t g_kp_wgrad_patch;
 
-static int use_mfma() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("KP_DISABLE_MFMA");
-        v = (e && e[0] == '1') ? 0 : 1;
-    }
-    return v;
-}
+extern kp_knob_t g_kp_disable_mfma;   // kp_config(KP_CFG_DISABLE_MFMA, 1)
+static int use_mfma() { return g_kp_disable_mfma ? 0 : 1; }
 
 extern "C" {
 
@@ -88,7 +82,6 @@ int kp_conv_fwd(const void* x, const void* w, const float* bias, void* y, float*
         int rc = kp_conv_fwd_f32mfma((const float*)x, (const float*)w, bias, (float*)y, stats, N, Hi, Wi, C, K, (hipStream_t)stream);
         if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_F32MFMA); return rc; }
     }
-    if (getenv("KP_LOG_GENERIC")) fprintf(stderr, "generic conv: N=%d Hi=%d Wi=%d C=%d K=%d R=%d dtype=%d stats=%d\n", N, Hi, Wi, C, K, R, dtype, stats != nullptr);
     int rc = kp_conv_fwd_generic(x, w, bias, y, stats, N, Hi, Wi, C, K, R, dtype, (hipStream_t)stream);
     ps.done(KP_PROF_CONV_GENERIC);
     return rc;
@@ -172,7 +165,6 @@ int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, 
         int rc = kp_conv_wgrad_f32mfma((const float*)x, (const float*)dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
         if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_WGRAD_F32MFMA); return rc; }
     }
-    if (getenv("KP_LOG_GENERIC")) fprintf(stderr, "generic wgrad: N=%d Ho=%d Wo=%d C=%d K=%d R=%d dp=%d dtype=%d\n", N, Ho, Wo, C, K, R, dy_pad, dtype);
     int rc = kp_conv_wgrad_generic(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, dtype, (hipStream_t)stream);
     ps.done(KP_PROF_WGRAD_GENERIC);
     return rc;

@@ -453,7 +453,6 @@ long long wgrad_plan(int N, int Ho, int Wo, int C, int K, long long& ppb, int& t
         int cus = kp_device_cus();
         if (cus <= 0) cus = 256;
         slots = (e == hipSuccess && per_cu > 0 ? per_cu : 3) * cus;
-        if (getenv("KP_LOG_GENERIC")) fprintf(stderr, "fp32 wgrad: %d resident workgroups per CU (row3 %d)\n", per_cu, (int)wgrad_row3(Wo, C, K));
     }
     long long splits = slots / tiles;
     if (splits < 1) splits = 1;

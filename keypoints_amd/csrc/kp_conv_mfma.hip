@@ -325,13 +325,10 @@ static int launch_linear(const void* x, const void* w, const float* bias, void* 
     return kp_check_launch("conv3x3_mfma");
 }
 
-extern kp_knob_t g_kp_conv_patch;   // kp_api.hip: kp_config(KP_CFG_CONV_PATCH, v); -1 = read KP_CONV_PATCH from the environment once
-static int patch_mode() {   // 0 forces the linear implicit-GEMM kernel, 1 the first-generation patch kernel (A/B measurements)
-    if (g_kp_conv_patch < 0) {
-        const char* e = getenv("KP_CONV_PATCH");
-        g_kp_conv_patch = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;   // (the pair kernel measured no faster: opt-in)
-    }
-    return g_kp_conv_patch;
+extern kp_knob_t g_kp_conv_patch;   // kp_api.hip: kp_config(KP_CFG_CONV_PATCH, v); 0 the linear implicit-GEMM kernel, 1 (default) the LDS-patch kernel,
+static int patch_mode() {            // 2 its pair-tile generation first (measured equal: opt-in, docs/experiments/notebook_r01-r04.md 3.10)
+    const int v = g_kp_conv_patch;
+    return v < 0 ? 1 : v;
 }
 
 // LDS-patch kernels over a 16x16-tileable window: the pair kernel (kp_conv_pair.hip: two pixel tiles per workgroup, 128 x 64 wave

@@ -24,6 +24,7 @@
 //   wavefronts of a workgroup are summed through LDS, then fp32 atomics into the zeroed scratch.
 #include <type_traits>
 #include "kp_common.h"
+extern kp_knob_t g_kp_wg16;   // kp_api.hip: kp_config(KP_CFG_WG16, bits), default 7
 
 namespace {
 
@@ -1270,7 +1271,6 @@ __global__ __launch_bounds__(w16_waves(K, C, W3) * 64, w16_waves(K, C, W3) == 6 
 bool small_ch(int v) { return v == 16 || v == 32; }
 // measurement: KP_WG16 bits -- 1: the 16 x 16 x 32 kernel at all (0: the 32 x 32 x 16 kernel for every channel pair), 2: for the (32, 32) pair too,
 // 4: three wavefronts with both tiles each for the pairs with one 32-channel side (else six wavefronts with one tile each)
-static const int g_kp_wg16 = getenv("KP_WG16") ? atoi(getenv("KP_WG16")) : 7;
 
 // band plan of the 16 x 16 x 32 weight gradient: rows per band (0: not its shape / the rows do not fit), grid = min(bands, 2 per CU)
 // `allow_w3`: the three-wave variant's staging capacities may be planned for (the launch site must then launch that variant);

@@ -292,6 +292,10 @@ def test_package_reads_no_environment_variable_outside_probe():
             code = ln.split('#', 1)[0]
             if re.search(r'os\.environ|getenv|_os\.environ', code):
                 bad.append(f'{f.name}:{i}: {ln.strip()}')
+    for f in list((root / 'csrc').glob('*.hip')) + list((root / 'csrc').glob('*.h')) + list((root / 'csrc').glob('*.inc')):
+        for i, ln in enumerate(f.read_text().splitlines(), 1):
+            if re.search(r'\bgetenv\s*\(', ln.split('//', 1)[0]):
+                bad.append(f'csrc/{f.name}:{i}: {ln.strip()}')     # (library knobs are kp_config keys: include/kp_hip.h)
     assert not bad, bad
 
 
