@@ -448,8 +448,8 @@ class UnitFunction(torch.autograd.Function):
                          ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
                          ptr(bn.num_batches_tracked) if track else None, mom, float(bn.eps), count, K, st)
                 else:
-                    if record:
-                        raise NotImplementedError('backward through eval-mode BatchNorm is not implemented')
+                    # eval mode: the running statistics are constants of the layer (nn.BatchNorm2d.eval()); the backward then has
+                    # no batch-mean terms (see `eval_bn` there)
                     mean = bn.running_mean
                     invstd = torch.rsqrt(bn.running_var + bn.eps)
             tail = stp['tail']
@@ -478,7 +478,8 @@ class UnitFunction(torch.autograd.Function):
                 call('kp_bn_act_fwd', ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), stp['slope'], TAILS[tail],
                      ptr(a_next), out_pad, ptr(argmax), N, H, W, K, code, st)
             if record:
-                saved.append(dict(a=a, fin=fin, y=y, mean=mean, invstd=invstd, argmax=argmax, wd=wd, H=H, W=W, C=C, Cl=Cl, K=K))
+                saved.append(dict(a=a, fin=fin, y=y, mean=mean, invstd=invstd, argmax=argmax, wd=wd, H=H, W=W, C=C, Cl=Cl, K=K,
+                                  eval_bn=bn is not None and not training))
             a, fin, C, H, W = a_next, fin_next, K, Ho, Wo
         head = plan[-1]
         hconv = head['conv']
@@ -703,6 +704,13 @@ class UnitFunction(torch.autograd.Function):
                 g2rows = _allreduce_rows(partials[:prows], sync[0])
                 call('kp_bn_bwd_finalize', ptr(g2rows), ptr(ws), 2, K, ptr(sums), None, None, st)
                 sums = sums * (1.0 / sync[1])
+            if sv.get('eval_bn'):
+                # BatchNorm in eval mode is the affine map z = (y - running_mean) * invstd * gamma + beta with CONSTANT statistics:
+                # dy = gamma * invstd * gh without the two batch-mean terms (zero sums for the apply pass), dgamma / dbeta are the
+                # sums the finalize just wrote, and the conv bias in front of it does get a gradient: sum dy = gamma * invstd * sum gh
+                if conv.bias is not None:
+                    gv[id(conv.bias)].add_(bn.weight.detach() * sv['invstd'] * sums[:K])
+                sums = torch.zeros_like(sums)
             need_dx = idx > 0 or need_x
             dp = 2 if need_dx else 0
             dy = torch.empty(N, H + 2 * dp, W + 2 * dp, K, device=dev, dtype=tdt)

@@ -469,3 +469,45 @@ def test_unit_forward_cat_equals_cat_then_forward(precision):
     assert torch.equal(o1, o2) and torch.equal(z1, z2) and torch.equal(m1, m2)
     for a, b in zip(p1, p2):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('core,slope_core', [([16, 32], 'leaky'), ([64, 'M', 64, 'U', 64], 'relu')])
+def test_backward_through_eval_mode_batchnorm(core, slope_core):
+    """`net.eval()` + a backward (fine-tuning with frozen statistics: nn.BatchNorm2d in eval mode is an affine map with constant
+    running statistics): the Unit's forward and every gradient -- input, conv weights AND conv biases (non-zero here, unlike in front
+    of train-mode BatchNorm), gamma, beta -- against the oracle's eval-mode Unit under torch autograd, strict fp32."""
+    import torch.nn as nn
+    from keypoints_amd.models import knn, vgg
+    from oracle import kp_oracle as O
+    torch.manual_seed(5)
+    kw = dict(nonlinearity=nn.LeakyReLU, nonlinearity_kwargs={'inplace': True}) if slope_core == 'leaky' else {}
+    cin, cout = 3, 5
+    unit = knn.Unit(cin, cout, vgg.make_layers(core, **kw))
+    for m in unit.modules():      # non-trivial parameters and running statistics
+        if isinstance(m, nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.3); m.running_var.uniform_(0.5, 2.0); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu'); m.bias.data.normal_(0, 0.1)
+    plan = O.unit_plan(core, cin, cout, 0.01 if slope_core == 'leaky' else 0.0)
+    P = {f'u.{n}': p.detach().clone().double().requires_grad_(True) for n, p in unit.named_parameters()}
+    Bf = {f'u.{n}': b.detach().clone().double() if b.dtype.is_floating_point else b.detach().clone() for n, b in unit.named_buffers()}
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(4, cin, 16, 16, generator=g)
+    xo = x.double().requires_grad_(True)
+    out_o = O.unit_forward(plan, P, 'u', xo, Bf, training=False)
+    w = torch.randn(out_o.shape, generator=g)
+    (out_o * w.double()).sum().backward()
+    unit = unit.cuda().eval()
+    before = {n: b.detach().clone() for n, b in unit.named_buffers()}
+    xh = x.cuda().requires_grad_(True)
+    out = unit(xh)
+    (out * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    close = lambda a, b, tol: float((a.detach().cpu().double() - b.detach()).abs().max()) <= tol * max(1e-6, float(b.detach().abs().max()))
+    assert close(out, out_o, 2e-5)
+    assert close(xh.grad, xo.grad, 1e-4)
+    for n, p in unit.named_parameters():
+        assert close(p.grad, P[f'u.{n}'].grad, 2e-4), n
+        assert float(p.grad.abs().max()) > 0, n          # conv biases included: eval-mode BatchNorm does not cancel them
+    for n, b in unit.named_buffers():                    # eval mode leaves the running statistics alone
+        assert torch.equal(b, before[n]), n
