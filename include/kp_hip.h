@@ -172,6 +172,13 @@ int kp_conv_first_bwd_wgrad(const void* g, const void* x, const void* w, const f
                             const float* gamma, const float* beta, float slope, const float* sums, float* scratch, int N, int H, int W,
                             int C, int K, int dtype, void* stream);
 
+/* [N][Hs][Ws][C] -> the top-left corner of [N][Hd][Wd][C], zeros elsewhere (C * element size a multiple of 16).  With
+ * kp_conv_wgrad_pad_hw: the weight gradient of a matrix-core layer (vgg.py:30-33, autograd) on a map that is not a multiple of the
+ * tap-reuse kernel's 8 x 16 pixel block -- shapes no BASELINE network has, e.g. 100 x 100 inputs -- runs on zero-padded copies of
+ * its two operands (the zero gradient there makes every added pixel contribute exactly 0): 46-57 -> ~900 TFLOP/s. */
+int kp_pad_hw(const void* src, void* dst, int N, int Hs, int Ws, int Hd, int Wd, int C, int dtype, void* stream);
+int kp_conv_wgrad_pad_hw(int N, int Ho, int Wo, int C, int K, int dy_pad, int dtype, int* Hp, int* Wp);
+
 /* ---- weights ----------------------------------------------------------- */
 /* fp32 [K][C][R][R] (nn.Conv2d.weight) -> T [K][R][R][Cp] (forward operand) and,
  * if w_dgrad != NULL, T [Cp][R][R][K] with the taps flipped (dgrad operand); channels C..Cp-1 are zero. */

@@ -221,6 +221,11 @@ KP_DISPATCH(kp_conv_first_bwd_reduce, (const void* g, const void* x, const void*
             (g, x, w, bias, mean, invstd, gamma, beta, slope, partials, N, H, W, C, K, dtype, stream))
 KP_DISPATCH(kp_conv_first_bwd_wgrad, (const void* g, const void* x, const void* w, const float* bias, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, const float* sums, float* scratch, int N, int H, int W, int C, int K, int dtype, void* stream),
             (g, x, w, bias, mean, invstd, gamma, beta, slope, sums, scratch, N, H, W, C, K, dtype, stream))
+int kp_conv_wgrad_pad_hw__bf16(int, int, int, int, int, int, int, int*, int*);
+int kp_conv_wgrad_pad_hw__f16(int, int, int, int, int, int, int, int*, int*);
+int kp_conv_wgrad_pad_hw(int N, int Ho, int Wo, int C, int K, int dy_pad, int dtype, int* Hp, int* Wp) {
+    return dtype == KP_F16 ? kp_conv_wgrad_pad_hw__f16(N, Ho, Wo, C, K, dy_pad, dtype, Hp, Wp) : kp_conv_wgrad_pad_hw__bf16(N, Ho, Wo, C, K, dy_pad, dtype, Hp, Wp);
+}
 KP_DISPATCH(kp_pack_weights, (const float* w, void* w_fwd, void* w_dgrad, int K, int C, int Cp, int R, int dtype, void* stream),
             (w, w_fwd, w_dgrad, K, C, Cp, R, dtype, stream))
 KP_DISPATCH(kp_pack_weights_batch, (int n, const float* const* w, void* const* w_fwd, void* const* w_dgrad, const int* K, const int* C, const int* Cp, int dtype, void* stream),

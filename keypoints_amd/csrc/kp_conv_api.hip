@@ -170,6 +170,21 @@ int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, 
     return rc;
 }
 
+// A 3x3 layer with matrix-core channel counts on a map that is NOT a multiple of the tap-reuse kernel's 8 x 16 pixel block: the
+// per-tap fallback runs at ~50 TFLOP/s where the tap-reuse kernel reaches > 1000.  The zero border of dy makes padding exact: on a map
+// padded with ZERO gradient rows / columns (and any finite input there) every added pixel contributes 0 to every tap.  -> 1 and the
+// padded map size if kp_conv_wgrad on zero-padded copies (kp_pad_hw of x [N][Ho+2][Wo+2][C] and dy [N][Ho+2dp][Wo+2dp][K] into
+// [N][Hp+2][Wp+2][C] / [N][Hp+2dp][Wp+2dp][K]) takes the tap-reuse kernel; 0: call kp_conv_wgrad as it is.
+int kp_conv_wgrad_pad_hw(int N, int Ho, int Wo, int C, int K, int dy_pad, int dtype, int* Hp, int* Wp) {
+    if (dtype != KP_H16 || !use_mfma() || !g_kp_wgrad_patch || N <= 0 || Ho <= 0 || Wo <= 0) return 0;
+    if (kp_conv_wgrad_patch_partials(N, Ho, Wo, C, K, dy_pad) > 0) return 0;            // eligible as it is
+    const int hp = (Ho + 7) / 8 * 8, wp = (Wo + 15) / 16 * 16;
+    if (kp_conv_wgrad_patch_partials(N, hp, wp, C, K, dy_pad) <= 0) return 0;           // channels the kernel does not take
+    if (Hp) *Hp = hp;
+    if (Wp) *Wp = wp;
+    return 1;
+}
+
 // ---- 3x3 layers fed by another 3x3 layer: the previous layer's BatchNorm-apply + activation + replicate pad fused into the
 // consumer's staging (kp_conv_small.hip, BnIn).  Shapes without a fused kernel answer 0 / KP_E_UNSUPPORTED and the caller
 // runs kp_bn_act_fwd + kp_conv_fwd / kp_conv_wgrad instead: same results, bit for bit.

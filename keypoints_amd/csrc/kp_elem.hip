@@ -181,6 +181,22 @@ __global__ void nhwc_grad_to_nchw2_k(const T* __restrict__ g, float* __restrict_
     }
 }
 
+// [N][Hs][Ws][C] -> the top-left corner of [N][Hd][Wd][C], the rest zero: pads a map to the pixel-block multiple the tap-reuse weight
+// gradient wants (kp_conv_wgrad_pad_hw).  One thread per 16-byte chunk (C * element size a multiple of 16).
+__global__ __launch_bounds__(256) void pad_hw_k(const uint4* __restrict__ src, uint4* __restrict__ dst, int Hs, int Ws, int Hd, int Wd,
+                                                int cpp, long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int c = (int)(t % cpp);
+    const long long pix = t / cpp;
+    const int j = (int)(pix % Wd);
+    const int i = (int)((pix / Wd) % Hd);
+    const long long n = pix / ((long long)Wd * Hd);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (i < Hs && j < Ws) v = src[((n * Hs + i) * Ws + j) * cpp + c];
+    dst[t] = v;
+}
+
 // ---------------------------------------------------------------- weights
 template <typename T>
 __global__ void pack_weights_k(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int K, int C,
@@ -640,6 +656,19 @@ int kp_nhwc_grad_to_nchw2(const void* gsrc, float* dst0, int C0, float* dst1, in
     DISPATCH_T(dtype, nhwc_grad_to_nchw2_k<T><<<dim3(cdiv(total, TPB), cdiv(C0 + C1, 4)), TPB, 0, (hipStream_t)stream>>>((const T*)gsrc, dst0, C0, dst1, C1, N, Cp, H, W, pad));
     return kp_check_launch("nhwc_grad_to_nchw2");
 }
+
+#ifndef KP_F16_BUILD   // bytes only: defined once, by the bf16 build of this source
+int kp_pad_hw(const void* src, void* dst, int N, int Hs, int Ws, int Hd, int Wd, int C, int dtype, void* stream) {
+    const int esz = dtype == KP_F32 ? 4 : 2;
+    KP_REQUIRE(src && dst && N > 0 && Hs > 0 && Ws > 0 && Hd >= Hs && Wd >= Ws && C > 0 && (C * esz) % 16 == 0 && ((((size_t)src | (size_t)dst) & 15) == 0),
+               "kp_pad_hw: bad args (C * element size a multiple of 16, 16-byte aligned tensors)");
+    const int cpp = C * esz / 16;
+    const long long total = (long long)N * Hd * Wd * cpp;
+    kp_count_bytes((double)esz * C * ((double)N * Hs * Ws + (double)N * Hd * Wd));
+    pad_hw_k<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>((const uint4*)src, (uint4*)dst, Hs, Ws, Hd, Wd, cpp, total);
+    return kp_check_launch("pad_hw");
+}
+#endif
 
 int kp_nhwc_grad_to_nchw(const void* gsrc, float* dst, int N, int C, int Cp, int H, int W, int pad, int dtype,
                          void* stream) {

@@ -303,6 +303,22 @@ def _wgrad_layer(sv, dy, gw, parts, N, H, W, C, K, dp, tdt, code, dev):
     partial buffers, then kp_wgrad_unpack adds them into the arena view `gw` in a fixed order.  (A module-level function so that
     tools/probes can time a step without it: keypoints_amd._probe.ablate_wgrad.)"""
     wst = stream_ptr()
+    if sv['fin'] is None:
+        # matrix-core channels on a map that is not a multiple of the tap-reuse kernel's pixel block (no BASELINE shape): zero-padded
+        # copies of both operands take that kernel instead of the per-tap fallback -- exact (dy is zero there), ~15x faster
+        import ctypes
+        hp, wp = ctypes.c_int(0), ctypes.c_int(0)
+        if _lib.lib().kp_conv_wgrad_pad_hw(N, H, W, C, K, dp, code, ctypes.byref(hp), ctypes.byref(wp)) == 1:
+            Hp, Wp = hp.value, wp.value
+            xp = torch.empty(N, Hp + 2, Wp + 2, C, device=dev, dtype=tdt)
+            dyp = torch.empty(N, Hp + 2 * dp, Wp + 2 * dp, K, device=dev, dtype=tdt)
+            call('kp_pad_hw', ptr(sv['a']), ptr(xp), N, H + 2, W + 2, Hp + 2, Wp + 2, C, code, wst)
+            call('kp_pad_hw', ptr(dy), ptr(dyp), N, H + 2 * dp, W + 2 * dp, Hp + 2 * dp, Wp + 2 * dp, K, code, wst)
+            parts = _lib.lib().kp_conv_wgrad_partials(N, Hp, Wp, C, K, 3, dp, code)
+            scratch = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device=dev, dtype=torch.float32)
+            call('kp_conv_wgrad', ptr(xp), ptr(dyp), ptr(scratch), N, Hp, Wp, C, K, 3, dp, code, wst)
+            call('kp_wgrad_unpack', ptr(scratch), parts, ptr(gw), K, sv['Cl'], C, 3, wst)
+            return
     scratch = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device=dev, dtype=torch.float32)
     fused = False
     if sv['fin'] is not None:   # the input side is read from the previous layer's conv output (see forward)

@@ -387,3 +387,50 @@ def test_first_layer_full_size_against_gpu_fp32():
     scratch2 = torch.full((parts, K, 3, 3, C), float('nan'), device='cuda')
     call('kp_conv_wgrad', ptr(x), ptr(dy), ptr(scratch2), N, H, H, C, K, 3, 2, _lib.KP_BF16, st)
     assert torch.equal(scratch, scratch2)
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+@pytest.mark.parametrize('N,H,W,C,K,dp', [(4, 20, 28, 64, 128, 2), (3, 12, 12, 128, 128, 2), (2, 50, 70, 128, 64, 0), (5, 9, 17, 64, 128, 2)])
+def test_weight_gradient_on_zero_padded_copies_off_the_pixel_block(N, H, W, C, K, dp, dt):
+    """Matrix-core channels on a map that is not a multiple of the tap-reuse kernel's 8 x 16 pixel block (no BASELINE shape):
+    kp_conv_wgrad_pad_hw offers the padded size, kp_pad_hw makes the zero-padded copies, and the tap-reuse kernel's gradient equals
+    the per-tap fallback's on the original tensors (fp32 summation order) and an fp64 evaluation of the same 16-bit operands."""
+    import ctypes
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import precision_dtype, stream_ptr
+    L = _lib.lib()
+    tdt, code = precision_dtype(dt)
+    st = stream_ptr()
+    g = torch.Generator().manual_seed(N * 31 + H)
+    a = (torch.randn(N, H + 2, W + 2, C, generator=g) * 0.5).cuda().to(tdt)
+    dy = torch.zeros(N, H + 2 * dp, W + 2 * dp, K, device='cuda', dtype=tdt)
+    dy[:, dp:dp + H, dp:dp + W] = (torch.randn(N, H, W, K, generator=g) * 0.5).cuda().to(tdt)
+    hp, wp = ctypes.c_int(0), ctypes.c_int(0)
+    assert L.kp_conv_wgrad_pad_hw(N, H, W, C, K, dp, code, ctypes.byref(hp), ctypes.byref(wp)) == 1
+    Hp, Wp = hp.value, wp.value
+    assert Hp % 8 == 0 and Wp % 16 == 0 and 0 <= Hp - H < 8 and 0 <= Wp - W < 16
+    assert L.kp_conv_wgrad_pad_hw(N, Hp, Wp, C, K, dp, code, None, None) == 0          # already a multiple: nothing to pad
+    xp = torch.full((N, Hp + 2, Wp + 2, C), float('nan'), device='cuda', dtype=tdt)
+    dyp = torch.full((N, Hp + 2 * dp, Wp + 2 * dp, K), float('nan'), device='cuda', dtype=tdt)
+    call('kp_pad_hw', ptr(a), ptr(xp), N, H + 2, W + 2, Hp + 2, Wp + 2, C, code, st)
+    call('kp_pad_hw', ptr(dy), ptr(dyp), N, H + 2 * dp, W + 2 * dp, Hp + 2 * dp, Wp + 2 * dp, K, code, st)
+    assert torch.equal(xp[:, :H + 2, :W + 2], a) and float(xp[:, H + 2:].float().abs().max() if Hp > H else 0) == 0
+    assert torch.equal(dyp[:, :H + 2 * dp, :W + 2 * dp], dy) and float(dyp.float().abs().sum() - dy.float().abs().sum()) == 0
+
+    def wgrad(x_, dy_, h_, w_):
+        parts = L.kp_conv_wgrad_partials(N, h_, w_, C, K, 3, dp, code)
+        sc = (torch.zeros if parts == 1 else torch.empty)(parts, K, 3, 3, C, device='cuda')
+        call('kp_conv_wgrad', ptr(x_), ptr(dy_), ptr(sc), N, h_, w_, C, K, 3, dp, code, st)
+        dw = torch.zeros(K, C, 3, 3, device='cuda')
+        call('kp_wgrad_unpack', ptr(sc), parts, ptr(dw), K, C, C, 3, st)
+        return dw
+    dw_pad, dw_plain = wgrad(xp, dyp, Hp, Wp), wgrad(a, dy, H, W)
+    torch.cuda.synchronize()
+    scale = float(dw_plain.abs().max())
+    assert float((dw_pad - dw_plain).abs().max()) <= 2e-5 * scale
+    import torch.nn.functional as F
+    patches = F.unfold(a.float().permute(0, 3, 1, 2).double(), 3).view(N, C * 9, H * W)
+    d = dy[:, dp:dp + H, dp:dp + W].float().permute(0, 3, 1, 2).reshape(N, K, H * W).double()
+    ref = torch.einsum('nkp,ncp->kc', d, patches).view(K, C, 3, 3)
+    assert float((dw_pad.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
