@@ -415,8 +415,8 @@ def test_weight_gradient_on_zero_padded_copies_off_the_pixel_block(N, H, W, C, K
     dyp = torch.full((N, Hp + 2 * dp, Wp + 2 * dp, K), float('nan'), device='cuda', dtype=tdt)
     call('kp_pad_hw', ptr(a), ptr(xp), N, H + 2, W + 2, Hp + 2, Wp + 2, C, code, st)
     call('kp_pad_hw', ptr(dy), ptr(dyp), N, H + 2 * dp, W + 2 * dp, Hp + 2 * dp, Wp + 2 * dp, K, code, st)
-    assert torch.equal(xp[:, :H + 2, :W + 2], a) and float(xp[:, H + 2:].float().abs().max() if Hp > H else 0) == 0
-    assert torch.equal(dyp[:, :H + 2 * dp, :W + 2 * dp], dy) and float(dyp.float().abs().sum() - dy.float().abs().sum()) == 0
+    assert torch.equal(xp[:, :H + 2, :W + 2], a) and int((xp != 0).sum()) == int((a != 0).sum())
+    assert torch.equal(dyp[:, :H + 2 * dp, :W + 2 * dp], dy) and int((dyp != 0).sum()) == int((dy != 0).sum())   # zeros everywhere else
 
     def wgrad(x_, dy_, h_, w_):
         parts = L.kp_conv_wgrad_partials(N, h_, w_, C, K, 3, dp, code)
