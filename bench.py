@@ -602,6 +602,8 @@ def compact_line(line, detail_path):
                             workload=r['config']['workload'], bound=rf.get('bound'), kernel=rf.get('kernel'),
                             achieved=_round(rf.get('achieved')), unit=rf.get('unit'), frac=_round(rf.get('frac')),
                             step_frac=_round(rf.get('step_frac')), traffic=rf.get('traffic'), algorithmic_bytes=rf.get('algorithmic_bytes'))
+        if r.get('hip_graph'):
+            summary[key]['hip_graph'] = {k: _round(v, 1) if k == 'value' else _round(v) for k, v in r['hip_graph'].items() if not isinstance(v, str)} or r['hip_graph']
         if r.get('bf16_secondary'):
             summary[key]['bf16_secondary'] = dict(value=_round(r['bf16_secondary']['value'], 1), ms_per_step=_round(r['bf16_secondary']['ms_per_step']))
         if rf.get('step_hbm_frac') is not None:
@@ -689,6 +691,14 @@ def main():
                 r = run_leg(leg, rank, world, dev)
                 for k in ('n_gpus', 'higher_is_better', 'scaling', 'vs_baseline', 'data', 'unit'):
                     r.pop(k, None)
+                if key.startswith('config2'):   # the same leg replayed as ONE HIP graph (keypoints_amd.graph.GraphedTrainStep), timing only
+                    sec = copy.copy(leg)
+                    sec.graph, sec.profile_steps = 1, 0
+                    try:
+                        o2 = run_leg(sec, rank, world, dev)
+                        r['hip_graph'] = dict(value=o2['value'], ms_per_step=o2['ms_per_step'], ms_per_step_max=o2['ms_per_step_max_hipevent'], steps=o2['steps'])
+                    except Exception as e:
+                        r['hip_graph'] = dict(error=f'{type(e).__name__}: {e}'[:200])
                 if key.startswith('config3') and leg.precision == 'fp16':   # the same leg in bf16, timing only
                     sec = copy.copy(leg)
                     sec.precision, sec.profile_steps = 'bf16', 0
