@@ -179,6 +179,26 @@ int kp_conv_first_bwd_wgrad(const void* g, const void* x, const void* w, const f
 int kp_pad_hw(const void* src, void* dst, int N, int Hs, int Ws, int Hd, int Wd, int C, int dtype, void* stream);
 int kp_conv_wgrad_pad_hw(int N, int Ho, int Wo, int C, int K, int dy_pad, int dtype, int* Hp, int* Wp);
 
+/* ---- the head's backward fused with the BatchNorm backward of the 3x3 layer in front of it ------------------------------------------
+ * A Unit ends in conv3x3 + BatchNorm2d + activation -> Conv2d(1x1, K <= 4) + LeakyReLU (vgg.py:30-38 -> knn.py:123-125).  The plain
+ * backward writes the head's input gradient g [pixels][C] (kp_head_bwd / _bnin) and reads it back twice (kp_bn_act_bwd_reduce, _apply)
+ * next to three reads of the layer's conv output y.  g is K <= 4 FMAs per channel away from the head's own gradient: these two calls
+ * recompute it (rounded to the storage type where kp_head_bwd stores it) and g never exists.
+ *   kp_head_bnbwd_reduce == the weight / bias part of kp_head_bwd_bnin (dw, db: bit-identical, same fixed-order two-stage sum through
+ *                           ws = kp_head_bwd_ws_floats floats) + kp_bn_act_bwd_reduce(g, gp 0, tail none, y): bn_partials =
+ *                           kp_head_bnbwd_rows rows of [2][C] for kp_bn_bwd_finalize (another partition: fp32 summation order)
+ *   kp_head_bnbwd_apply  == the dx part of kp_head_bwd_bnin + kp_bn_act_bwd_apply: dy [N][H+2dp][W+2dp][C] with its zero border
+ * gout / out: the head's output gradient and saved output, fp32 NCHW [N][K][H][W]; yprev + mean .. slope_in: the 3x3 layer's conv
+ * output and BatchNorm / activation (as in kp_head_bwd_bnin); w, slope: the head.  16-bit storage, K <= 4, C / 8 a power of two <= 64
+ * (model F's decoder head 64 -> 3, the Pong nets' 16 -> 1 and 32 -> 4); kp_head_bnbwd_rows == 0 / KP_E_UNSUPPORTED otherwise. */
+long long kp_head_bnbwd_rows(int N, int H, int W, int C, int K, int dtype);
+int kp_head_bnbwd_reduce(const float* gout, const float* out, const void* yprev, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, float slope_in, const float* w, float slope, float* dw, float* db,
+                         float* ws, float* bn_partials, int N, int H, int W, int C, int K, int dtype, void* stream);
+int kp_head_bnbwd_apply(const float* gout, const float* out, const void* yprev, const float* mean, const float* invstd,
+                        const float* gamma, const float* beta, float slope_in, const float* w, float slope, const float* sums, void* dy,
+                        int dy_pad, int N, int H, int W, int C, int K, int dtype, void* stream);
+
 /* ---- weights ----------------------------------------------------------- */
 /* fp32 [K][C][R][R] (nn.Conv2d.weight) -> T [K][R][R][Cp] (forward operand) and,
  * if w_dgrad != NULL, T [Cp][R][R][K] with the taps flipped (dgrad operand); channels C..Cp-1 are zero. */

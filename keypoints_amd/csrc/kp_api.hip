@@ -328,6 +328,16 @@ long long kp_conv_first_fused_rows(int N, int H, int W, int C, int K, int dtype)
     return dtype == KP_F16 ? kp_conv_first_fused_rows__f16(N, H, W, C, K, dtype) : kp_conv_first_fused_rows__bf16(N, H, W, C, K, dtype);
 }
 
+long long kp_head_bnbwd_rows__bf16(int, int, int, int, int, int);
+long long kp_head_bnbwd_rows__f16(int, int, int, int, int, int);
+long long kp_head_bnbwd_rows(int N, int H, int W, int C, int K, int dtype) {
+    return dtype == KP_F16 ? kp_head_bnbwd_rows__f16(N, H, W, C, K, dtype) : kp_head_bnbwd_rows__bf16(N, H, W, C, K, dtype);
+}
+KP_DISPATCH(kp_head_bnbwd_reduce, (const float* gout, const float* out, const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope_in, const float* w, float slope, float* dw, float* db, float* ws, float* bn_partials, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (gout, out, yprev, mean, invstd, gamma, beta, slope_in, w, slope, dw, db, ws, bn_partials, N, H, W, C, K, dtype, stream))
+KP_DISPATCH(kp_head_bnbwd_apply, (const float* gout, const float* out, const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope_in, const float* w, float slope, const float* sums, void* dy, int dy_pad, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (gout, out, yprev, mean, invstd, gamma, beta, slope_in, w, slope, sums, dy, dy_pad, N, H, W, C, K, dtype, stream))
+
 long long kp_head_bwd_ws_floats__bf16(int, int, int, int, int, int);
 long long kp_head_bwd_ws_floats__f16(int, int, int, int, int, int);
 long long kp_head_bwd_ws_floats(int N, int H, int W, int C, int K, int dtype) {

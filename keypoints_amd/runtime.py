@@ -279,3 +279,20 @@ def fuse_first_layer() -> bool:
 def set_fuse_first_layer(on: bool) -> None:
     global _FUSE_FIRST
     _FUSE_FIRST = bool(on)
+
+
+_FUSE_HEAD_BN_BWD = True
+
+
+def fuse_head_bn_bwd() -> bool:
+    """A Unit whose 1x1 head (<= 4 output channels) reads the conv output of its last 3x3 layer: the head's backward runs inside that
+    layer's two BatchNorm-backward passes (kp_head_bnbwd_reduce / _apply, include/kp_hip.h) and the head's input gradient -- a tensor
+    as large as the layer's activation, written once and read twice by the plain sequence -- is never materialised.  Head weight /
+    bias gradients are bit-identical, the BatchNorm sums equal up to the order of fp32 additions.  `set_fuse_head_bn_bwd(False)`
+    restores the plain sequence (A/B, tests)."""
+    return _FUSE_HEAD_BN_BWD
+
+
+def set_fuse_head_bn_bwd(on: bool) -> None:
+    global _FUSE_HEAD_BN_BWD
+    _FUSE_HEAD_BN_BWD = bool(on)
