@@ -64,8 +64,8 @@ def apply_env(env=None) -> list:
     if env.get('KP_FIRST_KTN'):   # 32-channel blocks per wavefront in kp_conv_first_fwd_bnact (library knob KP_CFG_FIRST_KTN = 10)
         from ._lib import call
         call('kp_config', 10, int(env['KP_FIRST_KTN'])); used.append('KP_FIRST_KTN=' + env['KP_FIRST_KTN'])
-    if env.get('KP_NO_HEAD_BN_FUSE'):
-        runtime.set_fuse_head_bn_bwd(False); used.append('KP_NO_HEAD_BN_FUSE')
+    if env.get('KP_HEAD_BN_FUSE'):
+        runtime.set_fuse_head_bn_bwd(True); used.append('KP_HEAD_BN_FUSE')
     if env.get('KP_NO_FIRST_FUSE'):
         runtime.set_fuse_first_layer(False); used.append('KP_NO_FIRST_FUSE')
     if env.get('KP_EAGER_BLEND'):

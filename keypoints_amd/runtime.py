@@ -281,15 +281,17 @@ def set_fuse_first_layer(on: bool) -> None:
     _FUSE_FIRST = bool(on)
 
 
-_FUSE_HEAD_BN_BWD = True
+_FUSE_HEAD_BN_BWD = False   # (measured neutral, see the docstring: opt-in)
 
 
 def fuse_head_bn_bwd() -> bool:
     """A Unit whose 1x1 head (<= 4 output channels) reads the conv output of its last 3x3 layer: the head's backward runs inside that
     layer's two BatchNorm-backward passes (kp_head_bnbwd_reduce / _apply, include/kp_hip.h) and the head's input gradient -- a tensor
     as large as the layer's activation, written once and read twice by the plain sequence -- is never materialised.  Head weight /
-    bias gradients are bit-identical, the BatchNorm sums equal up to the order of fp32 additions.  `set_fuse_head_bn_bwd(False)`
-    restores the plain sequence (A/B, tests)."""
+    bias gradients are bit-identical, the BatchNorm sums equal up to the order of fp32 additions.
+    OFF by default: measured NEUTRAL (docs/experiments/r05.md section 9: model F 32.89 vs 32.88 ms, config 2 2.601 vs 2.600 ms) --
+    the small-head kernels are bound by VALU work and latency, not by the bytes of g: the two fused kernels take 242 + 266 us at model
+    F's decoder head where the four plain ones take 142 + 86 + 108 + 158.  `set_fuse_head_bn_bwd(True)` selects it."""
     return _FUSE_HEAD_BN_BWD
 
 

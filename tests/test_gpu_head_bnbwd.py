@@ -60,7 +60,7 @@ def test_fused_head_batchnorm_backward_equals_the_plain_sequence(N, H, W, C, K, 
 
 @pytest.mark.parametrize('precision,typ,cin,z,K,size', [('fp16', 'F', 3, 64, 10, 128), ('bf16', 'VGG_PONG_LAYERNECK', 1, 16, 4, 84)])
 def test_train_step_with_and_without_the_fused_head_backward(precision, typ, cin, z, K, size):
-    """One Transporter step with kp_head_bnbwd_* (default) and with the plain sequence: loss and outputs identical (forward untouched),
+    """One Transporter step with kp_head_bnbwd_* (opt-in: set_fuse_head_bn_bwd(True)) and with the plain sequence (default): loss and outputs identical (forward untouched),
     the head's gradients bit-identical, every other gradient the same direction and size (the BatchNorm sums differ in their last
     bits: summation order)."""
     import keypoints_amd as ka
@@ -83,7 +83,7 @@ def test_train_step_with_and_without_the_fused_head_backward(precision, typ, cin
             torch.cuda.synchronize()
             res.append((float(loss), out[0].detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()}))
         finally:
-            ka.set_fuse_head_bn_bwd(True)
+            ka.set_fuse_head_bn_bwd(False)
     (l1, x1, g1), (l0, x0, g0) = res
     assert l1 == l0 and torch.equal(x1, x0)
     assert torch.equal(g1['decoder.out_block.0.weight'], g0['decoder.out_block.0.weight'])
