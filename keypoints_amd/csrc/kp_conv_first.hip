@@ -13,6 +13,10 @@
 #include "kp_mfma_util.h"
 
 namespace {
+// The wave-private input strip is written as dwords and read as 16-bit elements: both through may_alias types, so type-based
+// alias analysis cannot move the reads across the writes (kp_conv_first_fused.hip met that failure).
+typedef uint32_t cf_u32_a __attribute__((may_alias));
+typedef short cf_s16_a __attribute__((may_alias));
 
 constexpr int TPB = 256;
 
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256) void conv3_first_fwd_mfma_k(const h16_t* __res
     unsigned char* stg = xs + F_XSZ;
     const int px = lane & 31, h = lane >> 5;
     const int Ho = Hi - 2, Wo = Wi - 2;
-    if (lane < 4) *reinterpret_cast<uint32_t*>(xs + 3 * F_RS + lane * 4) = 0u;
+    if (lane < 4) *reinterpret_cast<cf_u32_a*>(xs + 3 * F_RS + lane * 4) = 0u;
 
     // weights [K][J] -> A fragments (row = output channel, 8 consecutive reduction indices per lane), once per wave
     h16x8 wa[KT][NS];
@@ -364,13 +368,13 @@ __global__ __launch_bounds__(256) void conv3_first_fwd_mfma_k(const h16_t* __res
     for (long long g = g0; g < g1; ++g) {
         if (lane < ND) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) *reinterpret_cast<uint32_t*>(xs + r * F_RS + lane * 4) = xr[r];
+            for (int r = 0; r < 3; ++r) *reinterpret_cast<cf_u32_a*>(xs + r * F_RS + lane * 4) = xr[r];
         }
         h16x8 xb[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) xb[s][i] = *reinterpret_cast<const short*>(xs + xo[s][i]);
+            for (int i = 0; i < 8; ++i) xb[s][i] = *reinterpret_cast<const cf_s16_a*>(xs + xo[s][i]);
         if (g + 1 < g1) fetch();
         f32x16 acc[KT];
 #pragma unroll
@@ -486,14 +490,14 @@ __global__ __launch_bounds__(1024) void conv3_first_wgrad_mfma_k(const h16_t* __
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this group's dy tile and input rows have arrived
         if (lane < ND) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) *reinterpret_cast<uint32_t*>(xs + r * F_RS + lane * 4) = xr[r];
+            for (int r = 0; r < 3; ++r) *reinterpret_cast<cf_u32_a*>(xs + r * F_RS + lane * 4) = xr[r];
         }
         if (g + 1 < g1) fetch(buf ^ 1);                       // in flight during this group's reads and MFMAs
         h16x8 xb[2];
 #pragma unroll
         for (int R = 0; R < 2; ++R)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) xb[R][i] = *reinterpret_cast<const short*>(xs + xoff + (R * 16 + i) * CIN * 2);
+            for (int i = 0; i < 8; ++i) xb[R][i] = *reinterpret_cast<const cf_s16_a*>(xs + xoff + (R * 16 + i) * CIN * 2);
         const unsigned char* tile = dyb + buf * DYB;
         h16x8 a[KT][2];
 #pragma unroll
