@@ -89,6 +89,7 @@ int kp_config(int key, int value);
 #define KP_CFG_FIN_WIDE 11      /* 1: the 1024-thread statistics finalize for every layer (measurement); 0 (default): the 4-wave kernel for C <= 32 */
 #define KP_CFG_DISABLE_MFMA 12  /* 1: every convolution on the generic VALU kernels (measurement / debugging); 0 (default) */
 #define KP_CFG_WG16 13          /* bit mask (default 7): which small-channel weight gradients take the 16 x 16 x 32 matrix-core kernel */
+#define KP_CFG_FIRST_ROWS 14   /* single-channel first layers with 16 / 32 filters: 1 (default) the row kernel (a lane = one pixel x eight channels, weights in registers), 0: conv3_first_fwd_k, > 1: workgroups per launch of the row kernel (measurement) */
 #define KP_CFG_FIRST_KTN 10  /* kp_conv_first_fwd_bnact: 2 (default) one wavefront computes all 64 channels of its groups (66 us at 128 x 128 x 128: the plain convolution's time); 1: a pair of wavefronts, 32 channels each (75 us) */
 #define KP_CFG_CUS 6          /* CU budget the persistent kernels size their grids to (launches on a CU-masked stream); 0 = whole device */
 #define KP_CFG_TRACE 2        /* device buffer of 512 int64: s_memtime stamps of workgroup 0 of the patch conv kernel */

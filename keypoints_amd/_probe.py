@@ -61,6 +61,9 @@ def apply_env(env=None) -> list:
         if env.get(var):
             from ._lib import call
             call('kp_config', key, int(env[var], 0)); used.append(f'{var}={env[var]}')
+    if env.get('KP_FIRST_ROWS'):   # row kernel of the single-channel first layers (library knob KP_CFG_FIRST_ROWS = 14): 0 off, > 1 workgroups
+        from ._lib import call
+        call('kp_config', 14, int(env['KP_FIRST_ROWS'])); used.append('KP_FIRST_ROWS=' + env['KP_FIRST_ROWS'])
     if env.get('KP_FIRST_KTN'):   # 32-channel blocks per wavefront in kp_conv_first_fwd_bnact (library knob KP_CFG_FIRST_KTN = 10)
         from ._lib import call
         call('kp_config', 10, int(env['KP_FIRST_KTN'])); used.append('KP_FIRST_KTN=' + env['KP_FIRST_KTN'])

@@ -25,6 +25,7 @@ kp_knob_t g_kp_bred_patch{1};    // kp_config(KP_CFG_BRED_PATCH, v)
 kp_knob_t g_kp_fin_wide{0};      // kp_config(KP_CFG_FIN_WIDE, 1): the 1024-thread statistics finalize for every layer (measurement)
 kp_knob_t g_kp_disable_mfma{0};  // kp_config(KP_CFG_DISABLE_MFMA, 1): every convolution on the generic VALU kernels (measurement / debugging)
 kp_knob_t g_kp_wg16{7};          // kp_config(KP_CFG_WG16, bits): which small-channel weight gradients take the 16 x 16 x 32 kernel
+kp_knob_t g_kp_first_rows{1};    // kp_config(KP_CFG_FIRST_ROWS, v): row kernel for single-channel first layers (1 default, 0 off, > 1: workgroups per launch)
 kp_knob_t g_kp_first_ktn{2};     // kp_config(KP_CFG_FIRST_KTN, v): 32-channel blocks per wavefront in kp_conv_first_fwd_bnact (2 default, 1)
 // Memory walk order of the passes (kp_common.h: KP_WALK_*; kp_config(KP_CFG_WALK, mask), 0 = every pass front to back):
 // a pass that follows a producer sweeps the producer's output back to front, so that it starts on what is still in the
@@ -106,6 +107,7 @@ int kp_config(int key, int value) {
     if (key == KP_CFG_FIN_WIDE) { g_kp_fin_wide = value ? 1 : 0; return KP_OK; }
     if (key == KP_CFG_DISABLE_MFMA) { g_kp_disable_mfma = value ? 1 : 0; return KP_OK; }
     if (key == KP_CFG_WG16) { g_kp_wg16 = value & 7; return KP_OK; }
+    if (key == KP_CFG_FIRST_ROWS) { g_kp_first_rows = value < 0 ? 0 : value; return KP_OK; }
     if (key == KP_CFG_FIRST_KTN) { g_kp_first_ktn = value == 1 ? 1 : 2; return KP_OK; }
     if (key == KP_CFG_BRED_PATCH) { g_kp_bred_patch = value < 0 ? 0 : (value > 2 ? 2 : value); return KP_OK; }
     if (key == KP_CFG_WGRAD_PATCH) { g_kp_wgrad_patch = value ? 1 : 0; return KP_OK; }

@@ -17,6 +17,7 @@ namespace {
 // alias analysis cannot move the reads across the writes (kp_conv_first_fused.hip met that failure).
 typedef uint32_t cf_u32_a __attribute__((may_alias));
 typedef short cf_s16_a __attribute__((may_alias));
+typedef unsigned short cf_u16_a __attribute__((may_alias));
 
 constexpr int TPB = 256;
 
@@ -138,6 +139,117 @@ __global__ __launch_bounds__(TPB) void conv3_first_fwd_k(const h16_t* __restrict
     if (partials) {
         __syncthreads();
         for (int i = tid; i < 2 * K; i += TPB)
+            partials[(long long)bid * 2 * K + i] = ((red[i] + red[2 * K + i]) + red[4 * K + i]) + red[6 * K + i];
+    }
+}
+
+// Single-channel inputs with 16 / 32 filters (the Pong-class first layers).  conv3_first_fwd_k reads every weight from LDS
+// for every pixel (36 x ds_read_b128 per 64 pixels at K = 16: ~290 LDS-pipe cycles, the kernel's bound: 121 MB in 47 us).
+// Here a lane owns ONE pixel x EIGHT channels: its 72 weights stay in registers, a wave-iteration covers 64 / KB consecutive
+// pixels of an output row, and the 16 bytes a lane produces go out as one store (lanes of a wave: one contiguous KiB; no
+// staging tile).  A wavefront walks whole output rows: the three input rows arrive as dwords (Wi even), are laid down in the
+// wave's LDS strip as they lie in memory, and a lane picks its nine 16-bit values from there.  The fp32 accumulation order per
+// output element is conv3_first_fwd_k's (bias, then the nine taps in order): the stored tensor is bit-identical.
+constexpr int FR_RS = 512;        // bytes per staged input row (Wi <= 256)
+
+template <int KB, bool WIDE>   // WIDE: input rows of more than 128 pixels (two dwords per lane and row)
+__global__ __launch_bounds__(256, WIDE ? 3 : 4) void conv3_first_fwd_rows_k(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
+                                                              const float* __restrict__ bias, h16_t* __restrict__ y,
+                                                              float* __restrict__ partials, int Hi, int Wi, long long rows,
+                                                              int hb, long long xh, long long yh) {
+    constexpr int K = KB * 8, PPI = 64 / KB;
+    int bid = blockIdx.x, nblk = gridDim.x;
+    if (hb) {   // kp_conv_fwd_pair: two launches of hb workgroups in one grid (see conv3_first_fwd_k)
+        const int hf = bid >= hb ? 1 : 0;
+        bid -= hf * hb; nblk = hb;
+        x += hf * xh; y += hf * yh;
+        if (partials) partials += (long long)hf * hb * 2 * K;
+    }
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 3 * FR_RS + 4 * 2 * K * sizeof(float)];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* xs = smem + wave * 3 * FR_RS;
+    float* red = reinterpret_cast<float*>(smem + 4 * 3 * FR_RS);
+    const int kb = lane % KB, p = lane / KB;
+    const int Ho = Hi - 2, Wo = Wi - 2, ND = Wi >> 1;
+
+    float wr[9][8], bs[8], sm[8], sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bs[e] = bias ? bias[kb * 8 + e] : 0.f;
+        sm[e] = sq[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) wr[j][e] = h2f(w[(kb * 8 + e) * 9 + j]);
+    }
+    const long long nw = (long long)nblk * 4;
+    long long row = (long long)bid * 4 + wave;
+    uint32_t xr[3][WIDE ? 2 : 1] = {};
+    auto fetch = [&](long long rw) {
+        const long long n = rw / Ho;
+        const int pr = (int)(rw - n * Ho);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(x + (n * Hi + pr) * Wi);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (lane < ND) xr[r][0] = src[r * ND + lane];
+            if (WIDE && lane + 64 < ND) xr[r][WIDE ? 1 : 0] = src[r * ND + lane + 64];
+        }
+    };
+    if (row < rows) fetch(row);
+    for (; row < rows; row += nw) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (lane < ND) *reinterpret_cast<cf_u32_a*>(xs + r * FR_RS + lane * 4) = xr[r][0];
+            if (WIDE && lane + 64 < ND) *reinterpret_cast<cf_u32_a*>(xs + r * FR_RS + (lane + 64) * 4) = xr[r][WIDE ? 1 : 0];
+        }
+        if (row + nw < rows) fetch(row + nw);               // in flight during this row's arithmetic
+        h16_t* yr = y + row * Wo * K + kb * 8;
+        for (int q0 = 0; q0 < Wo; q0 += PPI) {
+            const int q = q0 + p;
+            const bool valid = q < Wo;
+            const int qq = valid ? q : Wo - 1;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = bs[e];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const float xv = h2f((h16_t)*reinterpret_cast<const cf_u16_a*>(xs + r * FR_RS + (qq + t) * 2));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(xv, wr[r * 3 + t][e], acc[e]);
+                }
+            if (valid) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sm[e] += acc[e];
+                    sq[e] = fmaf(acc[e], acc[e], sq[e]);
+                }
+                uint4 pk;
+                pk.x = pack_h16x2(acc[0], acc[1]);
+                pk.y = pack_h16x2(acc[2], acc[3]);
+                pk.z = pack_h16x2(acc[4], acc[5]);
+                pk.w = pack_h16x2(acc[6], acc[7]);
+                *reinterpret_cast<uint4*>(yr + (long long)q * K) = pk;
+            }
+        }
+    }
+    // ONE statistics row per workgroup: the lanes of a channel block, then the four wavefronts, in a fixed order
+    if (partials) {
+#pragma unroll
+        for (int o = KB; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sm[e] += __shfl_xor(sm[e], o, 64);
+                sq[e] += __shfl_xor(sq[e], o, 64);
+            }
+        if (p == 0)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(wave * 2 + 0) * K + kb * 8 + e] = sm[e];
+                red[(wave * 2 + 1) * K + kb * 8 + e] = sq[e];
+            }
+        __syncthreads();
+        for (int i = tid; i < 2 * K; i += 256)
             partials[(long long)bid * 2 * K + i] = ((red[i] + red[2 * K + i]) + red[4 * K + i]) + red[6 * K + i];
     }
 }
@@ -558,6 +670,26 @@ int kp_conv_first_fwd(const void* x, const void* w, const float* bias, void* y, 
         }
 #undef KP_FIRST_FWD_M
         return kp_check_launch("conv3_first_fwd_mfma");
+    }
+    extern kp_knob_t g_kp_first_rows;
+    const int rows_knob = g_kp_first_rows;
+    if (C == 1 && (K == 16 || K == 32) && (Wi & 1) == 0 && Wi <= 256 && rows_knob) {
+        // row kernel: whole output rows per wavefront, 4 wavefronts per workgroup, one statistics row per workgroup
+        const long long rows = (long long)Nh * (Hi - 2);
+        long long wg = (rows + 3) / 4;
+        const long long cap = rows_knob > 1 ? rows_knob : 768;   // measured 256 .. 2048 (profiles/r05l_first_rows.txt): flat between 512 and 1024
+        if (wg > cap) wg = cap;
+        const unsigned grid = (unsigned)wg;
+        if (stats) kp_set_last_rows((long long)grid);
+        KP_QUERY_RETURN();
+        const long long xh = (long long)Nh * Hi * Wi, yh = M * K;
+#define KP_FIRST_ROWS(KBv, WIDEv)                                                                                             \
+    conv3_first_fwd_rows_k<KBv, WIDEv><<<pair ? 2 * grid : grid, 256, 0, st>>>((const h16_t*)x, (const h16_t*)w, bias, (h16_t*)y, \
+                                                                               stats, Hi, Wi, rows, pair ? (int)grid : 0, xh, yh)
+        if (K == 16) { if (Wi > 128) KP_FIRST_ROWS(2, true); else KP_FIRST_ROWS(2, false); }
+        else { if (Wi > 128) KP_FIRST_ROWS(4, true); else KP_FIRST_ROWS(4, false); }
+#undef KP_FIRST_ROWS
+        return kp_check_launch("conv3_first_fwd_rows");
     }
     long long wgs = (M + TPB - 1) / TPB;
     if (wgs > 2048) wgs = 2048;                     // (the caller's statistics buffer holds M / 64 rows)
