@@ -298,3 +298,20 @@ def fuse_head_bn_bwd() -> bool:
 def set_fuse_head_bn_bwd(on: bool) -> None:
     global _FUSE_HEAD_BN_BWD
     _FUSE_HEAD_BN_BWD = bool(on)
+
+
+_KEEP_SAVED = False
+
+
+def keep_saved_activations() -> bool:
+    """`loss.backward(retain_graph=True)`: a Unit's backward releases its saved activations when it returns (hundreds of MB per
+    Unit that autograd would otherwise hold until the graph dies) -- a second backward through the same forward then raises.  With
+    `set_keep_saved_activations(True)` they stay with the graph and every further backward accumulates into `.grad` as torch's
+    does (nothing in a backward writes a saved buffer).  The reference's train loops (/root/reference/transporter.py:85-89,
+    keypoints.py:86-90) run one backward per forward: OFF by default."""
+    return _KEEP_SAVED
+
+
+def set_keep_saved_activations(on: bool) -> None:
+    global _KEEP_SAVED
+    _KEEP_SAVED = bool(on)

@@ -601,7 +601,8 @@ class UnitFunction(torch.autograd.Function):
             raise RuntimeError('keypoints_amd Unit: backward without an output gradient')
         if getattr(ctx, 'saved', None) is None:
             raise RuntimeError('keypoints_amd Unit: backward was already run for this forward; the saved activations are '
-                               'released after the first backward (retain_graph=True is not supported)')
+                               'released after the first backward (for retain_graph=True call '
+                               'keypoints_amd.runtime.set_keep_saved_activations(True) before the forward)')
         unit, saved, a_last = ctx.unit, ctx.saved, ctx.head_in
         (out,) = ctx.saved_tensors
         N, Cin, H0, W0, Hh, Wh, Ch, Kout, pad0 = ctx.dims
@@ -813,7 +814,8 @@ class UnitFunction(torch.autograd.Function):
             dx = torch.empty(N, Cin, H0, W0, device=dev, dtype=torch.float32)
             call('kp_nhwc_grad_to_nchw', ptr(g), ptr(dx), N, Cin, ctx.cp0, H0, W0, gp, code, st)
         # release the saved activations now (not when the graph dies): hundreds of MB per Unit
-        ctx.saved = ctx.head_in = ctx.unit = None
+        if not runtime.keep_saved_activations():
+            ctx.saved = ctx.head_in = ctx.unit = None
         if side is not None:
             cur.wait_stream(side)
             runtime._used.discard(side)

@@ -511,3 +511,35 @@ def test_backward_through_eval_mode_batchnorm(core, slope_core):
         assert float(p.grad.abs().max()) > 0, n          # conv biases included: eval-mode BatchNorm does not cancel them
     for n, b in unit.named_buffers():                    # eval mode leaves the running statistics alone
         assert torch.equal(b, before[n]), n
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16'])
+def test_second_backward_with_kept_activations(precision):
+    """`backward(retain_graph=True)` twice through one forward (runtime.set_keep_saved_activations): the second pass accumulates the
+    same gradients again -- `.grad` exactly doubles (fp32 g + g), the input gradient is bit-identical -- and without the switch the
+    second backward raises instead of reading released buffers."""
+    from keypoints_amd import runtime
+    from keypoints_amd.models import knn, vgg
+    torch.manual_seed(3)
+    unit = knn.Unit(3, 5, vgg.make_layers([64, 'M', 64, 'U', 64])).cuda()
+    unit.precision = precision
+    x = torch.randn(4, 3, 32, 32, device='cuda', requires_grad=True)
+    w = torch.randn(4, 5, 32, 32, device='cuda')
+    runtime.set_keep_saved_activations(True)
+    try:
+        loss = (unit(x) * w).sum()
+        loss.backward(retain_graph=True)
+        g1 = [p.grad.clone() for p in unit.parameters()]
+        x1 = x.grad.clone()
+        x.grad = None
+        loss.backward()
+        for a, (name, p) in zip(g1, unit.named_parameters()):
+            assert torch.equal(p.grad, a + a), name
+            assert p.dim() == 1 or float(a.abs().max()) > 0, name   # (conv biases in front of train-mode BatchNorm: zero gradient)
+        assert torch.equal(x.grad, x1)
+    finally:
+        runtime.set_keep_saved_activations(False)
+    loss = (unit(x) * w).sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match='set_keep_saved_activations'):
+        loss.backward()

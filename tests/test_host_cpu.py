@@ -265,8 +265,8 @@ def test_round4_support_queries_answer_without_a_device():
     assert L.kp_head_t_supported(128, 16, 16, 512, 64, FP16) == 0 and L.kp_keypoint_bottleneck_t_supported(128, 64, 10, 16, 16, FP16) == 0
     assert L.kp_conv_pair_supported(256, 128, 128, 3, 64, 1, FP16) == 0 and L.kp_conv_pair_supported(511, 84, 84, 1, 16, 1, BF) == 0
     # a pair launch writes the rows of the separate call, per half
-    # (first-layer kernel: one row per workgroup of <= 2 048; band kernel: one row per workgroup of 512)
-    assert L.kp_conv_fwd_stats_rows(256, 86, 86, 1, 16, 3, BF) == 2048 and L.kp_conv_fwd_stats_rows(256, 86, 86, 16, 32, 3, BF) == 512
+    # (first-layer row kernel: one row per workgroup of <= 768; band kernel: one row per workgroup of 512)
+    assert L.kp_conv_fwd_stats_rows(256, 86, 86, 1, 16, 3, BF) == 768 and L.kp_conv_fwd_stats_rows(256, 86, 86, 16, 32, 3, BF) == 512
     torch.manual_seed(0)
     net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, 4, combine_mode='max').set_precision('bf16')
     assert head_dims(net.feature, 84, 84) == (84, 84, 32, 16) and head_dims(net.keypoint, 84, 84) == (84, 84, 32, 4)
