@@ -93,6 +93,7 @@ int kp_config(int key, int value);
 #define KP_CFG_FIRST_KTN 10  /* kp_conv_first_fwd_bnact: 2 (default) one wavefront computes all 64 channels of its groups (66 us at 128 x 128 x 128: the plain convolution's time); 1: a pair of wavefronts, 32 channels each (75 us) */
 #define KP_CFG_CUS 6          /* CU budget the persistent kernels size their grids to (launches on a CU-masked stream); 0 = whole device */
 #define KP_CFG_TRACE 2        /* device buffer of 512 int64: s_memtime stamps of workgroup 0 of the patch conv kernel */
+#define KP_CFG_RING_STREAM 15 /* kp_config_ptr, THREAD-LOCAL: a hipStream_t.  The border ring of this thread's matrix-core data gradients (kp_conv_dgrad, kp_conv_dgrad_bnred: 16x16-tileable maps, channels multiples of 64) is launched there as a one-wavefront, LDS-free kernel that runs BESIDE the persistent interior kernel instead of after it; the call orders the two streams itself (the ring stream waits for the call's stream, the call's stream waits for the ring).  NULL (default): everything on the call's stream.  Results bit-identical. */
 int kp_config_ptr(int key, void* value);
 
 /* ---- measurement (bench.py roofline leg; not used by the model code) ------- */

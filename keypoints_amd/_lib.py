@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libkp_hip.so')
 KP_F32, KP_BF16, KP_F16 = 0, 1, 2
 TAIL_NONE, TAIL_MAXPOOL2, TAIL_UPSAMPLE2 = 0, 1, 2
 KP_CFG_CUS = 6   # kp_config key: CU budget of the persistent kernels (include/kp_hip.h)
+KP_CFG_RING_STREAM = 15   # kp_config_ptr key (thread-local): stream of the data gradients' border ring (include/kp_hip.h)
 COMBINE = {'sum_and_clamp': 1, 'pretrained_network': 2, 'loop': 3}
 
 _p, _i, _f, _z, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong

@@ -69,6 +69,11 @@ def apply_env(env=None) -> list:
         call('kp_config', 10, int(env['KP_FIRST_KTN'])); used.append('KP_FIRST_KTN=' + env['KP_FIRST_KTN'])
     if env.get('KP_HEAD_BN_FUSE'):
         runtime.set_fuse_head_bn_bwd(True); used.append('KP_HEAD_BN_FUSE')
+    if env.get('KP_RING_BESIDE'):
+        runtime.set_ring_beside(True); used.append('KP_RING_BESIDE')
+    if env.get('KP_RING_MIN_SIDE'):
+        from . import unit_engine
+        unit_engine.RING_MIN_SIDE = int(env['KP_RING_MIN_SIDE']); used.append('KP_RING_MIN_SIDE=' + env['KP_RING_MIN_SIDE'])
     if env.get('KP_NO_FIRST_FUSE'):
         runtime.set_fuse_first_layer(False); used.append('KP_NO_FIRST_FUSE')
     if env.get('KP_EAGER_BLEND'):

@@ -116,8 +116,12 @@ int kp_config(int key, int value) {
     return KP_E_ARG;
 }
 
+static thread_local hipStream_t t_ring_stream = nullptr;
+hipStream_t kp_ring_stream() { return t_ring_stream; }
+
 int kp_config_ptr(int key, void* value) {
     if (key == KP_CFG_TRACE) { g_kp_trace = (long long*)value; return KP_OK; }
+    if (key == KP_CFG_RING_STREAM) { t_ring_stream = (hipStream_t)value; return KP_OK; }
     kp_set_error("kp_config_ptr: unknown key %d", key);
     return KP_E_ARG;
 }

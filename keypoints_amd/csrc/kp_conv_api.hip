@@ -47,7 +47,9 @@ long long kp_conv_ring_bred_rows(int, int, int);
 int kp_conv_patch_launch_bred(const void*, const void*, void*, const void*, const float*, const float*, const float*, const float*, float, float*,
                               int, int, int, int, int, hipStream_t);
 int kp_conv_ring_dgrad_bred(const void*, const void*, void*, const void*, const float*, const float*, const float*, const float*, float, float*,
-                            int, int, int, int, int, hipStream_t);
+                            int, int, int, int, int, hipStream_t, int lite = 0);
+bool kp_ring_fork(hipStream_t st, hipStream_t& rs, hipEvent_t (&ev)[2]);
+int kp_ring_join(hipStream_t st, hipStream_t rs, hipEvent_t (&ev)[2]);
 extern kp_knob_t g_kp_bred_patch;   // kp_config(KP_CFG_BRED_PATCH, v): 1 (default) the matrix-core layers' data gradient offers the fused form
 extern kp_knob_t g_kp_wgrad_patch;
 
@@ -297,9 +299,16 @@ int kp_conv_dgrad_bnred(const void* dy, const void* w_dgrad, void* gx, const voi
     kp_set_last_rows(prows + kp_conv_ring_bred_rows(N, H, W));
     KP_QUERY_RETURN();
     ProfScope ps(KP_PROF_CONV_MFMA, flops, (hipStream_t)stream, bytes);
+    hipStream_t rs; hipEvent_t ev[2];
+    const bool fork = kp_ring_fork((hipStream_t)stream, rs, ev);   // the ring beside the interior (kp_config_ptr(KP_CFG_RING_STREAM))
     int rc = kp_conv_patch_launch_bred(dy, w_dgrad, gx, yred, mean, invstd, gamma, beta, slope, partials, N, H, W, K, C, (hipStream_t)stream);
     if (rc == KP_OK)
-        rc = kp_conv_ring_dgrad_bred(dy, w_dgrad, gx, yred, mean, invstd, gamma, beta, slope, partials + prows * 2 * C, N, H, W, K, C, (hipStream_t)stream);
+        rc = kp_conv_ring_dgrad_bred(dy, w_dgrad, gx, yred, mean, invstd, gamma, beta, slope, partials + prows * 2 * C, N, H, W, K, C,
+                                     fork ? rs : (hipStream_t)stream, fork ? 1 : 0);
+    if (fork) {
+        const int rj = kp_ring_join((hipStream_t)stream, rs, ev);
+        if (rc == KP_OK) rc = rj;
+    }
     ps.done(KP_PROF_CONV_MFMA);
     return rc;
 }

@@ -315,3 +315,24 @@ def keep_saved_activations() -> bool:
 def set_keep_saved_activations(on: bool) -> None:
     global _KEEP_SAVED
     _KEEP_SAVED = bool(on)
+
+
+_RING_BESIDE = False   # (measured: no gain, see the docstring)
+
+
+def ring_beside() -> bool:
+    """The data gradient of a matrix-core layer = the persistent LDS-patch kernel on the 16x16-tileable interior + a short launch for the
+    1-pixel ring of the padded domain (19 per model-F step, 0.73 ms of ramp-up and drain).  `set_ring_beside(True)` sends the ring to a
+    side stream as conv3x3_ring_lite_k -- one wavefront per workgroup, no LDS, <= 128 registers: it fits on a CU beside the interior
+    kernel's workgroup -- with the two cross-stream dependencies the library adds around it (kp_config_ptr(KP_CFG_RING_STREAM)).
+    Bit-identical results (tests/test_gpu_ring_lite.py).  OFF by default: measured on model F, alternating on one box
+    (docs/experiments/r05.md section 13): 32.59 -> 33.64 ms with every layer's ring beside its interior (the one-wave kernel takes
+    194 us on average where the LDS kernel takes 38 alone: on the 16 x 16 and 32 x 32 maps it outlasts the interior), 33.62 -> 33.68 /
+    33.55 -> 33.60 with only the 128 x 128 layers' rings (hidden there, and the two cross-queue waits per layer cost what the ring
+    did)."""
+    return _RING_BESIDE
+
+
+def set_ring_beside(on: bool) -> None:
+    global _RING_BESIDE
+    _RING_BESIDE = bool(on)

@@ -298,6 +298,33 @@ def _materialise(fin, N, H, W, C, pad, tdt, code, st):
     return a
 
 
+RING_MIN_SIDE = 0   # (keypoints_amd._probe: KP_RING_MIN_SIDE)
+
+
+class _ring_beside:
+    """`with _ring_beside(...)`: with `runtime.set_ring_beside(True)` (OFF by default: measured, no gain) the border ring of a matrix-core
+    data gradient issued inside the block runs on the side stream 'ring', beside the persistent interior kernel instead of after it
+    (kp_config_ptr(KP_CFG_RING_STREAM), include/kp_hip.h: the library orders the two streams around its own launches, so nothing has
+    to be joined here).  Matrix-core layers only; results bit-identical."""
+
+    def __init__(self, side_ok, H, W, C, K):
+        self._s = None
+        if (side_ok and runtime.ring_beside() and runtime.multi_stream('ring') and C % 64 == 0 and K % 64 == 0 and H % 16 == 0
+                and W % 16 == 0 and min(H, W) >= RING_MIN_SIDE):
+            self._s = runtime.side_stream('ring')
+            runtime._used.discard(self._s)   # (joined by the library call itself)
+
+    def __enter__(self):
+        if self._s is not None:
+            call('kp_config_ptr', _lib.KP_CFG_RING_STREAM, self._s.cuda_stream)
+        return self
+
+    def __exit__(self, *exc):
+        if self._s is not None:
+            call('kp_config_ptr', _lib.KP_CFG_RING_STREAM, None)
+        return False
+
+
 def _wgrad_layer(sv, dy, gw, parts, N, H, W, C, K, dp, tdt, code, dev):
     """Weight gradient of one 3x3 layer on torch's current stream: kp_conv_wgrad (or its fused-BatchNorm-input form) into `parts`
     partial buffers, then kp_wgrad_unpack adds them into the arena view `gw` in a fixed order.  (A module-level function so that
@@ -770,12 +797,14 @@ class UnitFunction(torch.autograd.Function):
                     svb, bnb = saved[idx - 1], below['bn']
                     rows_b = _lib.lib().kp_conv_dgrad_bnred_rows(N, H, W, K, C, code)
                     part_b = torch.empty(rows_b, 2, C, device=dev, dtype=torch.float32)
-                    call('kp_conv_dgrad_bnred', ptr(dy), ptr(sv['wd']), ptr(gx), ptr(svb['y']), ptr(svb['mean']), ptr(svb['invstd']),
-                         ptr(bnb.weight if bnb is not None else None), ptr(bnb.bias if bnb is not None else None), below['slope'],
-                         ptr(part_b), N, H, W, K, C, code, st)
+                    with _ring_beside(side_ok, H, W, C, K):
+                        call('kp_conv_dgrad_bnred', ptr(dy), ptr(sv['wd']), ptr(gx), ptr(svb['y']), ptr(svb['mean']), ptr(svb['invstd']),
+                             ptr(bnb.weight if bnb is not None else None), ptr(bnb.bias if bnb is not None else None), below['slope'],
+                             ptr(part_b), N, H, W, K, C, code, st)
                     pending_red = (part_b, rows_b)
                 else:
-                    call('kp_conv_dgrad', ptr(dy), ptr(sv['wd']), ptr(gx), N, H, W, K, C, code, st)
+                    with _ring_beside(side_ok, H, W, C, K):
+                        call('kp_conv_dgrad', ptr(dy), ptr(sv['wd']), ptr(gx), N, H, W, K, C, code, st)
                 g, gp = gx, 1
             else:
                 g = None
