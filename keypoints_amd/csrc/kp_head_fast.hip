@@ -35,15 +35,16 @@ __device__ __forceinline__ float group_sum(float v, int CV) {
     return v;
 }
 
-// KB = compile-time bound on K (4 or 16); CV = C/8 is a power of two <= 64 (checked by the launcher).
-// All three kernels keep the thread's weight columns (or accumulators) in registers, are branch-free over k (rows
+// KB = compile-time bound on K (1, 4 or 16); CV = C/8 is a power of two <= 64 (checked by the launcher).
+// The backward kernels keep the thread's weight columns (or accumulators) in registers, are branch-free over k (rows
 // k >= K are zero-padded: a `k < K` test inside the unrolled loop put every strided gout / out load behind its own
-// s_waitcnt, 16 serialised round trips per pixel), issue every load of an iteration before the first use, and walk TWO
-// pixels per iteration.  Pixel indices fit 32 bits (checked by the launcher), so the per-pixel (image, offset) split is a
-// 32-bit division.
+// s_waitcnt, 16 serialised round trips per pixel), walk TWO pixels per iteration and, for KB <= 4, issue the loads of the
+// NEXT iteration before the arithmetic of the current one.  Pixel indices fit 32 bits (checked by the launcher), so the
+// per-pixel (image, offset) split is a 32-bit division.
 constexpr int PIX = 2;   // pixels in flight per thread
 
-// forward: weights in LDS (the register-resident variant measured slower: 173 VGPRs at KB = 16)
+// forward, general form (K > 4 or C not 16 / 32 / 64; the image heads take head_fwd_k4_k below): weights in LDS (the
+// register-resident variant measured slower at KB = 16: 173 VGPRs)
 // BNIN (all three kernels that read x): x is the producing layer's conv output and `bn` its BatchNorm / activation, applied
 // to each 16-byte chunk as it is loaded (KpBnIn, kp_common.h) -- a thread's 8 channels are fixed, their constants live in registers
 template <int KB, bool BNIN>
