@@ -28,7 +28,7 @@ def timeit(f, n=20):
 
 
 N = 128
-for H, C in [(16, 512), (32, 256), (64, 128)]:
+for H, C in [(16, 512), (32, 256), (64, 256), (64, 128)]:   # model F's three 'U' entries, + the 128-channel shape of profiles/r05n_bn_up.txt
     y = torch.randn(N, H, H, C, device='cuda').to(dt)
     mean, invstd = torch.randn(C, device='cuda') * 0.1, torch.rand(C, device='cuda') + 0.5
     gamma, beta = torch.rand(C, device='cuda') + 0.5, torch.randn(C, device='cuda') * 0.1
