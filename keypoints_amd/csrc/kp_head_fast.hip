@@ -112,8 +112,8 @@ __global__ __launch_bounds__(TPB) void head_fwd_k4_k(const h16_t* __restrict__ x
     if (BNIN) k8.load(bn, cv * V);
     const int m0 = (int)((long long)blockIdx.x * ppb), Mi = (int)M;
     int n = (m0 + pl) / HW, hw = (m0 + pl) - n * HW;          // of pixel m0 + i (u = 0); u > 0 adds u * NPL
-    uint4 raw[PF], rawn[PF];
-    int m[PF], mn[PF];
+    uint4 raw[PF] = {}, rawn[PF] = {};   // (zero: the last rotation copies a `rawn` nothing was fetched into)
+    int m[PF] = {}, mn[PF] = {};
     auto issue = [&](int i, uint4 (&rw)[PF], int (&mm)[PF]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(TPB) void head_dx_small_k(const float* __restrict__
         }
     const int m0 = (int)((long long)blockIdx.x * ppb), Mi = (int)M;
     constexpr bool PIPE = KB <= 4;
-    DzLoad<KB, QUAD> cur[PIX], nxt[PIX];
-    int m[PIX], mn[PIX];
+    DzLoad<KB, QUAD> cur[PIX] = {}, nxt[PIX] = {};   // (zero: the last rotation copies a `nxt` nothing was fetched into)
+    int m[PIX] = {}, mn[PIX] = {};
     auto issue = [&](int i, DzLoad<KB, QUAD> (&r)[PIX], int (&mm)[PIX]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < PIX; ++u) {
@@ -327,9 +327,9 @@ __global__ __launch_bounds__(TPB) void head_dw_small_k(const float* __restrict__
     }
     const int m0 = (int)((long long)blockIdx.x * ppb), Mi = (int)M;
     constexpr bool PIPE = KB <= 4;
-    DzLoad<KB, QUAD> cur[PIX], nxt[PIX];
-    uint4 raw[PIX], rawn[PIX];
-    int m[PIX], mn[PIX];
+    DzLoad<KB, QUAD> cur[PIX] = {}, nxt[PIX] = {};   // (zero: the last rotation copies a `nxt` nothing was fetched into)
+    uint4 raw[PIX] = {}, rawn[PIX] = {};
+    int m[PIX] = {}, mn[PIX] = {};
     auto issue = [&](int i, DzLoad<KB, QUAD> (&r)[PIX], uint4 (&rw)[PIX], int (&mm)[PIX]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < PIX; ++u) {
