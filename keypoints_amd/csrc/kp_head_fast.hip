@@ -625,9 +625,9 @@ bool kp_head_small_shape(long long M, int C, int K) { return small_shape(C, K) &
 int kp_head_dx_fast(const float* gout, const float* out, const float* w, float slope, void* dx, long long M, int HW,
                     int C, int K, hipStream_t st) {
     if (!small_shape(C, K) || M >= (1LL << 31)) return KP_E_UNSUPPORTED;
-    // the register-resident weights are loaded once per thread: 8..32 pixels per thread, at least ~2048 workgroups
+    // the register-resident weights are loaded once per thread: 8..32 pixels per thread, ~4096 workgroups where the map allows
     const int npl = TPB / (C / V);
-    long long per = M / ((long long)npl * 2048);
+    long long per = M / ((long long)npl * 4096);   // (measured at model F's head, ~1024 / 2048 / 4096 workgroups: 96 / 90 / 85 us)
     per = per < 8 ? 8 : (per > 32 ? 32 : per);
     const int ppb = npl * (int)per;
     const unsigned grid = (unsigned)((M + ppb - 1) / ppb);
@@ -641,7 +641,8 @@ static long long dw_fast_plan(long long M, int C, int K, long long& ppb) {
     const int npl = TPB / (C / V);
     const size_t lds = ((size_t)npl * 4 * C + (size_t)npl * 4 + TPB) * sizeof(float);   // KC = 4 channels per reduction pass
     if (lds > 64 * 1024) return 0;
-    ppb = (M + 2047) / 2048;                    // ~2048 workgroups, each a contiguous run of pixels
+    ppb = (M + 1023) / 1024;                    // ~1024 workgroups (four per CU: one resident round at the kernels' 4 waves per SIMD), each a
+                                                // contiguous run of pixels; measured 512 / 768 / 1024 / 2048 / 4096: 114 / 99 / 93 / 99 / 110 us at model F's head
     if (ppb < npl) ppb = npl;
     ppb = (ppb + npl - 1) / npl * npl;
     return (M + ppb - 1) / ppb;
