@@ -60,6 +60,10 @@ int kp_device_cus(void);
 #define KP_CFG_CONV_PATCH 0   /* 1 (default): LDS-patch 3x3 kernel where eligible; 2: its pair-tile generation first (kp_conv_pair.hip: measured equal, opt-in); 0: linear implicit-GEMM kernel */
 #define KP_CFG_DEBUG 1        /* ablation mask for kernel measurements (0 = normal operation) */
 int kp_config(int key, int value);
+/* the value kp_config(key, .) last stored (the default if never set): KP_CFG_CUS, KP_CFG_CONV_PATCH, KP_CFG_DEBUG, KP_CFG_WALK, KP_CFG_BN_FAST,
+ * KP_CFG_BRED_PATCH, KP_CFG_FIRST_ROWS; a caller that changes a process-global knob for its own lifetime (keypoints_amd.dist.GradReducer:
+ * the reduced persistent grid of the overlap mode) restores what it found.  KP_E_ARG (negative) for any other key. */
+int kp_config_get(int key);
 #define KP_CFG_WGRAD_PATCH 3  /* 1 (default): tap-reuse weight-gradient kernel where eligible; 0: per-tap kernel */
 #define KP_CFG_BN_FAST 4      /* 1 (default): multi-row unrolled bf16 BatchNorm/activation kernels; 0: general kernels */
 #define KP_CFG_WALK 5         /* memory walk order of the passes, a mask of KP_WALK_* (default KP_WALK_DEFAULT; 0 = every pass front to back,

@@ -116,6 +116,20 @@ int kp_config(int key, int value) {
     return KP_E_ARG;
 }
 
+// The raw value of an integer knob (what the last kp_config(key, .) stored; the library's default if never set), so that a caller
+// that changes a process-global knob for its own lifetime can put back what it found.  Negative: KP_E_ARG (unknown key).
+int kp_config_get(int key) {
+    if (key == KP_CFG_CUS) return g_kp_cus;
+    if (key == KP_CFG_CONV_PATCH) return g_kp_conv_patch;
+    if (key == KP_CFG_DEBUG) return g_kp_debug;
+    if (key == KP_CFG_WALK) return g_kp_walk;
+    if (key == KP_CFG_BN_FAST) return g_kp_bn_fast;
+    if (key == KP_CFG_BRED_PATCH) return g_kp_bred_patch;
+    if (key == KP_CFG_FIRST_ROWS) return g_kp_first_rows;
+    kp_set_error("kp_config_get: unknown key %d", key);
+    return KP_E_ARG;
+}
+
 static thread_local hipStream_t t_ring_stream = nullptr;
 hipStream_t kp_ring_stream() { return t_ring_stream; }
 

@@ -679,6 +679,9 @@ int kp_conv_first_fwd(const void* x, const void* w, const float* bias, void* y, 
         long long wg = (rows + 3) / 4;
         const long long cap = rows_knob > 1 ? rows_knob : 768;   // measured 256 .. 2048 (profiles/r05l_first_rows.txt): flat between 512 and 1024
         if (wg > cap) wg = cap;
+        // one statistics row per workgroup: the caller's buffer (include/kp_hip.h, kp_conv_fwd) holds ceil(M / 64) rows, which four output
+        // rows per workgroup exceed on maps narrower than 16 pixels -- the grid-stride loop of the kernel takes any grid
+        if (wg > M / 64) wg = M / 64;
         const unsigned grid = (unsigned)wg;
         if (stats) kp_set_last_rows((long long)grid);
         KP_QUERY_RETURN();

@@ -88,7 +88,8 @@ class NativeComm:
 
 class GradReducer:
     def __init__(self, root: torch.nn.Module, group=None, broadcast_init: bool = True, tail_fraction: float = 0.6,
-                 transport: str = 'fp32', overlap: bool = True, sync_bn: bool = False, comm: str = 'torch', reserve_cus: int = 32):
+                 transport: str = 'fp32', overlap: bool = True, sync_bn: bool = False, comm: str = 'torch', reserve_cus: int = 32,
+                 reserve_alone: bool = False):
         """overlap: True -- pieces are all-reduced from the backward hooks, concurrently with the rest of the backward;
         False -- the hooks only note which arenas are final and `finish()` reduces them back to back (the exchange is then
         fully exposed, ~1 ms for model F over xGMI, but no RCCL kernel ever shares the CUs with the persistent MFMA
@@ -99,7 +100,9 @@ class GradReducer:
         that many CUs -- 4 per XCD at the default 32 -- permanently free for RCCL's channel workgroups: a collective that starts in
         the middle of a persistent launch finds CUs of its own instead of queueing workgroups of the NEXT launch behind it.  Cap
         RCCL to as many channels (`NCCL_MAX_NCHANNELS=<reserve_cus>` in the launcher's environment, before the communicator is
-        created: bench.py --dp-overlap 1 does).  0 = the whole device for the kernels (round 4's behaviour).
+        created: bench.py --dp-overlap 1 does).  0 = the whole device for the kernels (round 4's behaviour).  The knob is process-global, so
+        the reservation is made only with more than one rank (`reserve_alone=True`: also for a lone rank -- the single-GPU measurement
+        of what the reduced grid costs) and the previous value of the knob is restored when overlap is switched off / `detach()`.
         Why 32: measured on one GPU (bench.py --grid-cus, profiles/r05c_grid_cus.txt), model F fp16 step: 256 CUs 33.08 ms, 248
         34.39, 240 34.06, 224 33.66 -- the tile lists of the BASELINE layers divide evenly over 28 workgroups per XCD and not over
         30 or 31, so 224 costs 1.8 % where 240 costs 3 %.
@@ -119,7 +122,9 @@ class GradReducer:
         self.world = dist.get_world_size(group)
         self.transport = transport
         self.reserve_cus = max(0, int(reserve_cus))
-        self.grid_cus = None     # CU budget of the persistent kernels while overlap is on (None: the whole device)
+        self.reserve_alone = bool(reserve_alone)
+        self.grid_cus = None     # CU budget of the persistent kernels while this reducer holds a reservation (None: it holds none)
+        self._cus_before = 0     # what KP_CFG_CUS held when the reservation was made (restored when it ends)
         self._overlap = False
         self.overlap = overlap   # (property: reserves / releases the CUs)
         self._ready = []     # overlap=False: arena slices noted by the hooks, reduced in finish()
@@ -154,13 +159,23 @@ class GradReducer:
         on = bool(on)
         p0 = next(self.root.parameters(), None)
         on_device = p0 is not None and p0.is_cuda   # (the CPU / gloo tests of the bookkeeping have no library knob to set)
-        self.grid_cus = None
-        if on and self.reserve_cus > 0 and on_device:
+        # KP_CFG_CUS is process-global: the reservation is made only where a collective can actually run beside the kernels (more than
+        # one rank -- a lone rank would pay the reduced grid's ~1.8 % for nothing -- or `reserve_alone` for the single-GPU measurement
+        # of that cost), and what the knob held before (a budget the caller set, bench.py --grid-cus; another reducer's) is put back
+        # when the reservation ends instead of being overwritten with 0
+        want = None
+        if on and self.reserve_cus > 0 and on_device and (self.world > 1 or self.reserve_alone):
             total = torch.cuda.get_device_properties(p0.device).multi_processor_count
             # a multiple of the 8 XCDs (the persistent kernels round their grids down to one anyway), never below one CU per XCD
-            self.grid_cus = max(8, (total - self.reserve_cus) // 8 * 8)
+            want = max(8, (total - self.reserve_cus) // 8 * 8)
         if on_device:
-            _lib.call('kp_config', _lib.KP_CFG_CUS, self.grid_cus or 0)
+            if want is not None:
+                if self.grid_cus is None:
+                    self._cus_before = int(_lib.lib().kp_config_get(_lib.KP_CFG_CUS))
+                _lib.call('kp_config', _lib.KP_CFG_CUS, want)
+            elif self.grid_cus is not None:
+                _lib.call('kp_config', _lib.KP_CFG_CUS, max(0, self._cus_before))
+        self.grid_cus = want
         self._overlap = on
 
     @staticmethod

@@ -347,13 +347,21 @@ class LazyNCHW(torch.Tensor):
     def __init__(self, a, pad, code):
         self._kp_src = (a, int(pad), code)
         self._kp_val = None
+        self._kp_detached = False   # _kp_val was made under no_grad although the source carries a graph (see materialize)
 
     def materialize(self) -> torch.Tensor:
-        if self._kp_val is None:
-            a, pad, code = self._kp_src
-            self._kp_val = padded_t_to_nchw(a, pad, code)
+        """The real tensor.  A copy made while autograd was OFF (image logging under torch.no_grad()) of a source that requires grad
+        has no graph: it serves the no_grad uses, but the source is kept and the first use with autograd ON makes the copy again, with
+        its graph -- a loss on the returned map then reaches the encoders exactly as the reference's `phi_xs` would."""
+        if self._kp_val is not None and not (self._kp_detached and torch.is_grad_enabled()):
+            return self._kp_val
+        a, pad, code = self._kp_src
+        val = padded_t_to_nchw(a, pad, code)
+        self._kp_val = val
+        self._kp_detached = bool(a.requires_grad) and not torch.is_grad_enabled()
+        if not self._kp_detached:
             self._kp_src = None
-        return self._kp_val
+        return val
 
     # metadata that is known without the values
     _META = {'shape', 'dtype', 'device', 'ndim', 'layout', 'is_cuda', 'is_sparse', 'is_quantized', 'is_meta', 'names'}

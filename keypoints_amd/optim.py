@@ -23,7 +23,11 @@ def _loss_ws(device):
     key = (device.index, torch.cuda.current_stream(device).stream_id)
     ws = _LOSS_WS.get(key)
     if ws is None:
-        ws = _LOSS_WS[key] = torch.zeros(2, device=device, dtype=torch.float64)
+        ws = torch.zeros(2, device=device, dtype=torch.float64)
+        # created while a HIP graph is being captured, the zero-fill is only RECORDED: such a workspace belongs to that graph (its
+        # replays zero it first) and is not handed to eager calls on the same stream id, which would find it uninitialised
+        if not torch.cuda.is_current_stream_capturing():
+            _LOSS_WS[key] = ws
     return ws
 
 
@@ -39,7 +43,12 @@ class _L2Loss(torch.autograd.Function):
         loss = torch.empty(1, device=x.device, dtype=torch.float32)
         # (the mean -- fp64 sum / n, rounded once to fp32 -- is written by the kernel's last workgroup: no zero-fill, no division
         #  launch between the forward and the backward)
-        call('kp_l2_loss_mean', ptr(x), ptr(target), ptr(mask), ptr(_loss_ws(x.device)), ptr(loss), ptr(grad), n, stream_ptr())
+        try:
+            call('kp_l2_loss_mean', ptr(x), ptr(target), ptr(mask), ptr(_loss_ws(x.device)), ptr(loss), ptr(grad), n, stream_ptr())
+        except Exception:
+            # a launch that did not complete may leave the sum / arrival counter non-zero: never reuse that workspace
+            _LOSS_WS.pop((x.device.index, torch.cuda.current_stream(x.device).stream_id), None)
+            raise
         ctx.save_for_backward(grad)
         return loss.reshape(())
 

@@ -493,7 +493,9 @@ class UnitFunction(torch.autograd.Function):
                 else:
                     # eval mode: the running statistics are constants of the layer (nn.BatchNorm2d.eval()); the backward then has
                     # no batch-mean terms (see `eval_bn` there)
-                    mean = bn.running_mean
+                    # (both are SNAPSHOTS when a backward may follow: the backward recomputes xhat from them, and a train-mode forward
+                    #  of the same module or a load_state_dict between this forward and its backward must not change one of the two)
+                    mean = bn.running_mean.clone() if record else bn.running_mean
                     invstd = torch.rsqrt(bn.running_var + bn.eps)
             tail = stp['tail']
             Ho, Wo = _tail_dims(H, W, tail)

@@ -20,6 +20,9 @@ SHAPES = [  # N, Hi, Wi, K, workgroup cap (0 = the default)
     (4, 12, 90, 32, 2),
     (4, 10, 200, 16, 0),     # more than 128 pixels per input row: two dwords per lane
     (4, 10, 200, 32, 2),
+    (64, 10, 10, 16, 0),     # maps narrower than 16 pixels: four output rows per workgroup would be MORE rows than the ceil(M / 64) the
+    (64, 10, 10, 32, 0),     # kp_conv_fwd contract gives the statistics buffer (128 > 64): the grid is capped at M / 64
+    (16, 6, 18, 16, 0),
 ]
 
 
@@ -59,10 +62,12 @@ def test_rows_kernel_forward_and_statistics(N, Hi, Wi, K, cap, dt):
         rows = _lib.last_rows()
         assert rows == _lib.lib().kp_conv_fwd_stats_rows(N, Hi, Wi, 1, K, 3, code)
         torch.cuda.synchronize()
-        out[knob] = (y.cpu(), stats[:rows].cpu(), rows)
+        out[knob] = (y.cpu(), stats[:rows].cpu(), rows, stats.cpu())
     new, old = out[cap if cap else 1], out[0]
-    want_rows = min((N * Ho + 3) // 4, cap if cap else 768)
+    want_rows = min((N * Ho + 3) // 4, cap if cap else 768, N * Ho * Wo // 64)
     assert new[2] == want_rows, 'the row kernel did not take this shape'
+    assert new[2] <= new[3].shape[0], 'more statistics rows than the kp_conv_fwd contract allots (ceil(M / 64))'
+    assert torch.isnan(new[3][new[2]:]).all()   # nothing written behind the rows the call reported
     assert torch.isfinite(new[0].float()).all() and torch.isfinite(new[1]).all()
     # the tensor: the same fp32 accumulation as the kernel it replaces
     assert torch.equal(new[0].view(torch.int16), old[0].view(torch.int16))

@@ -96,6 +96,107 @@ def test_transporter_pong_golden_fp32(golden, tag, size, K):
                     assert maxerr(sd_now[name], ref) <= tol * max(1.0, np.abs(ref).max()), name
 
 
+def _reference_criterion(x, x_, loss_mask=None):
+    """The loss the reference's train script defines inline (/root/reference/transporter.py:56-60): plain torch arithmetic."""
+    loss = (x - x_) ** 2
+    if loss_mask is not None:
+        loss = loss * loss_mask
+    return torch.mean(loss)
+
+
+@pytest.mark.parametrize('tag,size,K', [('32', 32, 3), ('84', 84, 4)])
+def test_reference_loop_plain_torch_adam(golden, tag, size, K):
+    """The drop-in claim for the one line of the train script that does not change: `optim = Adam(transporter_net.parameters(),
+    lr=1e-4)` (/root/reference/transporter.py:47) and the loop of :79-89 as written -- `optim.zero_grad()` (torch's default:
+    gradients set to None), forward, the script's own inline criterion, `loss.backward()`, `optim.step()` -- on the modules
+    `install_as_keypoints()` puts under the reference's import paths.  No FusedAdam, no bind, no keypoints_amd loss: parameters and
+    gradients stay torch's, the gradient arena re-installs its views after every set-to-None.  Three steps against the reference's
+    own three steps (tests/golden/transporter_pong_*.npz) at the tolerances of test_transporter_pong_golden_fp32."""
+    import keypoints_amd as ka
+    ka.install_as_keypoints()
+    from keypoints.models import transporter            # the reference's import path (transporter.py:6)
+    from torch.optim import Adam                         # (transporter.py:3)
+    z = golden(f'transporter_pong_{tag}.npz')
+    transporter_net = transporter.make('VGG_PONG_LAYERNECK', 1, 16, K, load=None).to('cuda')
+    sd = {k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith('p0.') or k.startswith('b0.')}
+    transporter_net.load_state_dict(sd, strict=True)
+    optim = Adam(transporter_net.parameters(), lr=1e-4)
+    criterion = _reference_criterion
+    x, x_ = torch.tensor(z['xs']).to('cuda'), torch.tensor(z['xt']).to('cuda')
+    noise = pre_bn_bias_names(transporter_net)
+    for step in range(1, 4):
+        optim.zero_grad()
+        assert all(p.grad is None for p in transporter_net.parameters())      # torch's default zero_grad(set_to_none=True)
+        x_t, zf, k, m, p, heatmap, mask_xs, mask_xt = transporter_net(x, x_)
+        loss = criterion(x_t, x_, None)
+        loss.backward()
+        if step == 1:
+            assert maxerr(x_t, z['x_t']) <= 1.5e-4 * np.abs(z['x_t']).max()
+            assert maxerr(k, z['k']) <= 2e-5 and maxerr(m, z['m']) <= 2.5e-4
+            for n, prm in transporter_net.named_parameters():
+                if n in noise:
+                    assert float(prm.grad.abs().max()) == 0.0
+                else:
+                    assert rel_l2(prm.grad, z['g.' + n]) <= 1e-3, n
+        assert abs(loss.item() - float(z[f'loss{step}'])) <= 2e-5 * abs(float(z[f'loss{step}']))
+        optim.step()
+        if step in (1, 3):
+            sd_now = transporter_net.state_dict()
+            for key in z.files:
+                if not key.startswith(f'p{step}.') and not key.startswith(f'b{step}.'):
+                    continue
+                name = key[3:]
+                if name in noise:
+                    continue
+                ref = z[key]
+                if name.endswith('num_batches_tracked'):
+                    assert int(sd_now[name].item()) == int(ref)
+                else:
+                    tol = 1e-4 if (name.endswith('running_mean') and step > 1) else 2e-5
+                    assert maxerr(sd_now[name], ref) <= tol * max(1.0, np.abs(ref).max()), name
+
+
+def test_reference_loop_plain_torch_adam_model_F(golden):
+    """The same loop on the north-star architecture (F 128 x 128 x 3, K = 10, B = 2, strict fp32): one step with torch.optim.Adam and
+    the script's criterion; outputs, loss and gradients against the reference's run (tests/golden/transporter_F_128.npz), and the Adam
+    update itself: with bias correction the first step moves every parameter by lr * sign(g) (|g| >> eps)."""
+    import keypoints_amd as ka
+    ka.install_as_keypoints()
+    from torch.optim import Adam
+    z = golden('transporter_F_128.npz')
+    plans, P, Bf, net, xs, xt = _f_setup(z)
+    net = net.to('cuda').set_precision('fp32')
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    optim = Adam(net.parameters(), lr=1e-4)
+    x, x_ = xs.cuda(), xt.cuda()
+    optim.zero_grad()
+    x_t, zf, k, m, p, heatmap, mask_xs, mask_xt = net(x, x_)
+    loss = _reference_criterion(x_t, x_, None)
+    loss.backward()
+    assert maxerr(x_t, z['x_t']) <= 1.5e-4 * np.abs(z['x_t']).max()
+    assert maxerr(k, z['k']) <= 2e-5
+    assert abs(loss.item() - float(z['loss'])) <= 1e-5 * float(z['loss'])
+    noise = pre_bn_bias_names(net)
+    for n, (e_s, e_n, own) in _grad_errors(net, z, noise).items():
+        tol = max(3e-3, 8 * float(z['gnoise.' + n]), 4 * own)
+        assert e_s <= tol and e_n <= max(3e-3, 8 * float(z['gnoise.' + n])), (n, e_s, e_n, tol)
+    grads = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+    optim.step()
+    for n, prm in net.named_parameters():
+        g = grads[n]
+        want = before[n] - 1e-4 * g / (g.abs() + 1e-8)      # Adam, step 1: m_hat = g, v_hat = g^2
+        assert float((prm.detach() - want).abs().max()) <= 1.5e-7, n      # (half an ulp of a parameter of magnitude 1 + 1e-6 of the step)
+    optim.zero_grad()
+    assert all(p.grad is None for p in net.parameters())
+    # a second step runs (the arena re-installs its views after set-to-None) and moves the loss
+    x_t2 = net(x, x_)[0]
+    loss2 = _reference_criterion(x_t2, x_, None)
+    loss2.backward()
+    optim.step()
+    assert all(p.grad is not None for p in net.parameters())
+    assert torch.isfinite(loss2) and float(loss2) != float(loss)
+
+
 def _f_setup(z):
     from keypoints_amd.models import transporter
     from oracle import kp_oracle as O

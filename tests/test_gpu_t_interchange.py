@@ -326,3 +326,34 @@ def test_returned_blend_is_made_on_first_use_and_equals_the_eager_copy():
             ka.set_lazy_outputs(True)
     (a0, s0, e0, d0), (a1, s1, e1, d1) = vals
     assert torch.equal(a0, a1) and s0 == s1 and e0 == e1 and torch.equal(d0, d1)
+
+
+def test_lazy_blend_first_touched_under_no_grad_still_carries_its_graph_afterwards():
+    """A first use under torch.no_grad() (image logging between forward and backward) must not pin a graph-less copy: a later
+    differentiable use of the returned map -- a loss on phi, transporter.py:64's second output -- reaches the encoders, with the same
+    gradients as when the map is used with autograd on from the start."""
+    import keypoints_amd as ka
+    from keypoints_amd.models import functional as MF
+    g = torch.Generator().manual_seed(29)
+    xs = torch.rand(4, 1, 84, 84, generator=g).cuda()
+    xt = torch.rand(4, 1, 84, 84, generator=g).cuda()
+    grads = []
+    for touch_first in (True, False):
+        net = _pong_net('bf16')
+        out = net(xs, xt)
+        phi = out[1]
+        assert type(phi) is MF.LazyNCHW
+        if touch_first:
+            with torch.no_grad():
+                logged = phi.clamp(0, 1).sum().item()           # no graph: serves the log
+            assert phi._kp_detached and phi._kp_src is not None
+            with torch.no_grad():
+                assert phi.clamp(0, 1).sum().item() == logged    # (the graph-less copy is reused under no_grad)
+        loss = (phi * phi).mean()
+        assert loss.requires_grad
+        loss.backward()
+        assert not phi._kp_detached and phi._kp_src is None
+        gr = [p.grad.detach().clone() for p in net.feature.parameters() if p.grad is not None]
+        assert gr and any(float(t.abs().max()) > 0 for t in gr)
+        grads.append(gr)
+    assert len(grads[0]) == len(grads[1]) and all(torch.equal(a, b) for a, b in zip(*grads))
