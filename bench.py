@@ -22,6 +22,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Before the HIP runtime initialises: its kernel-argument pool at 64 MiB (keypoints_amd.runtime.configure_hip_runtime has the
+# measurement: with the default pool the launching thread blocks 8-16 ms every 15-35 steps of the launch-bound config-2 step).
+os.environ.setdefault('HSA_KERNARG_POOL_SIZE', str(64 << 20))
+
 import torch
 import torch.distributed as dist
 
@@ -100,6 +104,10 @@ def parse():
                     help='1 (default): the first pass of a BatchNorm backward (its two sums) runs in the epilogue of the data gradient that '
                          'produces its incoming gradient (kp_conv_dgrad_bnred); 0: as a pass of its own (A/B)')
     ap.add_argument('--lib', default='', help='development: time another build of libkp_hip.so (A/B on one box)')
+    ap.add_argument('--reserve-mem', type=int, default=1,
+                    help='1 (default): after the second warm-up step hand the caching allocator one segment of 1.25 x its peak '
+                         '(keypoints_amd.runtime.reserve_memory): no hipMalloc inside the timed region (without it the config-2 leg grows '
+                         'its pool by ~4 segments per 100 steps: tools/cfg2_stall.py); 0: the allocator as torch leaves it')
     return ap.parse_args()
 
 
@@ -154,6 +162,32 @@ def cpu_baseline(args):
                 s_per_step_median=dt, s_per_step_min=times[0], s_per_step_max=times[-1],
                 sample=f'oracle/kp_oracle.py transporter_train_step fp32, batch {B}, {args.cpu_warmup} warm-up + {args.cpu_steps} '
                        f'timed steps (median), torch CPU {torch.get_num_threads()} threads on {cores} usable cores of "{cpu_model()}"')
+
+
+def cpu_baseline_c1():
+    """BASELINE config 1 / BASELINE.md section 3: the oracle's train step of VGG_PONG_LAYERNECK 84 x 84 grey, K = 4, batch 4 on the host
+    cores -- the reference's own CPU-runnable case (configs/transporter_pong_grey.yaml), the CPU number config 2's GPU figure stands
+    next to.  3 warm-up + 20 timed steps (a step is ~20-40 ms), median."""
+    from oracle import kp_oracle as O
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    plans = O.transporter_plans('VGG_PONG_LAYERNECK', 1, 16, 4)
+    P, Bf = O.init_params(plans, seed=0)
+    g = torch.Generator().manual_seed(1234)
+    xs = torch.rand(4, 1, 84, 84, generator=g) * 2 - 1
+    xt = torch.rand(4, 1, 84, 84, generator=g) * 2 - 1
+    state = {}
+    for _ in range(3):
+        O.transporter_train_step(plans, P, Bf, state, xs, xt)
+    times = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        O.transporter_train_step(plans, P, Bf, state, xs, xt)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    dt = 0.5 * (times[9] + times[10])
+    return dict(value=4 / dt, unit='image-pairs/sec', cores=cores, kind='port', s_per_step_median=dt,
+                sample='oracle transporter_train_step fp32, VGG_PONG_LAYERNECK 84x84x1 K=4, batch 4 (BASELINE config 1), 3 warm-up + 20 timed steps, median')
 
 
 class PowerSampler:
@@ -294,14 +328,31 @@ def _run_leg(args, rank, world, dev):
     if args.graph:
         # the whole step as one HIP graph launch (keypoints_amd/graph.py): for launch-bound nets / batch sizes.  The batch is
         # copied into the graph's input buffers every step, as a training loop would; the roofline legs run eagerly.
-        assert world == 1 and args.net == 'transporter', '--graph: single-GPU Transporter step only'
-        gstep = ka.graph.GraphedTrainStep(net, opt, None, (xs, xt), warmup=2)
+        assert world == 1, '--graph: single-GPU step only'
+        if args.net == 'keynet':
+            # the augmentation draws its parameters on the host (data_augments.py:6-10) and stays outside the graph, as a data
+            # loader would; the graph is net + masked loss + backward + Adam on the (x, x_, mask) it is handed
+            x0, x1, m0 = augment(xs, xt)
+            has_mask = m0 is not None
+            gstep = ka.graph.GraphedTrainStep((lambda x, x_, *m: net(x, x_)), opt,
+                                              (lambda out, inp: ka.l2_reconstruction_loss(out[0], inp[1], inp[2] if has_mask else None)),
+                                              (x0, x1, m0) if has_mask else (x0, x1), warmup=2)
 
-        def step():
-            return gstep(xs, xt)
+            def step():
+                x, x_, mask = augment(xs, xt)
+                return gstep(x, x_, mask) if has_mask else gstep(x, x_)
+        else:
+            gstep = ka.graph.GraphedTrainStep(net, opt, None, (xs, xt), warmup=2)
 
-    for _ in range(args.warmup):
+            def step():
+                return gstep(xs, xt)
+
+    reserved = None
+    for i in range(args.warmup):
         step()
+        if i == 1 and args.reserve_mem and not args.graph:
+            reserved = ka.runtime.reserve_memory()
+    alloc_before = torch.cuda.memory_stats().get('num_device_alloc', 0)
     # The network, its plans and the optimizer state are a few hundred thousand long-lived Python objects; a full (generation
     # 2) collection of the cyclic garbage collector walks all of them: ~40 ms on this host, once every few dozen steps --
     # nothing for model F (the launch queue is several milliseconds deep) but a quarter of the Pong-class step, whose
@@ -347,6 +398,7 @@ def _run_leg(args, rank, world, dev):
     elapsed, step_ms, loss = timed(args.steps)
     power = power.stop() if power is not None else None
     median_ms = med(step_ms)
+    allocs_in_timed = torch.cuda.memory_stats().get('num_device_alloc', 0) - alloc_before
 
     # ---- N > 1: the self-check of the multi-GPU record (outside the timed region).  How many ranks the collective saw,
     # the exposed part of the exchange per step, and BOTH placements of the all-reduces back to back, so that one driver
@@ -532,7 +584,9 @@ def _run_leg(args, rank, world, dev):
                                          f'{"augment+" if args.net == "keynet" and not args.no_augment else ""}fwd+loss+bwd+Adam',
                                 global_batch=B * world, per_gpu_batch=B, parallelism=f'dp{world}',
                                 dp_overlap=bool(args.dp_overlap) if world > 1 else None, grid_cus=(reducer.grid_cus if reducer is not None else (args.grid_cus or None)), side_streams=bool(args.streams), hip_graph=bool(args.graph),
-                                gflop_per_pair=flop_pair / 1e9, loss=float(loss.item()), lib_sha16=lib_sha16, **({'probe_knobs': probe_knobs} if probe_knobs else {})),
+                                gflop_per_pair=flop_pair / 1e9, loss=float(loss.item()), lib_sha16=lib_sha16,
+                                hipmalloc_in_timed_region=int(allocs_in_timed), reserved_bytes=reserved,
+                                kernarg_pool=os.environ.get('HSA_KERNARG_POOL_SIZE'), **({'probe_knobs': probe_knobs} if probe_knobs else {})),
                     roofline=roofline)
         if dp is not None:
             line['dp'] = dp
@@ -590,7 +644,8 @@ def compact_line(line, detail_path):
                                    s_per_step_median=_round(c.get('s_per_step_median')), sample=c['sample'])
     summary = {}
     for prec, o in (line.get('extra') or {}).items():
-        summary[f'config4_{prec}'] = dict(value=_round(o['value'], 1), ms_per_step=_round(o['ms_per_step']), dtype=o['dtype'],
+        summary[f'config4_{prec}'] = dict(value=_round(o['value'], 1), ms_per_step=_round(o['ms_per_step']),
+                                          ms_per_step_median=_round(o.get('ms_per_step_median_hipevent')), dtype=o['dtype'],
                                           ratio_to_headline=_round(o['ratio_to_headline']))
     for key, r in (line.get('extra_configs') or {}).items():
         if 'error' in r:
@@ -608,6 +663,13 @@ def compact_line(line, detail_path):
             summary[key]['bf16_secondary'] = dict(value=_round(r['bf16_secondary']['value'], 1), ms_per_step=_round(r['bf16_secondary']['ms_per_step']))
         if rf.get('step_hbm_frac') is not None:
             summary[key]['step_hbm_frac'] = _round(rf['step_hbm_frac'])
+        if rf.get('traffic') is None:
+            summary[key]['traffic_reason'] = (rf.get('traffic_reason') or 'no PMC pass')[:120]
+        if rf.get('peak') is not None:
+            summary[key]['peak'] = rf['peak']
+        if r.get('cpu_baseline_c1'):
+            c1 = r['cpu_baseline_c1']
+            summary[key]['cpu_baseline_c1'] = {k: (_round(v) if isinstance(v, float) else v) for k, v in c1.items()}
     if detail_path:
         out['detail_file'] = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT) else detail_path
     out['summary'] = summary
@@ -627,6 +689,12 @@ EXTRA_CONFIGS = [
                                           size=128, batch=128, precision='fp16'), 2),
     ('config5_F256_K30_fp16_b256', dict(net='transporter', model_type='F', model_in_channels=3, model_z_channels=64,
                                         model_keypoints=30, size=256, batch=256, precision='fp16'), 1),
+    # the headline workload in STRICT fp32 (apex O0; the mode that meets SURVEY 8c's tolerances as written): fp32 matrix cores, 157.3 TFLOP/s
+    ('fp32_strict_c4', dict(net='transporter', model_type='F', model_in_channels=3, model_z_channels=64, model_keypoints=10,
+                            size=128, batch=128, precision='fp32'), 0.6),
+    # config 3 at the reference's SHIPPED batch (configs/keypoints_celeba.yaml:18: batch_size 16): launch-bound, eager and as one HIP graph
+    ('config3_keynet_tps_fp16_b16', dict(net='keynet', model_type='F', model_in_channels=3, model_z_channels=64, model_keypoints=10,
+                                         size=128, batch=16, precision='fp16'), 8),
 ]
 
 
@@ -686,17 +754,18 @@ def main():
             #  switch of stream mode measured its dominant family 8 % below the standalone run of the same workload)
             # (warm-up: config 2's 3 ms steps get 16 -- the caching allocator starts this leg empty, and a step that needs a new block
             #  after the warm-up stalls on hipMalloc for tens of steps' worth of time: one 25 ms step in 30 was measured once)
-            leg.steps, leg.warmup, leg.profile_steps, leg.no_augment = args.extra_steps * mult, (16 if mult > 1 else 2 + mult), (3 if mult > 1 else 1), False
+            leg.steps, leg.warmup, leg.profile_steps, leg.no_augment = max(3, int(args.extra_steps * mult)), (16 if mult > 2 else 2 + int(mult)), (3 if mult > 2 else 1), False
             try:
                 r = run_leg(leg, rank, world, dev)
                 for k in ('n_gpus', 'higher_is_better', 'scaling', 'vs_baseline', 'data', 'unit'):
                     r.pop(k, None)
-                if key.startswith('config2'):   # the same leg replayed as ONE HIP graph (keypoints_amd.graph.GraphedTrainStep), timing only
+                if key.startswith('config2') or key.endswith('_b16'):   # the same leg replayed as ONE HIP graph (keypoints_amd.graph.GraphedTrainStep), timing only
                     sec = copy.copy(leg)
                     sec.graph, sec.profile_steps = 1, 0
                     try:
                         o2 = run_leg(sec, rank, world, dev)
-                        r['hip_graph'] = dict(value=o2['value'], ms_per_step=o2['ms_per_step'], ms_per_step_max=o2['ms_per_step_max_hipevent'], steps=o2['steps'])
+                        r['hip_graph'] = dict(value=o2['value'], ms_per_step=o2['ms_per_step'], ms_per_step_median=o2['ms_per_step_median_hipevent'],
+                                              ms_per_step_max=o2['ms_per_step_max_hipevent'], steps=o2['steps'])
                     except Exception as e:
                         r['hip_graph'] = dict(error=f'{type(e).__name__}: {e}'[:200])
                 if key.startswith('config3') and leg.precision == 'fp16':   # the same leg in bf16, timing only
@@ -712,6 +781,11 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.net == 'transporter':
             line['cpu_baseline'] = cpu_baseline(args)
+            if 'config2_pong_bf16_b256' in (line.get('extra_configs') or {}):
+                try:
+                    line['extra_configs']['config2_pong_bf16_b256']['cpu_baseline_c1'] = cpu_baseline_c1()
+                except Exception as e:
+                    line['extra_configs']['config2_pong_bf16_b256']['cpu_baseline_c1'] = dict(error=f'{type(e).__name__}: {e}'[:200])
         # The printed line is the COMPACT record (a few KB: the driver keeps an 8 KB tail of stdout and round 3's 22 KB line
         # lost the config-2 leg and `extra.bf16` to it); the per-kernel tables of every leg go to --out / --detail.
         detail = args.out or args.detail

@@ -182,6 +182,37 @@ def freeze_gc():
     gc.freeze()
 
 
+def configure_hip_runtime(**kw) -> bool:
+    """`keypoints_amd.hip_env.configure` (the one module of the package that touches the process environment -- it WRITES a variable
+    of the HIP runtime on the application's behalf, before HIP initialises; nothing in the package reads one)."""
+    from . import hip_env
+    return hip_env.configure(**kw)
+
+
+def reserve_memory(factor: float = 1.25, device=None) -> int:
+    """Call once after the first one or two train steps of a launch-bound network: hands the caching allocator ONE segment of
+    `factor` x the peak it has reserved so far (and drops the unused segments of the warm-up), so that every later request is a
+    split of memory the process already owns.  Without it a step whose tensor lifetimes differ slightly from the warm-up's (a
+    garbage collection that ran later, a side stream that was a little behind) can need a block no cached segment fits, and
+    hipMalloc of a few hundred MB in the middle of a 2.6 ms step costs 10-25 ms (tools/cfg2_stall.py).  Returns the bytes of the
+    new segment (0: nothing was needed).  Not needed under a HIP graph (its private pool is fixed at capture)."""
+    dev = torch.cuda.current_device() if device is None else device
+    torch.cuda.synchronize(dev)
+    peak = torch.cuda.max_memory_reserved(dev)
+    torch.cuda.empty_cache()
+    need = int(factor * peak) - torch.cuda.memory_reserved(dev)
+    if need <= 0:
+        return 0
+    need = (need + (1 << 21) - 1) >> 21 << 21
+    free, _ = torch.cuda.mem_get_info(dev)
+    need = min(need, int(0.9 * free))
+    if need <= 0:
+        return 0
+    t = torch.empty(need, dtype=torch.uint8, device=torch.device('cuda', dev) if isinstance(dev, int) else dev)
+    del t
+    return need
+
+
 _FUSE_BN_INPUT = True
 
 

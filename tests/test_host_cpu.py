@@ -286,7 +286,7 @@ def test_package_reads_no_environment_variable_outside_probe():
     root = pathlib.Path(keypoints_amd.__file__).parent
     bad = []
     for f in list(root.glob('*.py')) + list((root / 'models').glob('*.py')):
-        if f.name == '_probe.py':
+        if f.name in ('_probe.py', 'hip_env.py'):   # (hip_env WRITES one variable of the HIP runtime for the application; see its docstring)
             continue
         for i, ln in enumerate(f.read_text().splitlines(), 1):
             code = ln.split('#', 1)[0]
@@ -297,6 +297,15 @@ def test_package_reads_no_environment_variable_outside_probe():
             if re.search(r'\bgetenv\s*\(', ln.split('//', 1)[0]):
                 bad.append(f'csrc/{f.name}:{i}: {ln.strip()}')     # (library knobs are kp_config keys: include/kp_hip.h)
     assert not bad, bad
+    # hip_env is reachable only through an explicit call (runtime.configure_hip_runtime imports it lazily): importing the package must
+    # not touch the environment
+    import subprocess
+    import sys
+    code = ("import os; before = dict(os.environ); import keypoints_amd, keypoints_amd.runtime, keypoints_amd.models.transporter; "
+            "assert dict(os.environ) == before; import sys; assert 'keypoints_amd.hip_env' not in sys.modules; "
+            "assert keypoints_amd.runtime.configure_hip_runtime() is True and os.environ['HSA_KERNARG_POOL_SIZE'] == str(64 << 20)")
+    env = {k: v for k, v in __import__('os').environ.items() if k != 'HSA_KERNARG_POOL_SIZE'}
+    subprocess.run([sys.executable, '-c', code], check=True, cwd=str(root.parent), env=env)
 
 
 def test_probe_apply_env_turns_variables_into_setters():
