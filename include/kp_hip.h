@@ -95,6 +95,8 @@ int kp_config_get(int key);
 #define KP_CFG_WG16 13          /* bit mask (default 7): which small-channel weight gradients take the 16 x 16 x 32 matrix-core kernel */
 #define KP_CFG_FIRST_ROWS 14   /* single-channel first layers with 16 / 32 filters: 1 (default) the row kernel (a lane = one pixel x eight channels, weights in registers), 0: conv3_first_fwd_k, > 1: workgroups per launch of the row kernel (measurement) */
 #define KP_CFG_FIRST_KTN 10  /* kp_conv_first_fwd_bnact: 2 (default) one wavefront computes all 64 channels of its groups (66 us at 128 x 128 x 128: the plain convolution's time); 1: a pair of wavefronts, 32 channels each (75 us) */
+#define KP_CFG_FIN_FOLD 16     /* 1 (default): kp_conv_fwd_fin runs the BatchNorm finalize in the tail of the persistent patch convolution (last workgroup of each output-channel tile); 0: always as the kp_bn_finalize launch behind it (A/B) */
+#define KP_CFG_FIN_NT 17       /* 256 (default since round 6) / 1024: threads per workgroup of the one-launch statistics / backward-sums finalize of the > 32-channel layers.  A 16-wave workgroup needs four free wave slots on every SIMD of one CU and waited 100-430 us for them beside the other streams' persistent kernels (profiles/r05v_F_timeline_streams1.txt:32); four waves of ~20 registers are resident at once.  Model F step -0.07 ms (5 of 6 alternations on two boxes, profiles/r06_fin_fold_ab.txt) */
 #define KP_CFG_CUS 6          /* CU budget the persistent kernels size their grids to (launches on a CU-masked stream); 0 = whole device */
 #define KP_CFG_TRACE 2        /* device buffer of 512 int64: s_memtime stamps of workgroup 0 of the patch conv kernel */
 #define KP_CFG_RING_STREAM 15 /* kp_config_ptr, THREAD-LOCAL: a hipStream_t.  The border ring of this thread's matrix-core data gradients (kp_conv_dgrad, kp_conv_dgrad_bnred: 16x16-tileable maps, channels multiples of 64) is launched there as a one-wavefront, LDS-free kernel that runs BESIDE the persistent interior kernel instead of after it; the call orders the two streams itself (the ring stream waits for the call's stream, the call's stream waits for the ring).  NULL (default): everything on the call's stream.  Results bit-identical. */
@@ -316,6 +318,20 @@ int kp_bn_ws_doubles(int C);
 int kp_bn_finalize(const float* stats, long long rows, double* ws, float* save_mean, float* save_invstd, float* running_mean,
                    float* running_var, long long* num_batches_tracked, float momentum, float eps, long long count,
                    int C, void* stream);
+/* kp_conv_fwd(..., stats) + kp_bn_finalize(stats, kp_last_rows(), ...) as ONE call: the pair vgg.py:33-35 (Conv2d, BatchNorm2d in training
+ * mode) turns into.  Where the convolution runs on the persistent patch kernel with one statistics row per workgroup (model F's layers at
+ * the BASELINE batches), the finalize runs in the TAIL of the convolution -- the last workgroup of each output-channel tile to arrive
+ * (a device-scope ticket per tile) sums that tile's rows in a fixed order in fp64 and writes mean / invstd / running statistics for
+ * its channels -- so the dependent kp_bn_finalize launch (5-7 us of work that waits 100-400 us for a CU beside the other streams'
+ * persistent kernels, profiles/r05v_F_timeline_streams1.txt) does not exist; anywhere else the call launches kp_bn_finalize itself.
+ * Same numbers either way up to the order of the fp64 additions (<= 1 ulp of the fp32 results); deterministic.
+ * tickets: KP_FIN_TICKETS (64) zero-initialised 32-bit counters the call may use and leaves zero (one buffer per stream: launches on
+ * one stream may share it); NULL: never fold.  ws: as kp_bn_finalize.  kp_conv_fwd_fin_folds: 1 if this shape folds (pure query). */
+#define KP_FIN_TICKETS 64
+int kp_conv_fwd_fin(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C, int K, int R,
+                    int dtype, double* ws, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                    long long* num_batches_tracked, float momentum, float eps, long long count, unsigned* tickets, void* stream);
+int kp_conv_fwd_fin_folds(int N, int Hi, int Wi, int C, int K, int R, int dtype);
 /* out = tail(act((y - mean) * invstd * gamma + beta)); act = LeakyReLU(slope) (slope 0 = ReLU).
  * y: [N][H][W][C] T.  out: [N][Ho+2*out_pad][Wo+2*out_pad][C] T with replicated border where
  * (Ho,Wo) = (H,W) | (H/2,W/2) | (2H,2W) for tail none | maxpool2 | upsample2.

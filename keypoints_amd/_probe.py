@@ -74,6 +74,14 @@ def apply_env(env=None) -> list:
     if env.get('KP_RING_MIN_SIDE'):
         from . import unit_engine
         unit_engine.RING_MIN_SIDE = int(env['KP_RING_MIN_SIDE']); used.append('KP_RING_MIN_SIDE=' + env['KP_RING_MIN_SIDE'])
+    if env.get('KP_NO_FIN_FOLD'):   # convolution + statistics finalize as two launches again (kp_conv_fwd, kp_bn_finalize)
+        runtime.set_fold_finalize(False); used.append('KP_NO_FIN_FOLD')
+    if env.get('KP_FIN_NT'):        # threads per workgroup of the one-launch finalize kernels (library knob KP_CFG_FIN_NT = 17): 256 / 1024
+        from ._lib import call
+        call('kp_config', 17, int(env['KP_FIN_NT'])); used.append('KP_FIN_NT=' + env['KP_FIN_NT'])
+    if env.get('KP_BRED_PATCH'):    # BatchNorm-backward sums in the patch data gradient's epilogue (library knob KP_CFG_BRED_PATCH = 9): 0 / 1 / 2
+        from ._lib import call
+        call('kp_config', 9, int(env['KP_BRED_PATCH'])); used.append('KP_BRED_PATCH=' + env['KP_BRED_PATCH'])
     if env.get('KP_NO_FIRST_FUSE'):
         runtime.set_fuse_first_layer(False); used.append('KP_NO_FIRST_FUSE')
     if env.get('KP_EAGER_BLEND'):

@@ -16,12 +16,16 @@ void kp_set_last_rows(long long r) { g_last_rows = r; }
 static thread_local int g_query = 0;
 int kp_query_mode() { return g_query; }
 void kp_set_query_mode(int on) { g_query = on; }
+static thread_local KpFinRequest* g_fin = nullptr;
+KpFinRequest* kp_fin_request() { return g_fin; }
+void kp_set_fin_request(KpFinRequest* r) { g_fin = r; }
 kp_knob_ptr_t g_kp_trace{nullptr};   // kp_config_ptr(KP_CFG_TRACE, dev_ptr): s_memtime trace buffer (512 x i64) or NULL
 kp_knob_t g_kp_wgrad_patch{1};   // kp_config(KP_CFG_WGRAD_PATCH, v)
 kp_knob_t g_kp_small_band{1};    // kp_config(KP_CFG_SMALL_BAND, v)
 kp_knob_t g_kp_bn_fast{1};       // kp_config(KP_CFG_BN_FAST, v)
 kp_knob_t g_kp_bn_flat{1};       // kp_config(KP_CFG_BN_FLAT, v)
 kp_knob_t g_kp_bred_patch{1};    // kp_config(KP_CFG_BRED_PATCH, v)
+kp_knob_t g_kp_fin_nt{256};     // kp_config(KP_CFG_FIN_NT, 256 | 1024): threads per workgroup of the one-launch statistics / backward-sums finalize of the > 32-channel layers
 kp_knob_t g_kp_fin_wide{0};      // kp_config(KP_CFG_FIN_WIDE, 1): the 1024-thread statistics finalize for every layer (measurement)
 kp_knob_t g_kp_disable_mfma{0};  // kp_config(KP_CFG_DISABLE_MFMA, 1): every convolution on the generic VALU kernels (measurement / debugging)
 kp_knob_t g_kp_wg16{7};          // kp_config(KP_CFG_WG16, bits): which small-channel weight gradients take the 16 x 16 x 32 kernel
@@ -78,6 +82,7 @@ void kp_prof_event_release(hipEvent_t e) {
     g_event_pool.push_back(e);
 }
 
+kp_knob_t g_kp_fin_fold{1};      // kp_config(KP_CFG_FIN_FOLD, v): 1 (default) kp_conv_fwd_fin folds the finalize into the convolution's tail where it can; 0: always the separate launch
 kp_knob_t g_kp_conv_patch{1};    // kp_config(KP_CFG_CONV_PATCH, v): 1 (default) the LDS-patch kernel, 0 linear, 2 pair tile first
 
 extern "C" {
@@ -100,6 +105,8 @@ int kp_device_cus(void) {
 int kp_config(int key, int value) {
     if (key == KP_CFG_CONV_PATCH) { g_kp_conv_patch = value < 0 ? 0 : (value > 2 ? 2 : value); return KP_OK; }
     if (key == KP_CFG_DEBUG) { g_kp_debug = value; return KP_OK; }
+    if (key == KP_CFG_FIN_FOLD) { g_kp_fin_fold = value ? 1 : 0; return KP_OK; }
+    if (key == KP_CFG_FIN_NT) { g_kp_fin_nt = value == 256 ? 256 : 1024; return KP_OK; }
     if (key == KP_CFG_WALK) { g_kp_walk = value; return KP_OK; }
     if (key == KP_CFG_CUS) { g_kp_cus = value > 0 ? value : 0; return KP_OK; }
     if (key == KP_CFG_BN_FAST) { g_kp_bn_fast = value ? 1 : 0; return KP_OK; }
@@ -252,6 +259,32 @@ KP_DISPATCH(kp_pack_weights_batch, (int n, const float* const* w, void* const* w
             (n, w, w_fwd, w_dgrad, K, C, Cp, dtype, stream))
 KP_DISPATCH(kp_conv_fwd, (const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C, int K, int R, int dtype, void* stream),
             (x, w, bias, y, stats, N, Hi, Wi, C, K, R, dtype, stream))
+// conv + BatchNorm finalize as ONE call; the finalize runs in the tail of the convolution kernel where the launcher takes the request
+// (KpFinRequest, kp_common.h), else as the kp_bn_finalize launch behind it -- the same numbers either way up to the order of the fp64 sums
+int kp_conv_fwd_fin(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C, int K, int R,
+                    int dtype, double* ws, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                    long long* num_batches_tracked, float momentum, float eps, long long count, unsigned* tickets, void* stream) {
+    if (!stats || !ws || !save_mean || !save_invstd || count <= 0) { kp_set_error("kp_conv_fwd_fin: bad args"); return KP_E_ARG; }
+    KpFinRequest rq{save_mean, save_invstd, running_mean, running_var, num_batches_tracked, momentum, eps, count, tickets, 0};
+    kp_set_fin_request((tickets && g_kp_fin_fold) ? &rq : nullptr);
+    const int rc = kp_conv_fwd(x, w, bias, y, stats, N, Hi, Wi, C, K, R, dtype, stream);
+    kp_set_fin_request(nullptr);
+    if (rc != KP_OK || rq.taken) return rc;
+    return kp_bn_finalize(stats, kp_last_rows(), ws, save_mean, save_invstd, running_mean, running_var, num_batches_tracked, momentum, eps,
+                          count, K, stream);
+}
+// 1 if kp_conv_fwd_fin would fold the finalize into the convolution for this shape (tests / records; a pure query)
+int kp_conv_fwd_fin_folds(int N, int Hi, int Wi, int C, int K, int R, int dtype) {
+    if (!g_kp_fin_fold) return 0;
+    unsigned dummy_t = 0; float dummy;
+    KpFinRequest rq{&dummy, &dummy, nullptr, nullptr, nullptr, 0.f, 0.f, 1, &dummy_t, 0};
+    kp_set_query_mode(1);
+    kp_set_fin_request(&rq);
+    const int rc = kp_conv_fwd(nullptr, nullptr, nullptr, nullptr, &dummy, N, Hi, Wi, C, K, R, dtype, nullptr);
+    kp_set_fin_request(nullptr);
+    kp_set_query_mode(0);
+    return (rc == KP_OK && rq.taken) ? 1 : 0;
+}
 KP_DISPATCH(kp_conv_dgrad, (const void* dy, const void* w_dgrad, void* gx, int N, int H, int W, int K, int C, int dtype, void* stream),
             (dy, w_dgrad, gx, N, H, W, K, C, dtype, stream))
 KP_DISPATCH(kp_conv_wgrad_partials, (int N, int Ho, int Wo, int C, int K, int R, int dy_pad, int dtype),

@@ -568,6 +568,7 @@ int kp_bn_bwd_fast(int, const void*, int, int, const unsigned char*, const void*
                    const float*, const float*, float, float*, const float*, void*, int, int, int, int, int, hipStream_t);
 int kp_upsample2_bwd_fast(const void*, int, void*, int, int, int, int, hipStream_t);
 extern kp_knob_t g_kp_bn_fast;
+extern kp_knob_t g_kp_fin_nt;     // kp_config(KP_CFG_FIN_NT, 256): measurement
 extern kp_knob_t g_kp_fin_wide;   // kp_config(KP_CFG_FIN_WIDE, 1): measurement -- the 1024-thread finalize for every layer
 
 extern "C" {
@@ -592,6 +593,9 @@ int kp_bn_finalize(const float* stats, long long rows, double* ws, float* save_m
 #define KP_WIDE0(CPWv) bn_reduce_finalize_wide_k<0, CPWv><<<cdiv(C, CPWv), 1024, 0, st>>>(stats, rows, C, save_mean, save_invstd, running_mean, \
                                                                                running_var, num_batches_tracked, momentum, eps, count)
         if (narrow)   // a 4-wave workgroup (see the kernel)
+            bn_reduce_finalize_wide_k<0, 4, 256><<<cdiv(C, 4), 256, 0, st>>>(stats, rows, C, save_mean, save_invstd, running_mean,
+                                                                              running_var, num_batches_tracked, momentum, eps, count);
+        else if (g_kp_fin_nt == 256)   // (default since round 6: a 4-wave workgroup becomes resident beside a persistent matrix-core kernel at once)
             bn_reduce_finalize_wide_k<0, 4, 256><<<cdiv(C, 4), 256, 0, st>>>(stats, rows, C, save_mean, save_invstd, running_mean,
                                                                               running_var, num_batches_tracked, momentum, eps, count);
         else if (C >= 256) KP_WIDE0(16); else if (C >= 128) KP_WIDE0(8); else KP_WIDE0(4);
@@ -679,6 +683,9 @@ int kp_bn_bwd_finalize(const float* partials, double* ws, long long rows, int C,
 #define KP_WIDE1(CPWv) bn_reduce_finalize_wide_k<1, CPWv><<<cdiv(C, CPWv), 1024, 0, st>>>(partials, rows, C, sums, nullptr, dbeta, dgamma, \
                                                                                nullptr, 0.f, 0.f, 1)
         if (C <= 32 && !g_kp_fin_wide)
+            bn_reduce_finalize_wide_k<1, 4, 256><<<cdiv(C, 4), 256, 0, st>>>(partials, rows, C, sums, nullptr, dbeta, dgamma, nullptr,
+                                                                              0.f, 0.f, 1);
+        else if (g_kp_fin_nt == 256)
             bn_reduce_finalize_wide_k<1, 4, 256><<<cdiv(C, 4), 256, 0, st>>>(partials, rows, C, sums, nullptr, dbeta, dgamma, nullptr,
                                                                               0.f, 0.f, 1);
         else if (C >= 256) KP_WIDE1(16); else if (C >= 128) KP_WIDE1(8); else KP_WIDE1(4);

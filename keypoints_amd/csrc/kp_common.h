@@ -208,6 +208,20 @@ int kp_check_launch(const char* what);
 // the launch it is about to make (operands + results, each once); `launch` = 0 adds bytes to the launch counted before.
 void kp_count_bytes(double bytes, int launch = 1);
 void kp_set_last_rows(long long rows);   // see kp_last_rows() in kp_hip.h
+// kp_conv_fwd_fin (kp_api.hip): the BatchNorm finalize that follows a statistics-producing convolution, to be run in the TAIL of that
+// convolution where its launcher can (the persistent patch kernel with one statistics row per workgroup: the last workgroup of each
+// output-channel tile to arrive finalizes that tile's channels).  Thread-local request, set and cleared inside ONE public call; a
+// launcher that takes it sets `taken` (the caller then launches kp_bn_finalize itself when nobody did).
+struct KpFinRequest {
+    float *mean, *invstd, *running_mean, *running_var;
+    long long* nbt;
+    float momentum, eps;
+    long long count;
+    unsigned* tickets;   // >= KP_FIN_TICKETS zero-initialised counters (zero again when the kernel ends)
+    int taken;
+};
+KpFinRequest* kp_fin_request();
+void kp_set_fin_request(KpFinRequest* r);
 // Query mode (kp_conv_fwd_stats_rows / kp_bn_bwd_rows): the dispatch runs as usual, every launcher records its row count
 // and returns before launching anything.  Thread-local, set and cleared inside ONE public call.
 int kp_query_mode();

@@ -50,6 +50,11 @@ struct PatchArgs {
     long long* trace;     // optional: s_memtime stamps of workgroup 0 / wave 0 (512 entries), measurement only
     // BRED (data gradient of layer L that also leaves the first pass of layer L - 1's BatchNorm backward, see below)
     const h16_t* yred; const float *mean, *invstd, *gamma, *beta; float slope; float* rpart;
+    // FIN (compact STATS launches, kp_conv_fwd_fin): the BatchNorm finalize in this kernel's tail.  fin_tickets != NULL: one counter per
+    // k-tile; the LAST of the grid / ktiles workgroups of a k-tile to have written its statistics row sums that tile's rows (fixed
+    // order, fp64) and writes mean / invstd / running statistics of the tile's channels -- no finalize launch behind this one.
+    unsigned* fin_tickets; float *fin_mean, *fin_invstd, *fin_rmean, *fin_rvar; long long* fin_nbt; float fin_momentum, fin_eps;
+    long long fin_count;
 };
 
 // Persistent workgroups: the (tile, 64-channel chunk, tap) steps of all tiles of a workgroup form ONE software
@@ -106,7 +111,77 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         float* rowp = A.rpart + (long long)blockIdx.x * 4 * 2 * K;
         for (int i = tid; i < 4 * 2 * K; i += TPB) rowp[i] = 0.f;
     }
-    if (tile >= tile_hi) return;
+    // FIN (linear tile walk only: the launcher checks): the k-tile of workgroup b is (b >> 3) % ktiles -- its first tile id
+    // (b & 7) * per_xcd + (b >> 3) modulo the k-tiles, and (grid / 8) % ktiles == 0 in the compact launches, so every tile of a workgroup
+    // has it and each k-tile has exactly E = grid / ktiles workgroups (idle ones included): match m of k-tile kt is workgroup
+    // (((m >> 3) * ktiles + kt) << 3) | (m & 7), ascending in m.
+    // Called by every workgroup of a FIN launch once its statistics row is in memory (all threads; the row's stores are this thread's
+    // own, released by the fence).  LDS: NP * 2 * BN doubles at offset 0 (the patch buffers: nobody reads them any more).
+    auto fin_fold = [&](int kt) {
+        if constexpr (STATS) {
+            // the row's stores (all threads) have reached this XCD's L2 when the barrier releases; ONE device-scope release behind it
+            // (thread 0: an L2 write-back -- 512 of them per workgroup cost the launch ~25 us, profiles/r06_fin_fold_ab.txt) makes
+            // them visible to the other XCDs before the ticket is taken
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* flag = reinterpret_cast<int*>(smem + OFF_TRACE);
+            const int E = (int)gridDim.x / A.ktiles;
+            if (tid == 0) {
+                __threadfence();
+                const unsigned old = __hip_atomic_fetch_add(A.fin_tickets + kt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = old == (unsigned)E - 1u;
+            }
+            __syncthreads();
+            if (!*flag) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other workgroups' rows (written back by their releases) are read from memory
+            // 2 * BN columns (sum | sum of squares of the tile's channels) x NP row parts: part p adds matches p, p + NP, ... in ascending
+            // order (loads of 8 matches in flight), the parts are added in index order through LDS -> one fixed summation order
+            constexpr int NP = TPB / (2 * BN);
+            const int col = tid % (2 * BN), part = tid / (2 * BN);
+            const int which = col / BN, kl = col - which * BN;
+            const float* colp = A.partials + (long long)which * K + kt * BN + kl;
+            const long long rstride = 2LL * K;
+            auto row_of = [&](int m) { return (long long)(((((m >> 3) * A.ktiles) + kt) << 3) | (m & 7)) * rstride; };
+            double acc64 = 0.0;
+            int m = part;
+            for (; m + 7 * NP < E; m += 8 * NP) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = colp[row_of(m + u * NP)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc64 += (double)v[u];
+            }
+            for (; m < E; m += NP) acc64 += (double)colp[row_of(m)];
+            double* red64 = reinterpret_cast<double*>(smem);
+            red64[part * 2 * BN + col] = acc64;
+            __syncthreads();
+            if (tid < BN) {
+                double sum = 0.0, sq = 0.0;
+#pragma unroll
+                for (int pp = 0; pp < NP; ++pp) { sum += red64[pp * 2 * BN + tid]; sq += red64[pp * 2 * BN + BN + tid]; }
+                const int c = kt * BN + tid;
+                const double count = (double)A.fin_count;
+                const double mu = sum / count;              // (the expressions of bn_reduce_finalize_wide_k, kp_bn.hip)
+                double var = sq / count - mu * mu;
+                if (var < 0.0) var = 0.0;
+                A.fin_mean[c] = (float)mu;
+                A.fin_invstd[c] = (float)(1.0 / sqrt(var + (double)A.fin_eps));
+                if (A.fin_rmean) A.fin_rmean[c] = (1.f - A.fin_momentum) * A.fin_rmean[c] + A.fin_momentum * (float)mu;
+                if (A.fin_rvar) {
+                    const double unbiased = A.fin_count > 1 ? var * count / (double)(A.fin_count - 1) : var;
+                    A.fin_rvar[c] = (1.f - A.fin_momentum) * A.fin_rvar[c] + A.fin_momentum * (float)unbiased;
+                }
+            }
+            if (tid == 0) {
+                if (A.fin_nbt && kt == 0) *A.fin_nbt += 1;
+                __hip_atomic_store(A.fin_tickets + kt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch on this stream
+            }
+        }
+    };
+    if (tile >= tile_hi) {
+        if constexpr (STATS) if (A.compact && A.fin_tickets) { __syncthreads(); fin_fold((int)(blockIdx.x >> 3) % A.ktiles); }   // (an idle workgroup's row: the zeros above)
+        return;
+    }
     const int tiles_x = A.W / TS, tiles_y = A.H / TS;
 
     struct TileRef { int n, oy0, ox0, k0, pt, kt, tx, ty; };
@@ -553,6 +628,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                 const float t = ((red[(0 * 2 + which) * BN + kl] + red[(1 * 2 + which) * BN + kl]) + red[(2 * 2 + which) * BN + kl]) + red[(3 * 2 + which) * BN + kl];
                 A.partials[((long long)blockIdx.x * 2 + which) * K + cur.k0 + kl] = t;
             }
+            if (A.fin_tickets) fin_fold(cur.kt);
         }
     }
     if constexpr (BRED) {   // lanes l, l + CPP, l + 2 CPP, ... hold the same 8 channels: fold them, lanes 0 .. CPP-1 write
@@ -626,6 +702,7 @@ int kp_conv_patch_launch_bred(const void* dy, const void* w, void* gx, const voi
     { extern kp_knob_t g_kp_walk; a.linear = (g_kp_walk & KP_WALK_CONV_LINEAR) ? 1 : 0; }
     a.ktiles = ktiles; a.ntiles = ntiles; a.compact = 0;
     a.yred = (const h16_t*)yred; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.slope = slope; a.rpart = rpart;
+    a.fin_tickets = nullptr; a.fin_mean = a.fin_invstd = a.fin_rmean = a.fin_rvar = nullptr; a.fin_nbt = nullptr; a.fin_momentum = a.fin_eps = 0.f; a.fin_count = 1;
     if (C % 128 == 0) conv3x3_patch_k<128, false, false, true><<<grid, TPB, 0, st>>>(a);
     else conv3x3_patch_k<64, false, false, true><<<grid, TPB, 0, st>>>(a);
     return kp_check_launch("conv3x3_patch_bred");
@@ -661,6 +738,14 @@ int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* 
     if (grid > need) grid = need;
     a.compact = (stats && ptiles >= grid && ((grid / 8) % a.ktiles) == 0) ? 1 : 0;
     if (stats) kp_set_last_rows(a.compact ? (long long)grid * CROWS : ptiles * 4);
+    a.fin_tickets = nullptr; a.fin_mean = a.fin_invstd = a.fin_rmean = a.fin_rvar = nullptr; a.fin_nbt = nullptr; a.fin_momentum = a.fin_eps = 0.f; a.fin_count = 1;
+    if (KpFinRequest* rq = kp_fin_request()) {   // kp_conv_fwd_fin: the finalize in this launch's tail (one row per workgroup, <= KP_FIN_TICKETS k-tiles)
+        if (stats && a.compact && a.linear && CROWS == 1 && a.ktiles <= KP_FIN_TICKETS && !a.trace && !a.dbg) {
+            a.fin_tickets = rq->tickets; a.fin_mean = rq->mean; a.fin_invstd = rq->invstd; a.fin_rmean = rq->running_mean; a.fin_rvar = rq->running_var;
+            a.fin_nbt = rq->nbt; a.fin_momentum = rq->momentum; a.fin_eps = rq->eps; a.fin_count = rq->count;
+            rq->taken = 1;
+        }
+    }
     KP_QUERY_RETURN();
     if ((a.trace || a.dbg) && bn == 128 && stats) conv3x3_patch_k<128, true, true><<<grid, TPB, 0, st>>>(a);
     else if (bn == 128 && stats) conv3x3_patch_k<128, true, false><<<grid, TPB, 0, st>>>(a);

@@ -189,6 +189,40 @@ def configure_hip_runtime(**kw) -> bool:
     return hip_env.configure(**kw)
 
 
+_FOLD_FINALIZE = False
+
+
+def fold_finalize() -> bool:
+    """OPT-IN (measured slower, docs/experiments/r06.md section 2): a statistics-producing convolution and the BatchNorm finalize behind
+    it go to the library as ONE call (kp_conv_fwd_fin): on the persistent matrix-core kernel the finalize then runs in the
+    convolution's tail (last workgroup of each output-channel tile) instead of as a dependent launch.  Results equal up to the order
+    of the fp64 additions.  Model F step, alternating on one box: 32.71 ms with the separate launch, 32.89 ms folded (the device-scope
+    release every workgroup needs before its ticket, and ~3 us of one workgroup summing alone, 56 times per step, cost more than the
+    5 us launches they replace); the first build -- a release per THREAD -- cost 1.9 ms."""
+    return _FOLD_FINALIZE
+
+
+def set_fold_finalize(on: bool) -> None:
+    global _FOLD_FINALIZE
+    _FOLD_FINALIZE = bool(on)
+
+
+_TICKET_WS = {}
+
+
+def ticket_ws(device):
+    """The KP_FIN_TICKETS zero-initialised counters of kp_conv_fwd_fin for torch's current stream on `device`: every launch leaves them
+    zero, so launches on one stream share them; launches on different streams may overlap and get their own.  Created while a HIP
+    graph is being captured, the zero-fill is only recorded: such a buffer belongs to that graph and is not cached."""
+    key = (device.index, torch.cuda.current_stream(device).stream_id)
+    ws = _TICKET_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(64, device=device, dtype=torch.int32)
+        if not torch.cuda.is_current_stream_capturing():
+            _TICKET_WS[key] = ws
+    return ws
+
+
 def reserve_memory(factor: float = 1.25, device=None) -> int:
     """Call once after the first one or two train steps of a launch-bound network: hands the caching allocator ONE segment of
     `factor` x the peak it has reserved so far (and drops the unused segments of the warm-up), so that every later request is a

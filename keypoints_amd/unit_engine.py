@@ -461,35 +461,45 @@ class UnitFunction(torch.autograd.Function):
                 continue
             y = torch.empty(N, H, W, K, device=dev, dtype=tdt)
             stats = torch.empty((N * H * W + 63) // 64, 2, K, device=dev, dtype=torch.float32) if training else None
+            mean = invstd = None
+            finalized = False
+            if training:
+                mean = torch.empty(K, device=dev, dtype=torch.float32)
+                invstd = torch.empty(K, device=dev, dtype=torch.float32)
+                track = bn.track_running_stats and bn.running_mean is not None
+                if bn.momentum is None:
+                    # torch: cumulative moving average, factor 1 / num_batches_tracked (after this batch's increment).
+                    # The counter lives on the device; reading it here is a host sync, taken only in this
+                    # non-default mode (the reference never sets momentum=None).
+                    mom = 1.0 / (int(bn.num_batches_tracked.item()) + 1) if track else 0.0
+                else:
+                    mom = float(bn.momentum)
+                ws = torch.empty(128 * K, device=dev, dtype=torch.float64)
+                fin_args = (ptr(ws), ptr(mean), ptr(invstd), ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                            ptr(bn.num_batches_tracked) if track else None, mom, float(bn.eps))
             if fin is not None:
                 # the previous layer's BatchNorm-apply + activation + replicate pad run on this convolution's staging path
                 # (kp_conv_fwd_bnin): its padded activation was never written
                 call('kp_conv_fwd_bnin', ptr(fin['y']), *fin['bn'], fin['slope'], ptr(wf), ptr(conv.bias), ptr(y), ptr(stats),
                      N, H, W, C, K, code, st)
+            elif training and unit.sync_bn is None and runtime.fold_finalize():
+                # convolution + statistics finalize as one call: on the persistent matrix-core kernel the finalize runs in the
+                # convolution's tail (kp_conv_fwd_fin, include/kp_hip.h) -- no dependent launch between the convolution and its
+                # BatchNorm pass; elsewhere the library launches kp_bn_finalize itself
+                call('kp_conv_fwd_fin', ptr(a), ptr(wf), ptr(conv.bias), ptr(y), ptr(stats), N, H + 2, W + 2, C, K, 3, code,
+                     *fin_args, N * H * W, ptr(runtime.ticket_ws(dev)), st)
+                finalized = True
             else:
                 call('kp_conv_fwd', ptr(a), ptr(wf), ptr(conv.bias), ptr(y), ptr(stats), N, H + 2, W + 2, C, K, 3, code, st)
             srows = _lib.lib().kp_conv_fwd_stats_rows(N, H + 2, W + 2, C, K, 3, code) if training else 0
-            mean = invstd = None
             if bn is not None:
                 if training:
-                    mean = torch.empty(K, device=dev, dtype=torch.float32)
-                    invstd = torch.empty(K, device=dev, dtype=torch.float32)
-                    track = bn.track_running_stats and bn.running_mean is not None
-                    if bn.momentum is None:
-                        # torch: cumulative moving average, factor 1 / num_batches_tracked (after this batch's increment).
-                        # The counter lives on the device; reading it here is a host sync, taken only in this
-                        # non-default mode (the reference never sets momentum=None).
-                        mom = 1.0 / (int(bn.num_batches_tracked.item()) + 1) if track else 0.0
-                    else:
-                        mom = float(bn.momentum)
-                    ws = torch.empty(128 * K, device=dev, dtype=torch.float64)
                     count = N * H * W
                     sync = unit.sync_bn
                     if sync is not None:   # batch statistics over the ranks' shards together (world x count samples)
                         stats, srows, count = _allreduce_rows(stats[:srows], sync[0]), 2, count * sync[1]
-                    call('kp_bn_finalize', ptr(stats), srows, ptr(ws), ptr(mean), ptr(invstd),
-                         ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
-                         ptr(bn.num_batches_tracked) if track else None, mom, float(bn.eps), count, K, st)
+                    if not finalized:
+                        call('kp_bn_finalize', ptr(stats), srows, *fin_args, count, K, st)
                 else:
                     # eval mode: the running statistics are constants of the layer (nn.BatchNorm2d.eval()); the backward then has
                     # no batch-mean terms (see `eval_bn` there)

@@ -64,5 +64,16 @@ for g, i in gaps[:30]:
         print('     ', '>>' if j == i else '  ', f'{(rows[j][0] - rows[i][0]) / 1e6:9.3f} ms  dur {(rows[j][1] - rows[j][0]) / 1e3:8.1f} us  q{rows[j][3]} s{rows[j][4]}  {rows[j][2]}')
 PY
   ;;
+ab)   # alternating A/B of the model-F step on ONE box: bash tools/r06.sh ab <out> "<env A>" "<env B>" ["<env C>" ...]  (env = KP_* of keypoints_amd/_probe.py, or '-')
+  o=gpurun_out/$1; mkdir -p $o; shift
+  : > $o/ab.txt
+  for rep in 1 2 3; do
+    for e in "$@"; do
+      ee=$e; [ "$e" = "-" ] && ee="KP_NONE=1"
+      env $ee python bench.py --steps 20 --warmup 8 --no-cpu-baseline --profile-steps 0 --extra 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('rep $rep  %-40s' % '$e', round(d['ms_per_step'],3), 'median', round(d['ms_per_step_median_hipevent'],3), round(d['value'],1))" >> $o/ab.txt
+    done
+  done
+  cat $o/ab.txt
+  ;;
 *) echo "unknown subcommand $sub"; exit 2;;
 esac
