@@ -499,7 +499,7 @@ def _run_leg(args, rank, world, dev):
         # HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the
         # gfx950 correction + WRITE_SIZE), condensed by tools/pmc_summary.py into profiles/ -- not measurable from
         # inside the process, so it is the committed per-launch figure of the last profiled build (or null).
-        # Only a summary STAMPED with the sha256 of the library that is loaded now is quoted (tools/r05_records.sh writes the stamp):
+        # Only a summary STAMPED with the sha256 of the library that is loaded now is quoted (tools/records.sh writes the stamp):
         # a figure of another build is reported as null with the reason, not as this build's.
         traffic, pmc, pmc_file, traffic_reason = None, None, None, None
         pmc_key = 'conv_small_band_bf16' if dom[0] == 'conv_small_16bit' else 'conv_patch_bf16_bn128'

@@ -99,7 +99,6 @@ int kp_config_get(int key);
 #define KP_CFG_FIN_NT 17       /* 256 (default since round 6) / 1024: threads per workgroup of the one-launch statistics / backward-sums finalize of the > 32-channel layers.  A 16-wave workgroup needs four free wave slots on every SIMD of one CU and waited 100-430 us for them beside the other streams' persistent kernels (profiles/r05v_F_timeline_streams1.txt:32); four waves of ~20 registers are resident at once.  Model F step -0.07 ms (5 of 6 alternations on two boxes, profiles/r06_fin_fold_ab.txt) */
 #define KP_CFG_CUS 6          /* CU budget the persistent kernels size their grids to (launches on a CU-masked stream); 0 = whole device */
 #define KP_CFG_TRACE 2        /* device buffer of 512 int64: s_memtime stamps of workgroup 0 of the patch conv kernel */
-#define KP_CFG_RING_STREAM 15 /* kp_config_ptr, THREAD-LOCAL: a hipStream_t.  The border ring of this thread's matrix-core data gradients (kp_conv_dgrad, kp_conv_dgrad_bnred: 16x16-tileable maps, channels multiples of 64) is launched there as a one-wavefront, LDS-free kernel that runs BESIDE the persistent interior kernel instead of after it; the call orders the two streams itself (the ring stream waits for the call's stream, the call's stream waits for the ring).  NULL (default): everything on the call's stream.  Results bit-identical. */
 int kp_config_ptr(int key, void* value);
 
 /* ---- measurement (bench.py roofline leg; not used by the model code) ------- */
@@ -187,26 +186,6 @@ int kp_conv_first_bwd_wgrad(const void* g, const void* x, const void* w, const f
 int kp_pad_hw(const void* src, void* dst, int N, int Hs, int Ws, int Hd, int Wd, int C, int dtype, void* stream);
 int kp_conv_wgrad_pad_hw(int N, int Ho, int Wo, int C, int K, int dy_pad, int dtype, int* Hp, int* Wp);
 
-/* ---- the head's backward fused with the BatchNorm backward of the 3x3 layer in front of it ------------------------------------------
- * A Unit ends in conv3x3 + BatchNorm2d + activation -> Conv2d(1x1, K <= 4) + LeakyReLU (vgg.py:30-38 -> knn.py:123-125).  The plain
- * backward writes the head's input gradient g [pixels][C] (kp_head_bwd / _bnin) and reads it back twice (kp_bn_act_bwd_reduce, _apply)
- * next to three reads of the layer's conv output y.  g is K <= 4 FMAs per channel away from the head's own gradient: these two calls
- * recompute it (rounded to the storage type where kp_head_bwd stores it) and g never exists.
- *   kp_head_bnbwd_reduce == the weight / bias part of kp_head_bwd_bnin (dw, db: bit-identical, same fixed-order two-stage sum through
- *                           ws = kp_head_bwd_ws_floats floats) + kp_bn_act_bwd_reduce(g, gp 0, tail none, y): bn_partials =
- *                           kp_head_bnbwd_rows rows of [2][C] for kp_bn_bwd_finalize (another partition: fp32 summation order)
- *   kp_head_bnbwd_apply  == the dx part of kp_head_bwd_bnin + kp_bn_act_bwd_apply: dy [N][H+2dp][W+2dp][C] with its zero border
- * gout / out: the head's output gradient and saved output, fp32 NCHW [N][K][H][W]; yprev + mean .. slope_in: the 3x3 layer's conv
- * output and BatchNorm / activation (as in kp_head_bwd_bnin); w, slope: the head.  16-bit storage, K <= 4, C / 8 a power of two <= 64
- * (model F's decoder head 64 -> 3, the Pong nets' 16 -> 1 and 32 -> 4); kp_head_bnbwd_rows == 0 / KP_E_UNSUPPORTED otherwise. */
-long long kp_head_bnbwd_rows(int N, int H, int W, int C, int K, int dtype);
-int kp_head_bnbwd_reduce(const float* gout, const float* out, const void* yprev, const float* mean, const float* invstd,
-                         const float* gamma, const float* beta, float slope_in, const float* w, float slope, float* dw, float* db,
-                         float* ws, float* bn_partials, int N, int H, int W, int C, int K, int dtype, void* stream);
-int kp_head_bnbwd_apply(const float* gout, const float* out, const void* yprev, const float* mean, const float* invstd,
-                        const float* gamma, const float* beta, float slope_in, const float* w, float slope, const float* sums, void* dy,
-                        int dy_pad, int N, int H, int W, int C, int K, int dtype, void* stream);
-
 /* ---- weights ----------------------------------------------------------- */
 /* fp32 [K][C][R][R] (nn.Conv2d.weight) -> T [K][R][R][Cp] (forward operand) and,
  * if w_dgrad != NULL, T [Cp][R][R][K] with the taps flipped (dgrad operand); channels C..Cp-1 are zero. */
@@ -269,26 +248,6 @@ int kp_conv_fwd_bnin(const void* yprev, const float* mean, const float* invstd, 
                      int dtype, void* stream);
 int kp_conv_wgrad_bnin(const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta,
                        float slope, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int dy_pad, int dtype,
-                       void* stream);
-
-/* Winograd F(2, 3) form of the 3x3 layers (kp_conv_wino.hip; replaces the same reference statement as kp_conv_fwd / kp_conv_dgrad:
- * nn.Conv2d(3x3) after ReplicationPad2d(1), keypoints/models/vgg.py:30-33, and its autograd data gradient).  fp16 storage only.
- * Output rows are computed in pairs from four input rows with 4 instead of 6 products per filter column: 1.5x fewer MACs on the
- * matrix cores.  The transformed operands (row differences / sums of the activation, filter-row combinations of the weights) are
- * re-rounded to fp16; accumulation and the output transform are fp32.
- *   kp_conv_wino_supported: 1 where the kernel takes the shape (C % 32 == 0, C >= 64, K % 64 == 0, H and W multiples of 16, an even
- *     number of 16x16 pixel tiles; with_stats: the BatchNorm partial rows also fit its per-workgroup layout).
- *   kp_conv_wino_pack: u[K][4][3][C] from a packed 16-bit weight w_packed[K][3][3][C] (kp_pack_weights' w_fwd; for the data gradient
- *     the flipped pack w_dgrad[C][3][3][K], read as "K" = C, "C" = K).
- *   kp_conv_fwd_wino: kp_conv_fwd (R = 3) with u in place of w; statistics rows: kp_conv_fwd_wino_rows.
- *   kp_conv_dgrad_wino: kp_conv_dgrad; the interior through u_dgrad, the 3-tap border ring through w_dgrad (direct).
- * KP_E_UNSUPPORTED where the shape / dtype has no kernel: the caller runs kp_conv_fwd / kp_conv_dgrad. */
-int kp_conv_wino_supported(int N, int H, int W, int C, int K, int with_stats, int dtype);
-int kp_conv_wino_pack(const void* w_packed, void* u, int K, int C, int dtype, void* stream);
-int kp_conv_fwd_wino(const void* x, const void* u, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C, int K,
-                     int dtype, void* stream);
-long long kp_conv_fwd_wino_rows(int N, int Hi, int Wi, int C, int K, int dtype);
-int kp_conv_dgrad_wino(const void* dy, const void* u_dgrad, const void* w_dgrad, void* gx, int N, int H, int W, int K, int C, int dtype,
                        void* stream);
 
 /* The data gradient of a 3x3 layer L that also leaves the first pass of layer L - 1's BatchNorm backward (the layer whose padded

@@ -1,6 +1,6 @@
 """keypoints_amd -- MI355X-native (gfx950) Transporter / KeyNet train-step hot path behind the
 `keypoints.models` surface of DuaneNielsen/keypoints.  See DESIGN.md / INTEGRATION.md."""
-from .runtime import default_precision, set_default_precision, set_multi_stream, set_fuse_bn_input, set_fuse_bn_reduce, set_t_interchange, set_pair_calls, set_lazy_outputs, set_fuse_first_layer, set_fuse_head_bn_bwd, set_fold_finalize  # noqa: F401
+from .runtime import default_precision, set_default_precision, set_multi_stream, set_fuse_bn_input, set_fuse_bn_reduce, set_t_interchange, set_pair_calls, set_lazy_outputs, set_fuse_first_layer, set_fold_finalize  # noqa: F401
 from . import models  # noqa: F401
 from . import data_augments, tps  # noqa: F401
 from .optim import FusedAdam, l2_reconstruction_loss  # noqa: F401

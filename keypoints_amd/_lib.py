@@ -15,7 +15,6 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libkp_hip.so')
 KP_F32, KP_BF16, KP_F16 = 0, 1, 2
 TAIL_NONE, TAIL_MAXPOOL2, TAIL_UPSAMPLE2 = 0, 1, 2
 KP_CFG_CUS = 6   # kp_config key: CU budget of the persistent kernels (include/kp_hip.h)
-KP_CFG_RING_STREAM = 15   # kp_config_ptr key (thread-local): stream of the data gradients' border ring (include/kp_hip.h)
 COMBINE = {'sum_and_clamp': 1, 'pretrained_network': 2, 'loop': 3}
 
 _p, _i, _f, _z, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
@@ -30,8 +29,6 @@ SIGNATURES = {
     'kp_conv_first_fwd_bnact': [_p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _i, _p],
     'kp_conv_first_bwd_reduce': [_p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _i, _p],
     'kp_conv_first_bwd_wgrad': [_p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    'kp_head_bnbwd_reduce': [_p, _p, _p, _p, _p, _p, _p, _f, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    'kp_head_bnbwd_apply': [_p, _p, _p, _p, _p, _p, _p, _f, _p, _f, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'kp_pad_hw': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'kp_pack_weights': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     'kp_pack_weights_batch': [_i, _p, _p, _p, _p, _p, _p, _i, _p],
@@ -89,9 +86,6 @@ SIGNATURES = {
     'kp_conv_fwd_fin': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _f, _ll, _p, _p],
     'kp_conv_fwd_bnin': [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'kp_conv_wgrad_bnin': [_p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
-    'kp_conv_wino_pack': [_p, _p, _i, _i, _i, _p],
-    'kp_conv_fwd_wino': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    'kp_conv_dgrad_wino': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'kp_comm_unique_id': [_p],
     'kp_comm_init': [_p, _i, _i, _p],
     'kp_comm_allreduce': [_p, _p, _z, _i, _i, _p],
@@ -105,7 +99,7 @@ SIGNATURES = {
     'kp_prof_bytes': [_i, _p],
     'kp_prof_step_bytes': [_p, _p],
 }
-PLAIN = {'kp_config_get': ([_i], _i), 'kp_conv_fwd_fin_folds': ([_i] * 7, _i), 'kp_comm_available': ([], _i), 'kp_conv_pair_supported': ([_i] * 7, _i), 'kp_head_pair_supported': ([_i] * 7, _i), 'kp_conv_wgrad_pad_hw': ([_i] * 7 + [_p, _p], _i), 'kp_conv_first_fused_supported': ([_i] * 6, _i), 'kp_conv_first_fused_rows': ([_i] * 6, _ll), 'kp_head_bnbwd_rows': ([_i] * 6, _ll), 'kp_bn_finalize_pair_supported': ([_ll, _i], _i), 'kp_head_t_supported': ([_i] * 6, _i), 'kp_keypoint_bottleneck_t_supported': ([_i] * 6, _i), 'kp_conv_wino_supported': ([_i] * 7, _i), 'kp_conv_fwd_wino_rows': ([_i] * 6, _ll), 'kp_conv_bnin_supported': ([_i] * 6, _i), 'kp_head_bnin_supported': ([_i] * 6, _i), 'kp_conv_dgrad_bnred_supported': ([_i] * 6, _i), 'kp_conv_dgrad_bnred_rows': ([_i] * 6, _ll), 'kp_unit_infer_param_floats': ([_i, _i, _p], _ll), 'kp_conv_wgrad_partials': ([_i] * 8, _i), 'kp_conv_fwd_stats_rows': ([_i] * 7, _ll), 'kp_bn_bwd_rows': ([_i] * 7, _ll), 'kp_head_bwd_ws_floats': ([_i] * 6, _ll), 'kp_last_rows': ([], _ll), 'kp_bn_ws_doubles': ([_i], _i), 'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
+PLAIN = {'kp_config_get': ([_i], _i), 'kp_conv_fwd_fin_folds': ([_i] * 7, _i), 'kp_comm_available': ([], _i), 'kp_conv_pair_supported': ([_i] * 7, _i), 'kp_head_pair_supported': ([_i] * 7, _i), 'kp_conv_wgrad_pad_hw': ([_i] * 7 + [_p, _p], _i), 'kp_conv_first_fused_supported': ([_i] * 6, _i), 'kp_conv_first_fused_rows': ([_i] * 6, _ll), 'kp_bn_finalize_pair_supported': ([_ll, _i], _i), 'kp_head_t_supported': ([_i] * 6, _i), 'kp_keypoint_bottleneck_t_supported': ([_i] * 6, _i), 'kp_conv_bnin_supported': ([_i] * 6, _i), 'kp_head_bnin_supported': ([_i] * 6, _i), 'kp_conv_dgrad_bnred_supported': ([_i] * 6, _i), 'kp_conv_dgrad_bnred_rows': ([_i] * 6, _ll), 'kp_unit_infer_param_floats': ([_i, _i, _p], _ll), 'kp_conv_wgrad_partials': ([_i] * 8, _i), 'kp_conv_fwd_stats_rows': ([_i] * 7, _ll), 'kp_bn_bwd_rows': ([_i] * 7, _ll), 'kp_head_bwd_ws_floats': ([_i] * 6, _ll), 'kp_last_rows': ([], _ll), 'kp_bn_ws_doubles': ([_i], _i), 'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
 
 _lib = None
 

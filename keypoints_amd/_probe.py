@@ -67,13 +67,6 @@ def apply_env(env=None) -> list:
     if env.get('KP_FIRST_KTN'):   # 32-channel blocks per wavefront in kp_conv_first_fwd_bnact (library knob KP_CFG_FIRST_KTN = 10)
         from ._lib import call
         call('kp_config', 10, int(env['KP_FIRST_KTN'])); used.append('KP_FIRST_KTN=' + env['KP_FIRST_KTN'])
-    if env.get('KP_HEAD_BN_FUSE'):
-        runtime.set_fuse_head_bn_bwd(True); used.append('KP_HEAD_BN_FUSE')
-    if env.get('KP_RING_BESIDE'):
-        runtime.set_ring_beside(True); used.append('KP_RING_BESIDE')
-    if env.get('KP_RING_MIN_SIDE'):
-        from . import unit_engine
-        unit_engine.RING_MIN_SIDE = int(env['KP_RING_MIN_SIDE']); used.append('KP_RING_MIN_SIDE=' + env['KP_RING_MIN_SIDE'])
     if env.get('KP_NO_FIN_FOLD'):   # convolution + statistics finalize as two launches again (kp_conv_fwd, kp_bn_finalize)
         runtime.set_fold_finalize(False); used.append('KP_NO_FIN_FOLD')
     if env.get('KP_FIN_NT'):        # threads per workgroup of the one-launch finalize kernels (library knob KP_CFG_FIN_NT = 17): 256 / 1024

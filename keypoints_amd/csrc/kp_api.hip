@@ -137,12 +137,9 @@ int kp_config_get(int key) {
     return KP_E_ARG;
 }
 
-static thread_local hipStream_t t_ring_stream = nullptr;
-hipStream_t kp_ring_stream() { return t_ring_stream; }
 
 int kp_config_ptr(int key, void* value) {
     if (key == KP_CFG_TRACE) { g_kp_trace = (long long*)value; return KP_OK; }
-    if (key == KP_CFG_RING_STREAM) { t_ring_stream = (hipStream_t)value; return KP_OK; }
     kp_set_error("kp_config_ptr: unknown key %d", key);
     return KP_E_ARG;
 }
@@ -299,12 +296,6 @@ KP_DISPATCH(kp_conv_wgrad_bnin, (const void* yprev, const float* mean, const flo
 KP_DISPATCH(kp_conv_dgrad_bnred_supported, (int N, int H, int W, int K, int C, int dtype), (N, H, W, K, C, dtype))
 KP_DISPATCH(kp_conv_dgrad_bnred, (const void* dy, const void* w_dgrad, void* gx, const void* yred, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, float* partials, int N, int H, int W, int K, int C, int dtype, void* stream),
             (dy, w_dgrad, gx, yred, mean, invstd, gamma, beta, slope, partials, N, H, W, K, C, dtype, stream))
-KP_DISPATCH(kp_conv_wino_supported, (int N, int H, int W, int C, int K, int with_stats, int dtype), (N, H, W, C, K, with_stats, dtype))
-KP_DISPATCH(kp_conv_wino_pack, (const void* w_packed, void* u, int K, int C, int dtype, void* stream), (w_packed, u, K, C, dtype, stream))
-KP_DISPATCH(kp_conv_fwd_wino, (const void* x, const void* u, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C, int K, int dtype, void* stream),
-            (x, u, bias, y, stats, N, Hi, Wi, C, K, dtype, stream))
-KP_DISPATCH(kp_conv_dgrad_wino, (const void* dy, const void* u_dgrad, const void* w_dgrad, void* gx, int N, int H, int W, int K, int C, int dtype, void* stream),
-            (dy, u_dgrad, w_dgrad, gx, N, H, W, K, C, dtype, stream))
 KP_DISPATCH(kp_bn_act_fwd, (const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, int tail, void* out, int out_pad, unsigned char* argmax, int N, int H, int W, int C, int dtype, void* stream),
             (y, mean, invstd, gamma, beta, slope, tail, out, out_pad, argmax, N, H, W, C, dtype, stream))
 KP_DISPATCH(kp_bn_act_bwd_reduce, (const void* gsrc, int gp, int tail, const unsigned char* argmax, const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, float* partials, int N, int H, int W, int C, int dtype, void* stream),
@@ -381,15 +372,6 @@ long long kp_conv_first_fused_rows(int N, int H, int W, int C, int K, int dtype)
     return dtype == KP_F16 ? kp_conv_first_fused_rows__f16(N, H, W, C, K, dtype) : kp_conv_first_fused_rows__bf16(N, H, W, C, K, dtype);
 }
 
-long long kp_head_bnbwd_rows__bf16(int, int, int, int, int, int);
-long long kp_head_bnbwd_rows__f16(int, int, int, int, int, int);
-long long kp_head_bnbwd_rows(int N, int H, int W, int C, int K, int dtype) {
-    return dtype == KP_F16 ? kp_head_bnbwd_rows__f16(N, H, W, C, K, dtype) : kp_head_bnbwd_rows__bf16(N, H, W, C, K, dtype);
-}
-KP_DISPATCH(kp_head_bnbwd_reduce, (const float* gout, const float* out, const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope_in, const float* w, float slope, float* dw, float* db, float* ws, float* bn_partials, int N, int H, int W, int C, int K, int dtype, void* stream),
-            (gout, out, yprev, mean, invstd, gamma, beta, slope_in, w, slope, dw, db, ws, bn_partials, N, H, W, C, K, dtype, stream))
-KP_DISPATCH(kp_head_bnbwd_apply, (const float* gout, const float* out, const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope_in, const float* w, float slope, const float* sums, void* dy, int dy_pad, int N, int H, int W, int C, int K, int dtype, void* stream),
-            (gout, out, yprev, mean, invstd, gamma, beta, slope_in, w, slope, sums, dy, dy_pad, N, H, W, C, K, dtype, stream))
 
 long long kp_head_bwd_ws_floats__bf16(int, int, int, int, int, int);
 long long kp_head_bwd_ws_floats__f16(int, int, int, int, int, int);
@@ -403,14 +385,6 @@ long long kp_conv_fwd_stats_rows(int N, int Hi, int Wi, int C, int K, int R, int
     kp_set_query_mode(1);
     float dummy;   // non-NULL stats: the launchers only look at the pointer's truth value in query mode
     const int rc = kp_conv_fwd(nullptr, nullptr, nullptr, nullptr, &dummy, N, Hi, Wi, C, K, R, dtype, nullptr);
-    kp_set_query_mode(0);
-    return rc == KP_OK ? kp_last_rows() : (long long)rc;
-}
-
-long long kp_conv_fwd_wino_rows(int N, int Hi, int Wi, int C, int K, int dtype) {
-    kp_set_query_mode(1);
-    float dummy;
-    const int rc = kp_conv_fwd_wino(nullptr, nullptr, nullptr, nullptr, &dummy, N, Hi, Wi, C, K, dtype, nullptr);
     kp_set_query_mode(0);
     return rc == KP_OK ? kp_last_rows() : (long long)rc;
 }

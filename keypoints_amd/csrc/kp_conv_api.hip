@@ -8,7 +8,6 @@ int kp_conv_fwd_generic(const void*, const void*, const float*, void*, float*, i
 int kp_conv_wgrad_generic(const void*, const void*, float*, int, int, int, int, int, int, int, int, hipStream_t);
 int kp_conv_fwd_mfma(const void*, const void*, const float*, void*, float*, int, int, int, int, int, int,
                      hipStream_t);   // bf16 only; returns KP_E_UNSUPPORTED when the shape is not eligible
-int kp_conv_wgrad_mfma(const void*, const void*, float*, int, int, int, int, int, int, int, hipStream_t);
 int kp_conv_dgrad_mfma(const void*, const void*, void*, int, int, int, int, int, hipStream_t);
 int kp_conv_wgrad_patch(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 long long kp_conv_wgrad_patch_partials(int, int, int, int, int, int);
@@ -32,24 +31,18 @@ int kp_conv_small_first_wgrad(const void*, const void*, float*, int, int, int, i
 long long kp_conv_small_first_wgrad_partials(int, int, int, int, int);
 long long kp_conv_small_wgrad_partials(int, int, int, int, int);
 long long kp_conv_wgrad_generic_partials(int, int, int, int, int, int);
-int kp_conv_wgrad_mfma_accepts(int, int, int, int, int, int);
 // strict fp32 on the matrix cores (kp_conv_f32.hip, v_mfma_f32_32x32x2_f32): 3x3, C % 16 == 0, K % 64 == 0
 int kp_conv_fwd_f32mfma(const float*, const float*, const float*, float*, float*, int, int, int, int, int, hipStream_t);
 long long kp_conv_wgrad_f32mfma_partials(int, int, int, int, int);
 int kp_conv_wgrad_f32mfma(const float*, const float*, float*, int, int, int, int, int, int, hipStream_t);
 
-int kp_conv_wino_launch(const void*, const void*, const float*, void*, float*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
-int kp_conv_wino_pack_impl(const void*, void*, int, int, hipStream_t);
-int kp_conv_ring_dgrad(const void*, const void*, void*, int, int, int, int, int, hipStream_t);
 
 long long kp_conv_patch_bred_rows(int, int, int, int, int);
 long long kp_conv_ring_bred_rows(int, int, int);
 int kp_conv_patch_launch_bred(const void*, const void*, void*, const void*, const float*, const float*, const float*, const float*, float, float*,
                               int, int, int, int, int, hipStream_t);
 int kp_conv_ring_dgrad_bred(const void*, const void*, void*, const void*, const float*, const float*, const float*, const float*, float, float*,
-                            int, int, int, int, int, hipStream_t, int lite = 0);
-bool kp_ring_fork(hipStream_t st, hipStream_t& rs, hipEvent_t (&ev)[2]);
-int kp_ring_join(hipStream_t st, hipStream_t rs, hipEvent_t (&ev)[2]);
+                            int, int, int, int, int, hipStream_t);
 extern kp_knob_t g_kp_bred_patch;   // kp_config(KP_CFG_BRED_PATCH, v): 1 (default) the matrix-core layers' data gradient offers the fused form
 extern kp_knob_t g_kp_wgrad_patch;
 
@@ -122,11 +115,6 @@ int kp_conv_wgrad_partials(int N, int Ho, int Wo, int C, int K, int R, int dy_pa
         const long long p = kp_conv_small_wgrad_partials(N, Ho, Wo, C, K);
         if (p > 0) return (int)p;
     }
-    // the per-tap MFMA fallback (kp_wgrad_mfma.hip: 64-multiples the tap-reuse kernel declines): one partial per pixel split
-    if (dtype == KP_H16 && use_mfma()) {
-        const int p = kp_conv_wgrad_mfma_accepts(N, Ho, Wo, C, K, R);
-        if (p > 0) return p;
-    }
     if (dtype == KP_F32 && R == 3 && use_mfma()) {
         const long long p = kp_conv_wgrad_f32mfma_partials(N, Ho, Wo, C, K);
         if (p > 0 && p < 0x7fffffffLL) return (int)p;
@@ -148,8 +136,8 @@ int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, 
         int rc = (R == 3 && g_kp_wgrad_patch) ? kp_conv_wgrad_patch(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream)
                                               : KP_E_UNSUPPORTED;
         if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_WGRAD_MFMA); return rc; }
-        rc = kp_conv_wgrad_mfma(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, (hipStream_t)stream);
-        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_WGRAD_MFMA); return rc; }
+        // (64-multiple channels on a map that is not a multiple of the tap-reuse kernel's 8 x 16 pixel block: the caller pads both operands
+        //  with zeros -- kp_conv_wgrad_pad_hw + kp_pad_hw, exact -- and calls again; called as it is, such a shape takes the generic kernel)
         if (R == 3 && C <= 4 && (K == 16 || K == 32)) {
             rc = kp_conv_small_first_wgrad(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
             if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_FIRST); return rc; }
@@ -299,65 +287,10 @@ int kp_conv_dgrad_bnred(const void* dy, const void* w_dgrad, void* gx, const voi
     kp_set_last_rows(prows + kp_conv_ring_bred_rows(N, H, W));
     KP_QUERY_RETURN();
     ProfScope ps(KP_PROF_CONV_MFMA, flops, (hipStream_t)stream, bytes);
-    hipStream_t rs; hipEvent_t ev[2];
-    const bool fork = kp_ring_fork((hipStream_t)stream, rs, ev);   // the ring beside the interior (kp_config_ptr(KP_CFG_RING_STREAM))
     int rc = kp_conv_patch_launch_bred(dy, w_dgrad, gx, yred, mean, invstd, gamma, beta, slope, partials, N, H, W, K, C, (hipStream_t)stream);
     if (rc == KP_OK)
         rc = kp_conv_ring_dgrad_bred(dy, w_dgrad, gx, yred, mean, invstd, gamma, beta, slope, partials + prows * 2 * C, N, H, W, K, C,
-                                     fork ? rs : (hipStream_t)stream, fork ? 1 : 0);
-    if (fork) {
-        const int rj = kp_ring_join((hipStream_t)stream, rs, ev);
-        if (rc == KP_OK) rc = rj;
-    }
-    ps.done(KP_PROF_CONV_MFMA);
-    return rc;
-}
-
-// ---- Winograd F(2, 3) forward / data gradient of the 3x3 layers (kp_conv_wino.hip; fp16 storage only) -------------------------
-// `u` = kp_conv_wino_pack of the layer's packed weights: [K][4][3][C] for the forward (from w_fwd [K][3][3][C]), [C][4][3][K] for the
-// data gradient (from the flipped pack w_dgrad [C][3][3][K]).  Results: the convolution of kp_conv_fwd / kp_conv_dgrad with the two
-// 16-bit operands of every product re-rounded after the transform (tolerance: tests/test_gpu_conv_wino.py).
-int kp_conv_wino_supported(int N, int H, int W, int C, int K, int with_stats, int dtype) {
-    if (dtype != KP_F16 || KP_H16 != KP_F16 || !use_mfma() || N <= 0 || H <= 0 || W <= 0) return 0;
-    static float dummy_stats;
-    kp_set_query_mode(1);
-    const int rc = kp_conv_wino_launch(nullptr, nullptr, nullptr, nullptr, with_stats ? &dummy_stats : nullptr, N, H + 2, W + 2, 0, H, W, 0, H, W, C, K, nullptr);
-    kp_set_query_mode(0);
-    return rc == KP_OK ? 1 : 0;
-}
-
-int kp_conv_wino_pack(const void* w_packed, void* u, int K, int C, int dtype, void* stream) {
-    KP_REQUIRE(w_packed && u && K > 0 && C > 0, "kp_conv_wino_pack: bad arguments");
-    if (dtype != KP_F16 || KP_H16 != KP_F16) return KP_E_UNSUPPORTED;
-    return kp_conv_wino_pack_impl(w_packed, u, K, C, (hipStream_t)stream);
-}
-
-int kp_conv_fwd_wino(const void* x, const void* u, const float* bias, void* y, float* stats, int N, int Hi, int Wi, int C, int K,
-                     int dtype, void* stream) {
-    KP_REQUIRE(kp_query_mode() || (x && u && y), "kp_conv_fwd_wino: null pointer");
-    KP_REQUIRE(N > 0 && C > 0 && K > 0 && Hi >= 3 && Wi >= 3, "kp_conv_fwd_wino: bad dims");
-    if (dtype != KP_F16 || KP_H16 != KP_F16 || !use_mfma()) return KP_E_UNSUPPORTED;
-    const int Ho = Hi - 2, Wo = Wi - 2;
-    const double flops = 2.0 * N * (double)Ho * Wo * C * K * 9;   // the ALGORITHMIC count of the direct convolution
-    const double bytes = 2.0 * ((double)N * Hi * Wi * C + (double)N * Ho * Wo * K + 12.0 * C * K);
-    ProfScope ps(KP_PROF_CONV_MFMA, flops, (hipStream_t)stream, bytes);
-    const int rc = kp_conv_wino_launch(x, u, bias, y, stats, N, Hi, Wi, 0, Ho, Wo, 0, Ho, Wo, C, K, (hipStream_t)stream);
-    if (rc == KP_E_UNSUPPORTED) { ps.cancel(); return rc; }
-    ps.done(KP_PROF_CONV_MFMA);
-    return rc;
-}
-
-int kp_conv_dgrad_wino(const void* dy, const void* u_dgrad, const void* w_dgrad, void* gx, int N, int H, int W, int K, int C, int dtype,
-                       void* stream) {
-    KP_REQUIRE(dy && u_dgrad && w_dgrad && gx, "kp_conv_dgrad_wino: null pointer");
-    KP_REQUIRE(N > 0 && C > 0 && K > 0 && H > 0 && W > 0, "kp_conv_dgrad_wino: bad dims");
-    if (dtype != KP_F16 || KP_H16 != KP_F16 || !use_mfma() || !kp_conv_wino_supported(N, H, W, K, C, 0, dtype)) return KP_E_UNSUPPORTED;
-    const double flops = 2.0 * N * (double)H * W * C * K * 9;
-    const double bytes = 2.0 * ((double)N * (H + 4) * (W + 4) * K + (double)N * (H + 2) * (W + 2) * C + 12.0 * C * K);
-    ProfScope ps(KP_PROF_CONV_MFMA, flops, (hipStream_t)stream, bytes);
-    // interior [1, H] x [1, W] of the padded domain: valid correlation of dy (zero border 2) read from offset (1, 1)
-    int rc = kp_conv_wino_launch(dy, u_dgrad, nullptr, gx, nullptr, N, H + 4, W + 4, 1, H + 2, W + 2, 1, H, W, K, C, (hipStream_t)stream);
-    if (rc == KP_OK) rc = kp_conv_ring_dgrad(dy, w_dgrad, gx, N, H, W, K, C, (hipStream_t)stream);   // 3 live taps per ring pixel: direct
+                                     (hipStream_t)stream);
     ps.done(KP_PROF_CONV_MFMA);
     return rc;
 }

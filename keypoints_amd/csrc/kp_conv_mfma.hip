@@ -290,149 +290,6 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_mfma_k(const h16_t* __restrict
 }
 
 
-// ---- the data gradient's border ring BESIDE its interior -----------------------------------------------------------------
-// conv3x3_mfma_k<.., 2> above needs 48-64 KB of LDS and 4 wavefronts per workgroup: it cannot start on a CU whose LDS the persistent
-// interior kernel (149 KB, kp_conv_patch.hip) holds, so the ring ran AFTER the interior: 19 short launches per model-F step, 0.73 ms of
-// ramp-up and drain.  This form takes nothing the interior kernel needs: ONE wavefront per workgroup, no LDS, <= 128 registers (the
-// interior's two waves per SIMD at 179 registers leave 144).  MFMA fragments come straight from global memory / L2 (a lane's 8
-// consecutive channels of its pixel / its output channel are 16 contiguous bytes in both operands), 64 ring pixels x 64 output
-// channels per wavefront, the next reduction slice's four fragments in flight during the four MFMAs of the current one.  Launched on
-// another stream than the interior (kp_config_ptr(KP_CFG_RING_STREAM)) its waves fill the gaps of the interior's.
-// Same ring-pixel order (m-tiles of 128 = two halves of 64), same taps, same reduction order as MODE 2: bit-identical gx and rows.
-template <bool BRED>
-__global__ __launch_bounds__(64, 4) void conv3x3_ring_lite_k(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
-                                                          h16_t* __restrict__ y, float* __restrict__ partials, int N, int Hi, int Wi,
-                                                          int C, int K, int ktiles, const RingBred rb) {
-    const int Ho = Hi - 2, Wo = Wi - 2;
-    const int lane = threadIdx.x, fr = lane & 31, fh = lane >> 5;
-    const int kt = blockIdx.x % ktiles, mt64 = blockIdx.x / ktiles;
-    int mt = mt64 >> 1;
-    const int half = mt64 & 1, mt_global = mt;
-    const long long s01 = (long long)N * Wo, s23 = (long long)N * (Ho - 2);
-    const int t01 = (int)((s01 + BM - 1) / BM), t23 = (int)((s23 + BM - 1) / BM);
-    int grp = 0;
-    if (mt < t01) { grp = 0; }
-    else if (mt < 2 * t01) { grp = 1; mt -= t01; }
-    else if (mt < 2 * t01 + t23) { grp = 2; mt -= 2 * t01; }
-    else { grp = 3; mt -= 2 * t01 + t23; }
-    const long long M = grp < 2 ? s01 : s23;
-    const long long m0 = (long long)mt * BM + half * 64;
-    if (m0 >= M) return;   // (the empty half of a group's last tile: its rows stay as the launcher zeroed them)
-    const int k0 = kt * 64;
-
-    const unsigned char* xb[2];
-    const unsigned char* wb[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        long long m = m0 + b * 32 + fr;
-        if (m >= M) m = M - 1;   // tail pixels: load something valid, masked at the store
-        long long n; int p, q;
-        pix_decode<2>(m, Ho, Wo, grp, n, p, q);
-        xb[b] = (const unsigned char*)x + (((n * Hi + p) * Wi + q) * (long long)C + fh * 8) * 2;
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a) wb[a] = (const unsigned char*)w + (((long long)(k0 + a * 32 + fr) * 9) * C + fh * 8) * 2;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-
-    // reduction slices of 16 channels: t = (live tap j, slice); j-th live tap of this edge group: top (2,j), bottom (0,j), left (j,2), right (j,0)
-    const int ks = C >> 4, T = 3 * ks;
-    struct Frag { h16x8 x[2], w[2]; };
-    auto fetch = [&](Frag& f, int t) {
-        const int tapj = t / ks, c0 = (t - tapj * ks) << 4;
-        const int tap = grp == 0 ? 6 + tapj : (grp == 1 ? tapj : (grp == 2 ? 3 * tapj + 2 : 3 * tapj));
-        const long long xo = (((long long)(tap / 3) * Wi + (tap % 3)) * C + c0) * 2;
-        const long long wo = ((long long)tap * C + c0) * 2;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) f.x[b] = *reinterpret_cast<const h16x8*>(xb[b] + xo);
-#pragma unroll
-        for (int a = 0; a < 2; ++a) f.w[a] = *reinterpret_cast<const h16x8*>(wb[a] + wo);
-    };
-    auto mma = [&](const Frag& f) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = kp_mfma16(f.w[a], f.x[b], acc[a][b], 0, 0, 0);
-    };
-    Frag f0, f1;
-    fetch(f0, 0);
-    for (int t = 0; t < T; t += 2) {   // (T = 3 C / 16 is even or odd; the second half of the last pair is guarded)
-        if (t + 1 < T) fetch(f1, t + 1);
-        mma(f0);
-        if (t + 2 < T) fetch(f0, t + 2);
-        if (t + 1 < T) mma(f1);
-    }
-
-    // ---- epilogue: D[k_out][pixel]; lane: pixel = fr, k_out = 8*(reg>>2) + 4*fh + (reg&3)   (conv3x3_mfma_k's, one wave)
-    const long long prow = (long long)mt_global * 2 + half;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int kb = k0 + a * 32;
-        float s[16], sq[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = sq[i] = 0.f;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const long long m = m0 + b * 32 + fr;
-            const bool ok = m < M;
-            long long opix = 0, rpix = 0;
-            if (ok) {
-                long long n; int p, q;
-                pix_decode<2>(m, Ho, Wo, grp, n, p, q);
-                opix = (n * Ho + p) * Wo + q;
-                if constexpr (BRED) {   // clamped source pixel in the unpadded map [Ho - 2][Wo - 2]
-                    const int sp = p < 1 ? 0 : (p > Ho - 2 ? Ho - 3 : p - 1), sqx = q < 1 ? 0 : (q > Wo - 2 ? Wo - 3 : q - 1);
-                    rpix = (n * (Ho - 2) + sp) * (Wo - 2) + sqx;
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int kq = kb + 8 * g + 4 * fh;
-                if (ok) {
-                    uint2 pk;
-                    // (+ 0.f: the kernel above adds its absent bias as 0.f)
-                    pk.x = pack_h16x2(acc[a][b][g * 4 + 0] + 0.f, acc[a][b][g * 4 + 1] + 0.f);
-                    pk.y = pack_h16x2(acc[a][b][g * 4 + 2] + 0.f, acc[a][b][g * 4 + 3] + 0.f);
-                    *reinterpret_cast<uint2*>(y + opix * K + kq) = pk;
-                    if constexpr (BRED) {   // on the stored (rounded) values, the expressions of kp_bn_act_bwd_reduce
-                        float gr[4], yv[4];
-                        unpack_h16x2(pk.x, gr[0], gr[1]); unpack_h16x2(pk.y, gr[2], gr[3]);
-                        const uint2 yw = *reinterpret_cast<const uint2*>(rb.yred + rpix * K + kq);
-                        unpack_h16x2(yw.x, yv[0], yv[1]); unpack_h16x2(yw.y, yv[2], yv[3]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const bool aff = rb.mean != nullptr;
-                            const float mu = aff ? rb.mean[kq + e] : 0.f, is = aff ? rb.invstd[kq + e] : 1.f;
-                            const float ga = aff ? rb.gamma[kq + e] : 1.f, be = aff ? rb.beta[kq + e] : -0.f;
-                            const float xh = (yv[e] - mu) * is;
-                            const float z = xh * ga + be;
-                            const float gh = gr[e] * act_grad(z, rb.slope);
-                            s[g * 4 + e] += gh;
-                            sq[g * 4 + e] += gh * xh;
-                        }
-                    }
-                }
-            }
-        }
-        if constexpr (BRED) {
-            int r1, r2;
-            const float ts = reduce16_over32(s, lane, r1);
-            const float tq = reduce16_over32(sq, lane, r2);
-            if ((lane & 1) == 0) {
-                const int k = kb + 8 * (r1 >> 2) + 4 * fh + (r1 & 3);
-                partials[(prow * 2 + 0) * K + k] = ts;
-                partials[(prow * 2 + 1) * K + k] = tq;
-            }
-        }
-    }
-}
-
 }  // namespace
 
 int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* y, float* stats, int N, int Hib,
@@ -506,66 +363,13 @@ int kp_conv_fwd_mfma(const void* x, const void* w, const float* bias, void* y, f
     return launch_linear<0>(x, w, bias, y, stats, N, Hi, Wi, C, K, st);
 }
 
-// ---- the ring on its own stream ------------------------------------------------------------------------------------------
-// kp_config_ptr(KP_CFG_RING_STREAM, s) (thread-local, kp_api.hip): the border ring of the matrix-core data gradients issued by this
-// thread runs as conv3x3_ring_lite_k on stream s, beside the interior kernel: s waits for what the call's stream has enqueued so far
-// (the gradient dy), the call's stream waits for the ring before the call returns to its caller's next launch.  NULL (default), the
-// same stream, or a stream under capture: everything on the call's stream (conv3x3_mfma_k<.., 2>).
-extern "C" hipStream_t kp_ring_stream();   // (kp_api.hip: the thread-local set by kp_config_ptr)
-long long kp_conv_ring_bred_rows(int N, int H, int W);
-bool kp_ring_fork(hipStream_t st, hipStream_t& rs, hipEvent_t (&ev)[2]) {
-    if (kp_query_mode()) return false;
-    rs = kp_ring_stream();
-    if (!rs || rs == st) return false;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
-    static thread_local hipEvent_t evs[2] = {nullptr, nullptr};
-    for (int i = 0; i < 2; ++i)
-        if (!evs[i] && hipEventCreateWithFlags(&evs[i], hipEventDisableTiming) != hipSuccess) return false;
-    ev[0] = evs[0]; ev[1] = evs[1];
-    if (hipEventRecord(ev[0], st) != hipSuccess || hipStreamWaitEvent(rs, ev[0], 0) != hipSuccess) return false;
-    return true;
-}
-int kp_ring_join(hipStream_t st, hipStream_t rs, hipEvent_t (&ev)[2]) {
-    if (hipEventRecord(ev[1], rs) != hipSuccess || hipStreamWaitEvent(st, ev[1], 0) != hipSuccess) return KP_E_LAUNCH;
-    return KP_OK;
-}
-static int ring_lite_launch(const void* dy, const void* w, void* gx, const RingBred* rb, float* rpart, int N, int H, int W, int K, int C,
-                            hipStream_t rs) {
-    const int Hi = H + 4, Wi = W + 4;
-    const long long mtiles = kp_conv_ring_bred_rows(N, H, W) / 2;   // 128-pixel tiles over the four edge groups
-    const int ktiles = C / 64;
-    if (mtiles * 2 * ktiles > 0x7fffffffLL) return KP_E_UNSUPPORTED;
-    const unsigned grid = (unsigned)(mtiles * 2 * ktiles);
-    if (rb) {
-        if (hipMemsetAsync(rpart, 0, (size_t)mtiles * 2 * 2 * C * sizeof(float), rs) != hipSuccess) return KP_E_LAUNCH;
-        conv3x3_ring_lite_k<true><<<grid, 64, 0, rs>>>((const h16_t*)dy, (const h16_t*)w, (h16_t*)gx, rpart, N, Hi, Wi, K, C, ktiles, *rb);
-    } else {
-        conv3x3_ring_lite_k<false><<<grid, 64, 0, rs>>>((const h16_t*)dy, (const h16_t*)w, (h16_t*)gx, nullptr, N, Hi, Wi, K, C, ktiles, RingBred{});
-    }
-    return kp_check_launch("conv3x3_ring_lite");
-}
-
 // Data-gradient of a 3x3 layer: gx[N][H+2][W+2][C] = valid correlation of dy[N][H+4][W+4][K] with the flipped pack,
 // where dy is KNOWN to carry a zero border of 2 pixels (written by kp_bn_act_bwd_apply).  Interior by the LDS-patch
 // kernel, border ring with 3 taps per pixel.  KP_E_UNSUPPORTED -> the caller falls back to kp_conv_fwd semantics.
 int kp_conv_dgrad_mfma(const void* dy, const void* w, void* gx, int N, int H, int W, int K, int C, hipStream_t st) {
     if (K % BK != 0 || C % 64 != 0 || H % 16 != 0 || W % 16 != 0 || H < 16 || W < 16 || !patch_mode()) return KP_E_UNSUPPORTED;
-    hipStream_t rs; hipEvent_t ev[2];
-    const bool fork = K % 16 == 0 && kp_ring_fork(st, rs, ev);
     int rc = patch_launch(dy, w, nullptr, gx, nullptr, N, H + 4, W + 4, 1, H + 2, W + 2, 1, H, W, K, C, st);
-    if (fork) {   // (the fork is joined whatever the interior returned)
-        const int rr = rc == KP_OK ? ring_lite_launch(dy, w, gx, nullptr, nullptr, N, H, W, K, C, rs) : KP_OK;
-        const int rj = kp_ring_join(st, rs, ev);
-        return rc != KP_OK ? rc : (rr != KP_OK ? rr : rj);
-    }
     if (rc != KP_OK) return rc;
-    return launch_linear<2>(dy, w, nullptr, gx, nullptr, N, H + 4, W + 4, K, C, st);
-}
-
-// The 3-tap border ring of a data gradient on its own (the interior comes from another kernel: kp_conv_dgrad_wino)
-int kp_conv_ring_dgrad(const void* dy, const void* w, void* gx, int N, int H, int W, int K, int C, hipStream_t st) {
-    if (K % BK != 0 || C % 64 != 0) return KP_E_UNSUPPORTED;
     return launch_linear<2>(dy, w, nullptr, gx, nullptr, N, H + 4, W + 4, K, C, st);
 }
 
@@ -577,12 +381,8 @@ long long kp_conv_ring_bred_rows(int N, int H, int W) {
 }
 int kp_conv_ring_dgrad_bred(const void* dy, const void* w, void* gx, const void* yred, const float* mean, const float* invstd,
                             const float* gamma, const float* beta, float slope, float* rpart, int N, int H, int W, int K, int C,
-                            hipStream_t st, int lite) {
+                            hipStream_t st) {
     if (K % BK != 0 || C % 64 != 0) return KP_E_UNSUPPORTED;
-    if (lite) {   // `st` is the ring stream of a fork (kp_ring_fork): the one-wave kernel that runs beside the interior
-        const RingBred rbl{(const h16_t*)yred, mean, invstd, gamma, beta, slope};
-        return ring_lite_launch(dy, w, gx, &rbl, rpart, N, H, W, K, C, st);
-    }
     const int Hi = H + 4, Wi = W + 4;
     const long long mtiles = kp_conv_ring_bred_rows(N, H, W) / 2;
     const int bn = (C % 128 == 0) ? 128 : 64;

@@ -648,9 +648,6 @@ bool kp_head_mfma_shape(long long, int, int, int);
 bool kp_head_mfma_fwd_shape(long long, int, int, int);
 long long kp_head_dw_parts_mfma(long long, int, int, int);
 long long kp_head_dw_parts_fast(long long, int, int);
-long long kp_head_bnbwd_rows_fast(long long, int, int);
-int kp_head_bnbwd_reduce_fast(const float*, const float*, const void*, const float*, float, float*, float*, long long, int, int, int, hipStream_t, const KpBnIn*);
-int kp_head_bnbwd_apply_fast(const float*, const float*, const void*, const float*, float, const float*, void*, int, int, int, int, int, int, hipStream_t, const KpBnIn*);
 int kp_head_dx_fast(const float*, const float*, const float*, float, void*, long long, int, int, int, hipStream_t);
 int kp_head_dw_fast(const float*, const float*, const void*, float, float*, float*, float*, long long, int, int, int, hipStream_t, const KpBnIn* = nullptr);
 bool kp_head_t_shape(long long, int, int, int);
@@ -905,42 +902,6 @@ int kp_head_bwd_bnin(const float* gout, const float* out, const void* yprev, con
     if (!head_bnin_ok((long long)N * H * W, H * W, C, K, dtype)) return KP_E_UNSUPPORTED;
     const KpBnIn bn{mean, invstd, gamma, beta, slope_in};
     return head_bwd_impl(gout, out, yprev, w, slope, dx, dw, db, ws, N, H, W, C, K, dtype, stream, &bn);
-}
-
-// ---- the head's backward fused with the BatchNorm backward of the 3x3 layer that feeds it (kp_head_fast.hip) -----------------
-long long kp_head_bnbwd_rows(int N, int H, int W, int C, int K, int dtype) {
-    if (dtype != KP_H16 || N <= 0 || H <= 0 || W <= 0) return 0;
-    const long long M = (long long)N * H * W;
-    if ((long long)N * (H + 4) * (W + 4) >= (1LL << 31)) return 0;
-    return kp_head_bnbwd_rows_fast(M, C, K);
-}
-
-int kp_head_bnbwd_reduce(const float* gout, const float* out, const void* yprev, const float* mean, const float* invstd,
-                         const float* gamma, const float* beta, float slope_in, const float* w, float slope, float* dw, float* db,
-                         float* ws, float* bn_partials, int N, int H, int W, int C, int K, int dtype, void* stream) {
-    KP_REQUIRE(gout && out && yprev && mean && invstd && gamma && beta && w && dw && ws && bn_partials && N > 0 && H > 0 && W > 0,
-               "kp_head_bnbwd_reduce: bad args");
-    KP_REQUIRE(slope_in >= 0.f && slope_in <= 1.f, "kp_head_bnbwd_reduce: activation slope of the producing layer must be in [0, 1]");
-    const long long parts = kp_head_bnbwd_rows(N, H, W, C, K, dtype);
-    if (parts <= 0 || ((((size_t)yprev) & 15) != 0)) return KP_E_UNSUPPORTED;
-    const long long M = (long long)N * H * W;
-    kp_count_bytes(8.0 * M * K + 2.0 * M * C);
-    const KpBnIn bn{mean, invstd, gamma, beta, slope_in};
-    if (int rc = kp_head_bnbwd_reduce_fast(gout, out, yprev, w, slope, ws, bn_partials, M, H * W, C, K, (hipStream_t)stream, &bn)) return rc;
-    const long long n = (long long)K * C + K;
-    head_dw_reduce(ws, parts, n, (long long)K * C, dw, db, (hipStream_t)stream);
-    return kp_check_launch("head_dw_reduce");
-}
-
-int kp_head_bnbwd_apply(const float* gout, const float* out, const void* yprev, const float* mean, const float* invstd,
-                        const float* gamma, const float* beta, float slope_in, const float* w, float slope, const float* sums, void* dy,
-                        int dy_pad, int N, int H, int W, int C, int K, int dtype, void* stream) {
-    KP_REQUIRE(gout && out && yprev && mean && invstd && gamma && beta && w && sums && dy && N > 0 && H > 0 && W > 0 && dy_pad >= 0,
-               "kp_head_bnbwd_apply: bad args");
-    if (kp_head_bnbwd_rows(N, H, W, C, K, dtype) <= 0 || dy_pad > 2 || ((((size_t)yprev | (size_t)dy) & 15) != 0)) return KP_E_UNSUPPORTED;
-    kp_count_bytes(8.0 * N * H * W * K + 2.0 * N * H * W * C + 2.0 * N * (H + 2.0 * dy_pad) * (W + 2.0 * dy_pad) * C);
-    const KpBnIn bn{mean, invstd, gamma, beta, slope_in};
-    return kp_head_bnbwd_apply_fast(gout, out, yprev, w, slope, sums, dy, dy_pad, N, H, W, C, K, (hipStream_t)stream, &bn);
 }
 
 int kp_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int pad, int dtype, void* stream) {

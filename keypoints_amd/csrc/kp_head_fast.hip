@@ -393,184 +393,6 @@ __global__ __launch_bounds__(TPB) void head_dw_small_k(const float* __restrict__
     }
 }
 
-// ---- the head's backward FUSED with the BatchNorm backward of the 3x3 layer that feeds it (kp_head_bnbwd_reduce / _apply) -----
-// The plain sequence writes the head's input gradient g [pixels][C] and reads it back twice (BatchNorm-backward reduce, then apply),
-// next to three reads of the layer's conv output y.  g is three FMAs per channel away from the head's own gradient dz [pixels][K <= 4]:
-// both kernels below recompute it from dz -- rounded to the storage type exactly where head_dx_small_k stores it -- and g never exists.
-//   reduce: the head's weight / bias gradient (head_dw_small_k<.., BNIN>: same partition, same partials -> bit-identical) AND the two
-//           BatchNorm-backward sums of the layer, one partial row [2][C] per workgroup, from ONE read of y
-//   apply : dy = gamma * invstd * (gh - sum_gh / M - xhat * sum_gh_xhat / M) written with its zero border of dp, from one more read of y
-// kp_bn_act_bwd_reduce's / _apply's arithmetic expression for expression on the same rounded values.
-template <int KB>
-__global__ __launch_bounds__(TPB) void head_dw_bnred_small_k(const float* __restrict__ gout, const float* __restrict__ out,
-                                                             const h16_t* __restrict__ y, const float* __restrict__ w, float slope,
-                                                             float* __restrict__ ws, float* __restrict__ bnpart, long long M, int HW,
-                                                             int C, int K, int ppb, KpBnIn bn) {
-    extern __shared__ __attribute__((aligned(16))) float red[];   // [npl][KC][C] (+ [npl][KC] for db, + TPB for block_sum_rows)
-    const int CV = C / V, cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
-    KpBnIn8 k8;
-    k8.load(bn, cv * V);
-    float wr[KB][V];
-#pragma unroll
-    for (int k = 0; k < KB; ++k)
-#pragma unroll
-        for (int e = 0; e < V; e += 4) {
-            const float4 q = k < K ? *reinterpret_cast<const float4*>(w + k * C + cv * V + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-            wr[k][e] = q.x; wr[k][e + 1] = q.y; wr[k][e + 2] = q.z; wr[k][e + 3] = q.w;
-        }
-    float acc[KB][V], dbs[KB], sb[V], sg[V];
-#pragma unroll
-    for (int k = 0; k < KB; ++k) {
-        dbs[k] = 0.f;
-#pragma unroll
-        for (int e = 0; e < V; ++e) acc[k][e] = 0.f;
-    }
-#pragma unroll
-    for (int e = 0; e < V; ++e) sb[e] = sg[e] = 0.f;
-    const int m0 = (int)((long long)blockIdx.x * ppb), Mi = (int)M;
-    for (int i = pl; i < ppb; i += PIX * npl) {
-        float dz[PIX][KB];
-        uint4 raw[PIX];
-#pragma unroll
-        for (int u = 0; u < PIX; ++u) {
-            int m = m0 + i + u * npl;
-            if (!(i + u * npl < ppb && m < Mi)) m = -1;
-            raw[u] = m >= 0 ? *reinterpret_cast<const uint4*>(y + (long long)m * C + cv * V) : make_uint4(0, 0, 0, 0);
-            load_dz<KB>(gout, out, m, HW, K, slope, dz[u], cv, CV);
-        }
-#pragma unroll
-        for (int u = 0; u < PIX; ++u) {
-            float yv[V], xv[V];
-            unpack8(raw[u], yv);
-            unpack8(k8.apply(raw[u], bn.slope), xv);     // the head's input: act(bn(y)), rounded as the plain pass stores it
-            float r[V];
-#pragma unroll
-            for (int e = 0; e < V; ++e) r[e] = 0.f;
-#pragma unroll
-            for (int k = 0; k < KB; ++k) {
-                dbs[k] += dz[u][k];
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    acc[k][e] = fmaf(dz[u][k], xv[e], acc[k][e]);
-                    r[e] = fmaf(dz[u][k], wr[k][e], r[e]);       // g = the head's input gradient (head_dx_small_k)
-                }
-            }
-            float g[V];
-            unpack8(make_uint4(pack_h16x2(r[0], r[1]), pack_h16x2(r[2], r[3]), pack_h16x2(r[4], r[5]), pack_h16x2(r[6], r[7])), g);
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                const float xh = (yv[e] - k8.mu[e]) * k8.is[e];
-                const float z = xh * k8.ga[e] + k8.be[e];
-                const float gh = g[e] * act_grad(z, bn.slope);
-                sb[e] += gh;
-                sg[e] += gh * xh;
-            }
-        }
-    }
-    // block reduction over the pixel lanes, KC output channels at a time (LDS = npl * KC * C floats, <= 32 KB): head_dw_small_k's
-    constexpr int KC = 4;
-    float* rdb = red + (size_t)npl * KC * C;
-    for (int k0 = 0; k0 < K; k0 += KC) {
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < KB; ++k) {
-            if (k >= k0 && k < k0 + KC && k < K) {
-#pragma unroll
-                for (int e = 0; e < V; ++e) red[((size_t)pl * KC + (k - k0)) * C + cv * V + e] = acc[k][e];
-                if (cv == 0) rdb[pl * KC + (k - k0)] = dbs[k];
-            }
-        }
-        __syncthreads();
-        const int kn = K - k0 < KC ? K - k0 : KC;
-        float* part = rdb + (size_t)npl * KC;
-        float* wsb = ws + (size_t)blockIdx.x * ((size_t)K * C + K);   // this workgroup's partial
-        block_sum_rows(red, npl, KC * C, kn * C, part, [&](int i, float s) { wsb[(size_t)k0 * C + i] = s; });
-        block_sum_rows(rdb, npl, KC, kn, part, [&](int i, float s) { wsb[(size_t)K * C + k0 + i] = s; });
-    }
-    // the layer's BatchNorm-backward sums: [npl][2][C] through the same LDS, pixel lanes added in order
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < V; ++e) {
-        red[((size_t)pl * 2 + 0) * C + cv * V + e] = sb[e];
-        red[((size_t)pl * 2 + 1) * C + cv * V + e] = sg[e];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += TPB) {
-        float s = 0.f;
-        for (int r2 = 0; r2 < npl; ++r2) s += red[(size_t)r2 * 2 * C + i];
-        bnpart[(size_t)blockIdx.x * 2 * C + i] = s;
-    }
-}
-
-// one thread = one 8-channel chunk of one position of the PADDED gradient dy [N][H + 2 dp][W + 2 dp][C]: zeros on the border
-template <int KB>
-__global__ __launch_bounds__(TPB) void head_dx_bnapply_small_k(const float* __restrict__ gout, const float* __restrict__ out,
-                                                               const h16_t* __restrict__ y, const float* __restrict__ w, float slope,
-                                                               const float* __restrict__ sums, float invM, h16_t* __restrict__ dy,
-                                                               int dp, long long Mp, int H, int Wd, int C, int K, int ppb, KpBnIn bn) {
-    const int CV = C / V, cv = threadIdx.x % CV, pl = threadIdx.x / CV, npl = TPB / CV;
-    const int Hp = H + 2 * dp, Wp = Wd + 2 * dp, HW = H * Wd;
-    KpBnIn8 k8;
-    k8.load(bn, cv * V);
-    float wr[KB][V], dbm[V], dgm[V];
-#pragma unroll
-    for (int k = 0; k < KB; ++k)
-#pragma unroll
-        for (int e = 0; e < V; e += 4) {
-            const float4 q = k < K ? *reinterpret_cast<const float4*>(w + k * C + cv * V + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-            wr[k][e] = q.x; wr[k][e + 1] = q.y; wr[k][e + 2] = q.z; wr[k][e + 3] = q.w;
-        }
-#pragma unroll
-    for (int e = 0; e < V; ++e) {
-        dbm[e] = bn.mean ? sums[cv * V + e] * invM : 0.f;
-        dgm[e] = bn.mean ? sums[C + cv * V + e] * invM : 0.f;
-    }
-    const int t0 = (int)((long long)blockIdx.x * ppb), Mpi = (int)Mp;
-    for (int i = pl; i < ppb; i += PIX * npl) {
-        float dz[PIX][KB];
-        uint4 raw[PIX];
-        int t[PIX], m[PIX];
-#pragma unroll
-        for (int u = 0; u < PIX; ++u) {
-            t[u] = t0 + i + u * npl;
-            if (!(i + u * npl < ppb && t[u] < Mpi)) t[u] = -1;
-            m[u] = -1;
-            if (t[u] >= 0) {
-                const int j = t[u] % Wp, r2 = t[u] / Wp, ii = r2 % Hp, n = r2 / Hp;
-                const int h = ii - dp, wq = j - dp;
-                if (h >= 0 && h < H && wq >= 0 && wq < Wd) m[u] = (n * H + h) * Wd + wq;
-            }
-            raw[u] = m[u] >= 0 ? *reinterpret_cast<const uint4*>(y + (long long)m[u] * C + cv * V) : make_uint4(0, 0, 0, 0);
-            load_dz<KB>(gout, out, m[u], HW, K, slope, dz[u], cv, CV);
-        }
-#pragma unroll
-        for (int u = 0; u < PIX; ++u) {
-            if (t[u] < 0) continue;
-            uint4 pk = make_uint4(0, 0, 0, 0);       // the zero border
-            if (m[u] >= 0) {
-                float yv[V], r[V], g[V], res[V];
-                unpack8(raw[u], yv);
-#pragma unroll
-                for (int e = 0; e < V; ++e) r[e] = 0.f;
-#pragma unroll
-                for (int k = 0; k < KB; ++k)
-#pragma unroll
-                    for (int e = 0; e < V; ++e) r[e] = fmaf(dz[u][k], wr[k][e], r[e]);
-                unpack8(make_uint4(pack_h16x2(r[0], r[1]), pack_h16x2(r[2], r[3]), pack_h16x2(r[4], r[5]), pack_h16x2(r[6], r[7])), g);
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    const float xh = (yv[e] - k8.mu[e]) * k8.is[e];
-                    const float z = xh * k8.ga[e] + k8.be[e];
-                    const float gh = g[e] * act_grad(z, bn.slope);
-                    res[e] = bn.mean ? k8.ga[e] * k8.is[e] * (gh - dbm[e] - xh * dgm[e]) : gh;
-                }
-                pk = make_uint4(pack_h16x2(res[0], res[1]), pack_h16x2(res[2], res[3]), pack_h16x2(res[4], res[5]), pack_h16x2(res[6], res[7]));
-            }
-            *reinterpret_cast<uint4*>(dy + (long long)t[u] * C + cv * V) = pk;
-        }
-    }
-}
-
 bool small_shape(int C, int K) {
     const int CV = C / V;
     return C % V == 0 && CV >= 1 && CV <= 64 && (CV & (CV - 1)) == 0 && K >= 1 && K <= 16;
@@ -662,31 +484,3 @@ int kp_head_dw_fast(const float* gout, const float* out, const void* x, float sl
     return kp_check_launch("head_dw_fast");
 }
 
-// ---- fused head + BatchNorm backward (see the kernels): K <= 4, the small-shape partition of kp_head_dw_fast -----------------
-long long kp_head_bnbwd_rows_fast(long long M, int C, int K) {
-    long long ppb;
-    return K <= 4 ? dw_fast_plan(M, C, K, ppb) : 0;
-}
-int kp_head_bnbwd_reduce_fast(const float* gout, const float* out, const void* y, const float* w, float slope, float* ws, float* bnpart,
-                              long long M, int HW, int C, int K, hipStream_t st, const KpBnIn* bn) {
-    long long ppb;
-    const long long parts = K <= 4 ? dw_fast_plan(M, C, K, ppb) : 0;
-    if (parts <= 0 || !bn || !ws || !bnpart) return KP_E_UNSUPPORTED;
-    const int npl = TPB / (C / V);
-    const size_t lds = ((size_t)npl * 4 * C + (size_t)npl * 4 + TPB) * sizeof(float);
-    head_dw_bnred_small_k<4><<<(unsigned)parts, TPB, lds, st>>>(gout, out, (const h16_t*)y, w, slope, ws, bnpart, M, HW, C, K, (int)ppb, *bn);
-    return kp_check_launch("head_dw_bnred_fast");
-}
-int kp_head_bnbwd_apply_fast(const float* gout, const float* out, const void* y, const float* w, float slope, const float* sums, void* dy,
-                             int dp, int N, int H, int W, int C, int K, hipStream_t st, const KpBnIn* bn) {
-    const long long Mp = (long long)N * (H + 2 * dp) * (W + 2 * dp);
-    if (!small_shape(C, K) || K > 4 || Mp >= (1LL << 31) || !bn) return KP_E_UNSUPPORTED;
-    const int npl = TPB / (C / V);
-    long long per = Mp / ((long long)npl * 2048);
-    per = per < 8 ? 8 : (per > 32 ? 32 : per);
-    const int ppb = npl * (int)per;
-    const unsigned grid = (unsigned)((Mp + ppb - 1) / ppb);
-    head_dx_bnapply_small_k<4><<<grid, TPB, 0, st>>>(gout, out, (const h16_t*)y, w, slope, sums, 1.0f / (float)((long long)N * H * W),
-                                                     (h16_t*)dy, dp, Mp, H, W, C, K, ppb, *bn);
-    return kp_check_launch("head_dx_bnapply_fast");
-}

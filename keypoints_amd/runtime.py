@@ -346,25 +346,6 @@ def set_fuse_first_layer(on: bool) -> None:
     _FUSE_FIRST = bool(on)
 
 
-_FUSE_HEAD_BN_BWD = False   # (measured neutral, see the docstring: opt-in)
-
-
-def fuse_head_bn_bwd() -> bool:
-    """A Unit whose 1x1 head (<= 4 output channels) reads the conv output of its last 3x3 layer: the head's backward runs inside that
-    layer's two BatchNorm-backward passes (kp_head_bnbwd_reduce / _apply, include/kp_hip.h) and the head's input gradient -- a tensor
-    as large as the layer's activation, written once and read twice by the plain sequence -- is never materialised.  Head weight /
-    bias gradients are bit-identical, the BatchNorm sums equal up to the order of fp32 additions.
-    OFF by default: measured NEUTRAL (docs/experiments/r05.md section 9: model F 32.89 vs 32.88 ms, config 2 2.601 vs 2.600 ms) --
-    the small-head kernels are bound by VALU work and latency, not by the bytes of g: the two fused kernels take 242 + 266 us at model
-    F's decoder head where the four plain ones take 142 + 86 + 108 + 158.  `set_fuse_head_bn_bwd(True)` selects it."""
-    return _FUSE_HEAD_BN_BWD
-
-
-def set_fuse_head_bn_bwd(on: bool) -> None:
-    global _FUSE_HEAD_BN_BWD
-    _FUSE_HEAD_BN_BWD = bool(on)
-
-
 _KEEP_SAVED = False
 
 
@@ -382,22 +363,3 @@ def set_keep_saved_activations(on: bool) -> None:
     _KEEP_SAVED = bool(on)
 
 
-_RING_BESIDE = False   # (measured: no gain, see the docstring)
-
-
-def ring_beside() -> bool:
-    """The data gradient of a matrix-core layer = the persistent LDS-patch kernel on the 16x16-tileable interior + a short launch for the
-    1-pixel ring of the padded domain (19 per model-F step, 0.73 ms of ramp-up and drain).  `set_ring_beside(True)` sends the ring to a
-    side stream as conv3x3_ring_lite_k -- one wavefront per workgroup, no LDS, <= 128 registers: it fits on a CU beside the interior
-    kernel's workgroup -- with the two cross-stream dependencies the library adds around it (kp_config_ptr(KP_CFG_RING_STREAM)).
-    Bit-identical results (tests/test_gpu_ring_lite.py).  OFF by default: measured on model F, alternating on one box
-    (docs/experiments/r05.md section 13): 32.59 -> 33.64 ms with every layer's ring beside its interior (the one-wave kernel takes
-    194 us on average where the LDS kernel takes 38 alone: on the 16 x 16 and 32 x 32 maps it outlasts the interior), 33.62 -> 33.68 /
-    33.55 -> 33.60 with only the 128 x 128 layers' rings (hidden there, and the two cross-queue waits per layer cost what the ring
-    did)."""
-    return _RING_BESIDE
-
-
-def set_ring_beside(on: bool) -> None:
-    global _RING_BESIDE
-    _RING_BESIDE = bool(on)

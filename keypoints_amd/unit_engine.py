@@ -298,33 +298,6 @@ def _materialise(fin, N, H, W, C, pad, tdt, code, st):
     return a
 
 
-RING_MIN_SIDE = 0   # (keypoints_amd._probe: KP_RING_MIN_SIDE)
-
-
-class _ring_beside:
-    """`with _ring_beside(...)`: with `runtime.set_ring_beside(True)` (OFF by default: measured, no gain) the border ring of a matrix-core
-    data gradient issued inside the block runs on the side stream 'ring', beside the persistent interior kernel instead of after it
-    (kp_config_ptr(KP_CFG_RING_STREAM), include/kp_hip.h: the library orders the two streams around its own launches, so nothing has
-    to be joined here).  Matrix-core layers only; results bit-identical."""
-
-    def __init__(self, side_ok, H, W, C, K):
-        self._s = None
-        if (side_ok and runtime.ring_beside() and runtime.multi_stream('ring') and C % 64 == 0 and K % 64 == 0 and H % 16 == 0
-                and W % 16 == 0 and min(H, W) >= RING_MIN_SIDE):
-            self._s = runtime.side_stream('ring')
-            runtime._used.discard(self._s)   # (joined by the library call itself)
-
-    def __enter__(self):
-        if self._s is not None:
-            call('kp_config_ptr', _lib.KP_CFG_RING_STREAM, self._s.cuda_stream)
-        return self
-
-    def __exit__(self, *exc):
-        if self._s is not None:
-            call('kp_config_ptr', _lib.KP_CFG_RING_STREAM, None)
-        return False
-
-
 def _wgrad_layer(sv, dy, gw, parts, N, H, W, C, K, dp, tdt, code, dev):
     """Weight gradient of one 3x3 layer on torch's current stream: kp_conv_wgrad (or its fused-BatchNorm-input form) into `parts`
     partial buffers, then kp_wgrad_unpack adds them into the arena view `gw` in a fixed order.  (A module-level function so that
@@ -667,24 +640,11 @@ class UnitFunction(torch.autograd.Function):
         head = plan[-1]
         hconv = head['conv']
         has_body = len(plan) > 1
-        # The head's backward fused with the BatchNorm backward of the 3x3 layer in front of it (kp_head_bnbwd_*): where the head read
-        # that layer's conv output (the forward's bnin form) and has <= 4 output channels -- the decoder's image head, the Pong nets'
-        # heads -- its input gradient g is recomputed inside the layer's two BatchNorm-backward passes and never written.
-        head_fused = 0
-        if (not out_t and isinstance(a_last, dict) and has_body and saved and not saved[-1].get('eval_bn') and not saved[-1].get('first_fused')
-                and plan[len(saved) - 1]['bn'] is not None and unit.sync_bn is None and runtime.fuse_head_bn_bwd()):
-            head_fused = int(_lib.lib().kp_head_bnbwd_rows(N, Hh, Wh, Ch, Kout, code))
-            if head_fused > 0:
-                gout = f32c(gout)
-                if (gout.data_ptr() | out.data_ptr()) & 15:
-                    head_fused = 0
-        g = torch.empty(N, Hh, Wh, Ch, device=dev, dtype=tdt) if ((has_body or need_x) and head_fused <= 0) else None
+        g = torch.empty(N, Hh, Wh, Ch, device=dev, dtype=tdt) if (has_body or need_x) else None
         # the workspace makes the head's weight gradient a fixed-order two-stage sum (bitwise reproducible step)
         hws = torch.empty(_lib.lib().kp_head_bwd_ws_floats(N, Hh, Wh, Ch, Kout, code), device=dev, dtype=torch.float32)
         hgrads = (ptr(g), ptr(gv[id(hconv.weight)]), ptr(gv[id(hconv.bias)]) if hconv.bias is not None else None, ptr(hws))
-        if head_fused > 0:
-            pass   # (everything about the head happens inside the last layer's BatchNorm backward below)
-        elif out_t:
+        if out_t:
             # output gradient and saved output are T [N][H][W][K] (see forward); should the library decline NOW (unaligned foreign
             # gradient tensor), both are turned into the fp32 planes of the plain entry points and the code below runs as usual
             gout = gout.to(tdt).contiguous()
@@ -702,7 +662,7 @@ class UnitFunction(torch.autograd.Function):
                 gout, out, out_t = g32, o32, False
         else:
             gout = f32c(gout)
-        if out_t or head_fused > 0:
+        if out_t:
             pass
         elif isinstance(a_last, dict):   # the forward's fused form: the head's input is recomputed from the conv output
             if not try_call('kp_head_bwd_bnin', ptr(gout), ptr(out), ptr(a_last['y']), *a_last['bn'], a_last['slope'], ptr(hconv.weight),
@@ -710,7 +670,7 @@ class UnitFunction(torch.autograd.Function):
                 # declined in the backward although the forward's shape query accepted (unaligned gradient tensors, a knob that
                 # changed in between): rebuild the activation the forward never wrote and run the plain kernel
                 a_last = _materialise(a_last, N, Hh, Wh, Ch, 0, tdt, code, st)
-        if not out_t and head_fused <= 0 and not isinstance(a_last, dict):
+        if not out_t and not isinstance(a_last, dict):
             if isinstance(ctx.head_in, dict):
                 hws = torch.empty(_lib.lib().kp_head_bwd_ws_floats(N, Hh, Wh, Ch, Kout, code), device=dev, dtype=torch.float32)
                 hgrads = hgrads[:3] + (ptr(hws),)
@@ -750,15 +710,7 @@ class UnitFunction(torch.autograd.Function):
                 g = None
                 unit._layer_done(idx)
                 continue
-            hf = head_fused > 0 and idx == len(saved) - 1
-            if hf:
-                partials = torch.empty(head_fused, 2, K, device=dev, dtype=torch.float32)
-                prows = head_fused
-                hf_args = (ptr(gout), ptr(out), ptr(sv['y']), *bn_args, stp['slope'], ptr(hconv.weight), head['slope'])
-                hws = torch.empty(head_fused * (Kout * K + Kout), device=dev, dtype=torch.float32)   # one partial [Kout][K] + [Kout] per workgroup
-                call('kp_head_bnbwd_reduce', *hf_args, ptr(gv[id(hconv.weight)]), ptr(gv[id(hconv.bias)]) if hconv.bias is not None else None,
-                     ptr(hws), ptr(partials), N, H, W, K, Kout, code, st)
-            elif pending_red is not None:   # the layer above left this layer's sums in its data gradient's epilogue (below)
+            if pending_red is not None:   # the layer above left this layer's sums in its data gradient's epilogue (below)
                 partials, prows = pending_red
                 pending_red = None
             else:
@@ -791,11 +743,8 @@ class UnitFunction(torch.autograd.Function):
             need_dx = idx > 0 or need_x
             dp = 2 if need_dx else 0
             dy = torch.empty(N, H + 2 * dp, W + 2 * dp, K, device=dev, dtype=tdt)
-            if hf:
-                call('kp_head_bnbwd_apply', *hf_args, ptr(sums), ptr(dy), dp, N, H, W, K, Kout, code, st)
-            else:
-                call('kp_bn_act_bwd_apply', ptr(g), gp, tcode, ptr(sv['argmax']), ptr(sv['y']), *bn_args, stp['slope'],
-                     ptr(sums), ptr(dy), dp, N, H, W, K, code, st)
+            call('kp_bn_act_bwd_apply', ptr(g), gp, tcode, ptr(sv['argmax']), ptr(sv['y']), *bn_args, stp['slope'],
+                 ptr(sums), ptr(dy), dp, N, H, W, K, code, st)
             # (conv bias in front of train-mode BN: analytically zero gradient -> its arena slot stays 0)
             parts = _lib.lib().kp_conv_wgrad_partials(N, H, W, C, K, 3, dp, code)
             if need_dx:
@@ -809,14 +758,12 @@ class UnitFunction(torch.autograd.Function):
                     svb, bnb = saved[idx - 1], below['bn']
                     rows_b = _lib.lib().kp_conv_dgrad_bnred_rows(N, H, W, K, C, code)
                     part_b = torch.empty(rows_b, 2, C, device=dev, dtype=torch.float32)
-                    with _ring_beside(side_ok, H, W, C, K):
-                        call('kp_conv_dgrad_bnred', ptr(dy), ptr(sv['wd']), ptr(gx), ptr(svb['y']), ptr(svb['mean']), ptr(svb['invstd']),
-                             ptr(bnb.weight if bnb is not None else None), ptr(bnb.bias if bnb is not None else None), below['slope'],
-                             ptr(part_b), N, H, W, K, C, code, st)
+                    call('kp_conv_dgrad_bnred', ptr(dy), ptr(sv['wd']), ptr(gx), ptr(svb['y']), ptr(svb['mean']), ptr(svb['invstd']),
+                         ptr(bnb.weight if bnb is not None else None), ptr(bnb.bias if bnb is not None else None), below['slope'],
+                         ptr(part_b), N, H, W, K, C, code, st)
                     pending_red = (part_b, rows_b)
                 else:
-                    with _ring_beside(side_ok, H, W, C, K):
-                        call('kp_conv_dgrad', ptr(dy), ptr(sv['wd']), ptr(gx), N, H, W, K, C, code, st)
+                    call('kp_conv_dgrad', ptr(dy), ptr(sv['wd']), ptr(gx), N, H, W, K, C, code, st)
                 g, gp = gx, 1
             else:
                 g = None

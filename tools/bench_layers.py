@@ -79,18 +79,7 @@ def main():
         scratch = torch.zeros(_lib.lib().kp_conv_wgrad_partials(N, H, W, C, K, 3, 2, DT), K, 3, 3, C, device='cuda')
         cols = []
         for mode in modes:
-            if mode == 3:   # Winograd F(2, 3) kernels (fp16 only): same algorithmic FLOPs, 1.5x fewer multiplications
-                if not (args.f16 and _lib.lib().kp_conv_wino_supported(N, H, W, C, K, 1, DT) == 1 and _lib.lib().kp_conv_wino_supported(N, H, W, K, C, 0, DT) == 1):
-                    cols += [0.0, 0.0]
-                    continue
-                uf = torch.empty(K, 4, 3, C, device='cuda', dtype=bf)
-                ud = torch.empty(C, 4, 3, K, device='cuda', dtype=bf)
-                call('kp_conv_wino_pack', ptr(wf), ptr(uf), K, C, DT, st)
-                call('kp_conv_wino_pack', ptr(wd), ptr(ud), C, K, DT, st)
-                wstats = torch.empty(max(1, _lib.lib().kp_conv_fwd_wino_rows(N, H + 2, W + 2, C, K, DT)), 2, K, device='cuda')
-                tf = timed(lambda: call('kp_conv_fwd_wino', ptr(a), ptr(uf), ptr(bias), ptr(y), ptr(wstats), N, H + 2, W + 2, C, K, DT, st), args.reps)
-                td = timed(lambda: call('kp_conv_dgrad_wino', ptr(dy), ptr(ud), ptr(wd), ptr(gx), N, H, W, K, C, DT, st), args.reps)
-            else:
+            if True:
                 call('kp_config', 0, mode)
                 tf = timed(lambda: call('kp_conv_fwd', ptr(a), ptr(wf), ptr(bias), ptr(y), ptr(stats), N, H + 2, W + 2, C, K,
                                         3, DT, st), args.reps)
@@ -101,12 +90,6 @@ def main():
             t[0] += nf * flops + nd * flops   # algorithmic (interior) flops
             t[1] += nf * tf + nd * td
         call('kp_config', 0, 1)
-        if args.ab:
-            call('kp_config', 3, 0)
-            tw0 = timed(lambda: call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, W, C, K, 3, 2, DT, st),
-                        args.reps)
-            cols.append(flops / tw0 / 1e12)
-            call('kp_config', 3, 1)
         tw = timed(lambda: call('kp_conv_wgrad', ptr(a), ptr(dy), ptr(scratch), N, H, W, C, K, 3, 2, DT, st),
                    args.reps)
         t = tot.setdefault('wgrad', [0.0, 0.0])

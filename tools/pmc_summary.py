@@ -37,7 +37,7 @@ def load(name):
 
 def main(tag, lib_sha16=None):
     out = {}
-    if lib_sha16:   # the library the counters were collected on (tools/r05_records.sh): bench.py quotes `traffic` only from a summary
+    if lib_sha16:   # the library the counters were collected on (tools/records.sh): bench.py quotes `traffic` only from a summary
         out['lib_sha16'] = lib_sha16   # whose stamp equals the loaded library's
     for suffix, kernels in (('', KERNELS), ('c2', KERNELS_C2)):
         summarise(out, suffix, kernels)
