@@ -9,6 +9,8 @@ int kp_conv_wgrad_generic(const void*, const void*, float*, int, int, int, int, 
 int kp_conv_fwd_mfma(const void*, const void*, const float*, void*, float*, int, int, int, int, int, int,
                      hipStream_t);   // bf16 only; returns KP_E_UNSUPPORTED when the shape is not eligible
 int kp_conv_dgrad_mfma(const void*, const void*, void*, int, int, int, int, int, hipStream_t);
+int kp_conv_wgrad_mfma(const void*, const void*, float*, int, int, int, int, int, int, int, hipStream_t);
+int kp_conv_wgrad_mfma_accepts(int, int, int, int, int, int);
 int kp_conv_wgrad_patch(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 long long kp_conv_wgrad_patch_partials(int, int, int, int, int, int);
 int kp_conv_small_fwd(const void*, const void*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
@@ -115,6 +117,12 @@ int kp_conv_wgrad_partials(int N, int Ho, int Wo, int C, int K, int R, int dy_pa
         const long long p = kp_conv_small_wgrad_partials(N, Ho, Wo, C, K);
         if (p > 0) return (int)p;
     }
+    // the per-tap MFMA kernel (kp_wgrad_mfma.hip): 64-multiple channels the tap-reuse kernel declines -- (64 x 64) gradient blocks (the
+    // 64 -> 64 layers of vgg_cfg 'B' / 'D' / 'E', vgg.py:55-57) and maps smaller than its pixel block; one partial per pixel split
+    if (dtype == KP_H16 && use_mfma()) {
+        const int p = kp_conv_wgrad_mfma_accepts(N, Ho, Wo, C, K, R);
+        if (p > 0) return p;
+    }
     if (dtype == KP_F32 && R == 3 && use_mfma()) {
         const long long p = kp_conv_wgrad_f32mfma_partials(N, Ho, Wo, C, K);
         if (p > 0 && p < 0x7fffffffLL) return (int)p;
@@ -136,8 +144,8 @@ int kp_conv_wgrad(const void* x, const void* dy, float* scratch, int N, int Ho, 
         int rc = (R == 3 && g_kp_wgrad_patch) ? kp_conv_wgrad_patch(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream)
                                               : KP_E_UNSUPPORTED;
         if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_WGRAD_MFMA); return rc; }
-        // (64-multiple channels on a map that is not a multiple of the tap-reuse kernel's 8 x 16 pixel block: the caller pads both operands
-        //  with zeros -- kp_conv_wgrad_pad_hw + kp_pad_hw, exact -- and calls again; called as it is, such a shape takes the generic kernel)
+        rc = kp_conv_wgrad_mfma(x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, (hipStream_t)stream);
+        if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_WGRAD_MFMA); return rc; }
         if (R == 3 && C <= 4 && (K == 16 || K == 32)) {
             rc = kp_conv_small_first_wgrad(x, dy, scratch, N, Ho, Wo, C, K, dy_pad, (hipStream_t)stream);
             if (rc != KP_E_UNSUPPORTED) { ps.done(KP_PROF_CONV_FIRST); return rc; }
