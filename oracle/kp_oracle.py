@@ -131,7 +131,17 @@ TOL16 = {
 # A single conditioned network scatters around the clauses above (which one a conditioning trajectory ends in depends on the last
 # bits of the fp32 path): tests assert each clause on the median of three trajectories and every single network inside this factor.
 # Measured: fp16 keypoints of config 3 over six trajectories 3.95 - 6.00 e-3 (median 4.2e-3), of config 4 over four 2.74 - 5.13 e-3.
-TOL16_PER_NETWORK = 1.5
+# Round 6: 1.5 -> 1.25.  Over every trajectory measured in rounds 4-5 (26 networks x 6 clauses x 2 types) the worst
+# single network stands at 1.20 x its clause on the HIP path (6.00e-3 keypoints, config 3, round 4) and at 1.19 x on the emulated
+# reference (5.95e-3, profiles/r05v_contract_c3.txt seed 102); every other clause stays below 0.5 x.  1.25 = that worst case + 4 %.
+TOL16_PER_NETWORK = 1.25
+# SURVEY 8c's clauses AS WRITTEN, for the premise checks of tests/test_gpu_fullsize.py (not tolerances of this contract): keypoints 5e-3
+# on at least SURVEY_KEYPOINT_QUORUM of the conditioned networks of a config with NO per-network factor; and where the HIP path breaks
+# "x_t <= 2e-2 max|x_t|" the emulated reference must break it too -- on the median network, and per network be at least
+# SURVEY_XT_NEAR x 2e-2 itself (a maximum over 6 M pixels that sits AT the threshold may fall either side of it).
+SURVEY_XT_MAX = 2e-2
+SURVEY_XT_NEAR = 0.75
+SURVEY_KEYPOINT_QUORUM = 2.0 / 3.0
 # The anchor (round 5): on every conditioned network and for every clause, the HIP path is held to the REFERENCE'S OWN arithmetic in
 # the same storage type -- unit_forward(quant=fp16_storage / bf16_storage) on the same weights and batch, measured against the same
 # fp64 run: hip <= TOL16_VS_EMULATION x emulation + TOL16_EMULATION_FLOOR x clause (the floor is for statistics that are ~0 in both:

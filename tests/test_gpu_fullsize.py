@@ -640,3 +640,21 @@ def test_conditioned_networks_meet_the_16bit_contract(cfg):
         for r, e in zip(rows, emus[precision]):
             for key in r:
                 assert r[key] <= O.TOL16_VS_EMULATION * e[key] + O.TOL16_EMULATION_FLOOR * T[key], (cfg, precision, key, 'vs emulation', r[key], e[key])
+    # ---- the PREMISE of the re-scoped x_t clause and SURVEY's keypoint clause without any factor (round 6), fp16 =
+    # the contract type.  (a) SURVEY 8c wrote "x_t <= 2e-2 max|x_t|"; oracle.TOL16 replaces it by a distribution statement because the
+    # REFERENCE'S OWN arithmetic in fp16 storage breaks it on these networks.  That is asserted here, not assumed: wherever the HIP path
+    # breaks the as-written clause, the emulated reference is at (>= SURVEY_XT_NEAR x) the threshold itself, and the median network of
+    # the emulation breaks it whenever the median network of the HIP path does.  (b) SURVEY's keypoint clause 5e-3 with no per-network
+    # factor holds on at least two of three networks.
+    rows, es = results['fp16'], emus['fp16']
+    hw, ew = [r['xt_worst'] for r in rows], [e['xt_worst'] for e in es]
+    hip_v, emu_v = [v > O.SURVEY_XT_MAX for v in hw], [v > O.SURVEY_XT_MAX for v in ew]
+    inside = [r['keypoints'] <= O.TOL16['fp16']['keypoints'] for r in rows]
+    print(f'premise     {cfg}, fp16: as-written x_t clause (2e-2 max) broken by HIP {hip_v} / by the emulated reference {emu_v}; worst pixel '
+          f'hip {[f"{v:.3f}" for v in hw]} emu {[f"{v:.3f}" for v in ew]}; keypoints inside 5e-3 (no factor): {sum(inside)} of {len(inside)}')
+    for h, e, hv in zip(hw, ew, hip_v):
+        assert (not hv) or e >= O.SURVEY_XT_NEAR * O.SURVEY_XT_MAX, (cfg, 'the HIP path breaks SURVEY\'s as-written x_t clause where the emulated reference is not near it', h, e)
+    if len(rows) >= 3:
+        med = lambda v: sorted(v)[len(v) // 2]
+        assert med(hw) <= O.SURVEY_XT_MAX or med(ew) > O.SURVEY_XT_MAX, (cfg, 'median network: HIP breaks the as-written x_t clause, the emulated reference does not', hw, ew)
+        assert sum(inside) >= O.SURVEY_KEYPOINT_QUORUM * len(inside) - 1e-9, (cfg, 'keypoints: fewer than two of three networks inside SURVEY\'s 5e-3', [r['keypoints'] for r in rows])
