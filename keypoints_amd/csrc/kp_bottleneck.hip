@@ -208,7 +208,11 @@ __global__ void transport_max_bwd_k(const float* __restrict__ g, const float* __
 // phi_0 = phi_s, phi_{i+1} = phi_i (1 - m_s,i)(1 - m_t,i) + phi_t m_t,i  for i < K (the masks returned are the last slices).
 constexpr int LOOP_MAXK = 64;
 
-template <int MODE>
+// KM ('loop' only): a compile-time bound on K (4 / 16 / LOOP_MAXK).  The per-keypoint arrays of a thread are indexed in fully unrolled
+// loops, so for K <= 16 they live in registers; with the run-time bound alone (rounds 1-5) the 5 x 64 floats of the backward sat in
+// scratch memory and 'loop' -- the DEFAULT combine_method of TransporterNet.__init__, transporter.py:14 -- took 3.6 x the fused 'max'
+// pair at config 2's bottleneck (tools/bench_f4.py, profiles/r06_f4_modes.txt).  Same expressions in the same order: bit-identical.
+template <int MODE, int KM = LOOP_MAXK>
 __global__ void transport_mode_fwd_k(const float* __restrict__ phi_s, const float* __restrict__ phi_t,
                                      const float* __restrict__ m_s, const float* __restrict__ m_t,
                                      float* __restrict__ phi, float* __restrict__ mask_s, float* __restrict__ mask_t,
@@ -218,14 +222,17 @@ __global__ void transport_mode_fwd_k(const float* __restrict__ phi_s, const floa
     const long long b = t / HW;
     const int pix = (int)(t % HW);
     if (MODE == 3) {
+        float vs[KM], vt[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (k < K) { vs[k] = m_s[(b * K + k) * HW + pix]; vt[k] = m_t[(b * K + k) * HW + pix]; }
         for (int c = 0; c < C; ++c) {
             const long long o = (b * C + c) * HW + pix;
             float p = phi_s[o];
             const float pt = phi_t[o];
-            for (int k = 0; k < K; ++k) {
-                const float vs = m_s[(b * K + k) * HW + pix], vt = m_t[(b * K + k) * HW + pix];
-                p = p * (1.f - vs) * (1.f - vt) + pt * vt;
-            }
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+                if (k < K) p = p * (1.f - vs[k]) * (1.f - vt[k]) + pt * vt[k];
             phi[o] = p;
         }
         mask_s[t] = m_s[(b * K + K - 1) * HW + pix];
@@ -250,7 +257,7 @@ __global__ void transport_mode_fwd_k(const float* __restrict__ phi_s, const floa
     }
 }
 
-template <int MODE>
+template <int MODE, int KM = LOOP_MAXK>
 __global__ void transport_mode_bwd_k(const float* __restrict__ g, const float* __restrict__ phi_s,
                                      const float* __restrict__ phi_t, const float* __restrict__ m_s,
                                      const float* __restrict__ m_t, float* __restrict__ d_phi_s,
@@ -261,33 +268,45 @@ __global__ void transport_mode_bwd_k(const float* __restrict__ g, const float* _
     const long long b = t / HW;
     const int pix = (int)(t % HW);
     if (MODE == 3) {
-        float vs[LOOP_MAXK], vt[LOOP_MAXK], gs[LOOP_MAXK], gt[LOOP_MAXK], pi[LOOP_MAXK];
-        for (int k = 0; k < K; ++k) {
-            vs[k] = m_s[(b * K + k) * HW + pix];
-            vt[k] = m_t[(b * K + k) * HW + pix];
+        float vs[KM], vt[KM], gs[KM], gt[KM], pi[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            if (k < K) {
+                vs[k] = m_s[(b * K + k) * HW + pix];
+                vt[k] = m_t[(b * K + k) * HW + pix];
+            }
             gs[k] = gt[k] = 0.f;
         }
         for (int c = 0; c < C; ++c) {
             const long long o = (b * C + c) * HW + pix;
             const float pt = phi_t[o];
             float p = phi_s[o];
-            for (int k = 0; k < K; ++k) {   // forward again, keeping every phi_i
-                pi[k] = p;
-                p = p * (1.f - vs[k]) * (1.f - vt[k]) + pt * vt[k];
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {   // forward again, keeping every phi_i
+                if (k < K) {
+                    pi[k] = p;
+                    p = p * (1.f - vs[k]) * (1.f - vt[k]) + pt * vt[k];
+                }
             }
             float gp = g[o], gpt = 0.f;
-            for (int k = K - 1; k >= 0; --k) {
-                gpt += gp * vt[k];
-                gt[k] += gp * (pt - pi[k] * (1.f - vs[k]));
-                gs[k] -= gp * pi[k] * (1.f - vt[k]);
-                gp = gp * (1.f - vs[k]) * (1.f - vt[k]);
+#pragma unroll
+            for (int k = KM - 1; k >= 0; --k) {
+                if (k < K) {
+                    gpt += gp * vt[k];
+                    gt[k] += gp * (pt - pi[k] * (1.f - vs[k]));
+                    gs[k] -= gp * pi[k] * (1.f - vt[k]);
+                    gp = gp * (1.f - vs[k]) * (1.f - vt[k]);
+                }
             }
             if (d_phi_s) d_phi_s[o] = gp;
             if (d_phi_t) d_phi_t[o] = gpt;
         }
-        for (int k = 0; k < K; ++k) {
-            if (d_m_s) d_m_s[(b * K + k) * HW + pix] = gs[k];
-            if (d_m_t) d_m_t[(b * K + k) * HW + pix] = gt[k];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            if (k < K) {
+                if (d_m_s) d_m_s[(b * K + k) * HW + pix] = gs[k];
+                if (d_m_t) d_m_t[(b * K + k) * HW + pix] = gt[k];
+            }
         }
         return;
     }
@@ -394,6 +413,8 @@ int kp_transport_fwd(int mode, const float* phi_s, const float* phi_t, const flo
     hipStream_t st = (hipStream_t)stream;
     if (mode == KP_COMBINE_SUM_AND_CLAMP) transport_mode_fwd_k<1><<<grid, TPB, 0, st>>>(phi_s, phi_t, m_s, m_t, phi, mask_s, mask_t, B, C, K, H * W);
     else if (mode == KP_COMBINE_PRETRAINED) transport_mode_fwd_k<2><<<grid, TPB, 0, st>>>(phi_s, phi_t, m_s, m_t, phi, mask_s, mask_t, B, C, K, H * W);
+    else if (mode == KP_COMBINE_LOOP && K <= 4) transport_mode_fwd_k<3, 4><<<grid, TPB, 0, st>>>(phi_s, phi_t, m_s, m_t, phi, mask_s, mask_t, B, C, K, H * W);
+    else if (mode == KP_COMBINE_LOOP && K <= 16) transport_mode_fwd_k<3, 16><<<grid, TPB, 0, st>>>(phi_s, phi_t, m_s, m_t, phi, mask_s, mask_t, B, C, K, H * W);
     else if (mode == KP_COMBINE_LOOP) transport_mode_fwd_k<3><<<grid, TPB, 0, st>>>(phi_s, phi_t, m_s, m_t, phi, mask_s, mask_t, B, C, K, H * W);
     else { kp_set_error("kp_transport_fwd: unknown mode %d (use kp_transport_max_fwd for 'max')", mode); return KP_E_ARG; }
     return kp_check_launch("transport_fwd");
@@ -410,6 +431,8 @@ int kp_transport_bwd(int mode, const float* gphi, const float* phi_s, const floa
     hipStream_t st = (hipStream_t)stream;
     if (mode == KP_COMBINE_SUM_AND_CLAMP) transport_mode_bwd_k<1><<<grid, TPB, 0, st>>>(gphi, phi_s, phi_t, m_s, m_t, d_phi_s, d_phi_t, d_m_s, d_m_t, B, C, K, H * W);
     else if (mode == KP_COMBINE_PRETRAINED) transport_mode_bwd_k<2><<<grid, TPB, 0, st>>>(gphi, phi_s, phi_t, m_s, m_t, d_phi_s, d_phi_t, d_m_s, d_m_t, B, C, K, H * W);
+    else if (mode == KP_COMBINE_LOOP && K <= 4) transport_mode_bwd_k<3, 4><<<grid, TPB, 0, st>>>(gphi, phi_s, phi_t, m_s, m_t, d_phi_s, d_phi_t, d_m_s, d_m_t, B, C, K, H * W);
+    else if (mode == KP_COMBINE_LOOP && K <= 16) transport_mode_bwd_k<3, 16><<<grid, TPB, 0, st>>>(gphi, phi_s, phi_t, m_s, m_t, d_phi_s, d_phi_t, d_m_s, d_m_t, B, C, K, H * W);
     else if (mode == KP_COMBINE_LOOP) transport_mode_bwd_k<3><<<grid, TPB, 0, st>>>(gphi, phi_s, phi_t, m_s, m_t, d_phi_s, d_phi_t, d_m_s, d_m_t, B, C, K, H * W);
     else { kp_set_error("kp_transport_bwd: unknown mode %d (use kp_transport_max_bwd for 'max')", mode); return KP_E_ARG; }
     return kp_check_launch("transport_bwd");

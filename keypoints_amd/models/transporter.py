@@ -145,10 +145,35 @@ class MaskMaker(nn.Module):
     def __init__(self, map_f):
         super().__init__()
         self.map = map_f
+        self._fused_unit, self._fused_key = None, None
+
+    def _fused(self):
+        """The mapper as ONE kernel (keypoints_amd.inference.FusedUnit: eval-mode BatchNorm folded into the weights, fp32 arithmetic)
+        where it has that form -- a frozen, eval-mode `TransporterMap` over a small-channel Unit on the device, which is what
+        transporter.make(combine_mode='pretrained_network') builds.  The layer chain of the 8-channel MAPPER runs on the generic VALU
+        kernels (~0.2 ms per layer and call at 256 x 84 x 84); fused, the whole mask costs one launch.  The folded weights are a snapshot
+        keyed on the parameters' / buffers' versions: a changed mapper is folded again.  None: run the Unit itself."""
+        unit = getattr(self.map, 'map', None)
+        if not isinstance(unit, knn.Unit) or unit.training or torch.is_grad_enabled():
+            return None
+        tensors = list(unit.parameters()) + list(unit.buffers())
+        if not tensors or not tensors[0].is_cuda:
+            return None
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if key != self._fused_key:
+            from ..inference import FusedUnit
+            try:
+                self._fused_unit = FusedUnit(unit)
+            except NotImplementedError:
+                self._fused_unit = None
+            self._fused_key = key
+        return self._fused_unit
 
     def __call__(self, k, height, width):
         with torch.no_grad():
-            return self.map(MF.point_map(k, height, width))
+            pm = MF.point_map(k, height, width)
+            fused = self._fused()
+            return fused(pm) if fused is not None else self.map(pm)
 
 
 class TransporterMap(knn.Container):

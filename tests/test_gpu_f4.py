@@ -56,6 +56,30 @@ def test_transport_modes_vs_oracle_autograd_bigger(mode):
         close(got.grad, ref.grad, atol=2e-5 * float(ref.grad.abs().max()), rtol=1e-4)
 
 
+@pytest.mark.parametrize('K', [1, 3, 4, 5, 16, 17, 40])
+def test_loop_mode_every_register_bound(K):
+    """'loop' (the reference's default combine_method, transporter.py:14,41-45) runs on three instantiations of the blend kernels --
+    K <= 4 and K <= 16 with the per-keypoint values in registers, up to 64 otherwise: each against the oracle's autograd in fp64,
+    at both sides of the two bounds."""
+    from keypoints_amd.models import functional as MF
+    from oracle import kp_oracle as O
+    g = torch.Generator().manual_seed(40 + K)
+    B, C, H, W = 3, 16, 12, 20
+    phi_s, phi_t = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    m_s = O.gaussian_like(torch.rand(B, K, 2, generator=g), H, W)
+    m_t = O.gaussian_like(torch.rand(B, K, 2, generator=g), H, W)
+    w = torch.randn(B, C, H, W, generator=g)
+    d = [t.cuda().requires_grad_(True) for t in (phi_s, phi_t, m_s, m_t)]
+    phi, ms, mt = MF.transport(*d, 'loop')
+    (phi * w.cuda()).sum().backward()
+    o = [t.double().requires_grad_(True) for t in (phi_s, phi_t, m_s, m_t)]
+    ophi, oms, omt = O.transport(*o, 'loop')
+    (ophi * w.double()).sum().backward()
+    close(phi, ophi, atol=1e-5); close(ms, oms); close(mt, omt)
+    for got, ref in zip(d, o):
+        close(got.grad, ref.grad, atol=2e-5 * float(ref.grad.abs().max()) + 1e-7, rtol=1e-4)
+
+
 def test_pretrained_network_model_wires_maskmaker():
     """transporter.make(combine_mode='pretrained_network'): key2map = MaskMaker(mapper) -- keypoints -> point_map ->
     frozen mapper Unit (mapper.py:50-52) -> ONE mask channel; forward equals composing the pieces by hand with the
@@ -78,7 +102,11 @@ def test_pretrained_network_model_wires_maskmaker():
         phi_s, _, k_s, _, m_s = net.extract(xs)
         phi_t, _, k_t, _, m_t = net.extract(xt)
         assert m_s.shape == (4, 1, 32, 32)
-        close(m_t, net.key2map.map(MF.point_map(k_t, 32, 32)))
+        # (MaskMaker runs the frozen eval-mode mapper as ONE kernel with BatchNorm folded into its weights -- fp32, another rounding
+        #  order than the layer chain it is compared with here)
+        chain = net.key2map.map(MF.point_map(k_t, 32, 32))
+        assert net.key2map._fused_unit is not None
+        close(m_t, chain, atol=2e-5 * float(chain.abs().max()), rtol=1e-4)
         ophi, _, _ = O.transport(phi_s.cpu(), phi_t.cpu(), m_s.cpu(), m_t.cpu(), 'pretrained_network')
     close(out[1], ophi, atol=1e-5)
     net.train()
