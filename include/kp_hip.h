@@ -184,6 +184,21 @@ int kp_conv_first_bwd_wgrad(const void* g, const void* x, const void* w, const f
  * tap-reuse kernel's 8 x 16 pixel block -- shapes no BASELINE network has, e.g. 100 x 100 inputs -- runs on zero-padded copies of
  * its two operands (the zero gradient there makes every added pixel contribute exactly 0): 46-57 -> ~900 TFLOP/s. */
 int kp_pad_hw(const void* src, void* dst, int N, int Hs, int Ws, int Hd, int Wd, int C, int dtype, void* stream);
+
+/* ---- inference: Conv2d(3x3) + eval-mode BatchNorm2d + (Leaky)ReLU of a matrix-core layer as ONE kernel (widened) -----
+ * Replaces, for a network in eval() mode, the statements vgg.py:30-38 turns into (nn.Conv2d -> nn.BatchNorm2d with its running
+ * statistics -> activation) -- the downstream consumers of a trained net run exactly that (atari_demo.py:35-36).  The BatchNorm is a
+ * per-channel affine map there: out = act(conv(x, w) * scale[k] + shift[k]) with scale = gamma / sqrt(running_var + eps),
+ * shift = beta + (conv_bias - running_mean) * scale (the caller forms the 2 K floats; no BatchNorm: scale = 1, shift = bias), applied
+ * to the fp32 accumulators in the convolution's epilogue, ONE rounding to the storage type: no statistics, no BatchNorm pass, no conv
+ * output in memory.  x: [N][H+2][W+2][C] T with its replicate border; w: kp_pack_weights' w_fwd [K][3][3][C]; out: the interior of
+ * [N][H+2p][W+2p][K] T (p = out_pad; the ring is left untouched: kp_pad_border fills it).  16-bit storage, C and K multiples of 64,
+ * H and W multiples of 16 (kp_conv_fwd_act_supported); KP_E_UNSUPPORTED otherwise -- the caller runs kp_conv_fwd + kp_bn_act_fwd.
+ * kp_pad_border: the replicate border of a padded NHWC tensor from its own interior (nn.ReplicationPad2d(pad), vgg.py:30). */
+int kp_conv_fwd_act_supported(int N, int H, int W, int C, int K, int dtype);
+int kp_conv_fwd_act(const void* x, const void* w, const float* scale, const float* shift, float slope, void* out, int out_pad, int N,
+                    int H, int W, int C, int K, int dtype, void* stream);
+int kp_pad_border(void* buf, int N, int H, int W, int C, int pad, int dtype, void* stream);
 int kp_conv_wgrad_pad_hw(int N, int Ho, int Wo, int C, int K, int dy_pad, int dtype, int* Hp, int* Wp);
 
 /* ---- weights ----------------------------------------------------------- */

@@ -30,6 +30,8 @@ SIGNATURES = {
     'kp_conv_first_bwd_reduce': [_p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _i, _p],
     'kp_conv_first_bwd_wgrad': [_p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'kp_pad_hw': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    'kp_conv_fwd_act': [_p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    'kp_pad_border': [_p, _i, _i, _i, _i, _i, _i, _p],
     'kp_pack_weights': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     'kp_pack_weights_batch': [_i, _p, _p, _p, _p, _p, _p, _i, _p],
     'kp_wgrad_unpack': [_p, _i, _p, _i, _i, _i, _i, _p],
@@ -99,7 +101,7 @@ SIGNATURES = {
     'kp_prof_bytes': [_i, _p],
     'kp_prof_step_bytes': [_p, _p],
 }
-PLAIN = {'kp_config_get': ([_i], _i), 'kp_conv_fwd_fin_folds': ([_i] * 7, _i), 'kp_comm_available': ([], _i), 'kp_conv_pair_supported': ([_i] * 7, _i), 'kp_head_pair_supported': ([_i] * 7, _i), 'kp_conv_wgrad_pad_hw': ([_i] * 7 + [_p, _p], _i), 'kp_conv_first_fused_supported': ([_i] * 6, _i), 'kp_conv_first_fused_rows': ([_i] * 6, _ll), 'kp_bn_finalize_pair_supported': ([_ll, _i], _i), 'kp_head_t_supported': ([_i] * 6, _i), 'kp_keypoint_bottleneck_t_supported': ([_i] * 6, _i), 'kp_conv_bnin_supported': ([_i] * 6, _i), 'kp_head_bnin_supported': ([_i] * 6, _i), 'kp_conv_dgrad_bnred_supported': ([_i] * 6, _i), 'kp_conv_dgrad_bnred_rows': ([_i] * 6, _ll), 'kp_unit_infer_param_floats': ([_i, _i, _p], _ll), 'kp_conv_wgrad_partials': ([_i] * 8, _i), 'kp_conv_fwd_stats_rows': ([_i] * 7, _ll), 'kp_bn_bwd_rows': ([_i] * 7, _ll), 'kp_head_bwd_ws_floats': ([_i] * 6, _ll), 'kp_last_rows': ([], _ll), 'kp_bn_ws_doubles': ([_i], _i), 'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
+PLAIN = {'kp_config_get': ([_i], _i), 'kp_conv_fwd_act_supported': ([_i] * 6, _i), 'kp_conv_fwd_fin_folds': ([_i] * 7, _i), 'kp_comm_available': ([], _i), 'kp_conv_pair_supported': ([_i] * 7, _i), 'kp_head_pair_supported': ([_i] * 7, _i), 'kp_conv_wgrad_pad_hw': ([_i] * 7 + [_p, _p], _i), 'kp_conv_first_fused_supported': ([_i] * 6, _i), 'kp_conv_first_fused_rows': ([_i] * 6, _ll), 'kp_bn_finalize_pair_supported': ([_ll, _i], _i), 'kp_head_t_supported': ([_i] * 6, _i), 'kp_keypoint_bottleneck_t_supported': ([_i] * 6, _i), 'kp_conv_bnin_supported': ([_i] * 6, _i), 'kp_head_bnin_supported': ([_i] * 6, _i), 'kp_conv_dgrad_bnred_supported': ([_i] * 6, _i), 'kp_conv_dgrad_bnred_rows': ([_i] * 6, _ll), 'kp_unit_infer_param_floats': ([_i, _i, _p], _ll), 'kp_conv_wgrad_partials': ([_i] * 8, _i), 'kp_conv_fwd_stats_rows': ([_i] * 7, _ll), 'kp_bn_bwd_rows': ([_i] * 7, _ll), 'kp_head_bwd_ws_floats': ([_i] * 6, _ll), 'kp_last_rows': ([], _ll), 'kp_bn_ws_doubles': ([_i], _i), 'kp_version': ([], _i), 'kp_last_error': ([], C.c_char_p), 'kp_device_cus': ([], _i)}
 
 _lib = None
 

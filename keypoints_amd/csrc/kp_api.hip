@@ -288,6 +288,9 @@ KP_DISPATCH(kp_conv_wgrad_partials, (int N, int Ho, int Wo, int C, int K, int R,
             (N, Ho, Wo, C, K, R, dy_pad, dtype))
 KP_DISPATCH(kp_conv_wgrad, (const void* x, const void* dy, float* scratch, int N, int Ho, int Wo, int C, int K, int R, int dy_pad, int dtype, void* stream),
             (x, dy, scratch, N, Ho, Wo, C, K, R, dy_pad, dtype, stream))
+KP_DISPATCH(kp_conv_fwd_act_supported, (int N, int H, int W, int C, int K, int dtype), (N, H, W, C, K, dtype))
+KP_DISPATCH(kp_conv_fwd_act, (const void* x, const void* w, const float* scale, const float* shift, float slope, void* out, int out_pad, int N, int H, int W, int C, int K, int dtype, void* stream),
+            (x, w, scale, shift, slope, out, out_pad, N, H, W, C, K, dtype, stream))
 KP_DISPATCH(kp_conv_bnin_supported, (int N, int H, int W, int C, int K, int dtype), (N, H, W, C, K, dtype))
 KP_DISPATCH(kp_conv_fwd_bnin, (const void* yprev, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, const void* w, const float* bias, void* y, float* stats, int N, int H, int W, int C, int K, int dtype, void* stream),
             (yprev, mean, invstd, gamma, beta, slope, w, bias, y, stats, N, H, W, C, K, dtype, stream))

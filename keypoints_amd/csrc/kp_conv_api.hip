@@ -9,6 +9,7 @@ int kp_conv_wgrad_generic(const void*, const void*, float*, int, int, int, int, 
 int kp_conv_fwd_mfma(const void*, const void*, const float*, void*, float*, int, int, int, int, int, int,
                      hipStream_t);   // bf16 only; returns KP_E_UNSUPPORTED when the shape is not eligible
 int kp_conv_dgrad_mfma(const void*, const void*, void*, int, int, int, int, int, hipStream_t);
+int kp_conv_patch_launch_act(const void*, const void*, const float*, const float*, float, void*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int kp_conv_wgrad_mfma(const void*, const void*, float*, int, int, int, int, int, int, int, hipStream_t);
 int kp_conv_wgrad_mfma_accepts(int, int, int, int, int, int);
 int kp_conv_wgrad_patch(const void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
@@ -299,6 +300,33 @@ int kp_conv_dgrad_bnred(const void* dy, const void* w_dgrad, void* gx, const voi
     if (rc == KP_OK)
         rc = kp_conv_ring_dgrad_bred(dy, w_dgrad, gx, yred, mean, invstd, gamma, beta, slope, partials + prows * 2 * C, N, H, W, K, C,
                                      (hipStream_t)stream);
+    ps.done(KP_PROF_CONV_MFMA);
+    return rc;
+}
+
+// ---- inference: Conv2d(3x3) + eval-mode BatchNorm2d + LeakyReLU as ONE kernel (row f3 widened to the matrix-core layers) ---------------
+// out[n][p + out_pad][q + out_pad][k] = act((x * w)[n][p][q][k] * scale[k] + shift[k]) into out [N][H + 2 out_pad][W + 2 out_pad][K]
+// (the border ring is NOT written: kp_pad_border replicates into it).  x: [N][H+2][W+2][C] with its replicate border; w: the packed
+// forward weights [K][3][3][C].  16-bit storage, C and K multiples of 64, H and W multiples of 16; KP_E_UNSUPPORTED otherwise.
+int kp_conv_fwd_act_supported(int N, int H, int W, int C, int K, int dtype) {
+    if (dtype != KP_H16 || !use_mfma() || N <= 0 || H <= 0 || W <= 0) return 0;
+    kp_set_query_mode(1);
+    const int rc = kp_conv_patch_launch_act(nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, N, H + 2, W + 2, 0, H, W, 0, H, W, C, K, nullptr);
+    kp_set_query_mode(0);
+    return rc == KP_OK ? 1 : 0;
+}
+
+int kp_conv_fwd_act(const void* x, const void* w, const float* scale, const float* shift, float slope, void* out, int out_pad, int N,
+                    int H, int W, int C, int K, int dtype, void* stream) {
+    KP_REQUIRE(x && w && scale && shift && out && N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && out_pad >= 0, "kp_conv_fwd_act: bad args");
+    KP_REQUIRE(slope >= 0.f && slope <= 1.f, "kp_conv_fwd_act: activation slope must be in [0, 1]");
+    if (dtype != KP_H16 || !use_mfma()) return KP_E_UNSUPPORTED;
+    const double flops = 2.0 * N * (double)H * W * C * K * 9;
+    const double bytes = 2.0 * ((double)N * (H + 2) * (W + 2) * C + (double)N * H * W * K + 9.0 * C * K);
+    ProfScope ps(KP_PROF_CONV_MFMA, flops, (hipStream_t)stream, bytes);
+    const int rc = kp_conv_patch_launch_act(x, w, scale, shift, slope, out, N, H + 2, W + 2, 0, H + 2 * out_pad, W + 2 * out_pad, out_pad, H, W,
+                                            C, K, (hipStream_t)stream);
+    if (rc == KP_E_UNSUPPORTED) { ps.cancel(); return rc; }
     ps.done(KP_PROF_CONV_MFMA);
     return rc;
 }

@@ -55,6 +55,9 @@ struct PatchArgs {
     // order, fp64) and writes mean / invstd / running statistics of the tile's channels -- no finalize launch behind this one.
     unsigned* fin_tickets; float *fin_mean, *fin_invstd, *fin_rmean, *fin_rvar; long long* fin_nbt; float fin_momentum, fin_eps;
     long long fin_count;
+    // EPI (inference, kp_conv_fwd_act): out = act(acc * ep_scale[k] + ep_shift[k]) -- an eval-mode BatchNorm (scale = gamma / sqrt(var + eps),
+    // shift = beta + (bias - mean) * scale) + LeakyReLU(ep_slope) applied to the fp32 accumulators before the one rounding to the storage type
+    const float *ep_scale, *ep_shift; float ep_slope;
 };
 
 // Persistent workgroups: the (tile, 64-channel chunk, tap) steps of all tiles of a workgroup form ONE software
@@ -77,9 +80,10 @@ struct PatchArgs {
 //       adjoint of the replicate pad) is not needed: sum_ij fold(g)_ij f_ij = sum_pq g_pq f[clamp(p-1)][clamp(q-1)], and an
 //       interior pixel (p, q) of the padded domain IS source pixel (p - 1, q - 1); the border ring adds its share in its own
 //       kernel (kp_conv_mfma.hip).  Rows: 4 per workgroup (one per pixel-row group), zero outside the workgroup's k-tile.
-template <int BN, bool STATS, bool TRACE, bool BRED = false>
+template <int BN, bool STATS, bool TRACE, bool BRED = false, bool EPI = false>
 __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     static_assert(!BRED || (!STATS && !TRACE), "BRED: data-gradient form");
+    static_assert(!EPI || (!STATS && !TRACE && !BRED), "EPI: inference form");
     constexpr int WBYTES = BN * ROWB;
     constexpr int NWI = BN / 64;          // weight DMA instructions per wave per step
     constexpr int WN = BN / 2;            // channels per wave
@@ -88,7 +92,8 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     constexpr int OFF_BIAS = OFF_DUMMY + 1024;            // [8 waves][64] fp32: each wave's own output-channel biases
     constexpr int OFF_TRACE = OFF_BIAS + NWAVE * 64 * 4;
     constexpr int OFF_RK = OFF_TRACE + 16;                 // BRED: [2 channel halves][8 chunks][mean, invstd, gamma, beta][8] fp32 (2 KB)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_TRACE + (TRACE ? 4096 : (BRED ? 16 + 2048 : 16))];
+    constexpr int OFF_EP = OFF_TRACE + 16;                 // EPI: [scale | shift][8 waves][64] fp32 (4 KB), each wave's own output channels
+    __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_TRACE + (TRACE ? 4096 : (BRED ? 16 + 2048 : (EPI ? 16 + 4096 : 16)))];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -368,9 +373,19 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float v[4];
+                    float4 esc, esh;
+                    if constexpr (EPI) {
+                        esc = *reinterpret_cast<const float4*>(smem + OFF_EP + (wave * 64 + a * 32 + 8 * g + 4 * fh) * 4);
+                        esh = *reinterpret_cast<const float4*>(smem + OFF_EP + 2048 + (wave * 64 + a * 32 + 8 * g + 4 * fh) * 4);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[e] = acc[a][b][g * 4 + e];
+                        if constexpr (EPI) {
+                            const float z = __builtin_fmaf(v[e], e == 0 ? esc.x : e == 1 ? esc.y : e == 2 ? esc.z : esc.w,
+                                                           e == 0 ? esh.x : e == 1 ? esh.y : e == 2 ? esh.z : esh.w);
+                            v[e] = fmaxf(z, z * A.ep_slope);   // (= LeakyReLU for 0 <= slope <= 1; slope 0: ReLU)
+                        }
                         if constexpr (STATS) {
                             sm[a][g * 4 + e] += v[e];
                             sq[a][g * 4 + e] = __builtin_fmaf(v[e], v[e], sq[a][g * 4 + e]);
@@ -454,6 +469,10 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         if (lane < WN) {
             const float bvl = A.bias ? A.bias[t.k0 + wn * WN + lane] : 0.f;
             reinterpret_cast<float*>(smem + OFF_BIAS)[wave * 64 + lane] = bvl;
+            if constexpr (EPI) {
+                reinterpret_cast<float*>(smem + OFF_EP)[wave * 64 + lane] = A.ep_scale[t.k0 + wn * WN + lane];
+                reinterpret_cast<float*>(smem + OFF_EP + 2048)[wave * 64 + lane] = A.ep_shift[t.k0 + wn * WN + lane];
+            }
         }
     };
     load_bias(cur);
@@ -703,6 +722,7 @@ int kp_conv_patch_launch_bred(const void* dy, const void* w, void* gx, const voi
     a.ktiles = ktiles; a.ntiles = ntiles; a.compact = 0;
     a.yred = (const h16_t*)yred; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.slope = slope; a.rpart = rpart;
     a.fin_tickets = nullptr; a.fin_mean = a.fin_invstd = a.fin_rmean = a.fin_rvar = nullptr; a.fin_nbt = nullptr; a.fin_momentum = a.fin_eps = 0.f; a.fin_count = 1;
+    a.ep_scale = a.ep_shift = nullptr; a.ep_slope = 1.f;
     if (C % 128 == 0) conv3x3_patch_k<128, false, false, true><<<grid, TPB, 0, st>>>(a);
     else conv3x3_patch_k<64, false, false, true><<<grid, TPB, 0, st>>>(a);
     return kp_check_launch("conv3x3_patch_bred");
@@ -739,6 +759,7 @@ int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* 
     a.compact = (stats && ptiles >= grid && ((grid / 8) % a.ktiles) == 0) ? 1 : 0;
     if (stats) kp_set_last_rows(a.compact ? (long long)grid * CROWS : ptiles * 4);
     a.fin_tickets = nullptr; a.fin_mean = a.fin_invstd = a.fin_rmean = a.fin_rvar = nullptr; a.fin_nbt = nullptr; a.fin_momentum = a.fin_eps = 0.f; a.fin_count = 1;
+    a.ep_scale = a.ep_shift = nullptr; a.ep_slope = 1.f;
     if (KpFinRequest* rq = kp_fin_request()) {   // kp_conv_fwd_fin: the finalize in this launch's tail (one row per workgroup, <= KP_FIN_TICKETS k-tiles)
         if (stats && a.compact && a.linear && CROWS == 1 && a.ktiles <= KP_FIN_TICKETS && !a.trace && !a.dbg) {
             a.fin_tickets = rq->tickets; a.fin_mean = rq->mean; a.fin_invstd = rq->invstd; a.fin_rmean = rq->running_mean; a.fin_rvar = rq->running_var;
@@ -753,4 +774,35 @@ int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* 
     else if (stats) conv3x3_patch_k<64, true, false><<<grid, TPB, 0, st>>>(a);
     else conv3x3_patch_k<64, false, false><<<grid, TPB, 0, st>>>(a);
     return kp_check_launch("conv3x3_patch");
+}
+
+// Inference form (kp_conv_fwd_act): the window convolution of kp_conv_patch_launch with the per-channel affine + LeakyReLU epilogue (EPI);
+// no bias operand (folded into `shift`), no statistics.  KP_E_UNSUPPORTED where the shape has no patch tiling.
+int kp_conv_patch_launch_act(const void* x, const void* w, const float* scale, const float* shift, float slope, void* y, int N, int Hib,
+                             int Wib, int ioff, int Hob, int Wob, int ooff, int H, int W, int C, int K, hipStream_t st) {
+    if (C % 64 != 0 || K % 64 != 0 || H % TS != 0 || W % TS != 0 || H <= 0 || W <= 0) return KP_E_UNSUPPORTED;
+    if ((long long)(PW + 1) * Wib * C * 2 >= 0x7fffffffLL || 128LL * 9 * C * 2 + 9LL * C * 2 >= 0x7fffffffLL) return KP_E_UNSUPPORTED;
+    PatchArgs a;
+    a.x = (const h16_t*)x; a.w = (const h16_t*)w; a.bias = nullptr; a.y = (h16_t*)y; a.partials = nullptr;
+    a.Hib = Hib; a.Wib = Wib; a.ioff = ioff; a.Hob = Hob; a.Wob = Wob; a.ooff = ooff; a.H = H; a.W = W;
+    a.C = C; a.K = K; a.dbg = 0; a.trace = nullptr; a.compact = 0;
+    a.yred = nullptr; a.mean = a.invstd = a.gamma = a.beta = nullptr; a.slope = 0.f; a.rpart = nullptr;
+    a.fin_tickets = nullptr; a.fin_mean = a.fin_invstd = a.fin_rmean = a.fin_rvar = nullptr; a.fin_nbt = nullptr; a.fin_momentum = a.fin_eps = 0.f; a.fin_count = 1;
+    a.ep_scale = scale; a.ep_shift = shift; a.ep_slope = slope;
+    { extern kp_knob_t g_kp_walk; a.linear = (g_kp_walk & KP_WALK_CONV_LINEAR) ? 1 : 0; }
+    const long long ptiles = (long long)N * (H / TS) * (W / TS);
+    const int bn = (K % 128 == 0) ? 128 : 64;
+    a.ktiles = K / bn;
+    if (ptiles * a.ktiles > 0x7fffffffLL) return KP_E_UNSUPPORTED;
+    a.ntiles = (int)(ptiles * a.ktiles);
+    int cus = kp_device_cus();
+    if (cus <= 0) cus = 256;
+    int grid = (cus / 8) * 8;
+    if (grid < 8) grid = 8;
+    const int need = ((a.ntiles + 7) / 8) * 8;
+    if (grid > need) grid = need;
+    KP_QUERY_RETURN();
+    if (bn == 128) conv3x3_patch_k<128, false, false, false, true><<<grid, TPB, 0, st>>>(a);
+    else conv3x3_patch_k<64, false, false, false, true><<<grid, TPB, 0, st>>>(a);
+    return kp_check_launch("conv3x3_patch_act");
 }

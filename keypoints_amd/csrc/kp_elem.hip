@@ -197,6 +197,25 @@ __global__ __launch_bounds__(256) void pad_hw_k(const uint4* __restrict__ src, u
     dst[t] = v;
 }
 
+// Replicate border of a padded NHWC tensor [N][H+2p][W+2p][C] from its interior (nn.ReplicationPad2d: every ring pixel = the clamped
+// interior pixel).  One thread per 16-byte chunk of a RING pixel; the interior is not touched.
+__global__ __launch_bounds__(256) void pad_border_k(uint4* __restrict__ buf, int H, int W, int p, int cpp, long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int Hp = H + 2 * p, Wp = W + 2 * p;
+    const int ring = Hp * Wp - H * W;
+    const int c = (int)(t % cpp);
+    const long long rp = t / cpp;
+    const int r = (int)(rp % ring);
+    const long long n = rp / ring;
+    int i, j;   // ring pixel r: the p top rows, the p bottom rows, then the left / right columns of the middle rows
+    if (r < p * Wp) { i = r / Wp; j = r - i * Wp; }
+    else if (r < 2 * p * Wp) { const int q = r - p * Wp; i = H + p + q / Wp; j = q % Wp; }
+    else { const int q = r - 2 * p * Wp; i = p + q / (2 * p); const int jj = q % (2 * p); j = jj < p ? jj : W + jj; }
+    const int si = min(max(i, p), H + p - 1), sj = min(max(j, p), W + p - 1);
+    buf[((n * Hp + i) * Wp + j) * cpp + c] = buf[((n * Hp + si) * Wp + sj) * cpp + c];
+}
+
 // ---------------------------------------------------------------- weights
 template <typename T>
 __global__ void pack_weights_k(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int K, int C,
@@ -699,6 +718,21 @@ int kp_pad_hw(const void* src, void* dst, int N, int Hs, int Ws, int Hd, int Wd,
     kp_count_bytes((double)esz * C * ((double)N * Hs * Ws + (double)N * Hd * Wd));
     pad_hw_k<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>((const uint4*)src, (uint4*)dst, Hs, Ws, Hd, Wd, cpp, total);
     return kp_check_launch("pad_hw");
+}
+#endif
+
+#ifndef KP_F16_BUILD   // bytes only
+int kp_pad_border(void* buf, int N, int H, int W, int C, int pad, int dtype, void* stream) {
+    const int esz = dtype == KP_F32 ? 4 : 2;
+    KP_REQUIRE(buf && N > 0 && H > 0 && W > 0 && C > 0 && pad >= 0 && (C * esz) % 16 == 0 && (((size_t)buf & 15) == 0),
+               "kp_pad_border: bad args (C * element size a multiple of 16, a 16-byte aligned tensor)");
+    if (pad == 0) return KP_OK;
+    const int cpp = C * esz / 16;
+    const long long ring = (long long)(H + 2 * pad) * (W + 2 * pad) - (long long)H * W;
+    const long long total = (long long)N * ring * cpp;
+    kp_count_bytes(2.0 * esz * C * (double)N * ring);
+    pad_border_k<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>((uint4*)buf, H, W, pad, cpp, total);
+    return kp_check_launch("pad_border");
 }
 #endif
 

@@ -91,6 +91,119 @@ class FusedUnit:
         return k, heat
 
 
+class FusedUnitF:
+    """Eval-mode forward of a matrix-core Unit (model F's class: 3x3 layers with channel widths that are multiples of 64 on maps that
+    are multiples of 16, 16-bit storage) with every BatchNorm folded into the epilogue of its convolution (`kp_conv_fwd_act`,
+    include/kp_hip.h): per layer ONE matrix-core launch that reads the previous layer's padded activation and writes the next one's --
+    no statistics, no BatchNorm pass, no conv output in memory, nothing saved.  What remains beside the convolutions: the
+    replicate ring of a padded output (`kp_pad_border`, a few KB per image), the MaxPool2d / UpsamplingBilinear2d steps (the
+    training pass kernel with identity constants) and the 1x1 head.  The image-sized first layer (Cin <= 3 -> 64) runs on the
+    recompute kernel of the train path with the running statistics as its constants (`kp_conv_first_fwd_bnact`).
+
+    Built from a `knn.Unit` in a 16-bit precision on the device; raises NotImplementedError otherwise, or when no layer of the Unit
+    would take the fused kernel at all.  Layers the kernel declines (odd map sizes) run as the plain pair kernel + pass.  The
+    scale / shift vectors are a snapshot of the BatchNorm buffers: build a new one after changing parameters or buffers."""
+
+    def __init__(self, unit):
+        from .runtime import precision_dtype
+        if unit.precision not in ('bf16', 'fp16'):
+            raise NotImplementedError('fused inference (matrix-core form): 16-bit storage only')
+        plan = unit.plan()
+        convs, head = plan[:-1], plan[-1]
+        if not convs:
+            raise NotImplementedError('fused inference: no 3x3 layer')
+        p0 = next(unit.parameters())
+        if p0.device.type != 'cuda':
+            raise RuntimeError('FusedUnitF: the Unit must live on a HIP device (no CPU fallback)')
+        if not any(s['conv'].in_channels % 64 == 0 and s['conv'].out_channels % 64 == 0 for s in convs):
+            raise NotImplementedError('fused inference (matrix-core form): no layer with 64-multiple channels')
+        self.unit, self.plan = unit, plan
+        self.tdt, self.code = precision_dtype(unit.precision)
+        self.cin = convs[0]['conv'].in_channels
+        self.K = head['conv'].out_channels
+        self._packs = {}
+        self.consts = []
+        with torch.no_grad():
+            for s in convs:
+                conv, bn = s['conv'], s['bn']
+                b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(conv.out_channels, device=p0.device)
+                if bn is None:
+                    scale, shift, mean, invstd = torch.ones_like(b), b.clone(), None, None
+                else:
+                    if bn.running_mean is None or bn.running_var is None:
+                        raise NotImplementedError('fused inference: BatchNorm without running statistics')
+                    invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+                    mean = bn.running_mean.detach().float().clone()
+                    scale = bn.weight.detach().float() * invstd
+                    shift = bn.bias.detach().float() + (b - mean) * scale
+                self.consts.append(dict(scale=scale.contiguous(), shift=shift.contiguous(), mean=mean, invstd=invstd))
+        self.fused_layers = 0     # layers of the LAST call that ran on kp_conv_fwd_act / kp_conv_first_fwd_bnact (diagnostics, tests)
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        from .unit_engine import TAILS, _first_cp, _pack_unit, _tail_dims
+        if not x.is_cuda or x.dim() != 4 or x.shape[1] != self.cin:
+            raise RuntimeError(f'FusedUnitF: expected a HIP tensor [B, {self.cin}, H, W]')
+        x = x.float().contiguous()
+        plan, tdt, code = self.plan, self.tdt, self.code
+        L = _lib.lib()
+        st = stream_ptr()
+        dev = x.device
+        N, Cin, H, W = x.shape
+        Cp0 = _first_cp(plan, Cin, self.unit.precision)
+        a = torch.empty(N, H + 2, W + 2, Cp0, device=dev, dtype=tdt)
+        call('kp_nchw_to_nhwc', ptr(x), ptr(a), N, Cin, Cp0, H, W, 1, code, st)
+        with shared_packs(self._packs):
+            packs = _pack_unit(plan, Cin, Cp0, False, dev, tdt, code, st)
+        C = Cin
+        fused = 0
+        for idx, stp in enumerate(plan[:-1]):
+            conv, bn, slope, tail = stp['conv'], stp['bn'], stp['slope'], stp['tail']
+            K = conv.out_channels
+            Cphys = Cp0 if idx == 0 else C
+            wf = packs[idx][0]
+            cst = self.consts[idx]
+            nxt = plan[idx + 1]
+            out_pad = 1 if nxt['kind'] == 'conv3' else 0
+            Ho, Wo = _tail_dims(H, W, tail)
+            if (idx == 0 and bn is not None and tail is None and nxt['kind'] == 'conv3' and Cp0 == Cin and 0.0 <= slope <= 1.0
+                    and L.kp_conv_first_fused_supported(N, H, W, Cin, K, code) == 1):
+                a_next = torch.empty(N, H + 2, W + 2, K, device=dev, dtype=tdt)
+                call('kp_conv_first_fwd_bnact', ptr(a), ptr(wf), ptr(conv.bias), ptr(cst['mean']), ptr(cst['invstd']), ptr(bn.weight), ptr(bn.bias),
+                     slope, ptr(a_next), N, H, W, Cin, K, code, st)
+                fused += 1
+            elif 0.0 <= slope <= 1.0 and L.kp_conv_fwd_act_supported(N, H, W, Cphys, K, code) == 1:
+                if tail is None:
+                    a_next = torch.empty(N, H + 2 * out_pad, W + 2 * out_pad, K, device=dev, dtype=tdt)
+                    call('kp_conv_fwd_act', ptr(a), ptr(wf), ptr(cst['scale']), ptr(cst['shift']), slope, ptr(a_next), out_pad, N, H, W, Cphys, K, code, st)
+                    if out_pad:
+                        call('kp_pad_border', ptr(a_next), N, H, W, K, out_pad, code, st)
+                else:   # the activated map, then MaxPool2d(2, 2) / bilinear x2 (+ the next layer's pad) as the pass kernel with identity constants
+                    act = torch.empty(N, H, W, K, device=dev, dtype=tdt)
+                    call('kp_conv_fwd_act', ptr(a), ptr(wf), ptr(cst['scale']), ptr(cst['shift']), slope, ptr(act), 0, N, H, W, Cphys, K, code, st)
+                    a_next = torch.empty(N, Ho + 2 * out_pad, Wo + 2 * out_pad, K, device=dev, dtype=tdt)
+                    call('kp_bn_act_fwd', ptr(act), None, None, None, None, 1.0, TAILS[tail], ptr(a_next), out_pad, None, N, H, W, K, code, st)
+                fused += 1
+            else:   # a shape the fused kernel declines: the plain convolution + the eval-mode pass (what Unit.forward runs)
+                y = torch.empty(N, H, W, K, device=dev, dtype=tdt)
+                call('kp_conv_fwd', ptr(a), ptr(wf), ptr(conv.bias), ptr(y), None, N, H + 2, W + 2, Cphys, K, 3, code, st)
+                a_next = torch.empty(N, Ho + 2 * out_pad, Wo + 2 * out_pad, K, device=dev, dtype=tdt)
+                call('kp_bn_act_fwd', ptr(y), ptr(cst['mean']), ptr(cst['invstd']), ptr(bn.weight if bn is not None else None),
+                     ptr(bn.bias if bn is not None else None), slope, TAILS[tail], ptr(a_next), out_pad, None, N, H, W, K, code, st)
+            a, C, H, W = a_next, K, Ho, Wo
+        head = plan[-1]
+        hconv = head['conv']
+        out = torch.empty(N, self.K, H, W, device=dev, dtype=torch.float32)
+        call('kp_head_fwd', ptr(a), ptr(hconv.weight), ptr(hconv.bias), head['slope'], ptr(out), N, H, W, C, self.K, code, st)
+        self.fused_layers = fused
+        return out
+
+    def keypoints(self, x: torch.Tensor):
+        """`spacial_logsoftmax(unit(x))`: (k [B, K, 2], heat [B, K, H, W])."""
+        heat = self(x)
+        return MF.spacial_logsoftmax(heat), heat
+
+
 class KeypointExtractor:
     """`k = KeypointExtractor(net)(x)`: keypoints `[B, K, 2]` (y, x in [0, 1]) of `x [B, C, H, W]`.
 
@@ -102,8 +215,9 @@ class KeypointExtractor:
     """
 
     def __init__(self, net, graph: bool = True, warmup: int = 3, fused='auto'):
-        """fused: 'auto' = the one-kernel Unit when the keypoint network has that form, True = require it, False = always
-        the layer-by-layer chain (the training kernels in eval mode, in the network's precision)."""
+        """fused: 'auto' = the one-kernel Unit (Pong-class, `FusedUnit`) or the BatchNorm-in-the-epilogue chain (matrix-core Units in
+        a 16-bit precision, `FusedUnitF`) when the keypoint network has one of those forms, True = require one, False = always the
+        layer-by-layer chain (the training kernels in eval mode, in the network's precision)."""
         self.net = net.eval()
         self.graph = graph
         self.warmup = warmup
@@ -126,8 +240,11 @@ class KeypointExtractor:
         try:
             self._fused_unit = FusedUnit(self.net.keypoint)
         except NotImplementedError:
-            if self.fused is True:
-                raise
+            try:     # not a Pong-class Unit: the matrix-core form (model F's class)
+                self._fused_unit = FusedUnitF(self.net.keypoint)
+            except NotImplementedError:
+                if self.fused is True:
+                    raise
 
     def refresh(self):
         """Forget the packed / folded weights and the captured graphs (the network's parameters changed)."""

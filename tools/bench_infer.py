@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Latency of the inference-only keypoint extractor (keypoints_amd/inference.py): eager chain of C-ABI launches vs the
-captured HIP graph, and (Pong-class) the one-kernel fused Unit, per frame, for the Pong-class network (84x84 grey, K=4) and model F (128x128x3, K=10).
+captured HIP graph, and the fused forms (Pong-class: the one-kernel Unit; model F: BatchNorm folded into each convolution's epilogue), per frame, for the Pong-class network (84x84 grey, K=4) and model F (128x128x3, K=10).
     python tools/bench_infer.py [--batch 1] [--frames 200]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,14 +14,12 @@ def main():
     ap = argparse.ArgumentParser(); ap.add_argument('--batch', type=int, default=1); ap.add_argument('--frames', type=int, default=200)
     args = ap.parse_args()
     for typ, cin, z, K, S, prec in (('VGG_PONG_LAYERNECK', 1, 16, 4, 84, 'fp32'), ('VGG_PONG_LAYERNECK', 1, 16, 4, 84, 'bf16'),
-                                    ('F', 3, 64, 10, 128, 'bf16')):
+                                    ('F', 3, 64, 10, 128, 'bf16'), ('F', 3, 64, 10, 128, 'fp16')):
         torch.manual_seed(0)
         net = transporter.make(typ, cin, z, K).cuda().set_precision(prec)
         x = torch.rand(args.batch, cin, S, S, device='cuda')
         line = f'{typ:>18} {S}x{S} batch {args.batch} {prec}:'
         for graph, fused in ((False, False), (True, False), (False, 'auto'), (True, 'auto')):
-            if fused == 'auto' and typ == 'F':
-                continue                      # model F has pooling steps: no one-kernel form
             ex = KeypointExtractor(net, graph=graph, fused=fused)
             for _ in range(5):
                 ex(x)
