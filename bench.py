@@ -190,6 +190,30 @@ def cpu_baseline_c1():
                 sample='oracle transporter_train_step fp32, VGG_PONG_LAYERNECK 84x84x1 K=4, batch 4 (BASELINE config 1), 3 warm-up + 20 timed steps, median')
 
 
+def inference_leg(dev, frames=60):
+    """latency of the inference-only keypoint extractor of a model-F Transporter (fp16, 128 x 128 x 3, K = 10; the consumer
+    reads the keypoints every frame, /root/reference/atari_demo.py:35-36) -- the fused form (BatchNorm in the convolutions' epilogues,
+    keypoints_amd.inference.FusedUnitF) and the layer chain, each replayed as a HIP graph, at batch 1 and 32.  us per call."""
+    from keypoints_amd.inference import KeypointExtractor
+    from keypoints_amd.models import transporter
+    torch.manual_seed(0)
+    net = transporter.make('F', 3, 64, 10).to(dev).set_precision('fp16')
+    out = {}
+    for B in (1, 32):
+        x = torch.rand(B, 3, 128, 128, device=dev)
+        for name, fused in (('fused', True), ('chain', False)):
+            ex = KeypointExtractor(net, graph=True, fused=fused)
+            for _ in range(5):
+                ex(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(frames):
+                ex(x)[0, 0, 0].item()
+            out[f'b{B}_{name}_us'] = 1e6 * (time.perf_counter() - t0) / frames
+    out['what'] = 'KeypointExtractor(graph=True) of Transporter F fp16 128x128x3 K=10, keypoints read back every call; us per call'
+    return out
+
+
 class PowerSampler:
     """Socket power and shader clock of this rank's GPU while the timed steps run, from the amdgpu hwmon files
     (power1_input [uW], power1_cap [uW], freq1_input [Hz] = sclk), sampled every 10 ms by a host thread.  The matrix-core
@@ -630,7 +654,7 @@ def compact_roofline(r):
 def compact_line(line, detail_path):
     """The record the driver reads: BASELINE's metric fields, `roofline`, `cpu_baseline`, and -- LAST, so that an 8 KB tail of
     stdout always holds it -- `summary` with one entry per other BASELINE configuration and for the other 16-bit type."""
-    out = {k: (_round(v) if isinstance(v, float) else v) for k, v in line.items() if k not in ('roofline', 'extra', 'extra_configs', 'cpu_baseline', 'dp')}
+    out = {k: (_round(v) if isinstance(v, float) else v) for k, v in line.items() if k not in ('roofline', 'extra', 'extra_configs', 'cpu_baseline', 'dp', 'inference_F_fp16')}
     if 'config' in out:
         out['config'] = {k: (_round(v) if isinstance(v, float) else v) for k, v in line['config'].items()}
     out['roofline'] = compact_roofline(line.get('roofline'))
@@ -673,6 +697,8 @@ def compact_line(line, detail_path):
         if r.get('cpu_baseline_c1'):
             c1 = r['cpu_baseline_c1']
             summary[key]['cpu_baseline_c1'] = {k: (_round(v) if isinstance(v, float) else v) for k, v in c1.items()}
+    if line.get('inference_F_fp16'):
+        summary['inference_F_fp16'] = {k: (_round(v, 1) if isinstance(v, float) else v) for k, v in line['inference_F_fp16'].items()}
     if detail_path:
         out['detail_file'] = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT) else detail_path
     out['summary'] = summary
@@ -794,6 +820,13 @@ def main():
             except Exception as e:   # a leg that fails must not take the headline number with it
                 line['extra_configs'][key] = dict(error=f'{type(e).__name__}: {e}')
                 torch.cuda.empty_cache()
+    if world == 1 and args.extra and headline:
+        try:
+            line['inference_F_fp16'] = inference_leg(dev)
+        except Exception as e:
+            line['inference_F_fp16'] = dict(error=f'{type(e).__name__}: {e}'[:200])
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.net == 'transporter':
             line['cpu_baseline'] = cpu_baseline(args)

@@ -595,7 +595,7 @@ def test_keypoint_extractor_graph_replay(cfg):
             kc = MF.spacial_logsoftmax(net.keypoint(x))      # the layer-by-layer chain (training kernels, eval mode)
         if typ == 'F':                                       # matrix-core class: BatchNorm in the convolutions' epilogues (FusedUnitF): one
             from keypoints_amd.inference import FusedUnitF   # rounding per layer where the chain rounds the conv output AND the activation
-            assert isinstance(ex._fused_unit, FusedUnitF) and ex._fused_unit.fused_layers == 9 and maxerr(ke, kc) <= 2e-2
+            assert isinstance(ex._fused_unit, FusedUnitF) and ex._fused_unit.fused_layers == 8 and maxerr(ke, kc) <= 2e-2
         else:                                                # Pong-class: the one-kernel Unit, fp32 like the chain here
             assert ex._fused_unit is not None and maxerr(ke, kc) <= 2e-5
     assert len(ex._captured) == 1
