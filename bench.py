@@ -526,7 +526,9 @@ def _run_leg(args, rank, world, dev):
         # Only a summary STAMPED with the sha256 of the library that is loaded now is quoted (tools/records.sh writes the stamp):
         # a figure of another build is reported as null with the reason, not as this build's.
         traffic, pmc, pmc_file, traffic_reason = None, None, None, None
-        pmc_key = 'conv_small_band_bf16' if dom[0] == 'conv_small_16bit' else 'conv_patch_bf16_bn128'
+        cname = config_name(args)
+        pmc_key = ('conv_small_band_bf16' if dom[0] == 'conv_small_16bit' else
+                   'conv_patch_bf16_bn128' + ('_c3' if cname == 'BASELINE config 3 shape' else '_c5' if cname == 'BASELINE config 5 shape' else ''))
         import glob
         stamps = []
         for cand in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_summary.json')), reverse=True):
@@ -555,8 +557,9 @@ def _run_leg(args, rank, world, dev):
             roofline = dict(bound='mfma', kernel=dom[0], achieved=dom[1]['tflops'], peak=peak, unit='TFLOP/s',
                             frac=dom[1]['tflops'] / peak,
                             # (the PMC passes were taken on the headline workload: other shapes get no traffic figure)
-                            traffic=traffic if (dom[0] == 'conv_mfma_16bit' and config_name(args) == 'BASELINE config 4 shape') else None,
-                            traffic_reason=traffic_reason if config_name(args) == 'BASELINE config 4 shape' else 'the PMC passes are taken on configs 4 and 2',
+                            traffic=traffic if (dom[0] == 'conv_mfma_16bit' and cname in ('BASELINE config 4 shape', 'BASELINE config 3 shape', 'BASELINE config 5 shape')
+                                                and args.batch in (128, 256)) else None,
+                            traffic_reason=traffic_reason if cname != 'custom shape' else 'the PMC passes are taken on the BASELINE configurations',
                             traffic_unit=f'HBM bytes per launch (rocprofv3 PMC of this library build on this command, profiles/{pmc_file}; '
                                          'not a measurement of this run)' if pmc_file else None,
                             algorithmic_bytes=dom[1]['algorithmic_bytes_per_launch'],

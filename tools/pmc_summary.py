@@ -41,6 +41,9 @@ def main(tag, lib_sha16=None):
         out['lib_sha16'] = lib_sha16   # whose stamp equals the loaded library's
     for suffix, kernels in (('', KERNELS), ('c2', KERNELS_C2)):
         summarise(out, suffix, kernels)
+    # configs 3 and 5 (round 6): the same patch / weight-gradient kernels on those workloads' shapes, labels suffixed _c3 / _c5
+    for suffix in ('c3', 'c5'):
+        summarise(out, suffix, {k: v + '_' + suffix for k, v in KERNELS.items()})
     json.dump(out, open(f'profiles/{tag}_pmc_summary.json', 'w'), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -5,7 +5,7 @@
 #      gpurun_out/<tag>_MANIFEST.json: library sha256[:16] (the one build() prints), git head, one sha256 per file.
 # Copy what is quoted into profiles/ (tools/collect.sh <tag>).  bench.py only quotes `roofline.traffic` from a PMC summary whose
 # lib_sha16 equals the loaded library's.
-T=${1:-r05x}; R=$PWD; O=$R/gpurun_out; mkdir -p $O
+T=${1:-r06x}; R=$PWD; O=$R/gpurun_out; mkdir -p $O
 SHA=$(sha256sum $R/keypoints_amd/csrc/libkp_hip.so | cut -c1-16)
 echo "library sha256[:16] = $SHA"
 C2="--model_type VGG_PONG_LAYERNECK --model_in_channels 1 --model_z_channels 16 --model_keypoints 4 --size 84 --batch 256 --precision bf16"
@@ -13,10 +13,10 @@ C3="--net keynet --precision fp16"
 C5="--size 256 --model_keypoints 30 --batch 256 --precision fp16"
 Q="--no-cpu-baseline --extra 0"
 # ---- PMC passes first (bench.py reads the summary for roofline.traffic of the records below)
-if [ "${R05_SKIP_PMC:-0}" != 1 ]; then
+if [ "${KP_SKIP_PMC:-0}" != 1 ]; then
 cd /tmp && export TMPDIR=/tmp
-for set in "" "c2"; do
-  ARGS=""; [ "$set" = c2 ] && ARGS="$C2"
+for set in "" "c2" "c3" "c5"; do
+  ARGS=""; [ "$set" = c2 ] && ARGS="$C2"; [ "$set" = c3 ] && ARGS="$C3"; [ "$set" = c5 ] && ARGS="$C5"
   for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
     n=$(echo $c | cut -d' ' -f1)$set
     rm -rf $O/pmc_$n
