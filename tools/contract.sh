@@ -2,12 +2,12 @@
 # The 16-bit contract over SIX conditioning trajectories per configuration, HIP path and the emulated reference side by side:
 #   bash tools/contract.sh <tag>  -> gpurun_out/<tag>_contract_c{3,4,5}.txt   (copy into profiles/)
 # Seeds 99-101 are the ones tests/test_gpu_fullsize.py asserts on (median of three + per-network rule); 102-104 widen the spread.
-T=${1:-r05x}; O=gpurun_out; mkdir -p $O
+T=${1:-r06x}; O=gpurun_out; mkdir -p $O
 for cfg in c4 c5 c3; do
   : > $O/${T}_contract_$cfg.txt
   for seed in 99 100 101 102 103 104; do
     KP_COND_SEED=$seed python -m pytest "tests/test_gpu_fullsize.py::test_conditioned_networks_meet_the_16bit_contract[$cfg]" -q -m gpu -s 2>&1 \
-      | grep -E "^conditioned|^emulation|^hip / emu|passed|failed" >> $O/${T}_contract_$cfg.txt
+      | grep -E "^conditioned|^emulation|^hip / emu|^premise|passed|failed" >> $O/${T}_contract_$cfg.txt
   done
   python - <<PY
 import re, ast, statistics
