@@ -95,6 +95,7 @@ int kp_config_get(int key);
 #define KP_CFG_WG16 13          /* bit mask (default 7): which small-channel weight gradients take the 16 x 16 x 32 matrix-core kernel */
 #define KP_CFG_FIRST_ROWS 14   /* single-channel first layers with 16 / 32 filters: 1 (default) the row kernel (a lane = one pixel x eight channels, weights in registers), 0: conv3_first_fwd_k, > 1: workgroups per launch of the row kernel (measurement) */
 #define KP_CFG_FIRST_KTN 10  /* kp_conv_first_fwd_bnact: 2 (default) one wavefront computes all 64 channels of its groups (66 us at 128 x 128 x 128: the plain convolution's time); 1: a pair of wavefronts, 32 channels each (75 us) */
+#define KP_CFG_STATS_STORE 18  /* 0 (default) / 1 (measurement): BatchNorm sums of the 128-channel-tile forward kernel taken at the store stage from the STORED (rounded) values in 16 registers instead of 64 -- the kernel then leaves room on a CU for one wave per SIMD of another stream's pass kernels; statistics differ by the storage rounding (docs/experiments/r06.md section 10) */
 #define KP_CFG_FIN_FOLD 16     /* 1 (default): kp_conv_fwd_fin runs the BatchNorm finalize in the tail of the persistent patch convolution (last workgroup of each output-channel tile); 0: always as the kp_bn_finalize launch behind it (A/B) */
 #define KP_CFG_FIN_NT 17       /* 256 (default since round 6) / 1024: threads per workgroup of the one-launch statistics / backward-sums finalize of the > 32-channel layers.  A 16-wave workgroup needs four free wave slots on every SIMD of one CU and waited 100-430 us for them beside the other streams' persistent kernels (profiles/r05v_F_timeline_streams1.txt:32); four waves of ~20 registers are resident at once.  Model F step -0.07 ms (5 of 6 alternations on two boxes, profiles/r06_fin_fold_ab.txt) */
 #define KP_CFG_CUS 6          /* CU budget the persistent kernels size their grids to (launches on a CU-masked stream); 0 = whole device */

@@ -72,6 +72,9 @@ def apply_env(env=None) -> list:
     if env.get('KP_FIN_NT'):        # threads per workgroup of the one-launch finalize kernels (library knob KP_CFG_FIN_NT = 17): 256 / 1024
         from ._lib import call
         call('kp_config', 17, int(env['KP_FIN_NT'])); used.append('KP_FIN_NT=' + env['KP_FIN_NT'])
+    if env.get('KP_STATS_STORE'):   # forward statistics at the store stage (library knob KP_CFG_STATS_STORE = 18; measurement)
+        from ._lib import call
+        call('kp_config', 18, int(env['KP_STATS_STORE'])); used.append('KP_STATS_STORE=' + env['KP_STATS_STORE'])
     if env.get('KP_BRED_PATCH'):    # BatchNorm-backward sums in the patch data gradient's epilogue (library knob KP_CFG_BRED_PATCH = 9): 0 / 1 / 2
         from ._lib import call
         call('kp_config', 9, int(env['KP_BRED_PATCH'])); used.append('KP_BRED_PATCH=' + env['KP_BRED_PATCH'])

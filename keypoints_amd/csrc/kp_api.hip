@@ -82,6 +82,7 @@ void kp_prof_event_release(hipEvent_t e) {
     g_event_pool.push_back(e);
 }
 
+kp_knob_t g_kp_stats_store{0};   // kp_config(KP_CFG_STATS_STORE, 1): measurement -- forward statistics of the 128-channel-tile patch kernel at the store stage (kp_conv_patch.hip, SST)
 kp_knob_t g_kp_fin_fold{1};      // kp_config(KP_CFG_FIN_FOLD, v): 1 (default) kp_conv_fwd_fin folds the finalize into the convolution's tail where it can; 0: always the separate launch
 kp_knob_t g_kp_conv_patch{1};    // kp_config(KP_CFG_CONV_PATCH, v): 1 (default) the LDS-patch kernel, 0 linear, 2 pair tile first
 
@@ -105,6 +106,7 @@ int kp_device_cus(void) {
 int kp_config(int key, int value) {
     if (key == KP_CFG_CONV_PATCH) { g_kp_conv_patch = value < 0 ? 0 : (value > 2 ? 2 : value); return KP_OK; }
     if (key == KP_CFG_DEBUG) { g_kp_debug = value; return KP_OK; }
+    if (key == KP_CFG_STATS_STORE) { g_kp_stats_store = value ? 1 : 0; return KP_OK; }
     if (key == KP_CFG_FIN_FOLD) { g_kp_fin_fold = value ? 1 : 0; return KP_OK; }
     if (key == KP_CFG_FIN_NT) { g_kp_fin_nt = value == 256 ? 256 : 1024; return KP_OK; }
     if (key == KP_CFG_WALK) { g_kp_walk = value; return KP_OK; }

@@ -80,10 +80,16 @@ struct PatchArgs {
 //       adjoint of the replicate pad) is not needed: sum_ij fold(g)_ij f_ij = sum_pq g_pq f[clamp(p-1)][clamp(q-1)], and an
 //       interior pixel (p, q) of the padded domain IS source pixel (p - 1, q - 1); the border ring adds its share in its own
 //       kernel (kp_conv_mfma.hip).  Rows: 4 per workgroup (one per pixel-row group), zero outside the workgroup's k-tile.
-template <int BN, bool STATS, bool TRACE, bool BRED = false, bool EPI = false>
+// SST (measurement, kp_config(KP_CFG_STATS_STORE, 1); compact STATS launches only): the BatchNorm sums are taken at the STORE stage -- where a
+//       lane holds 8 consecutive channels of a pixel, the same 8 for every store of the launch -- from the values as STORED (rounded to the
+//       storage type: what apex O2's fp32 BatchNorm sees of an fp16 convolution output), in 16 registers instead of 64.  The kernel then
+//       leaves ~100 registers per SIMD free: one wave of a BatchNorm pass / finalize of the OTHER encoder chain fits beside it.  NOT the
+//       default: the statistics differ from the fp32-accumulator ones by the storage rounding (docs/experiments/r06.md section 10).
+template <int BN, bool STATS, bool TRACE, bool BRED = false, bool EPI = false, bool SST = false>
 __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     static_assert(!BRED || (!STATS && !TRACE), "BRED: data-gradient form");
     static_assert(!EPI || (!STATS && !TRACE && !BRED), "EPI: inference form");
+    static_assert(!SST || (STATS && !TRACE && !BRED && !EPI), "SST: a form of the forward statistics");
     constexpr int WBYTES = BN * ROWB;
     constexpr int NWI = BN / 64;          // weight DMA instructions per wave per step
     constexpr int WN = BN / 2;            // channels per wave
@@ -309,8 +315,13 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
     constexpr int CPP = WN / 8;            // 16-byte chunks per pixel (this wave's channels)
     // BN partial sums per lane (pixel) and accumulator register (channel).  A persistent workgroup (compact mode) keeps
     // them across its tiles and runs the cross-lane reduction once at its end: no cross-lane work in the epilogue.
-    float sm[STATS ? TN : 1][16], sq[STATS ? TN : 1][16];
-    if constexpr (STATS) {
+    float sm[(STATS && !SST) ? TN : 1][16], sq[(STATS && !SST) ? TN : 1][16];
+    float ss8[SST ? 8 : 1], sq8[SST ? 8 : 1];
+    if constexpr (SST) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss8[e] = sq8[e] = 0.f;
+    }
+    if constexpr (STATS && !SST) {
 #pragma unroll
         for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                         t.k0 + wn * WN;
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, 0x7ffffffe, 0x00020000);
         u32x4 gq[BRED ? 2 : 1][BRED ? NST : 1];
-        if constexpr (STATS) if (!A.compact) {   // per-tile rows: start from zero
+        if constexpr (STATS && !SST) if (!A.compact) {   // per-tile rows: start from zero
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                                                            e == 0 ? esh.x : e == 1 ? esh.y : e == 2 ? esh.z : esh.w);
                             v[e] = fmaxf(z, z * A.ep_slope);   // (= LeakyReLU for 0 <= slope <= 1; slope 0: ReLU)
                         }
-                        if constexpr (STATS) {
+                        if constexpr (STATS && !SST) {
                             sm[a][g * 4 + e] += v[e];
                             sq[a][g * 4 + e] = __builtin_fmaf(v[e], v[e], sq[a][g * 4 + e]);
                         }
@@ -406,6 +417,12 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                     const int soff = ((b * 2 + ((i * PPI) >> 4)) * A.Wob + ((i * PPI) & 15)) * K * 2;
                     __builtin_amdgcn_raw_buffer_store_b128(vv, yr, st_voff, soff, 0);
                     if constexpr (BRED) gq[b][i] = vv;
+                    if constexpr (SST) {
+                        float f[8];
+                        unpack_h16x2(vv[0], f[0], f[1]); unpack_h16x2(vv[1], f[2], f[3]); unpack_h16x2(vv[2], f[4], f[5]); unpack_h16x2(vv[3], f[6], f[7]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { ss8[e] += f[e]; sq8[e] = __builtin_fmaf(f[e], f[e], sq8[e]); }
+                    }
                 }
             }
         }
@@ -423,7 +440,7 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
-        if constexpr (STATS) if (!A.compact && !(dbg & 2)) {
+        if constexpr (STATS && !SST) if (!A.compact && !(dbg & 2)) {
 #pragma unroll
             for (int a = 0; a < TN; ++a) {
                 const int kb = t.k0 + wn * WN + a * 32;
@@ -623,8 +640,26 @@ __global__ __launch_bounds__(TPB, 2) void conv3x3_patch_k(const PatchArgs A) {
         // the finalize behind this launch -- a latency chain on the critical path of the layer -- reads a quarter of the rows
         float* red = reinterpret_cast<float*>(smem);   // [4 wm][2][BN] (the patch buffers are free: the last epilogue is behind a barrier-free tail, see below)
         if (CROWS == 1) __syncthreads();               // every wave is past its last epilogue's LDS reads
+        if constexpr (SST) {   // lanes l, l + CPP, ... hold the same 8 channels: fold them (fixed tree), lanes 0 .. CPP-1 write
+            static_assert(!SST || CROWS == 1, "SST: one statistics row per workgroup");
 #pragma unroll
-        for (int a = 0; a < TN; ++a) {
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int o = CPP; o < 64; o <<= 1) {
+                    ss8[e] += __shfl_xor(ss8[e], o, 64);
+                    sq8[e] += __shfl_xor(sq8[e], o, 64);
+                }
+            }
+            if (lane < CPP) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    red[(wm * 2 + 0) * BN + wn * WN + lane * 8 + e] = ss8[e];
+                    red[(wm * 2 + 1) * BN + wn * WN + lane * 8 + e] = sq8[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < (SST ? 0 : TN); ++a) {
             int rg, r2;
             const float ts = reduce16_over32(sm[a], lane, rg);
             const float tq = reduce16_over32(sq[a], lane, r2);
@@ -768,7 +803,9 @@ int kp_conv_patch_launch(const void* x, const void* w, const float* bias, void* 
         }
     }
     KP_QUERY_RETURN();
+    extern kp_knob_t g_kp_stats_store;
     if ((a.trace || a.dbg) && bn == 128 && stats) conv3x3_patch_k<128, true, true><<<grid, TPB, 0, st>>>(a);
+    else if (bn == 128 && stats && a.compact && CROWS == 1 && g_kp_stats_store) conv3x3_patch_k<128, true, false, false, false, true><<<grid, TPB, 0, st>>>(a);
     else if (bn == 128 && stats) conv3x3_patch_k<128, true, false><<<grid, TPB, 0, st>>>(a);
     else if (bn == 128) conv3x3_patch_k<128, false, false><<<grid, TPB, 0, st>>>(a);
     else if (stats) conv3x3_patch_k<64, true, false><<<grid, TPB, 0, st>>>(a);

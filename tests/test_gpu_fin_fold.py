@@ -156,3 +156,42 @@ def test_unit_forward_with_and_without_the_fold_agree():
             assert int(sd0[k]) == int(sd1[k]) == 1
     for a_, b_ in zip(g0, g1):
         assert float((a_ - b_).norm()) <= 2e-2 * float(b_.norm()) + 1e-8
+
+
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
+def test_store_stage_statistics_knob(dt):
+    """KP_CFG_STATS_STORE = 1 (measurement, not the default): the 128-channel-tile forward kernel takes its BatchNorm sums at the store
+    stage from the STORED values, in 16 registers instead of 64 (206 instead of 250: room on a CU for the other encoder chain's pass
+    kernels; model F step -0.22 ms, docs/experiments/r06.md section 10).  The convolution output is bit-identical; the sums are the
+    exact sums of the rounded tensor -- i.e. they differ from the default's fp32-accumulator sums by the storage rounding only."""
+    from keypoints_amd import _lib
+    from keypoints_amd._lib import call, ptr
+    from keypoints_amd.runtime import stream_ptr
+    KP_CFG_STATS_STORE = 18
+    code = _lib.KP_F16 if dt == torch.float16 else _lib.KP_BF16
+    N, H, W, C, K = 16, 64, 64, 128, 256
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(N, H + 2, W + 2, C, generator=g).cuda().to(dt)
+    w = (torch.randn(K, 3, 3, C, generator=g) * (2.0 / (9 * C)) ** 0.5).cuda().to(dt)
+    bias = torch.randn(K, generator=g).cuda()
+    st = stream_ptr()
+    res = []
+    for knob in (0, 1):
+        call('kp_config', KP_CFG_STATS_STORE, knob)
+        try:
+            y = torch.full((N, H, W, K), float('nan'), device='cuda', dtype=dt)
+            stats = torch.full(((N * H * W + 63) // 64, 2, K), float('nan'), device='cuda')
+            call('kp_conv_fwd', ptr(x), ptr(w), ptr(bias), ptr(y), ptr(stats), N, H + 2, W + 2, C, K, 3, code, st)
+            rows = _lib.last_rows()
+            torch.cuda.synchronize()
+            res.append((y, stats[:rows].double().sum(0)))
+        finally:
+            call('kp_config', KP_CFG_STATS_STORE, 0)
+    (y0, s0), (y1, s1) = res
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    yd = y1.double().reshape(-1, K)
+    exact = torch.stack((yd.sum(0), (yd * yd).sum(0)))
+    scale = torch.stack((yd.abs().sum(0), (yd * yd).sum(0)))
+    assert float(((s1 - exact).abs() / scale).max()) <= 2e-6            # the sums OF the stored tensor, to fp32 summation accuracy
+    ulp = 2.0 ** -11 if dt == torch.float16 else 2.0 ** -8
+    assert float(((s1 - s0).abs() / scale).max()) <= 0.05 * ulp         # = the default's sums up to the (zero-mean) storage rounding
