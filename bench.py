@@ -372,9 +372,11 @@ def _run_leg(args, rank, world, dev):
                 return gstep(xs, xt)
 
     reserved = None
+    torch.cuda.reset_peak_memory_stats(dev)     # (reserve_memory below sizes its segment from THIS leg's peak, not the process's)
     for i in range(args.warmup):
         step()
         if i == 1 and args.reserve_mem and not args.graph:
+            # (takes effect on the launch-bound legs only -- config 2, config 3 at batch 16: reserve_memory declines requests above 16 GiB)
             reserved = ka.runtime.reserve_memory()
     alloc_before = torch.cuda.memory_stats().get('num_device_alloc', 0)
     # The network, its plans and the optimizer state are a few hundred thousand long-lived Python objects; a full (generation

@@ -223,13 +223,17 @@ def ticket_ws(device):
     return ws
 
 
-def reserve_memory(factor: float = 1.25, device=None) -> int:
+def reserve_memory(factor: float = 1.25, device=None, max_bytes: int = 16 << 30) -> int:
     """Call once after the first one or two train steps of a launch-bound network: hands the caching allocator ONE segment of
     `factor` x the peak it has reserved so far (and drops the unused segments of the warm-up), so that every later request is a
     split of memory the process already owns.  Without it a step whose tensor lifetimes differ slightly from the warm-up's (a
     garbage collection that ran later, a side stream that was a little behind) can need a block no cached segment fits, and
     hipMalloc of a few hundred MB in the middle of a 2.6 ms step costs 10-25 ms (tools/cfg2_stall.py).  Returns the bytes of the
-    new segment (0: nothing was needed).  Not needed under a HIP graph (its private pool is fixed at capture)."""
+    new segment (0: nothing was needed).  Not needed under a HIP graph (its private pool is fixed at capture).
+    For LAUNCH-BOUND workloads only: the peak is the allocator's since the last `torch.cuda.reset_peak_memory_stats()` (call that
+    when the workload starts), the segment serves the CURRENT stream's pool (side streams keep their own), and a request above
+    `max_bytes` (16 GiB) is declined (returns 0) -- a step that holds tens of GB is not launch-bound, and 1.25 x its peak next to the
+    side streams' pools crowds the device (one 3.3 s step at config 5's 136 GB, profiles/r06v_cfg5_bench.json of the first records run)."""
     dev = torch.cuda.current_device() if device is None else device
     torch.cuda.synchronize(dev)
     peak = torch.cuda.max_memory_reserved(dev)
@@ -238,6 +242,8 @@ def reserve_memory(factor: float = 1.25, device=None) -> int:
     if need <= 0:
         return 0
     need = (need + (1 << 21) - 1) >> 21 << 21
+    if need > max_bytes:
+        return 0
     free, _ = torch.cuda.mem_get_info(dev)
     need = min(need, int(0.9 * free))
     if need <= 0:
