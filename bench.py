@@ -788,7 +788,7 @@ def main():
             #  switch of stream mode measured its dominant family 8 % below the standalone run of the same workload)
             # (warm-up: config 2's 3 ms steps get 16 -- the caching allocator starts this leg empty, and a step that needs a new block
             #  after the warm-up stalls on hipMalloc for tens of steps' worth of time: one 25 ms step in 30 was measured once)
-            leg.steps, leg.warmup, leg.profile_steps, leg.no_augment = max(3, int(args.extra_steps * mult)), (16 if mult > 2 else 2 + int(mult)), (3 if mult > 2 else 1), False
+            leg.steps, leg.warmup, leg.profile_steps, leg.no_augment = max(3, int(args.extra_steps * mult)), (16 if mult > 2 else max(3, 2 + int(mult))), (3 if mult > 2 else 1), False
             try:
                 r = run_leg(leg, rank, world, dev)
                 for k in ('n_gpus', 'higher_is_better', 'scaling', 'vs_baseline', 'data', 'unit'):

@@ -34,8 +34,8 @@ python bench.py --steps 30 --warmup 5 $Q --precision bf16 --out $O/${T}_bench_bf
 python bench.py --steps 100 --warmup 16 $Q $C2 --out $O/${T}_cfg2_bench.json > /dev/null 2>&1
 python bench.py --steps 100 --warmup 16 $Q $C2 --graph 1 --out $O/${T}_cfg2_bench_graph.json > /dev/null 2>&1
 python bench.py --steps 10 --warmup 3 $Q $C3 --out $O/${T}_cfg3_bench.json > /dev/null 2>&1
-python bench.py --steps 5 --warmup 2 $Q $C5 --out $O/${T}_cfg5_bench.json > /dev/null 2>&1
-python bench.py --steps 5 --warmup 2 $Q --precision fp32 --out $O/${T}_fp32_bench.json > /dev/null 2>&1
+python bench.py --steps 5 --warmup 4 $Q $C5 --out $O/${T}_cfg5_bench.json > /dev/null 2>&1
+python bench.py --steps 5 --warmup 4 $Q --precision fp32 --out $O/${T}_fp32_bench.json > /dev/null 2>&1
 # ---- rocprofv3 kernel stats / timelines
 cd /tmp && export TMPDIR=/tmp
 prof() {  # name, streams, steps, bench args...
