@@ -336,7 +336,10 @@ class LazyNCHW(torch.Tensor):
     kp_nhwc_to_nchw on the then-current stream and continues on the real tensor.  Autograd: the conversion is recorded when it runs
     (`padded_t_to_nchw` is an autograd Function), so a loss on the returned map reaches the encoders like any other -- as long as it is
     formed before the graph of that forward is freed by a backward, which is when the reference's tensor would have to be used too.
-    keypoints_amd's own entry points (`Unit.forward*`, `l2_reconstruction_loss`, the functional ops) unwrap it explicitly."""
+    keypoints_amd's own entry points (`Unit.forward*`, `l2_reconstruction_loss`, the functional ops) unwrap it explicitly.
+    Known limit: the wrapper object itself reports `requires_grad == False` (wrapper subclasses cannot carry a grad_fn); every torch
+    function applied to it runs on the materialised tensor, which does carry the graph -- code that BRANCHES on `phi.requires_grad`
+    before touching the values sees False.  `set_lazy_outputs(False)` returns the plain tensor."""
 
     @staticmethod
     def __new__(cls, a, pad, code):
